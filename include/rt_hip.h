@@ -1,0 +1,150 @@
+/*
+ * rt_hip.h -- C ABI of librt_hip.so: the MI355X path-tracing back end.
+ *
+ * The reference (cozis/ray_tracing) has no FFI seam for this path: the work is done by N worker
+ * pthreads inside main.c.  This header is the seam a maintainer would bind instead.  Each entry
+ * point names the reference code it replaces (paths relative to the reference repo).
+ *
+ *   reference today                                    this library
+ *   -----------------------------------------------    ------------------------------------------
+ *   Scene scene; parse_scene_file()   main.c:54,493    rt_parse_scene_file() + rt_set_scene()
+ *   Cubemap skybox; load_cubemap()    main.c:55,500    rt_load_cubemap()     + rt_set_skybox()
+ *   camera.c statics                  camera.c:28-35   rt_camera + rt_set_camera()
+ *   start_workers()/worker()/render_column()/pixel()
+ *     + accum[] += ... + update_frame() resolve
+ *                          main.c:695,324,274,131,467  rt_render()  (one synchronous call)
+ *   move_frame_to_the_gpu(w,h,frame)  main.c:479       caller passes the filled Vector3[w*h] on
+ *
+ * Conventions: every function returns 0 on success and a negative rt_status on failure and never
+ * aborts (the reference abort()s / exit()s: main.c:373,425-434); rt_last_error() gives the text.
+ * All host pointers are caller-owned and not retained after the call returns.  A context is bound
+ * to one GPU and must be used from one host thread at a time.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "rt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_API __attribute__((visibility("default")))
+
+typedef enum {
+	RT_OK            =  0,
+	RT_ERR_ARGUMENT  = -1,   /* NULL / out-of-range argument                     */
+	RT_ERR_DEVICE    = -2,   /* HIP runtime error (text in rt_last_error())      */
+	RT_ERR_STATE     = -3,   /* scene / skybox / camera not set before rendering */
+	RT_ERR_IO        = -4,   /* file could not be read                           */
+	RT_ERR_FORMAT    = -5,   /* scene text or JPEG stream rejected               */
+	RT_ERR_MEMORY    = -6
+} rt_status;
+
+typedef struct rt_context rt_context;
+
+/* Kernel selection.  RT_KERNEL_AUTO picks the tuned kernel; RT_KERNEL_SIMPLE is the path loop in
+ * the reference's own order, kept as an on-GPU cross-check. */
+enum { RT_KERNEL_AUTO = 0, RT_KERNEL_SIMPLE = 1, RT_KERNEL_WAVEFRONT = 2 };
+
+/*
+ * What the reference hard-codes or lacks, made explicit:
+ *   spp          number of 1-sample passes accumulated (reference: until the camera moves, main.c:357)
+ *   max_bounces  main.c:156's literal 10
+ *   seed         `counter` RNG mode: path (pixel p, sample s) starts from rt_path_seed(seed, p, s);
+ *                the reference's thread-local stream (utils.c:60) cannot be evaluated in parallel
+ *   row_block/rank/world   interleaved row-block partition for multi-GPU: this call renders the row
+ *                blocks b with b % world == rank into a compact strip (see rt_strip_rows()).
+ *                Single GPU: row_block = any (>0), rank = 0, world = 1 -> the strip is the frame.
+ */
+typedef struct {
+	int      width, height;
+	int      spp;
+	int      max_bounces;
+	uint64_t seed;
+	int      row_block, rank, world;
+	int      kernel;            /* RT_KERNEL_* */
+} rt_render_params;
+
+RT_API void rt_default_params(rt_render_params *p, int width, int height, int spp, int max_bounces);
+
+/* ---- context ------------------------------------------------------------------------------ */
+RT_API int  rt_create(rt_context **out, int device_id);
+RT_API void rt_destroy(rt_context *ctx);
+RT_API const char *rt_last_error(void);
+
+/* ---- inputs: replaces the globals of main.c:54-55 and the statics of camera.c:28,33-35 ------ */
+RT_API int rt_set_scene(rt_context *ctx, const Scene *scene);
+/* chan must be 3 or 4 (what stb_image returns for the shipped JPEGs is 3); all faces w x h */
+RT_API int rt_set_skybox(rt_context *ctx, const Cubemap *skybox);
+RT_API int rt_set_camera(rt_context *ctx, const rt_camera *camera);
+
+/* ---- the hot path: replaces start_workers()+worker()+update_frame() ------------------------ */
+/* Renders the whole frame (world must be 1) into caller-allocated host memory: width*height
+ * Vector3, row-major, frame[j*width+i], row 0 = bottom of the displayed image, values in [0,1] --
+ * exactly what update_frame() hands to move_frame_to_the_gpu() (main.c:467-479). */
+RT_API int rt_render(rt_context *ctx, const rt_render_params *params, Vector3 *frame_out);
+
+/* Same, but the destination is DEVICE memory (rt_strip_rows()*width*12 bytes) and the call only
+ * enqueues work on `hip_stream` (a hipStream_t; NULL = the context's own stream).  No sync. */
+RT_API int rt_render_device(rt_context *ctx, const rt_render_params *params, void *d_strip, void *hip_stream);
+
+/* Rows held by one rank's strip, padded so every rank has the same count (gather-friendly). */
+RT_API int rt_strip_rows(int height, int row_block, int world);
+
+/* Root side of the multi-GPU exchange: `d_strips` = world strips back to back (what one RCCL
+ * gather / all-gather delivers) -> d_frame = height*width Vector3 in frame order. */
+RT_API int rt_deinterleave_device(rt_context *ctx, const void *d_strips, void *d_frame,
+                                  int width, int height, int row_block, int world, void *hip_stream);
+
+RT_API int rt_synchronize(rt_context *ctx);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+/* When enabled, every rt_render_device()/rt_render() brackets its trace kernel with hipEvents on
+ * the launch stream; rt_profile_collect() synchronises and returns the summed kernel time and the
+ * number of launches since the last collect. */
+RT_API int rt_profile_enable(rt_context *ctx, int on);
+RT_API int rt_profile_collect(rt_context *ctx, double *kernel_ms_total, int *launches);
+
+/* ---- host-side mirror of the reference's loaders / camera (plain C, no GPU needed) ---------- */
+/* scene.c:611 parse_scene_file(): same grammar, defaults, range checks, float accumulation and
+ * stderr diagnostics.  Returns RT_OK / RT_ERR_IO / RT_ERR_FORMAT. */
+RT_API int rt_parse_scene_file(const char *file, Scene *scene);
+RT_API int rt_parse_scene_string(const char *src, size_t len, Scene *scene);
+
+/* gpu_and_windowing.c:24-40 load_cubemap()/free_cubemap(): decodes six baseline JPEGs with the
+ * arithmetic of stb_image v2.29 (the decoder the reference vendors), so texel bytes are identical.
+ * `files` is indexed by CubeFace.  Unlike the reference it returns an error instead of abort(). */
+RT_API int  rt_load_cubemap(Cubemap *c, const char *files[6]);
+RT_API void rt_free_cubemap(Cubemap *c);
+/* one image: *out is malloc()ed w*h*chan bytes */
+RT_API int  rt_decode_jpeg_file(const char *file, uint8_t **out, int *w, int *h, int *chan);
+
+/* camera.c:28,33-35 defaults; camera.c:99-118 frame constants (tan() in double on the host) */
+RT_API void rt_camera_default(rt_camera *cam);
+RT_API void rt_camera_basis_for(const rt_camera *cam, float aspect_ratio, rt_camera_basis *out);
+/* camera.c:80-88 move_camera(), camera.c:42-78 rotate_camera() on explicit state */
+typedef enum { RT_DIR_UP, RT_DIR_DOWN, RT_DIR_LEFT, RT_DIR_RIGHT } rt_direction;
+typedef struct { int first_mouse; float yaw, pitch, last_x, last_y; } rt_mouse_state;
+RT_API void rt_mouse_state_default(rt_mouse_state *m);
+RT_API void rt_move_camera(rt_camera *cam, rt_direction dir, float speed);
+RT_API void rt_rotate_camera(rt_camera *cam, rt_mouse_state *m, double mouse_x, double mouse_y);
+
+/* `counter`-mode path seed (shared definition with the kernels and the oracle) */
+RT_API uint64_t rt_path_seed(uint64_t seed, uint32_t pixel_index, uint32_t sample_index);
+
+/* Headless stand-in for the reference's presenter hand-off, same signature as
+ * move_frame_to_the_gpu() (gpu_and_windowing.h:44): a registered sink receives the frame. */
+typedef void (*rt_frame_sink)(int w, int h, Vector3 *data, void *user);
+RT_API void rt_set_frame_sink(rt_frame_sink sink, void *user);
+RT_API void rt_move_frame_to_the_gpu(int w, int h, Vector3 *data);
+/* screenshot() main.c:637-681: float -> u8 by truncating *255, vertical flip; written as binary PPM */
+RT_API int  rt_write_ppm(const char *file, int w, int h, const Vector3 *data);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RT_HIP_H */

@@ -1,0 +1,266 @@
+"""ray_tracing_amd -- MI355X (gfx950) back end for the path-tracing hot path of cozis/ray_tracing.
+
+The product is ``librt_hip.so`` (hand-written HIP kernels behind a C ABI, see include/rt_hip.h).
+This module is only a thin ctypes binding over that ABI for tests, bench.py and Python hosts; it
+contains no rendering logic and no CPU fallback: if the library is missing it raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+ROOT = os.path.dirname(_HERE)
+DATA_DIR = os.path.join(ROOT, "data")
+
+MAX_OBJECTS = 1024
+SCENE_BYTES = 68 * MAX_OBJECTS + 4          # sizeof(Scene), reference scene.h:33-36
+FACE_NAMES = ["front", "back", "left", "right", "top", "bottom"]   # CubeFace order
+
+KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_WAVEFRONT = 0, 1, 2
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class Vector3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("pos", Vector3), ("front", Vector3), ("up", Vector3), ("fov", C.c_float)]
+
+
+class CameraBasis(C.Structure):
+    _fields_ = [("pos", Vector3), ("lower_left_corner", Vector3), ("horizontal", Vector3), ("vertical", Vector3)]
+
+
+class Cubemap(C.Structure):
+    _fields_ = [("data", C.c_void_p * 6), ("w", C.c_int), ("h", C.c_int), ("chan", C.c_int)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("spp", C.c_int), ("max_bounces", C.c_int),
+                ("seed", C.c_uint64), ("row_block", C.c_int), ("rank", C.c_int), ("world", C.c_int),
+                ("kernel", C.c_int)]
+
+
+class MouseState(C.Structure):
+    _fields_ = [("first_mouse", C.c_int), ("yaw", C.c_float), ("pitch", C.c_float),
+                ("last_x", C.c_float), ("last_y", C.c_float)]
+
+
+# every symbol include/rt_hip.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
+    "rt_set_camera", "rt_render", "rt_render_device", "rt_strip_rows", "rt_deinterleave_device",
+    "rt_synchronize", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
+    "rt_parse_scene_string", "rt_load_cubemap", "rt_free_cubemap", "rt_decode_jpeg_file",
+    "rt_camera_default", "rt_camera_basis_for", "rt_mouse_state_default", "rt_move_camera",
+    "rt_rotate_camera", "rt_path_seed", "rt_set_frame_sink", "rt_move_frame_to_the_gpu", "rt_write_ppm",
+]
+
+_lib = None
+
+
+def lib():
+    """Load librt_hip.so (once).  Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtError(f"{LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      f"or `make -C ray_tracing_amd/csrc`")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as
+    # /opt/rocm's).  If torch is going to share this process (bench.py, multi-GPU tests) it must be
+    # loaded first so that librt_hip.so binds to the runtime torch uses; two runtimes in one process
+    # leave the second one without devices.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.rt_destroy.argtypes = [C.c_void_p]
+    L.rt_set_scene.argtypes = [C.c_void_p, C.c_void_p]
+    L.rt_set_skybox.argtypes = [C.c_void_p, C.POINTER(Cubemap)]
+    L.rt_set_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
+    L.rt_default_params.argtypes = [C.POINTER(RenderParams), C.c_int, C.c_int, C.c_int, C.c_int]
+    L.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p]
+    L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p]
+    L.rt_strip_rows.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.rt_deinterleave_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
+    L.rt_synchronize.argtypes = [C.c_void_p]
+    L.rt_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    L.rt_profile_collect.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.rt_parse_scene_file.argtypes = [C.c_char_p, C.c_void_p]
+    L.rt_parse_scene_string.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+    L.rt_load_cubemap.argtypes = [C.POINTER(Cubemap), C.POINTER(C.c_char_p)]
+    L.rt_free_cubemap.argtypes = [C.POINTER(Cubemap)]
+    L.rt_decode_jpeg_file.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.rt_camera_default.argtypes = [C.POINTER(Camera)]
+    L.rt_camera_basis_for.argtypes = [C.POINTER(Camera), C.c_float, C.POINTER(CameraBasis)]
+    L.rt_mouse_state_default.argtypes = [C.POINTER(MouseState)]
+    L.rt_move_camera.argtypes = [C.POINTER(Camera), C.c_int, C.c_float]
+    L.rt_rotate_camera.argtypes = [C.POINTER(Camera), C.POINTER(MouseState), C.c_double, C.c_double]
+    L.rt_path_seed.restype = C.c_uint64
+    L.rt_path_seed.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+    L.rt_write_ppm.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RtError(f"{what} failed ({rc}): {lib().rt_last_error().decode(errors='replace')}")
+
+
+# ---- host-side mirror of the reference loaders (no GPU needed) -----------------------------------
+
+def parse_scene_file(path):
+    """scene.c:611 parse_scene_file().  Returns (status, raw Scene buffer as uint8[69636])."""
+    buf = np.zeros(SCENE_BYTES, dtype=np.uint8)
+    rc = lib().rt_parse_scene_file(os.fsencode(path), buf.ctypes.data_as(C.c_void_p))
+    return rc, buf
+
+
+def parse_scene_string(text):
+    if isinstance(text, str):
+        text = text.encode()
+    buf = np.zeros(SCENE_BYTES, dtype=np.uint8)
+    rc = lib().rt_parse_scene_string(text, len(text), buf.ctypes.data_as(C.c_void_p))
+    return rc, buf
+
+
+def decode_jpeg(path):
+    p = C.POINTER(C.c_uint8)()
+    w, h, ch = C.c_int(), C.c_int(), C.c_int()
+    _check(lib().rt_decode_jpeg_file(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h), C.byref(ch)),
+           f"rt_decode_jpeg_file({path})")
+    try:
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, ch.value)).copy()
+    finally:
+        C.CDLL(None).free(p)
+
+
+_skybox_cache = {}
+
+
+def load_skybox(directory=None):
+    """gpu_and_windowing.c:24 load_cubemap() on <dir>/{front,back,left,right,top,bottom}.jpg
+    -> uint8 array (6, h, w, chan) in CubeFace order."""
+    directory = directory or os.path.join(DATA_DIR, "skybox")
+    if directory not in _skybox_cache:
+        _skybox_cache[directory] = np.stack([decode_jpeg(os.path.join(directory, n + ".jpg")) for n in FACE_NAMES])
+    return _skybox_cache[directory]
+
+
+def default_camera():
+    cam = Camera()
+    lib().rt_camera_default(C.byref(cam))
+    return cam
+
+
+def camera_basis(cam, aspect):
+    b = CameraBasis()
+    lib().rt_camera_basis_for(C.byref(cam), aspect, C.byref(b))
+    return b
+
+
+def strip_rows(height, row_block, world):
+    return lib().rt_strip_rows(height, row_block, world)
+
+
+# ---- the GPU path ---------------------------------------------------------------------------------
+
+class Renderer:
+    """One rt_context = one GPU.  Mirrors the life cycle of the reference's main(): set scene,
+    skybox and camera once, then render frames."""
+
+    def __init__(self, device=0):
+        self._ctx = C.c_void_p()
+        _check(lib().rt_create(C.byref(self._ctx), device), "rt_create")
+        self.device = device
+        self._keep = {}
+
+    def close(self):
+        if self._ctx:
+            lib().rt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_scene(self, scene):
+        """scene: path to a scene_*.txt, or a raw Scene buffer (uint8[69636])."""
+        if isinstance(scene, (str, bytes, os.PathLike)):
+            rc, buf = parse_scene_file(scene)
+            _check(rc, f"rt_parse_scene_file({scene})")
+        else:
+            buf = np.ascontiguousarray(scene, dtype=np.uint8)
+            assert buf.nbytes == SCENE_BYTES
+        _check(lib().rt_set_scene(self._ctx, buf.ctypes.data_as(C.c_void_p)), "rt_set_scene")
+        return buf
+
+    def set_skybox(self, faces):
+        """faces: uint8 (6, h, w, chan) in CubeFace order."""
+        faces = np.ascontiguousarray(faces, dtype=np.uint8)
+        cm = Cubemap()
+        for i in range(6):
+            cm.data[i] = faces[i].ctypes.data
+        cm.h, cm.w, cm.chan = faces.shape[1], faces.shape[2], faces.shape[3]
+        _check(lib().rt_set_skybox(self._ctx, C.byref(cm)), "rt_set_skybox")
+
+    def set_camera(self, pos=None, front=None, up=None, fov=None):
+        cam = default_camera()
+        if pos is not None:
+            cam.pos = Vector3(*pos)
+        if front is not None:
+            cam.front = Vector3(*front)
+        if up is not None:
+            cam.up = Vector3(*up)
+        if fov is not None:
+            cam.fov = fov
+        _check(lib().rt_set_camera(self._ctx, C.byref(cam)), "rt_set_camera")
+
+    @staticmethod
+    def params(width, height, spp, max_bounces, seed=0, row_block=8, rank=0, world=1, kernel=KERNEL_AUTO):
+        p = RenderParams()
+        lib().rt_default_params(C.byref(p), width, height, spp, max_bounces)
+        p.seed, p.row_block, p.rank, p.world, p.kernel = seed, row_block, rank, world, kernel
+        return p
+
+    def render(self, width, height, spp, max_bounces, seed=0, kernel=KERNEL_AUTO):
+        """Whole frame -> host float32 array (height, width, 3), row 0 = bottom (as the reference's `frame`)."""
+        p = self.params(width, height, spp, max_bounces, seed=seed, kernel=kernel)
+        out = np.empty((height, width, 3), dtype=np.float32)
+        _check(lib().rt_render(self._ctx, C.byref(p), out.ctypes.data_as(C.c_void_p)), "rt_render")
+        return out
+
+    def render_device(self, params, device_ptr, stream=None):
+        """Enqueue one strip render into device memory (no sync)."""
+        _check(lib().rt_render_device(self._ctx, C.byref(params), C.c_void_p(device_ptr),
+                                      C.c_void_p(stream) if stream else None), "rt_render_device")
+
+    def deinterleave_device(self, strips_ptr, frame_ptr, width, height, row_block, world, stream=None):
+        _check(lib().rt_deinterleave_device(self._ctx, C.c_void_p(strips_ptr), C.c_void_p(frame_ptr), width, height,
+                                            row_block, world, C.c_void_p(stream) if stream else None),
+               "rt_deinterleave_device")
+
+    def synchronize(self):
+        _check(lib().rt_synchronize(self._ctx), "rt_synchronize")
+
+    def profile(self, on=True):
+        _check(lib().rt_profile_enable(self._ctx, 1 if on else 0), "rt_profile_enable")
+
+    def profile_collect(self):
+        ms, n = C.c_double(), C.c_int()
+        _check(lib().rt_profile_collect(self._ctx, C.byref(ms), C.byref(n)), "rt_profile_collect")
+        return ms.value, n.value

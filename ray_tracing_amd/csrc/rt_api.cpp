@@ -1,0 +1,380 @@
+/*
+ * rt_api.cpp -- the C ABI of librt_hip.so (see include/rt_hip.h): context, input packing,
+ * launches.  Host-only code; the kernels are in rt_kernels.hip.
+ *
+ * Packing folds every ray-independent term of the reference's inner loops on the host, with the
+ * reference's own float roundings, so the kernels start from the same bits the CPU would compute:
+ *   cube far corner  origin*1 + size*1                         scene.c:27
+ *   sphere r*r                                                  scene.c:112
+ *   f0, 1-f0, albedo*(1-metallic), emission_color*power, metallic > 0.001
+ *                                                               main.c:219-221,128,248,232,241
+ *   first emitter and origin_of() of it                         main.c:140-146, scene.c:10-15
+ *   camera basis                                                camera.c:99-118
+ * This translation unit is compiled with -ffp-contract=off like everything else.
+ */
+#include <hip/hip_runtime_api.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_internal.h"
+
+#pragma clang fp contract(off)
+
+static thread_local char g_error[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_error, sizeof(g_error), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+	do {                                                                                    \
+		hipError_t e_ = (expr);                                                             \
+		if (e_ != hipSuccess)                                                               \
+			return fail(RT_ERR_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+	} while (0)
+
+struct rt_context {
+	int          device = 0;
+	hipStream_t  stream = nullptr;
+
+	rt_geom     *d_geom = nullptr;
+	rt_shade    *d_shade = nullptr;
+	int          num_objects = 0;
+	int          capacity = 0;
+	bool         have_scene = false;
+	int          light_index = -1;
+	float        light_pos[3] = {0, 0, 0};
+
+	uint32_t    *d_sky = nullptr;
+	size_t       sky_bytes = 0;
+	int          sky_w = 0, sky_h = 0;
+	bool         have_sky = false;
+
+	rt_camera    camera;
+	bool         have_camera = false;
+
+	float       *d_frame = nullptr;      /* scratch for rt_render() */
+	size_t       frame_bytes = 0;
+
+	bool         profiling = false;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+	std::vector<hipEvent_t> event_pool;
+};
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_error; }
+
+void rt_default_params(rt_render_params *p, int width, int height, int spp, int max_bounces)
+{
+	if (!p) return;
+	memset(p, 0, sizeof(*p));
+	p->width = width; p->height = height; p->spp = spp; p->max_bounces = max_bounces;
+	p->seed = 0; p->row_block = 8; p->rank = 0; p->world = 1; p->kernel = RT_KERNEL_AUTO;
+}
+
+int rt_create(rt_context **out, int device_id)
+{
+	if (!out) return fail(RT_ERR_ARGUMENT, "rt_create: out is NULL");
+	*out = nullptr;
+	int count = 0;
+	HIP_TRY(hipGetDeviceCount(&count));
+	if (device_id < 0 || device_id >= count)
+		return fail(RT_ERR_ARGUMENT, "rt_create: device %d out of range (%d visible)", device_id, count);
+	HIP_TRY(hipSetDevice(device_id));
+	rt_context *ctx = new (std::nothrow) rt_context();
+	if (!ctx) return fail(RT_ERR_MEMORY, "rt_create: out of host memory");
+	ctx->device = device_id;
+	hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+	if (e != hipSuccess) { delete ctx; return fail(RT_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
+	rt_camera_default(&ctx->camera);
+	ctx->have_camera = true;     /* the reference starts from its default pose too (camera.c:33-35) */
+	*out = ctx;
+	return RT_OK;
+}
+
+void rt_destroy(rt_context *ctx)
+{
+	if (!ctx) return;
+	(void) hipSetDevice(ctx->device);
+	(void) hipStreamSynchronize(ctx->stream);
+	for (auto &p : ctx->events) { (void) hipEventDestroy(p.first); (void) hipEventDestroy(p.second); }
+	for (auto &e : ctx->event_pool) (void) hipEventDestroy(e);
+	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
+	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame);
+	(void) hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+int rt_set_scene(rt_context *ctx, const Scene *scene)
+{
+	if (!ctx || !scene) return fail(RT_ERR_ARGUMENT, "rt_set_scene: NULL argument");
+	const int n = scene->num_objects;
+	if (n < 0 || n > MAX_OBJECTS) return fail(RT_ERR_ARGUMENT, "rt_set_scene: num_objects %d not in [0,%d]", n, MAX_OBJECTS);
+	HIP_TRY(hipSetDevice(ctx->device));
+
+	std::vector<rt_geom>  geom((size_t) n > 0 ? n : 1);
+	std::vector<rt_shade> shade((size_t) n > 0 ? n : 1);
+	memset(geom.data(), 0, geom.size() * sizeof(rt_geom));
+	memset(shade.data(), 0, shade.size() * sizeof(rt_shade));
+	int light = -1;
+	for (int i = 0; i < n; i++) {
+		const Object &o = scene->objects[i];
+		const Material &m = o.material;
+		rt_geom &g = geom[i];
+		if (o.type == OBJECT_CUBE) {
+			g.type = RT_GEOM_CUBE;
+			g.a[0] = o.cube.origin.x; g.a[1] = o.cube.origin.y; g.a[2] = o.cube.origin.z;
+			g.b0 = o.cube.origin.x * 1.0f + o.cube.size.x * 1.0f;
+			g.b1 = o.cube.origin.y * 1.0f + o.cube.size.y * 1.0f;
+			g.b2 = o.cube.origin.z * 1.0f + o.cube.size.z * 1.0f;
+		} else if (o.type == OBJECT_SPHERE) {
+			g.type = RT_GEOM_SPHERE;
+			g.a[0] = o.sphere.center.x; g.a[1] = o.sphere.center.y; g.a[2] = o.sphere.center.z;
+			g.b0 = o.sphere.radius * o.sphere.radius;
+		} else {
+			g.type = -1;   /* intersect_object() returns false for unknown types (scene.c:153) */
+		}
+
+		rt_shade &s = shade[i];
+		const float f0d = (float) (0.16 * (double) m.reflectance * (double) m.reflectance);
+		const float om  = 1 - m.metallic;
+		const float alb[3] = { m.albedo.x, m.albedo.y, m.albedo.z };
+		const float ecol[3] = { m.emission_color.x, m.emission_color.y, m.emission_color.z };
+		for (int k = 0; k < 3; k++) {
+			s.f0[k]           = f0d * om + alb[k] * m.metallic;
+			s.one_minus_f0[k] = 1.0f * 1.0f + s.f0[k] * -1.0f;
+			s.tint[k]         = alb[k] * om;
+			s.emission[k]     = ecol[k] * m.emission_power;
+		}
+		s.roughness = m.roughness;
+		s.is_metal  = ((double) m.metallic > 0.001) ? 1 : 0;
+		if (light < 0 && m.emission_power > 0) light = i;
+	}
+	ctx->light_index = light;
+	if (light >= 0) {
+		const Object &o = scene->objects[light];
+		if (o.type == OBJECT_SPHERE) {
+			ctx->light_pos[0] = o.sphere.center.x; ctx->light_pos[1] = o.sphere.center.y; ctx->light_pos[2] = o.sphere.center.z;
+		} else {
+			ctx->light_pos[0] = o.cube.origin.x * 1.0f + o.cube.size.x * 0.5f;
+			ctx->light_pos[1] = o.cube.origin.y * 1.0f + o.cube.size.y * 0.5f;
+			ctx->light_pos[2] = o.cube.origin.z * 1.0f + o.cube.size.z * 0.5f;
+		}
+	}
+
+	if (n > ctx->capacity || !ctx->d_geom) {
+		(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
+		ctx->d_geom = nullptr; ctx->d_shade = nullptr; ctx->capacity = 0;
+		const int cap = n > 16 ? n : 16;
+		HIP_TRY(hipMalloc((void**) &ctx->d_geom, (size_t) cap * sizeof(rt_geom)));
+		HIP_TRY(hipMalloc((void**) &ctx->d_shade, (size_t) cap * sizeof(rt_shade)));
+		ctx->capacity = cap;
+	}
+	if (n > 0) {
+		HIP_TRY(hipMemcpy(ctx->d_geom, geom.data(), (size_t) n * sizeof(rt_geom), hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(ctx->d_shade, shade.data(), (size_t) n * sizeof(rt_shade), hipMemcpyHostToDevice));
+	}
+	ctx->num_objects = n;
+	ctx->have_scene = true;
+	return RT_OK;
+}
+
+int rt_set_skybox(rt_context *ctx, const Cubemap *sky)
+{
+	if (!ctx || !sky) return fail(RT_ERR_ARGUMENT, "rt_set_skybox: NULL argument");
+	if (sky->w <= 0 || sky->h <= 0) return fail(RT_ERR_ARGUMENT, "rt_set_skybox: bad size %dx%d", sky->w, sky->h);
+	if (sky->chan != 3 && sky->chan != 4)
+		return fail(RT_ERR_ARGUMENT, "rt_set_skybox: %d channels unsupported (need 3 or 4)", sky->chan);
+	for (int f = 0; f < 6; f++)
+		if (!sky->data[f]) return fail(RT_ERR_ARGUMENT, "rt_set_skybox: face %d is NULL", f);
+	HIP_TRY(hipSetDevice(ctx->device));
+
+	/* RGBA8 repack: one aligned dword per texel for the kernel's gather (sample_cubemap reads
+	 * bytes [0..2] of a `chan`-strided texel, gpu_and_windowing.c:106-111) */
+	const size_t texels = (size_t) sky->w * sky->h;
+	const size_t bytes = texels * 6 * sizeof(uint32_t);
+	uint32_t *staging = nullptr;
+	HIP_TRY(hipHostMalloc((void**) &staging, bytes, hipHostMallocDefault));
+	for (int f = 0; f < 6; f++) {
+		const uint8_t *src = sky->data[f];
+		uint32_t *dst = staging + (size_t) f * texels;
+		const int ch = sky->chan;
+		for (size_t t = 0; t < texels; t++, src += ch)
+			dst[t] = (uint32_t) src[0] | ((uint32_t) src[1] << 8) | ((uint32_t) src[2] << 16) | 0xff000000u;
+	}
+	if (bytes != ctx->sky_bytes) {
+		(void) hipFree(ctx->d_sky); ctx->d_sky = nullptr; ctx->sky_bytes = 0;
+		hipError_t e = hipMalloc((void**) &ctx->d_sky, bytes);
+		if (e != hipSuccess) { (void) hipHostFree(staging); return fail(RT_ERR_DEVICE, "hipMalloc(skybox): %s", hipGetErrorString(e)); }
+		ctx->sky_bytes = bytes;
+	}
+	hipError_t e = hipMemcpy(ctx->d_sky, staging, bytes, hipMemcpyHostToDevice);
+	(void) hipHostFree(staging);
+	if (e != hipSuccess) return fail(RT_ERR_DEVICE, "hipMemcpy(skybox): %s", hipGetErrorString(e));
+	ctx->sky_w = sky->w; ctx->sky_h = sky->h;
+	ctx->have_sky = true;
+	return RT_OK;
+}
+
+int rt_set_camera(rt_context *ctx, const rt_camera *camera)
+{
+	if (!ctx || !camera) return fail(RT_ERR_ARGUMENT, "rt_set_camera: NULL argument");
+	ctx->camera = *camera;
+	ctx->have_camera = true;
+	return RT_OK;
+}
+
+int rt_strip_rows(int height, int row_block, int world)
+{
+	if (height <= 0 || row_block <= 0 || world <= 0) return 0;
+	const int blocks = (height + row_block - 1) / row_block;
+	const int per_rank = (blocks + world - 1) / world;
+	return per_rank * row_block;
+}
+
+static int check_params(const rt_context *ctx, const rt_render_params *p)
+{
+	if (!ctx || !p) return fail(RT_ERR_ARGUMENT, "render: NULL argument");
+	if (!ctx->have_scene)  return fail(RT_ERR_STATE, "render: no scene set (rt_set_scene)");
+	if (!ctx->have_sky)    return fail(RT_ERR_STATE, "render: no skybox set (rt_set_skybox)");
+	if (p->width < 2 || p->height < 2 || (int64_t) p->width * p->height > (int64_t) 1 << 30)
+		return fail(RT_ERR_ARGUMENT, "render: frame %dx%d unsupported (need >= 2x2, <= 2^30 pixels)", p->width, p->height);
+	if (p->spp < 1)         return fail(RT_ERR_ARGUMENT, "render: spp %d < 1", p->spp);
+	if (p->max_bounces < 0) return fail(RT_ERR_ARGUMENT, "render: max_bounces %d < 0", p->max_bounces);
+	if (p->row_block < 1 || p->world < 1 || p->rank < 0 || p->rank >= p->world)
+		return fail(RT_ERR_ARGUMENT, "render: bad partition row_block=%d rank=%d world=%d", p->row_block, p->rank, p->world);
+	if (p->kernel < RT_KERNEL_AUTO || p->kernel > RT_KERNEL_WAVEFRONT)
+		return fail(RT_ERR_ARGUMENT, "render: unknown kernel %d", p->kernel);
+	return RT_OK;
+}
+
+static hipEvent_t take_event(rt_context *ctx)
+{
+	if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+	hipEvent_t e = nullptr;
+	(void) hipEventCreate(&e);
+	return e;
+}
+
+int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, void *hip_stream)
+{
+	int rc = check_params(ctx, p);
+	if (rc != RT_OK) return rc;
+	if (!d_strip) return fail(RT_ERR_ARGUMENT, "rt_render_device: d_strip is NULL");
+	HIP_TRY(hipSetDevice(ctx->device));
+	hipStream_t stream = hip_stream ? (hipStream_t) hip_stream : ctx->stream;
+
+	rt_launch L;
+	memset(&L, 0, sizeof(L));
+	rt_camera_basis basis;
+	rt_camera_basis_for(&ctx->camera, (float) p->width / p->height, &basis);   /* main.c:281 */
+	const Vector3 *src[4] = { &basis.pos, &basis.lower_left_corner, &basis.horizontal, &basis.vertical };
+	float *dst[4] = { L.pos, L.llc, L.horiz, L.vert };
+	for (int k = 0; k < 4; k++) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; }
+	L.light_index = ctx->light_index;
+	memcpy(L.light_pos, ctx->light_pos, sizeof(L.light_pos));
+	L.num_objects = ctx->num_objects;
+	L.width = p->width; L.height = p->height;
+	L.spp = p->spp; L.max_bounces = p->max_bounces; L.seed = p->seed;
+	L.row_block = p->row_block; L.rank = p->rank; L.world = p->world;
+	/* rows this rank owns: blocks rank, rank+world, ... ; the last one may be partial or absent */
+	{
+		const int blocks = (p->height + p->row_block - 1) / p->row_block;
+		const int mine = blocks > p->rank ? (blocks - p->rank + p->world - 1) / p->world : 0;
+		L.local_rows = mine * p->row_block;
+	}
+	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h;
+	L.frame = (float*) d_strip;
+	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
+
+	if (rt_scene_lds_bytes(L.num_objects) > 160 * 1024)
+		return fail(RT_ERR_ARGUMENT, "render: scene needs %zu B of LDS (> 160 KiB)", rt_scene_lds_bytes(L.num_objects));
+
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	if (ctx->profiling) { e0 = take_event(ctx); e1 = take_event(ctx); HIP_TRY(hipEventRecord(e0, stream)); }
+	HIP_TRY(rt_launch_trace(L, p->kernel, stream));
+	if (ctx->profiling) { HIP_TRY(hipEventRecord(e1, stream)); ctx->events.emplace_back(e0, e1); }
+	return RT_OK;
+}
+
+int rt_render(rt_context *ctx, const rt_render_params *p, Vector3 *frame_out)
+{
+	int rc = check_params(ctx, p);
+	if (rc != RT_OK) return rc;
+	if (!frame_out) return fail(RT_ERR_ARGUMENT, "rt_render: frame_out is NULL");
+	if (p->world != 1) return fail(RT_ERR_ARGUMENT, "rt_render: world must be 1 (use rt_render_device for strips)");
+	HIP_TRY(hipSetDevice(ctx->device));
+	const int rows = rt_strip_rows(p->height, p->row_block, 1);
+	const size_t need = (size_t) rows * p->width * 3 * sizeof(float);
+	if (need > ctx->frame_bytes) {
+		(void) hipFree(ctx->d_frame); ctx->d_frame = nullptr; ctx->frame_bytes = 0;
+		HIP_TRY(hipMalloc((void**) &ctx->d_frame, need));
+		ctx->frame_bytes = need;
+	}
+	rc = rt_render_device(ctx, p, ctx->d_frame, ctx->stream);
+	if (rc != RT_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(frame_out, ctx->d_frame, (size_t) p->height * p->width * 3 * sizeof(float),
+	                       hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return RT_OK;
+}
+
+int rt_deinterleave_device(rt_context *ctx, const void *d_strips, void *d_frame,
+                           int width, int height, int row_block, int world, void *hip_stream)
+{
+	if (!ctx || !d_strips || !d_frame) return fail(RT_ERR_ARGUMENT, "rt_deinterleave_device: NULL argument");
+	if (width < 1 || height < 1 || row_block < 1 || world < 1)
+		return fail(RT_ERR_ARGUMENT, "rt_deinterleave_device: bad geometry");
+	HIP_TRY(hipSetDevice(ctx->device));
+	hipStream_t stream = hip_stream ? (hipStream_t) hip_stream : ctx->stream;
+	HIP_TRY(rt_launch_deinterleave((const float*) d_strips, (float*) d_frame, width, height, row_block, world,
+	                               rt_strip_rows(height, row_block, world), stream));
+	return RT_OK;
+}
+
+int rt_synchronize(rt_context *ctx)
+{
+	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_synchronize: NULL context");
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return RT_OK;
+}
+
+int rt_profile_enable(rt_context *ctx, int on)
+{
+	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_profile_enable: NULL context");
+	ctx->profiling = on != 0;
+	return RT_OK;
+}
+
+int rt_profile_collect(rt_context *ctx, double *kernel_ms_total, int *launches)
+{
+	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_profile_collect: NULL context");
+	HIP_TRY(hipSetDevice(ctx->device));
+	double total = 0;
+	int n = 0;
+	for (auto &p : ctx->events) {
+		HIP_TRY(hipEventSynchronize(p.second));
+		float ms = 0;
+		HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+		total += ms; n++;
+		ctx->event_pool.push_back(p.first); ctx->event_pool.push_back(p.second);
+	}
+	ctx->events.clear();
+	if (kernel_ms_total) *kernel_ms_total = total;
+	if (launches) *launches = n;
+	return RT_OK;
+}
+
+} /* extern "C" */

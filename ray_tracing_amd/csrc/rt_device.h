@@ -1,0 +1,65 @@
+/*
+ * rt_device.h -- device-side layouts shared by the host packer (rt_api.cpp) and the HIP kernels.
+ *
+ * The reference walks `Scene.objects[]` as 68-byte AoS records passed BY VALUE per test
+ * (scene.c:136,166).  Here every frame-constant term is folded on the host, once, with the
+ * reference's own roundings, and the scene is split into
+ *   - a 32-byte geometry record per object  -> staged in LDS, read as two wave-uniform b128 loads;
+ *   - a 64-byte shading record per object   -> staged in LDS, touched once per bounce.
+ */
+#ifndef RT_DEVICE_H
+#define RT_DEVICE_H
+
+#include <stdint.h>
+
+#define RT_GEOM_CUBE   0
+#define RT_GEOM_SPHERE 1
+
+/* 32 B.  cube: a = origin, b = origin*1 + size*1 (scene.c:27);  sphere: a = center, b0 = r*r (scene.c:112) */
+typedef struct {
+	float a[3];
+	float b0;
+	float b1, b2;
+	int   type;
+	int   pad;
+} rt_geom;
+
+/* 64 B.  All of main.c:212-249's per-material terms that do not depend on the ray. */
+typedef struct {
+	float f0[3];      /* combine(vec(0.16*r*r), albedo, 1-metallic, metallic)   main.c:219-221 */
+	float roughness;
+	float one_minus_f0[3]; /* combine(vec(1), f0, 1, -1)                        main.c:128     */
+	int   is_metal;   /* (double) metallic > 0.001                              main.c:241     */
+	float tint[3];    /* scalev(albedo, 1 - metallic)                           main.c:248     */
+	float pad0;
+	float emission[3];/* scalev(emission_color, emission_power)                 main.c:232,203 */
+	float pad1;
+} rt_shade;
+
+typedef struct {
+	/* camera.c:99-118, frame constants */
+	float pos[3], llc[3], horiz[3], vert[3];
+	/* first emitter (main.c:140-146) and its origin_of() (scene.c:10-15) */
+	int   light_index;
+	float light_pos[3];
+
+	int   num_objects;
+	int   width, height;       /* full frame                                   */
+	int   spp, max_bounces;
+	uint64_t seed;
+
+	/* interleaved row-block partition: local row r -> global row
+	 * ((r / row_block) * world + rank) * row_block + r % row_block          */
+	int   row_block, rank, world;
+	int   local_rows;          /* rows this launch renders (incl. none past `height`)        */
+
+	/* skybox: 6 faces of RGBA8 texels, face-major                            */
+	const uint32_t *sky;
+	int   sky_w, sky_h;
+
+	float *frame;              /* local_rows x width x 3 floats, resolved      */
+	const rt_geom  *geom;      /* num_objects records (global; staged to LDS)  */
+	const rt_shade *shade;
+} rt_launch;
+
+#endif

@@ -1,0 +1,13 @@
+/* rt_internal.h -- declarations shared between rt_api.cpp and rt_kernels.hip (not installed). */
+#ifndef RT_INTERNAL_H
+#define RT_INTERNAL_H
+
+#include <hip/hip_runtime_api.h>
+#include "rt_device.h"
+
+size_t     rt_scene_lds_bytes(int num_objects);
+hipError_t rt_launch_trace(const rt_launch &L, int variant, hipStream_t stream);
+hipError_t rt_launch_deinterleave(const float *strips, float *frame, int width, int height,
+                                  int row_block, int world, int rows_per_rank, hipStream_t stream);
+
+#endif

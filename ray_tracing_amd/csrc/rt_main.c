@@ -1,0 +1,121 @@
+/*
+ * rt_main.c -- headless host for librt_hip.so, shaped like the reference's main() (main.c:484-518):
+ * parse flags, load the scene and the six skybox faces, render, hand the frame to the presenter
+ * hook.  It keeps the reference's three flags (main.c:585-634) and adds the parameters the
+ * reference hard-codes:
+ *
+ *   --scene <file>       required, as in the reference
+ *   --threads <n>        accepted for command-line compatibility; the GPU replaces the worker threads
+ *   --init-scale <n>     accepted; the final image always accumulates full-resolution passes
+ *   --width/--height     frame size         (reference: window size, 1280x960, main.c:512)
+ *   --spp <n>            passes accumulated (reference: until the camera moves)
+ *   --bounces <n>        path length limit  (reference: 10, main.c:156)
+ *   --seed <n>           counter-mode seed
+ *   --skybox <dir>       directory with {right,left,top,bottom,front,back}.jpg (default assets/skybox)
+ *   --device <n>         GPU index
+ *   --out <file.ppm>     where the presenter hook writes the frame (default frame.ppm)
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "../../include/rt_hip.h"
+
+static const char *out_file = "frame.ppm";
+
+static void write_frame(int w, int h, Vector3 *data, void *user)
+{
+	(void) user;
+	int rc = rt_write_ppm(out_file, w, h, data);
+	if (rc != RT_OK) fprintf(stderr, "Could not write %s (%d)\n", out_file, rc);
+	else             fprintf(stderr, "Wrote %s (%dx%d)\n", out_file, w, h);
+}
+
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+}
+
+int main(int argc, char **argv)
+{
+	const char *scene_file = NULL, *sky_dir = "assets/skybox";
+	int width = 1280, height = 960, spp = 16, bounces = 10, device = 0;
+	unsigned long long seed = 0;
+
+	for (int i = 1; i < argc; i++) {
+		const char *a = argv[i];
+		const char *v = i + 1 < argc ? argv[i + 1] : NULL;
+#define NEED_VALUE() do { if (!v) { fprintf(stderr, "Error: Missing value after %s\n", a); return -1; } i++; } while (0)
+		if      (!strcmp(a, "--scene"))      { NEED_VALUE(); scene_file = v; }
+		else if (!strcmp(a, "--threads"))    { NEED_VALUE(); }
+		else if (!strcmp(a, "--init-scale")) { NEED_VALUE(); }
+		else if (!strcmp(a, "--width"))      { NEED_VALUE(); width = atoi(v); }
+		else if (!strcmp(a, "--height"))     { NEED_VALUE(); height = atoi(v); }
+		else if (!strcmp(a, "--spp"))        { NEED_VALUE(); spp = atoi(v); }
+		else if (!strcmp(a, "--bounces"))    { NEED_VALUE(); bounces = atoi(v); }
+		else if (!strcmp(a, "--seed"))       { NEED_VALUE(); seed = strtoull(v, NULL, 0); }
+		else if (!strcmp(a, "--skybox"))     { NEED_VALUE(); sky_dir = v; }
+		else if (!strcmp(a, "--device"))     { NEED_VALUE(); device = atoi(v); }
+		else if (!strcmp(a, "--out"))        { NEED_VALUE(); out_file = v; }
+		else fprintf(stderr, "Warning: Ignoring option %s\n", a);
+#undef NEED_VALUE
+	}
+	if (!scene_file) {
+		fprintf(stderr, "Error: Missing --scene <file>\n");
+		return -1;
+	}
+
+	static Scene scene;
+	if (rt_parse_scene_file(scene_file, &scene) != RT_OK) {
+		fprintf(stderr, "Couldn't parse scene\n");
+		return -1;
+	}
+	fprintf(stderr, "Scene parsed (%d objects)\n", scene.num_objects);
+
+	char paths[6][1024];
+	const char *files[6];
+	static const char *names[6] = { "front.jpg", "back.jpg", "left.jpg", "right.jpg", "top.jpg", "bottom.jpg" };
+	for (int f = 0; f < 6; f++) {
+		snprintf(paths[f], sizeof(paths[f]), "%s/%s", sky_dir, names[f]);
+		files[f] = paths[f];
+	}
+	Cubemap skybox;
+	if (rt_load_cubemap(&skybox, files) != RT_OK)
+		return -1;
+	fprintf(stderr, "Cubemap loaded (%dx%dx%d)\n", skybox.w, skybox.h, skybox.chan);
+
+	rt_context *ctx = NULL;
+	if (rt_create(&ctx, device) != RT_OK || rt_set_scene(ctx, &scene) != RT_OK || rt_set_skybox(ctx, &skybox) != RT_OK) {
+		fprintf(stderr, "Error: %s\n", rt_last_error());
+		return -1;
+	}
+	rt_camera cam;
+	rt_camera_default(&cam);
+	rt_set_camera(ctx, &cam);
+
+	Vector3 *frame = malloc(sizeof(Vector3) * (size_t) width * height);
+	if (!frame) { printf("OUT OF MEMORY\n"); return -1; }
+
+	rt_render_params p;
+	rt_default_params(&p, width, height, spp, bounces);
+	p.seed = seed;
+	double t0 = now_s();
+	if (rt_render(ctx, &p, frame) != RT_OK) {
+		fprintf(stderr, "Error: %s\n", rt_last_error());
+		return -1;
+	}
+	double dt = now_s() - t0;
+	fprintf(stderr, "Rendered %dx%d, %d spp, %d bounces in %.3f s (%.1f Msamples/s incl. copy-back)\n",
+	        width, height, spp, bounces, dt, (double) width * height * spp / dt / 1e6);
+
+	rt_set_frame_sink(write_frame, NULL);
+	rt_move_frame_to_the_gpu(width, height, frame);   /* where update_frame() hands off, main.c:479 */
+
+	free(frame);
+	rt_free_cubemap(&skybox);
+	rt_destroy(ctx);
+	return 0;
+}
