@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Msamples/s on BASELINE.json config C1
+(scene_0.txt, 1920x1080, 64 spp, 4 bounces) on N GPUs of one node.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one full frame through the hot path: every rank renders its interleaved row blocks with the
+HIP kernel (librt_hip.so, C ABI), then -- for N > 1 -- ONE RCCL gather of the finished strips to rank
+0 and a de-interleave kernel there.  Inputs (scene, skybox, camera) are resident in HBM before the
+timed region; the frame stays in HBM (the PCIe-inclusive rate is reported in DESIGN.md, not here).
+The same frame is split over N GPUs, so scaling is "strong".
+
+Rank 0 prints ONE JSON line; `roofline` is computed from HIP-event kernel times measured over the
+timed region and from ALGORITHMIC flops/bytes counted by the CPU oracle's instrumented build;
+`cpu_baseline` times the reference's own column-threaded renderer (oracle/_ref, the unmodified
+reference sources) -- or the oracle port if that build is absent -- on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import ray_tracing_amd as rt  # noqa: E402
+
+# BASELINE.json configs[1]
+WORKLOAD = dict(name="C1", scene="scene_0.txt", width=1920, height=1080, spp=64, max_bounces=4, seed=0)
+ROW_BLOCK = 8
+
+# MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 vector counts an FMA as 2 flops at 64 flop/clk/SIMD.  The
+# parity rules forbid FMA contraction, so the applicable issue peak is one flop per lane per issue:
+PEAK_VALU_NOFMA_TFLOPS = 157.3 / 2
+PEAK_HBM_GBPS = 8000.0
+
+
+def algorithmic_work(oracle_count, W, H, max_bounces, seed):
+    """Per-sample algorithmic flops (reference operations as written, SURVEY.md 8d cost table) and
+    bytes, counted by the instrumented oracle over the whole frame at 1 spp."""
+    oracle_count.counters_reset()
+    oracle_count.render_counter(W, H, 1, max_bounces, seed=seed)
+    c = oracle_count.counters()
+    n = max(c["samples"], 1)
+    return {k: c[k] / n for k in ("flops", "rays", "object_tests", "rng_draws", "sky_fetches")}
+
+
+def cpu_baseline(w, sky):
+    """Reference CPU path on this box: render_column() on one thread per column (main.c:333,363,377),
+    bounce limit patched to the workload's.  Bounded to ~10-25 s."""
+    from rtlibs import Oracle, Ref, ref_available
+    W, H, nb = w["width"], w["height"], w["max_bounces"]
+    cores = min(os.cpu_count() or 1, 32)          # MAX_COLUMNS = 32 (main.c:46)
+    while W % cores and cores > 1:                # the reference never renders W % columns pixels
+        cores -= 1
+    scene_path = os.path.join(rt.DATA_DIR, w["scene"])
+    if ref_available():
+        ref = Ref(bounce_patch=True)
+        ref.load_scene(scene_path); ref.set_skybox(sky); ref.set_bounce_limit(nb)
+        run = lambda passes: ref.time_columns(W, H, passes, cores)   # noqa: E731
+        kind = "reference"
+    else:
+        o = Oracle()
+        o.load_scene(scene_path); o.set_skybox(sky)
+        run = lambda passes: o.time_columns(W, H, passes, nb, cores)  # noqa: E731
+        kind = "port"
+    t = time.perf_counter(); run(1); one = time.perf_counter() - t
+    passes = int(max(1, min(64, 12.0 / max(one, 1e-3))))
+    t = time.perf_counter(); run(passes); dt = time.perf_counter() - t
+    return {"value": round(W * H * passes / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": kind,
+            "sample": f"{passes} full passes of {w['scene']} {W}x{H} at {nb} bounces = {W * H * passes / 1e6:.1f} Msamples, "
+                      f"static column split over {cores} threads as the reference does, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--kernel", type=int, default=rt.KERNEL_AUTO)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    w = WORKLOAD
+    W, H, spp, nb, seed = w["width"], w["height"], w["spp"], w["max_bounces"], w["seed"]
+    sky = rt.load_skybox()
+    gpu = rt.Renderer(local_rank)
+    gpu.set_scene(os.path.join(rt.DATA_DIR, w["scene"]))
+    gpu.set_skybox(sky)
+    gpu.set_camera()
+
+    rows = rt.strip_rows(H, ROW_BLOCK, world)
+    strip = torch.empty((rows, W, 3), dtype=torch.float32, device=dev)
+    params = gpu.params(W, H, spp, nb, seed=seed, row_block=ROW_BLOCK, rank=rank, world=world, kernel=args.kernel)
+    if world > 1 and rank == 0:
+        strips = torch.empty((world, rows, W, 3), dtype=torch.float32, device=dev)
+        gather_list = list(strips.unbind(0))
+        frame = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    else:
+        strips, gather_list, frame = None, None, strip     # 1 GPU: the strip is the frame
+
+    def step():
+        stream = torch.cuda.current_stream().cuda_stream
+        gpu.render_device(params, strip.data_ptr(), stream)
+        if world > 1:
+            dist.gather(strip, gather_list, dst=0)
+            if rank == 0:
+                gpu.deinterleave_device(strips.data_ptr(), frame.data_ptr(), W, H, ROW_BLOCK, world,
+                                        torch.cuda.current_stream().cuda_stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    gpu.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = gpu.profile_collect()
+    gpu.profile(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        samples_per_step = W * H * spp
+        value = samples_per_step * args.steps / elapsed / 1e6
+        out = {
+            "metric": "Msamples/s (rays/s) at 1920x1080x64spp scene_0; 1/2/4/8 GPU",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{w['name']}: {w['scene']} {W}x{H}, {spp} spp, {nb} bounces, default camera, "
+                                   f"counter-mode RNG seed {seed}, shipped skybox (6x2048x2048)",
+                       "partition": f"interleaved blocks of {ROW_BLOCK} rows over {world} GPU(s)"
+                                    + ("; one RCCL gather of the strips + de-interleave on rank 0" if world > 1 else ""),
+                       "kernel": {0: "auto", 1: "simple", 2: "wavefront"}.get(args.kernel, str(args.kernel))},
+        }
+        # ---- roofline of the dominant kernel (rank 0's launches; every rank runs the same kernel on 1/N of the rows)
+        from rtlibs import Oracle
+        try:
+            oc = Oracle(counters=True)
+            oc.load_scene(os.path.join(rt.DATA_DIR, w["scene"])); oc.set_skybox(sky); oc.set_camera()
+            work = algorithmic_work(oc, W, H, nb, seed)
+        except Exception as e:   # the oracle is a checker; the bench line must still print
+            work = None
+            out["roofline_error"] = repr(e)
+        if work and launches:
+            avg_ms = kernel_ms / launches
+            samples_per_launch = samples_per_step / world
+            flops = work["flops"] * samples_per_launch
+            # algorithmic bytes: 3 B per skybox fetch + 12 B per pixel written once per launch
+            bytes_ = 3.0 * work["sky_fetches"] * samples_per_launch + 12.0 * (samples_per_launch / spp)
+            achieved = flops / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "valu", "achieved": round(achieved, 3), "peak": round(PEAK_VALU_NOFMA_TFLOPS, 2),
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_VALU_NOFMA_TFLOPS, 4), "traffic": None,
+                "kernel": "rt_trace", "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
+                "flops_per_sample": round(work["flops"], 1), "rays_per_sample": round(work["rays"], 3),
+                "object_tests_per_sample": round(work["object_tests"], 2),
+                "rng_draws_per_sample": round(work["rng_draws"], 2),
+                "hbm": {"achieved": round(bytes_ / (avg_ms * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": round(bytes_ / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 6),
+                        "bytes_per_sample": round(bytes_ / samples_per_launch, 3)},
+                "note": "no MFMA/HBM bound applies (SURVEY.md 8d): peak = fp32 VALU issue rate without FMA "
+                        "(parity forbids contraction) = 157.3/2 TFLOP/s; flops counted as written in the reference",
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(w, sky)
+                out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+            except Exception as e:
+                out["cpu_baseline_error"] = repr(e)
+        print(json.dumps(out), flush=True)
+
+    gpu.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
