@@ -110,24 +110,10 @@ def main():
     gpu.set_skybox(sky)
     gpu.set_camera()
 
-    rows = rt.strip_rows(H, ROW_BLOCK, world)
-    strip = torch.empty((rows, W, 3), dtype=torch.float32, device=dev)
-    params = gpu.params(W, H, spp, nb, seed=seed, row_block=ROW_BLOCK, rank=rank, world=world, kernel=args.kernel)
-    if world > 1 and rank == 0:
-        strips = torch.empty((world, rows, W, 3), dtype=torch.float32, device=dev)
-        gather_list = list(strips.unbind(0))
-        frame = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
-    else:
-        strips, gather_list, frame = None, None, strip     # 1 GPU: the strip is the frame
-
-    def step():
-        stream = torch.cuda.current_stream().cuda_stream
-        gpu.render_device(params, strip.data_ptr(), stream)
-        if world > 1:
-            dist.gather(strip, gather_list, dst=0)
-            if rank == 0:
-                gpu.deinterleave_device(strips.data_ptr(), frame.data_ptr(), W, H, ROW_BLOCK, world,
-                                        torch.cuda.current_stream().cuda_stream)
+    from ray_tracing_amd.multi_gpu import TiledFrame
+    tiled = TiledFrame(gpu, W, H, spp, nb, seed=seed, row_block=ROW_BLOCK, rank=rank, world=world,
+                       kernel=args.kernel, device=dev)
+    step = tiled.step
 
     def fence():
         torch.cuda.synchronize()

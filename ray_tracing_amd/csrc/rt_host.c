@@ -41,8 +41,9 @@ static void eat_blanks(Reader *r)
 
 static char peek(const Reader *r) { return r->at < r->len ? r->text[r->at] : '\0'; }
 
-/* The reference matches a keyword only if strictly more than `need` characters remain
- * (`5 < len - i` for "sphere", scene.c:224): the keyword must not be the last bytes of the file. */
+/* The reference matches a keyword only if strictly more than `need` characters remain: `need` is
+ * the keyword length minus one (`5 < len - i` for "sphere", scene.c:224) except for "albedo", whose
+ * guard is its full length (`6 < len - i`, scene.c:271), so "albedo" cannot be the file's last bytes. */
 static int keyword(const Reader *r, const char *kw, size_t need)
 {
 	if (r->at > r->len) return 0;
