@@ -63,6 +63,9 @@ struct rt_context {
 	rt_camera    camera;
 	bool         have_camera = false;
 
+	unsigned int *d_counter = nullptr;   /* pixel-block counter of the persistent kernel */
+	int          num_cus = 256;
+
 	float       *d_frame = nullptr;      /* scratch for rt_render() */
 	size_t       frame_bytes = 0;
 
@@ -97,6 +100,13 @@ int rt_create(rt_context **out, int device_id)
 	ctx->device = device_id;
 	hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 	if (e != hipSuccess) { delete ctx; return fail(RT_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
+	{
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+			ctx->num_cus = prop.multiProcessorCount;
+		e = hipMalloc((void**) &ctx->d_counter, 64);
+		if (e != hipSuccess) { (void) hipStreamDestroy(ctx->stream); delete ctx; return fail(RT_ERR_DEVICE, "hipMalloc: %s", hipGetErrorString(e)); }
+	}
 	rt_camera_default(&ctx->camera);
 	ctx->have_camera = true;     /* the reference starts from its default pose too (camera.c:33-35) */
 	*out = ctx;
@@ -111,7 +121,7 @@ void rt_destroy(rt_context *ctx)
 	for (auto &p : ctx->events) { (void) hipEventDestroy(p.first); (void) hipEventDestroy(p.second); }
 	for (auto &e : ctx->event_pool) (void) hipEventDestroy(e);
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
-	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame);
+	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame); (void) hipFree(ctx->d_counter);
 	(void) hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -298,12 +308,12 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	L.frame = (float*) d_strip;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
 
-	if (rt_scene_lds_bytes(L.num_objects) > 160 * 1024)
-		return fail(RT_ERR_ARGUMENT, "render: scene needs %zu B of LDS (> 160 KiB)", rt_scene_lds_bytes(L.num_objects));
+	if (rt_wavefront_lds_bytes(L.num_objects) > 160 * 1024)
+		return fail(RT_ERR_ARGUMENT, "render: scene needs %zu B of LDS (> 160 KiB)", rt_wavefront_lds_bytes(L.num_objects));
 
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (ctx->profiling) { e0 = take_event(ctx); e1 = take_event(ctx); HIP_TRY(hipEventRecord(e0, stream)); }
-	HIP_TRY(rt_launch_trace(L, p->kernel, stream));
+	HIP_TRY(rt_launch_trace(L, p->kernel, ctx->d_counter, ctx->num_cus, stream));
 	if (ctx->profiling) { HIP_TRY(hipEventRecord(e1, stream)); ctx->events.emplace_back(e0, e1); }
 	return RT_OK;
 }

@@ -277,6 +277,299 @@ rt_trace_simple(const rt_launch L)
 	dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
 }
 
+/* =============================================================================================
+ * rt_trace_wavefront: the tuned kernel.  Same arithmetic as rt_trace_simple, different schedule.
+ *
+ * Profile of the simple kernel on C1 (profiles/r01): VALU-issue bound with only ~34 % of lanes
+ * active -- paths of one wave end at different bounces and half of the soft-shadow taps are skipped
+ * per lane (main.c:194), so most trace_ray() instructions run on half-empty waves.  Here every
+ * wave is a small wavefront path tracer of its own:
+ *
+ *   - persistent waves pull 8x8 pixel blocks from a global counter; inside a wave a lane that
+ *     finishes a pixel takes the next one of the wave's current block (ballot + mbcnt prefix),
+ *     so a lane never waits for its neighbours' pixels;
+ *   - a path lives in its lane's registers, but the RAYS it needs traced (next bounce ray +
+ *     up to three shadow taps, all known right after shading because the taps only feed the
+ *     light term that is added afterwards, main.c:257-261) are compacted into a per-wave LDS
+ *     queue with ballot/mbcnt prefix sums and traced in full batches of 64 by whichever lane
+ *     gets them -- trace_ray() runs on (nearly) full waves;
+ *   - the primary hit is traced once per pixel and re-used by all samples (the reference has no
+ *     sub-pixel jitter, main.c:293-296, so bounce 0 of every sample is the same ray): bit-exact;
+ *   - sky-only pixels cost one ray in total.
+ * The per-pixel sample sum is still formed in sample order (main.c:394), so results are
+ * bit-identical to rt_trace_simple and to the CPU oracle.
+ * ============================================================================================= */
+
+#define WF_QUEUE   256                 /* rays per wave per round: 64 lanes x (1 bounce ray + 3 taps) */
+#define WF_KIND_MAIN 0                 /* kinds 1..3 = shadow tap k-1 */
+
+struct WaveLDS {
+	float q[7][WF_QUEUE];              /* ray queue SoA: o.xyz, d.xyz (un-normalised), meta         */
+	float res[7][64];                  /* bounce/primary result per owner lane: xyz, nxyz, obj      */
+	int   tap[3][64];                  /* shadow tap results per owner lane: object index or -1     */
+	float cache[10][64];               /* per-lane primary hit: point, normal, obj, primary dir     */
+};
+
+RT_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+extern "C" __global__ void __launch_bounds__(RT_BLOCK)
+rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
+{
+	extern __shared__ float4 lds[];
+	const int n = L.num_objects;
+	const SceneLDS sc = stage_scene(L, lds);
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + 6 * n)[wave];
+
+	const int tiles_x = (L.width + 7) >> 3;
+	const int tiles_y = (L.local_rows + 7) >> 3;
+	const unsigned int num_blocks = (unsigned int) (tiles_x * tiles_y);
+	const V3 cam = ld3(L.pos);
+	const V3 light_pos = ld3(L.light_pos);
+	const bool have_light = L.light_index >= 0;
+	const float inv_spp = 1.0f / (float) L.spp;
+
+	/* wave-uniform pixel supply */
+	unsigned int cur_block = 0xffffffffu;   /* block being handed out */
+	int cur_next = 64;                      /* next pixel of cur_block to hand out (64 = none left) */
+	bool exhausted = false;
+
+	/* per-lane path state */
+	int   px_i = 0, px_lr = -1;             /* px_lr < 0: lane has no pixel */
+	uint32_t pixel_index = 0;
+	int   sample = 0, bounce = 0;
+	bool  has_hit = false;
+	V3    sum = mk3(0, 0, 0), carry = mk3(1, 1, 1), rad = mk3(0, 0, 0);
+	V3    hp = mk3(0, 0, 0), hn = mk3(0, 0, 0), hdir = mk3(0, 0, 0);
+	int   hobj = -1;
+	uint64_t rng = 0;
+
+	for (;;) {
+		/* ---- 1. hand pixels to idle lanes ----------------------------------------------- */
+		bool want = px_lr < 0;
+		bool primary = false;
+		V3 prim_dir = mk3(0, 0, 0);
+		for (int attempt = 0; attempt < 2; attempt++) {
+			const unsigned long long wmask = __ballot(want);
+			if (wmask == 0ull) break;
+			if (cur_next >= 64) {
+				if (exhausted) break;
+				unsigned int b = 0;
+				if (lane == 0) b = atomicAdd(block_counter, 1u);
+				b = (unsigned int) __builtin_amdgcn_readfirstlane((int) b);
+				if (b >= num_blocks) { exhausted = true; break; }
+				cur_block = b; cur_next = 0;
+			}
+			const int rank_in = __builtin_amdgcn_mbcnt_hi((unsigned int) (wmask >> 32),
+			                    __builtin_amdgcn_mbcnt_lo((unsigned int) wmask, 0u));
+			const int avail = 64 - cur_next;
+			if (want && rank_in < avail) {
+				const int q = cur_next + rank_in;
+				const int i = (int) (cur_block % (unsigned int) tiles_x) * 8 + (q & 7);
+				const int lr = (int) (cur_block / (unsigned int) tiles_x) * 8 + (q >> 3);
+				want = false;
+				const int j = global_row(L, lr);
+				if (i < L.width && lr < L.local_rows && j < L.height) {
+					px_i = i; px_lr = lr;
+					pixel_index = (uint32_t) (j * L.width + i);
+					float u = (float) i / (float) (L.width - 1);       /* main.c:293-296 */
+					float v = (float) j / (float) (L.height - 1);
+					u = 1.0f - u;
+					v = 1.0f - v;
+					prim_dir = primary_dir(L, u, v);
+					primary = true;
+				}
+			}
+			const int taken = __popcll(wmask);
+			cur_next += taken < avail ? taken : avail;
+		}
+		if (__ballot(px_lr >= 0) == 0ull) {
+			if (exhausted) break;
+			continue;                      /* e.g. a block of out-of-frame pixels: fetch again */
+		}
+
+		/* ---- 2. shade the pending hit of every live path (main.c:180-261) ------------------- */
+		int  tapmask = 0;
+		bool emit_main = primary;
+		V3   ray_o = cam, ray_d = prim_dir;
+		V3   tap_d0 = mk3(0, 0, 0), tap_d1 = mk3(0, 0, 0), tap_d2 = mk3(0, 0, 0);
+		if (has_hit) {
+			if (have_light) {
+				const V3 to_light = sub3(light_pos, hp);
+				{ const V3 jit = rng_direction(rng);
+				  if (dot3(jit, hn) > 0) { tap_d0 = unit3(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 1; } }
+				{ const V3 jit = rng_direction(rng);
+				  if (dot3(jit, hn) > 0) { tap_d1 = unit3(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 2; } }
+				{ const V3 jit = rng_direction(rng);
+				  if (dot3(jit, hn) > 0) { tap_d2 = unit3(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 4; } }
+			}
+			const float4 m0 = sc.shade[4 * hobj], m1 = sc.shade[4 * hobj + 1];
+			const float4 m2 = sc.shade[4 * hobj + 2], m3 = sc.shade[4 * hobj + 3];
+			const V3 f0 = mk3(m0.x, m0.y, m0.z), omf0 = mk3(m1.x, m1.y, m1.z);
+
+			const float n_dot_v = clamp01(dot3(hn, neg3(hdir)));
+			const double xg = 1.0 - (double) n_dot_v;
+			const double xg2 = xg * xg;
+			const float grazing = (float) (xg2 * xg2 * xg);
+			const V3 fresnel = madd3(f0, omf0, grazing);
+
+			V3 scatter = rng_direction(rng);
+			if (dot3(scatter, hn) < 0) scatter = neg3(scatter);
+
+			rad = add3(rad, had3(mk3(m3.x, m3.y, m3.z), carry));
+
+			bool specular = __float_as_int(m1.w) != 0;
+			if (!specular)
+				specular = rng_draw(rng) <= (fresnel.x + fresnel.y + fresnel.z) / 3.0f;
+			V3 out_dir;
+			if (specular) {
+				const V3 nneg = neg3(hn);
+				const float f = -2.0f * dot3(nneg, hdir);
+				out_dir = unit3(lin2(scatter, madd3(hdir, nneg, f), m0.w, 1.0f));
+			} else {
+				out_dir = scatter;
+				carry = had3(carry, mk3(m2.x, m2.y, m2.z));
+			}
+			bounce++;
+			emit_main = bounce < L.max_bounces;
+			ray_o = madd3(hp, out_dir, 0.001f);
+			ray_d = out_dir;
+			hdir = out_dir;
+			has_hit = false;
+		}
+
+		/* ---- 3. compact this round's rays into the wave queue (ballot + mbcnt prefix) -------- */
+		int total = 0;
+		{
+			const unsigned long long m = __ballot(emit_main);
+			if (emit_main) {
+				const int slot = total + (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32),
+				                 __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u));
+				W.q[0][slot] = ray_o.x; W.q[1][slot] = ray_o.y; W.q[2][slot] = ray_o.z;
+				W.q[3][slot] = ray_d.x; W.q[4][slot] = ray_d.y; W.q[5][slot] = ray_d.z;
+				W.q[6][slot] = __int_as_float(lane | (WF_KIND_MAIN << 8));
+			}
+			total += __popcll(m);
+		}
+#define WF_PUSH_TAP(K, DIR)                                                                          \
+		{                                                                                            \
+			const bool on = (tapmask >> (K)) & 1;                                                    \
+			const unsigned long long m = __ballot(on);                                               \
+			if (on) {                                                                                \
+				const int slot = total + (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32),   \
+				                 __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u));                   \
+				const V3 so = madd3(hp, DIR, 0.001f);                   /* main.c:198 */             \
+				W.q[0][slot] = so.x; W.q[1][slot] = so.y; W.q[2][slot] = so.z;                       \
+				W.q[3][slot] = DIR.x; W.q[4][slot] = DIR.y; W.q[5][slot] = DIR.z;                    \
+				W.q[6][slot] = __int_as_float(lane | (((K) + 1) << 8));                              \
+			}                                                                                        \
+			total += __popcll(m);                                                                    \
+		}
+		WF_PUSH_TAP(0, tap_d0)
+		WF_PUSH_TAP(1, tap_d1)
+		WF_PUSH_TAP(2, tap_d2)
+#undef WF_PUSH_TAP
+		wave_fence();
+
+		/* ---- 4. trace the queue in batches of 64 (scene.c:156-190 on full waves) ------------- */
+		for (int base = 0; base < total; base += 64) {
+			const int slot = base + lane;
+			if (slot < total) {
+				const V3 o = mk3(W.q[0][slot], W.q[1][slot], W.q[2][slot]);
+				const V3 dn = unit3(mk3(W.q[3][slot], W.q[4][slot], W.q[5][slot]));   /* scene.c:158 */
+				const int meta = __float_as_int(W.q[6][slot]);
+				const int owner = meta & 255, kind = meta >> 8;
+				const Hit hit = nearest_hit(sc, n, o, dn);
+				if (kind != WF_KIND_MAIN) {
+					W.tap[kind - 1][owner] = hit.obj;
+				} else {
+					V3 a, b = hit.n;
+					if (hit.obj >= 0) a = madd3(o, dn, hit.t);                       /* scene.c:186 */
+					else              a = sky_lookup(L, dn);                         /* main.c:170  */
+					W.res[0][owner] = a.x; W.res[1][owner] = a.y; W.res[2][owner] = a.z;
+					W.res[3][owner] = b.x; W.res[4][owner] = b.y; W.res[5][owner] = b.z;
+					W.res[6][owner] = __int_as_float(hit.obj);
+				}
+			}
+		}
+		wave_fence();
+
+		/* ---- 5. consume results ------------------------------------------------------------- */
+		if (px_lr >= 0) {
+			bool sample_done = false, pixel_done = false;
+			if (primary) {
+				const int obj = __float_as_int(W.res[6][lane]);
+				const V3 a = mk3(W.res[0][lane], W.res[1][lane], W.res[2][lane]);
+				if (obj < 0) {
+					/* sky-only pixel: every sample is clamp(0 + sky * 1) (main.c:171,267-269) */
+					const V3 c = mk3(clamp01(a.x), clamp01(a.y), clamp01(a.z));
+					for (int s = 0; s < L.spp; s++) sum = add3(sum, c);
+					pixel_done = true;
+				} else {
+					W.cache[0][lane] = a.x; W.cache[1][lane] = a.y; W.cache[2][lane] = a.z;
+					W.cache[3][lane] = W.res[3][lane]; W.cache[4][lane] = W.res[4][lane]; W.cache[5][lane] = W.res[5][lane];
+					W.cache[6][lane] = __int_as_float(obj);
+					W.cache[7][lane] = prim_dir.x; W.cache[8][lane] = prim_dir.y; W.cache[9][lane] = prim_dir.z;
+					sample = -1;
+					sample_done = true;            /* falls into "start next sample" with sample 0 */
+				}
+			} else {
+				if (tapmask) {
+					V3 lit = mk3(0, 0, 0);
+					int taps = 0;
+#pragma unroll
+					for (int k = 0; k < 3; k++)
+						if ((tapmask >> k) & 1) {
+							const int obj = W.tap[k][lane];
+							if (obj >= 0) { const float4 e = sc.shade[4 * obj + 3]; lit = add3(lit, mk3(e.x, e.y, e.z)); }
+							taps++;
+						}
+					lit = scale3(lit, 1.0f / (float) taps);                          /* main.c:208-209 */
+					if (!(tiny_f(lit.x) && tiny_f(lit.y) && tiny_f(lit.z))) {        /* main.c:257-261 */
+						const float w = 0.05f;
+						rad = madd3(rad, had3(lit, carry), w);
+						carry = scale3(carry, 1.0f - w);
+					}
+				}
+				if (emit_main) {
+					const int obj = __float_as_int(W.res[6][lane]);
+					const V3 a = mk3(W.res[0][lane], W.res[1][lane], W.res[2][lane]);
+					if (obj < 0) {
+						rad = add3(rad, had3(a, carry));                             /* main.c:171 */
+						sample_done = true;
+					} else {
+						hp = a; hn = mk3(W.res[3][lane], W.res[4][lane], W.res[5][lane]); hobj = obj;
+						has_hit = true;
+					}
+				} else
+					sample_done = true;            /* bounce limit (main.c:158) */
+				if (sample_done)
+					sum = add3(sum, mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z)));   /* main.c:267-269,394 */
+			}
+			if (sample_done && !pixel_done) {
+				sample++;
+				if (sample < L.spp) {
+					rng = path_seed(L.seed, pixel_index, (uint32_t) sample);
+					carry = mk3(1, 1, 1); rad = mk3(0, 0, 0); bounce = 0;
+					hp = mk3(W.cache[0][lane], W.cache[1][lane], W.cache[2][lane]);
+					hn = mk3(W.cache[3][lane], W.cache[4][lane], W.cache[5][lane]);
+					hobj = __float_as_int(W.cache[6][lane]);
+					hdir = mk3(W.cache[7][lane], W.cache[8][lane], W.cache[9][lane]);
+					has_hit = true;
+				} else
+					pixel_done = true;
+			}
+			if (pixel_done) {
+				const V3 res = scale3(sum, inv_spp);                                 /* main.c:476 */
+				float *dst = L.frame + ((size_t) px_lr * L.width + px_i) * 3;
+				dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+				px_lr = -1; sum = mk3(0, 0, 0); has_hit = false;
+			}
+		}
+		wave_fence();
+	}
+}
+
 /* ---- de-interleave: gathered per-rank strips -> full frame (multi-GPU root) ------------------- */
 extern "C" __global__ void __launch_bounds__(RT_BLOCK)
 rt_deinterleave(const float *strips, float *frame, int width, int height, int row_block, int world, int rows_per_rank)
@@ -296,14 +589,31 @@ rt_deinterleave(const float *strips, float *frame, int width, int height, int ro
 
 size_t rt_scene_lds_bytes(int num_objects) { return (size_t) num_objects * (sizeof(rt_geom) + sizeof(rt_shade)); }
 
-hipError_t rt_launch_trace(const rt_launch &L, int variant, hipStream_t stream)
+size_t rt_wavefront_lds_bytes(int num_objects) { return rt_scene_lds_bytes(num_objects) + (RT_BLOCK / 64) * sizeof(WaveLDS); }
+
+hipError_t rt_launch_trace(const rt_launch &L, int variant, unsigned int *block_counter, int num_cus, hipStream_t stream)
 {
 	if (L.local_rows <= 0 || L.width <= 0) return hipSuccess;
-	const int tiles_x = (L.width + RT_TILE_W - 1) / RT_TILE_W;
-	const int tiles_y = (L.local_rows + RT_TILE_H - 1) / RT_TILE_H;
-	const size_t lds = rt_scene_lds_bytes(L.num_objects);
-	(void) variant;
-	hipLaunchKernelGGL(rt_trace_simple, dim3(tiles_x * tiles_y), dim3(RT_BLOCK), lds, stream, L);
+	const bool simple = variant == 1 /* RT_KERNEL_SIMPLE */ || L.max_bounces < 1;
+	if (simple) {
+		const int tiles_x = (L.width + RT_TILE_W - 1) / RT_TILE_W;
+		const int tiles_y = (L.local_rows + RT_TILE_H - 1) / RT_TILE_H;
+		hipLaunchKernelGGL(rt_trace_simple, dim3(tiles_x * tiles_y), dim3(RT_BLOCK), rt_scene_lds_bytes(L.num_objects), stream, L);
+		return hipGetLastError();
+	}
+	/* persistent waves: as many workgroups as fit on the chip at once, capped by the work */
+	const size_t lds = rt_wavefront_lds_bytes(L.num_objects);
+	int per_cu = (int) ((160u * 1024u) / lds);
+	if (per_cu < 1) per_cu = 1;
+	if (per_cu > 4) per_cu = 4;
+	const long long blocks = (long long) ((L.width + 7) / 8) * ((L.local_rows + 7) / 8);
+	long long grid = (long long) num_cus * per_cu;
+	const long long useful = (blocks + (RT_BLOCK / 64) - 1) / (RT_BLOCK / 64);
+	if (grid > useful) grid = useful;
+	if (grid < 1) grid = 1;
+	hipError_t e = hipMemsetAsync(block_counter, 0, sizeof(unsigned int), stream);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(rt_trace_wavefront, dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, L, block_counter);
 	return hipGetLastError();
 }
 
