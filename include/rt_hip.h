@@ -108,6 +108,12 @@ RT_API int rt_synchronize(rt_context *ctx);
 RT_API int rt_profile_enable(rt_context *ctx, int on);
 RT_API int rt_profile_collect(rt_context *ctx, double *kernel_ms_total, int *launches);
 
+/* On-GPU self-test of the exact-arithmetic shortcuts the tuned kernel uses (shared-reciprocal
+ * division, vector normalisation): compares them bit-for-bit with the plain IEEE forms on
+ * blocks*256*iters random operand sets.  which = 0 (f32 divide), 1 (f64 divide), 2 (normalize).
+ * out[0] = mismatches (must be 0); out[1..7] = operands of one mismatch, for diagnosis. */
+RT_API int rt_selftest(rt_context *ctx, int which, uint64_t seed, int blocks, int iters, unsigned long long out[8]);
+
 /* ---- host-side mirror of the reference's loaders / camera (plain C, no GPU needed) ---------- */
 /* scene.c:611 parse_scene_file(): same grammar, defaults, range checks, float accumulation and
  * stderr diagnostics.  Returns RT_OK / RT_ERR_IO / RT_ERR_FORMAT. */

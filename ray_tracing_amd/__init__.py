@@ -56,7 +56,7 @@ class MouseState(C.Structure):
 EXPORTS = [
     "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
     "rt_set_camera", "rt_render", "rt_render_device", "rt_strip_rows", "rt_deinterleave_device",
-    "rt_synchronize", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
+    "rt_synchronize", "rt_selftest", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
     "rt_parse_scene_string", "rt_load_cubemap", "rt_free_cubemap", "rt_decode_jpeg_file",
     "rt_camera_default", "rt_camera_basis_for", "rt_mouse_state_default", "rt_move_camera",
     "rt_rotate_camera", "rt_path_seed", "rt_set_frame_sink", "rt_move_frame_to_the_gpu", "rt_write_ppm",
@@ -94,6 +94,7 @@ def lib():
     L.rt_strip_rows.argtypes = [C.c_int, C.c_int, C.c_int]
     L.rt_deinterleave_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
     L.rt_synchronize.argtypes = [C.c_void_p]
+    L.rt_selftest.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
     L.rt_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.rt_profile_collect.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.rt_parse_scene_file.argtypes = [C.c_char_p, C.c_void_p]
@@ -253,6 +254,11 @@ class Renderer:
         _check(lib().rt_deinterleave_device(self._ctx, C.c_void_p(strips_ptr), C.c_void_p(frame_ptr), width, height,
                                             row_block, world, C.c_void_p(stream) if stream else None),
                "rt_deinterleave_device")
+
+    def selftest(self, which, seed=1, blocks=4096, iters=256):
+        out = (C.c_ulonglong * 8)()
+        _check(lib().rt_selftest(self._ctx, which, seed, blocks, iters, out), "rt_selftest")
+        return list(out)
 
     def synchronize(self):
         _check(lib().rt_synchronize(self._ctx), "rt_synchronize")

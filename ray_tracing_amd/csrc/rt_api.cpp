@@ -353,6 +353,22 @@ int rt_deinterleave_device(rt_context *ctx, const void *d_strips, void *d_frame,
 	return RT_OK;
 }
 
+int rt_selftest(rt_context *ctx, int which, uint64_t seed, int blocks, int iters, unsigned long long out[8])
+{
+	if (!ctx || !out || which < 0 || which > 2 || blocks < 1 || iters < 1)
+		return fail(RT_ERR_ARGUMENT, "rt_selftest: bad argument");
+	HIP_TRY(hipSetDevice(ctx->device));
+	unsigned long long *d = nullptr;
+	HIP_TRY(hipMalloc((void**) &d, 8 * sizeof(unsigned long long)));
+	hipError_t e = hipMemsetAsync(d, 0, 8 * sizeof(unsigned long long), ctx->stream);
+	if (e == hipSuccess) e = rt_launch_selftest(which, seed, blocks, iters, d, ctx->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(out, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	(void) hipFree(d);
+	if (e != hipSuccess) return fail(RT_ERR_DEVICE, "rt_selftest: %s", hipGetErrorString(e));
+	return RT_OK;
+}
+
 int rt_synchronize(rt_context *ctx)
 {
 	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_synchronize: NULL context");

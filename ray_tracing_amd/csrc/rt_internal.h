@@ -11,4 +11,6 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, unsigned int *block_
 hipError_t rt_launch_deinterleave(const float *strips, float *frame, int width, int height,
                                   int row_block, int world, int rows_per_rank, hipStream_t stream);
 
+hipError_t rt_launch_selftest(int which, uint64_t seed, int blocks, int iters, unsigned long long *d_out, hipStream_t stream);
+
 #endif

@@ -115,6 +115,126 @@ RT_DEV Hit nearest_hit(const SceneLDS &sc, int n, V3 o, V3 d)
 	return best;
 }
 
+/* ---- tuned intersection: same results as box_entry/ball_entry/nearest_hit, fewer instructions ---
+ *  - the six slab quotients of a box share the ray's three refined reciprocals (rt_math.hip.h);
+ *  - the slab test is branch-free (a 64-ray batch is incoherent: an early-out would only idle lanes);
+ *  - the sphere roots share one refined fp64 reciprocal of 2a per ray, and the larger root is only
+ *    formed when the smaller one is negative (2a > 0, so (-b - sqrt(D))/2a <= (-b + sqrt(D))/2a after
+ *    every rounding: the reference's sort, scene.c:119-123, always ends with that order);
+ *  - the hit normal is formed once, for the winning object, instead of for every candidate.
+ * Every quotient is still the correctly rounded IEEE one; operands outside the window in which the
+ * shared-reciprocal form is exact (including zero numerators) fall back to `/` for the whole wave. */
+
+struct RayPrep {
+	V3     inv;        /* refined reciprocals of the direction components */
+	bool   inv_ok;
+	float  dd;         /* dot(d, d): `a` of every sphere test                      */
+	double den, rden;  /* (double)(2*a) and its refined reciprocal                 */
+	bool   den_ok;
+};
+
+RT_DEV RayPrep prepare_ray(V3 d)
+{
+	RayPrep p;
+	p.inv_ok = den_in_window(d.x) && den_in_window(d.y) && den_in_window(d.z);
+	p.inv = mk3(rcp_refined(d.x), rcp_refined(d.y), rcp_refined(d.z));
+	p.dd = dot3(d, d);
+	p.den = (double) (2.0f * p.dd);
+	p.den_ok = p.dd >= 0x1p-20f && p.dd <= 0x1p+20f;
+	p.rden = rcp_refined64(p.den);
+	return p;
+}
+
+RT_DEV bool wave_all(bool ok) { return __ballot(!ok) == 0ull; }
+
+RT_DEV bool box_entry_fast(V3 o, V3 d, const RayPrep &rp, V3 lo, V3 hi, float &t_entry, int &axis_out)
+{
+	const float n0 = lo.x - o.x, n1 = hi.x - o.x, n2 = lo.y - o.y, n3 = hi.y - o.y, n4 = lo.z - o.z, n5 = hi.z - o.z;
+	const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(n0), __builtin_fabsf(n1)),
+	                                                   __builtin_fmaxf(__builtin_fabsf(n2), __builtin_fabsf(n3))),
+	                                   __builtin_fmaxf(__builtin_fabsf(n4), __builtin_fabsf(n5)));
+	const float amin = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fabsf(n0), __builtin_fabsf(n1)),
+	                                                   __builtin_fminf(__builtin_fabsf(n2), __builtin_fabsf(n3))),
+	                                   __builtin_fminf(__builtin_fabsf(n4), __builtin_fabsf(n5)));
+	float ax, bx, ay, by, az, bz;
+	if (wave_all(rp.inv_ok && amin >= 0x1p-100f && amax <= 0x1p+30f)) {
+		ax = div_by_refined(n0, d.x, rp.inv.x); bx = div_by_refined(n1, d.x, rp.inv.x);
+		ay = div_by_refined(n2, d.y, rp.inv.y); by = div_by_refined(n3, d.y, rp.inv.y);
+		az = div_by_refined(n4, d.z, rp.inv.z); bz = div_by_refined(n5, d.z, rp.inv.z);
+	} else {
+		ax = n0 / d.x; bx = n1 / d.x; ay = n2 / d.y; by = n3 / d.y; az = n4 / d.z; bz = n5 / d.z;
+	}
+	const float nx = d.x >= 0 ? ax : bx, fx = d.x >= 0 ? bx : ax;
+	const float ny = d.y >= 0 ? ay : by, fy = d.y >= 0 ? by : ay;
+	const float nz = d.z >= 0 ? az : bz, fz = d.z >= 0 ? bz : az;
+	const bool miss_xy = nx > fy || ny > fx;                 /* scene.c:47 */
+	const bool y_in = ny > nx;                               /* scene.c:50 */
+	const float tn1 = y_in ? ny : nx;
+	const float tf1 = fy < fx ? fy : fx;                     /* scene.c:51 */
+	const bool miss_z = tn1 > fz || nz > tf1;                /* scene.c:61 */
+	const bool z_in = nz > tn1;                              /* scene.c:64 */
+	t_entry = z_in ? nz : tn1;
+	axis_out = z_in ? 2 : (y_in ? 1 : 0);
+	return !(miss_xy || miss_z);
+}
+
+RT_DEV bool ball_entry_fast(V3 o, V3 d, const RayPrep &rp, V3 center, float r2, float &t_entry)
+{
+	const V3 oc = sub3(center, o);
+	const float b = -2.0f * dot3(oc, d);
+	const float c = dot3(oc, oc) - r2;
+	const float discr = b * b - 4.0f * rp.dd * c;
+	if (!(discr > 0)) return false;
+	const double root = __builtin_sqrt((double) discr);
+	const double nb = (double) -b;
+	const double num_lo = nb - root, num_hi = nb + root;
+	const double alo = __builtin_fabs(num_lo), ahi = __builtin_fabs(num_hi);
+	float r_small, r_large;
+	if (wave_all(rp.den_ok && alo >= 0x1p-300 && alo <= 0x1p+300 && ahi >= 0x1p-300 && ahi <= 0x1p+300)) {
+		r_small = (float) div_by_refined64(num_lo, rp.den, rp.rden);
+		if (r_small >= 0) { t_entry = r_small; return true; }
+		r_large = (float) div_by_refined64(num_hi, rp.den, rp.rden);
+		if (r_large < 0) return false;
+		t_entry = r_large;
+		return true;
+	}
+	/* reference order, scene.c:117-127 */
+	float r0 = (float) (num_hi / rp.den);
+	float r1 = (float) (num_lo / rp.den);
+	if (r0 > r1) { const float tmp = r0; r0 = r1; r1 = tmp; }
+	if (r0 < 0) { r0 = r1; if (r0 < 0) return false; }
+	t_entry = r0;
+	return true;
+}
+
+RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d)
+{
+	const RayPrep rp = prepare_ray(d);
+	float best_t = 3.402823466e+38f;
+	int best_obj = -1, best_axis = 0;
+	for (int i = 0; i < n; i++) {
+		const float4 g0 = sc.geom[2 * i], g1 = sc.geom[2 * i + 1];
+		const int type = __float_as_int(g1.z);
+		float t = 0.0f; int axis = 0; bool hit = false;
+		if (type == RT_GEOM_CUBE)
+			hit = box_entry_fast(o, d, rp, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), t, axis);
+		else if (type == RT_GEOM_SPHERE)
+			hit = ball_entry_fast(o, d, rp, mk3(g0.x, g0.y, g0.z), g0.w, t);
+		if (hit && t >= 0 && t < best_t) { best_t = t; best_obj = i; best_axis = axis; }
+	}
+	Hit best; best.t = best_t; best.obj = best_obj; best.n = mk3(0, 0, 0);
+	if (best_obj >= 0) {
+		const float4 g0 = sc.geom[2 * best_obj], g1 = sc.geom[2 * best_obj + 1];
+		if (__float_as_int(g1.z) == RT_GEOM_CUBE) {
+			const float dc = best_axis == 0 ? d.x : (best_axis == 1 ? d.y : d.z);
+			const float s = dc > 0 ? -1.0f : 1.0f;                               /* scene.c:71-73 */
+			best.n = mk3(best_axis == 0 ? s : 0.0f, best_axis == 1 ? s : 0.0f, best_axis == 2 ? s : 0.0f);
+		} else
+			best.n = unit3_fast(sub3(madd3(o, d, best_t), mk3(g0.x, g0.y, g0.z)));   /* scene.c:146-147 */
+	}
+	return best;
+}
+
 /* ---- skybox: gpu_and_windowing.c:42-112 ---------------------------------------------------- */
 
 RT_DEV V3 sky_lookup(const rt_launch &L, V3 dir)
@@ -396,12 +516,12 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 		if (has_hit) {
 			if (have_light) {
 				const V3 to_light = sub3(light_pos, hp);
-				{ const V3 jit = rng_direction(rng);
-				  if (dot3(jit, hn) > 0) { tap_d0 = unit3(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 1; } }
-				{ const V3 jit = rng_direction(rng);
-				  if (dot3(jit, hn) > 0) { tap_d1 = unit3(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 2; } }
-				{ const V3 jit = rng_direction(rng);
-				  if (dot3(jit, hn) > 0) { tap_d2 = unit3(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 4; } }
+				{ const V3 jit = rng_direction<true>(rng);
+				  if (dot3(jit, hn) > 0) { tap_d0 = unit3_fast(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 1; } }
+				{ const V3 jit = rng_direction<true>(rng);
+				  if (dot3(jit, hn) > 0) { tap_d1 = unit3_fast(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 2; } }
+				{ const V3 jit = rng_direction<true>(rng);
+				  if (dot3(jit, hn) > 0) { tap_d2 = unit3_fast(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 4; } }
 			}
 			const float4 m0 = sc.shade[4 * hobj], m1 = sc.shade[4 * hobj + 1];
 			const float4 m2 = sc.shade[4 * hobj + 2], m3 = sc.shade[4 * hobj + 3];
@@ -413,7 +533,7 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 			const float grazing = (float) (xg2 * xg2 * xg);
 			const V3 fresnel = madd3(f0, omf0, grazing);
 
-			V3 scatter = rng_direction(rng);
+			V3 scatter = rng_direction<true>(rng);
 			if (dot3(scatter, hn) < 0) scatter = neg3(scatter);
 
 			rad = add3(rad, had3(mk3(m3.x, m3.y, m3.z), carry));
@@ -425,7 +545,7 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 			if (specular) {
 				const V3 nneg = neg3(hn);
 				const float f = -2.0f * dot3(nneg, hdir);
-				out_dir = unit3(lin2(scatter, madd3(hdir, nneg, f), m0.w, 1.0f));
+				out_dir = unit3_fast(lin2(scatter, madd3(hdir, nneg, f), m0.w, 1.0f));
 			} else {
 				out_dir = scatter;
 				carry = had3(carry, mk3(m2.x, m2.y, m2.z));
@@ -476,10 +596,10 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 			const int slot = base + lane;
 			if (slot < total) {
 				const V3 o = mk3(W.q[0][slot], W.q[1][slot], W.q[2][slot]);
-				const V3 dn = unit3(mk3(W.q[3][slot], W.q[4][slot], W.q[5][slot]));   /* scene.c:158 */
+				const V3 dn = unit3_fast(mk3(W.q[3][slot], W.q[4][slot], W.q[5][slot]));   /* scene.c:158 */
 				const int meta = __float_as_int(W.q[6][slot]);
 				const int owner = meta & 255, kind = meta >> 8;
-				const Hit hit = nearest_hit(sc, n, o, dn);
+				const Hit hit = nearest_hit_fast(sc, n, o, dn);
 				if (kind != WF_KIND_MAIN) {
 					W.tap[kind - 1][owner] = hit.obj;
 				} else {
@@ -583,6 +703,88 @@ rt_deinterleave(const float *strips, float *frame, int width, int height, int ro
 		const int lr = lblk * row_block + j % row_block;
 		frame[k] = strips[((size_t) rank * rows_per_rank + lr) * row_floats + c];
 	}
+}
+
+/* ---- self-test of the exact-arithmetic shortcuts (tests/test_gpu_selftest.py) -------------------
+ * which = 0: div_by_refined   vs `/`   on floats,  numerator in [2^-100, 2^30], denominator in [2^-30, 2^30]
+ *         1: div_by_refined64 vs `/`   on doubles, numerator in [2^-300, 2^300], denominator (double) 2a, a in [2^-20, 2^20]
+ *         2: unit3_fast       vs unit3 on vectors of every magnitude (incl. zero / tiny / huge components)
+ * out[0] = number of mismatching results, out[1..] = operands of one mismatch. */
+RT_DEV uint64_t st_next(uint64_t &s)
+{
+	s += 0x9E3779B97F4A7C15ull;
+	uint64_t z = s;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+
+RT_DEV float st_float(uint64_t r, int emin, int emax)    /* random sign/mantissa, exponent uniform in [emin, emax) */
+{
+	const uint32_t mant = (uint32_t) r & 0x7fffffu;
+	const uint32_t sign = (uint32_t) (r >> 23) & 1u;
+	const int e = emin + (int) ((r >> 32) % (uint64_t) (emax - emin));
+	return __uint_as_float((sign << 31) | ((uint32_t) (e + 127) << 23) | mant);
+}
+
+extern "C" __global__ void __launch_bounds__(RT_BLOCK)
+rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
+{
+	uint64_t s = seed + 0x1000003ull * (uint64_t) (blockIdx.x * RT_BLOCK + threadIdx.x);
+	unsigned long long bad = 0;
+	for (int it = 0; it < iters; it++) {
+		if (which == 0) {
+			const uint64_t r0 = st_next(s), r1 = st_next(s);
+			float n = st_float(r0, -100, 30), d = st_float(r1, -30, 30);
+			if ((r0 >> 60) == 0) d = __uint_as_float((__float_as_uint(d) & 0xff800000u) | ((uint32_t) (r1 >> 40) & 0x3u));   /* near powers of two */
+			if ((r1 >> 60) == 1) n = d * st_float(r0, -2, 2);                        /* correlated operands */
+			const float want = n / d;
+			const float got = div_by_refined(n, d, rcp_refined(d));
+			if (__float_as_uint(want) != __float_as_uint(got)) {
+				bad++;
+				out[1] = __float_as_uint(n); out[2] = __float_as_uint(d); out[3] = __float_as_uint(want); out[4] = __float_as_uint(got);
+			}
+		} else if (which == 1) {
+			const uint64_t r0 = st_next(s), r1 = st_next(s), r2 = st_next(s);
+			const float a = st_float(r0, -20, 20);
+			const double den = (double) (2.0f * __builtin_fabsf(a));
+			const int e = -300 + (int) (r1 % 600ull);
+			double num = __builtin_ldexp(1.0 + (double) (r2 >> 12) * 0x1p-52, e);
+			if (r1 >> 63) num = -num;
+			if ((r1 >> 58 & 15) == 0) num = (double) st_float(r2, -60, 30) - __builtin_sqrt((double) __builtin_fabsf(st_float(r1, -60, 30)));
+			if (!(__builtin_fabs(num) >= 0x1p-300 && __builtin_fabs(num) <= 0x1p+300)) continue;
+			const double want = num / den;
+			const double got = div_by_refined64(num, den, rcp_refined64(den));
+			if (__double_as_longlong(want) != __double_as_longlong(got)) {
+				bad++;
+				out[1] = (unsigned long long) __double_as_longlong(num); out[2] = (unsigned long long) __double_as_longlong(den);
+				out[3] = (unsigned long long) __double_as_longlong(want); out[4] = (unsigned long long) __double_as_longlong(got);
+			}
+		} else {
+			const uint64_t r0 = st_next(s), r1 = st_next(s), r2 = st_next(s), r3 = st_next(s);
+			int lo = -20, hi = 20;
+			switch (r3 & 7) { case 0: lo = -126; hi = 127; break; case 1: lo = -30; hi = -10; break; case 2: lo = 20; hi = 64; break; default: break; }
+			V3 v = mk3(st_float(r0, lo, hi), st_float(r1, lo, hi), st_float(r2, lo, hi));
+			if (((r3 >> 8) & 15) == 0) v.x = 0.0f;
+			if (((r3 >> 12) & 15) == 0) v.y = -0.0f;
+			if (((r3 >> 16) & 31) == 0) v.z = __uint_as_float((uint32_t) r2 & 0x807fffffu);   /* denormal */
+			if (((r3 >> 24) & 63) == 0) { const float k = 0.00001f / __builtin_sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); v = scale3(v, k); }
+			const V3 want = unit3(v), got = unit3_fast(v);
+			if (__float_as_uint(want.x) != __float_as_uint(got.x) || __float_as_uint(want.y) != __float_as_uint(got.y) ||
+			    __float_as_uint(want.z) != __float_as_uint(got.z)) {
+				bad++;
+				out[1] = __float_as_uint(v.x); out[2] = __float_as_uint(v.y); out[3] = __float_as_uint(v.z);
+				out[4] = __float_as_uint(want.x); out[5] = __float_as_uint(got.x);
+			}
+		}
+	}
+	if (bad) atomicAdd(&out[0], bad);
+}
+
+hipError_t rt_launch_selftest(int which, uint64_t seed, int blocks, int iters, unsigned long long *d_out, hipStream_t stream)
+{
+	hipLaunchKernelGGL(rt_selftest_kernel, dim3(blocks), dim3(RT_BLOCK), 0, stream, which, seed, iters, d_out);
+	return hipGetLastError();
 }
 
 /* ---- host-callable launchers (C++ linkage inside the library; the C ABI lives in rt_api.cpp) -- */

@@ -50,6 +50,76 @@ RT_DEV float clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); 
 RT_DEV float clamp11(float x) { return x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x); }
 RT_DEV bool  tiny_f(float f) { return (double) f < 0.0001 && (double) f > -0.0001; } /* vector.c:79 */
 
+
+/* ---- exact division with a shared reciprocal ---------------------------------------------------
+ * hipcc lowers an IEEE `n / d` to  v_div_scale x2, v_rcp, two Newton steps on the reciprocal, a
+ * product, two residual corrections (the last inside v_div_fmas) and v_div_fixup.  When neither
+ * operand needs rescaling -- both comfortably inside the normal range and their ratio too (the
+ * conditions of V_DIV_SCALE_F32 in the CDNA ISA guide) -- the scale/fixup instructions are
+ * identities and the quotient is exactly
+ *     r = rcp(d); r += r*(1 - d*r);  q = n*r;  q += r*(n - d*q);  q += r*(n - d*q)
+ * evaluated with fused multiply-adds.  The reciprocal part depends on d only, so a ray that
+ * divides many numerators by the same three direction components (the slab test, scene.c:31-59),
+ * or a vector divided by its length (vector.c:134-136), pays for it once.  The result is the same
+ * correctly rounded quotient, bit for bit; rt_selftest() (tests/test_gpu_selftest.py) checks that
+ * against `/` on 10^9 operand pairs.  Operands outside the safe window take the ordinary `/`.
+ */
+RT_DEV float rcp_refined(float d)
+{
+	const float r0 = __builtin_amdgcn_rcpf(d);
+	const float e  = __builtin_fmaf(-d, r0, 1.0f);
+	return __builtin_fmaf(e, r0, r0);
+}
+
+RT_DEV float div_by_refined(float n, float d, float r)
+{
+	float q = n * r;
+	q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+	q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+	return q;
+}
+
+/* |x| in [2^-30, 2^30]: a denominator for which rcp_refined/div_by_refined are exact (with a
+ * numerator accepted by num_in_window) */
+RT_DEV bool den_in_window(float x)
+{
+	const float a = __builtin_fabsf(x);
+	return a >= 0x1p-30f && a <= 0x1p+30f;
+}
+/* |x| in [2^-60, 2^30]; zero, NaN and infinities are outside */
+RT_DEV bool num_in_window(float lo_abs, float hi_abs) { return lo_abs >= 0x1p-60f && hi_abs <= 0x1p+30f; }
+
+RT_DEV double rcp_refined64(double d)
+{
+	double r = __builtin_amdgcn_rcp(d);
+	r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+	r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+	return r;
+}
+
+RT_DEV double div_by_refined64(double n, double d, double r)
+{
+	const double q = n * r;
+	return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+
+/* vector.c:129-138 with the three divisions sharing one reciprocal.  `len < 0.00001` compared in
+ * double is `len <= 0x3727C5AC` in float (the largest float below the double 0.00001). */
+RT_DEV V3 unit3_fast(V3 v)
+{
+	const float len = __builtin_sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+	if (len <= __uint_as_float(0x3727C5ACu))
+		return v;
+	const float ax = __builtin_fabsf(v.x), ay = __builtin_fabsf(v.y), az = __builtin_fabsf(v.z);
+	const float lo = __builtin_fminf(__builtin_fminf(ax, ay), az);
+	const float hi = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az);
+	if (__builtin_expect(len <= 0x1p+30f && num_in_window(lo, hi), 1)) {
+		const float r = rcp_refined(len);
+		return mk3(div_by_refined(v.x, len, r), div_by_refined(v.y, len, r), div_by_refined(v.z, len, r));
+	}
+	return mk3(v.x / len, v.y / len, v.z / len);
+}
+
 /* ---- RNG: utils.c:60-75 ---------------------------------------------------------------- */
 
 RT_DEV uint64_t fold_mul(uint64_t a, uint64_t b) { return __umul64hi(a, b) ^ (a * b); }
@@ -71,12 +141,13 @@ RT_DEV uint64_t path_seed(uint64_t seed, uint32_t pixel_index, uint32_t sample_i
 }
 
 /* vector.c:99-111: x, y, z drawn in that order */
+template <bool FAST = false>
 RT_DEV V3 rng_direction(uint64_t &state)
 {
 	float x = rng_draw(state) * 2.0f - 1.0f;
 	float y = rng_draw(state) * 2.0f - 1.0f;
 	float z = rng_draw(state) * 2.0f - 1.0f;
-	return unit3(mk3(x, y, z));
+	return FAST ? unit3_fast(mk3(x, y, z)) : unit3(mk3(x, y, z));
 }
 
 #endif
