@@ -12,6 +12,7 @@
  * fetch).  No MFMA: there is no contraction in this workload.
  */
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "rt_device.h"
 #include "rt_math.hip.h"
 
@@ -22,6 +23,17 @@
 #define RT_TILE_H   8
 
 struct Hit { float t; V3 n; int obj; };
+
+/* Development instrumentation (make stats): per-site counts of executions and of active lanes,
+ * accumulated in a device array.  Compiled out of the product build. */
+#ifdef RT_STATS
+__device__ unsigned long long rt_stats[64];
+#define STAT(site) do { const unsigned long long m_ = __ballot(true); \
+	if (__builtin_amdgcn_mbcnt_hi((unsigned int) (m_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_, 0u)) == 0) { \
+		atomicAdd(&rt_stats[2 * (site)], 1ull); atomicAdd(&rt_stats[2 * (site) + 1], (unsigned long long) __popcll(m_)); } } while (0)
+#else
+#define STAT(site) do {} while (0)
+#endif
 
 /* ---- LDS-resident scene ------------------------------------------------------------------- */
 
@@ -157,11 +169,20 @@ RT_DEV bool box_entry_fast(V3 o, V3 d, const RayPrep &rp, V3 lo, V3 hi, float &t
 	                                                   __builtin_fminf(__builtin_fabsf(n2), __builtin_fabsf(n3))),
 	                                   __builtin_fminf(__builtin_fabsf(n4), __builtin_fabsf(n5)));
 	float ax, bx, ay, by, az, bz;
+	STAT(1);
+#ifdef RT_STATS
+	if (!wave_all(rp.inv_ok)) STAT(18);
+	if (!wave_all(amin >= 0x1p-100f)) STAT(19);
+	if (!wave_all(amax <= 0x1p+30f)) STAT(20);
+	if (!wave_all(amin > 0.0f)) STAT(21);
+	if (!(amin > 0.0f) && rt_stats[50] < 40) { unsigned long long k = atomicAdd(&rt_stats[50], 1ull); if (k < 4) { unsigned long long *p = &rt_stats[51 + 3 * k]; p[0] = ((unsigned long long) __float_as_uint(o.x) << 32) | __float_as_uint(o.y); p[1] = ((unsigned long long) __float_as_uint(o.z) << 32) | __float_as_uint(lo.x); p[2] = ((unsigned long long) __float_as_uint(lo.y) << 32) | __float_as_uint(hi.y); } }
+#endif
 	if (wave_all(rp.inv_ok && amin >= 0x1p-100f && amax <= 0x1p+30f)) {
 		ax = div_by_refined(n0, d.x, rp.inv.x); bx = div_by_refined(n1, d.x, rp.inv.x);
 		ay = div_by_refined(n2, d.y, rp.inv.y); by = div_by_refined(n3, d.y, rp.inv.y);
 		az = div_by_refined(n4, d.z, rp.inv.z); bz = div_by_refined(n5, d.z, rp.inv.z);
 	} else {
+		STAT(2);
 		ax = n0 / d.x; bx = n1 / d.x; ay = n2 / d.y; by = n3 / d.y; az = n4 / d.z; bz = n5 / d.z;
 	}
 	const float nx = d.x >= 0 ? ax : bx, fx = d.x >= 0 ? bx : ax;
@@ -184,7 +205,9 @@ RT_DEV bool ball_entry_fast(V3 o, V3 d, const RayPrep &rp, V3 center, float r2, 
 	const float b = -2.0f * dot3(oc, d);
 	const float c = dot3(oc, oc) - r2;
 	const float discr = b * b - 4.0f * rp.dd * c;
+	STAT(3);
 	if (!(discr > 0)) return false;
+	STAT(4);
 	const double root = __builtin_sqrt((double) discr);
 	const double nb = (double) -b;
 	const double num_lo = nb - root, num_hi = nb + root;
@@ -193,12 +216,14 @@ RT_DEV bool ball_entry_fast(V3 o, V3 d, const RayPrep &rp, V3 center, float r2, 
 	if (wave_all(rp.den_ok && alo >= 0x1p-300 && alo <= 0x1p+300 && ahi >= 0x1p-300 && ahi <= 0x1p+300)) {
 		r_small = (float) div_by_refined64(num_lo, rp.den, rp.rden);
 		if (r_small >= 0) { t_entry = r_small; return true; }
+		STAT(5);
 		r_large = (float) div_by_refined64(num_hi, rp.den, rp.rden);
 		if (r_large < 0) return false;
 		t_entry = r_large;
 		return true;
 	}
 	/* reference order, scene.c:117-127 */
+	STAT(6);
 	float r0 = (float) (num_hi / rp.den);
 	float r1 = (float) (num_lo / rp.den);
 	if (r0 > r1) { const float tmp = r0; r0 = r1; r1 = tmp; }
@@ -420,7 +445,7 @@ rt_trace_simple(const rt_launch L)
  * bit-identical to rt_trace_simple and to the CPU oracle.
  * ============================================================================================= */
 
-#define WF_QUEUE   256                 /* rays per wave per round: 64 lanes x (1 bounce ray + 3 taps) */
+#define WF_QUEUE   128                 /* ring: at most 63 left over + 64 pushed at a time */
 #define WF_KIND_MAIN 0                 /* kinds 1..3 = shadow tap k-1 */
 
 struct WaveLDS {
@@ -432,7 +457,10 @@ struct WaveLDS {
 
 RT_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
-extern "C" __global__ void __launch_bounds__(RT_BLOCK)
+template <bool FAST> RT_DEV V3 unit3_sel(V3 v) { return FAST ? unit3_fast(v) : unit3(v); }
+
+template <bool FAST>
+__global__ void __launch_bounds__(RT_BLOCK, 4)
 rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 {
 	extern __shared__ float4 lds[];
@@ -513,15 +541,17 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 		bool emit_main = primary;
 		V3   ray_o = cam, ray_d = prim_dir;
 		V3   tap_d0 = mk3(0, 0, 0), tap_d1 = mk3(0, 0, 0), tap_d2 = mk3(0, 0, 0);
+		STAT(7);
 		if (has_hit) {
+			STAT(8);
 			if (have_light) {
 				const V3 to_light = sub3(light_pos, hp);
-				{ const V3 jit = rng_direction<true>(rng);
-				  if (dot3(jit, hn) > 0) { tap_d0 = unit3_fast(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 1; } }
-				{ const V3 jit = rng_direction<true>(rng);
-				  if (dot3(jit, hn) > 0) { tap_d1 = unit3_fast(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 2; } }
-				{ const V3 jit = rng_direction<true>(rng);
-				  if (dot3(jit, hn) > 0) { tap_d2 = unit3_fast(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 4; } }
+				{ const V3 jit = rng_direction<FAST>(rng);
+				  if (dot3(jit, hn) > 0) { STAT(9); tap_d0 = unit3_sel<FAST>(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 1; } }
+				{ const V3 jit = rng_direction<FAST>(rng);
+				  if (dot3(jit, hn) > 0) { STAT(10); tap_d1 = unit3_sel<FAST>(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 2; } }
+				{ const V3 jit = rng_direction<FAST>(rng);
+				  if (dot3(jit, hn) > 0) { STAT(11); tap_d2 = unit3_sel<FAST>(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 4; } }
 			}
 			const float4 m0 = sc.shade[4 * hobj], m1 = sc.shade[4 * hobj + 1];
 			const float4 m2 = sc.shade[4 * hobj + 2], m3 = sc.shade[4 * hobj + 3];
@@ -533,7 +563,7 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 			const float grazing = (float) (xg2 * xg2 * xg);
 			const V3 fresnel = madd3(f0, omf0, grazing);
 
-			V3 scatter = rng_direction<true>(rng);
+			V3 scatter = rng_direction<FAST>(rng);
 			if (dot3(scatter, hn) < 0) scatter = neg3(scatter);
 
 			rad = add3(rad, had3(mk3(m3.x, m3.y, m3.z), carry));
@@ -543,9 +573,10 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 				specular = rng_draw(rng) <= (fresnel.x + fresnel.y + fresnel.z) / 3.0f;
 			V3 out_dir;
 			if (specular) {
+				STAT(15);
 				const V3 nneg = neg3(hn);
 				const float f = -2.0f * dot3(nneg, hdir);
-				out_dir = unit3_fast(lin2(scatter, madd3(hdir, nneg, f), m0.w, 1.0f));
+				out_dir = unit3_sel<FAST>(lin2(scatter, madd3(hdir, nneg, f), m0.w, 1.0f));
 			} else {
 				out_dir = scatter;
 				carry = had3(carry, mk3(m2.x, m2.y, m2.z));
@@ -558,64 +589,62 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 			has_hit = false;
 		}
 
-		/* ---- 3. compact this round's rays into the wave queue (ballot + mbcnt prefix) -------- */
-		int total = 0;
-		{
-			const unsigned long long m = __ballot(emit_main);
-			if (emit_main) {
-				const int slot = total + (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32),
-				                 __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u));
-				W.q[0][slot] = ray_o.x; W.q[1][slot] = ray_o.y; W.q[2][slot] = ray_o.z;
-				W.q[3][slot] = ray_d.x; W.q[4][slot] = ray_d.y; W.q[5][slot] = ray_d.z;
-				W.q[6][slot] = __int_as_float(lane | (WF_KIND_MAIN << 8));
-			}
-			total += __popcll(m);
-		}
-#define WF_PUSH_TAP(K, DIR)                                                                          \
-		{                                                                                            \
-			const bool on = (tapmask >> (K)) & 1;                                                    \
-			const unsigned long long m = __ballot(on);                                               \
-			if (on) {                                                                                \
-				const int slot = total + (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32),   \
-				                 __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u));                   \
-				const V3 so = madd3(hp, DIR, 0.001f);                   /* main.c:198 */             \
-				W.q[0][slot] = so.x; W.q[1][slot] = so.y; W.q[2][slot] = so.z;                       \
-				W.q[3][slot] = DIR.x; W.q[4][slot] = DIR.y; W.q[5][slot] = DIR.z;                    \
-				W.q[6][slot] = __int_as_float(lane | (((K) + 1) << 8));                              \
-			}                                                                                        \
-			total += __popcll(m);                                                                    \
-		}
-		WF_PUSH_TAP(0, tap_d0)
-		WF_PUSH_TAP(1, tap_d1)
-		WF_PUSH_TAP(2, tap_d2)
-#undef WF_PUSH_TAP
-		wave_fence();
-
-		/* ---- 4. trace the queue in batches of 64 (scene.c:156-190 on full waves) ------------- */
-		for (int base = 0; base < total; base += 64) {
-			const int slot = base + lane;
-			if (slot < total) {
-				const V3 o = mk3(W.q[0][slot], W.q[1][slot], W.q[2][slot]);
-				const V3 dn = unit3_fast(mk3(W.q[3][slot], W.q[4][slot], W.q[5][slot]));   /* scene.c:158 */
-				const int meta = __float_as_int(W.q[6][slot]);
-				const int owner = meta & 255, kind = meta >> 8;
-				const Hit hit = nearest_hit_fast(sc, n, o, dn);
-				if (kind != WF_KIND_MAIN) {
-					W.tap[kind - 1][owner] = hit.obj;
-				} else {
-					V3 a, b = hit.n;
-					if (hit.obj >= 0) a = madd3(o, dn, hit.t);                       /* scene.c:186 */
-					else              a = sky_lookup(L, dn);                         /* main.c:170  */
-					W.res[0][owner] = a.x; W.res[1][owner] = a.y; W.res[2][owner] = a.z;
-					W.res[3][owner] = b.x; W.res[4][owner] = b.y; W.res[5][owner] = b.z;
-					W.res[6][owner] = __int_as_float(hit.obj);
+		/* ---- 3+4. compact this round's rays into the wave's ring queue (ballot + mbcnt prefix), one
+		 * kind at a time, and trace full batches of 64 as soon as they exist (scene.c:156-190 on full
+		 * waves); the remainder is flushed after the last kind -------------------------------------- */
+		int q_head = 0, q_tail = 0;
+#pragma unroll 1
+		for (int kind = 0; kind < 5; kind++) {
+			if (kind < 4) {
+				bool on = emit_main;
+				V3 qo = ray_o, qd = ray_d;
+				if (kind > 0) {
+					on = (tapmask >> (kind - 1)) & 1;
+					qd = kind == 1 ? tap_d0 : (kind == 2 ? tap_d1 : tap_d2);
+					qo = madd3(hp, qd, 0.001f);                                      /* main.c:198 */
 				}
+				const unsigned long long m = __ballot(on);
+				if (on) {
+					const int slot = (q_tail + (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32),
+					                  __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u))) & (WF_QUEUE - 1);
+					W.q[0][slot] = qo.x; W.q[1][slot] = qo.y; W.q[2][slot] = qo.z;
+					W.q[3][slot] = qd.x; W.q[4][slot] = qd.y; W.q[5][slot] = qd.z;
+					W.q[6][slot] = __int_as_float(lane | (kind << 8));
+				}
+				q_tail += __popcll(m);
+				wave_fence();
+			}
+			while (q_tail - q_head >= 64 || (kind == 4 && q_tail > q_head)) {
+				const int count = q_tail - q_head < 64 ? q_tail - q_head : 64;
+				STAT(12);
+				if (lane < count) {
+					STAT(13);
+					const int slot = (q_head + lane) & (WF_QUEUE - 1);
+					const V3 o = mk3(W.q[0][slot], W.q[1][slot], W.q[2][slot]);
+					const V3 dn = unit3_sel<FAST>(mk3(W.q[3][slot], W.q[4][slot], W.q[5][slot]));   /* scene.c:158 */
+					const int meta = __float_as_int(W.q[6][slot]);
+					const int owner = meta & 255, rkind = meta >> 8;
+					const Hit hit = FAST ? nearest_hit_fast(sc, n, o, dn) : nearest_hit(sc, n, o, dn);
+					if (rkind != WF_KIND_MAIN) {
+						W.tap[rkind - 1][owner] = hit.obj;
+					} else {
+						V3 a, b = hit.n;
+						if (hit.obj >= 0) a = madd3(o, dn, hit.t);                   /* scene.c:186 */
+						else            { STAT(14); a = sky_lookup(L, dn); }         /* main.c:170  */
+						W.res[0][owner] = a.x; W.res[1][owner] = a.y; W.res[2][owner] = a.z;
+						W.res[3][owner] = b.x; W.res[4][owner] = b.y; W.res[5][owner] = b.z;
+						W.res[6][owner] = __int_as_float(hit.obj);
+					}
+				}
+				q_head += count;
+				wave_fence();
 			}
 		}
-		wave_fence();
 
 		/* ---- 5. consume results ------------------------------------------------------------- */
+		STAT(16);
 		if (px_lr >= 0) {
+			STAT(17);
 			bool sample_done = false, pixel_done = false;
 			if (primary) {
 				const int obj = __float_as_int(W.res[6][lane]);
@@ -787,6 +816,19 @@ hipError_t rt_launch_selftest(int which, uint64_t seed, int blocks, int iters, u
 	return hipGetLastError();
 }
 
+#ifdef RT_STATS
+extern "C" __attribute__((visibility("default"))) int rt_stats_read(unsigned long long out[64], int reset)
+{
+	if (hipDeviceSynchronize() != hipSuccess) return -2;
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rt_stats), 64 * sizeof(unsigned long long)) != hipSuccess) return -2;
+	if (reset) {
+		unsigned long long zero[64] = {0};
+		if (hipMemcpyToSymbol(HIP_SYMBOL(rt_stats), zero, sizeof(zero)) != hipSuccess) return -2;
+	}
+	return 0;
+}
+#endif
+
 /* ---- host-callable launchers (C++ linkage inside the library; the C ABI lives in rt_api.cpp) -- */
 
 size_t rt_scene_lds_bytes(int num_objects) { return (size_t) num_objects * (sizeof(rt_geom) + sizeof(rt_shade)); }
@@ -808,6 +850,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, unsigned int *block_
 	int per_cu = (int) ((160u * 1024u) / lds);
 	if (per_cu < 1) per_cu = 1;
 	if (per_cu > 4) per_cu = 4;
+	if (const char *e = getenv("RT_WF_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }   /* tuning aid */
 	const long long blocks = (long long) ((L.width + 7) / 8) * ((L.local_rows + 7) / 8);
 	long long grid = (long long) num_cus * per_cu;
 	const long long useful = (blocks + (RT_BLOCK / 64) - 1) / (RT_BLOCK / 64);
@@ -815,7 +858,10 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, unsigned int *block_
 	if (grid < 1) grid = 1;
 	hipError_t e = hipMemsetAsync(block_counter, 0, sizeof(unsigned int), stream);
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(rt_trace_wavefront, dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, L, block_counter);
+	if (variant == 2 /* RT_KERNEL_WAVEFRONT: same schedule, plain IEEE operations */)
+		hipLaunchKernelGGL(rt_trace_wavefront<false>, dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, L, block_counter);
+	else
+		hipLaunchKernelGGL(rt_trace_wavefront<true>, dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, L, block_counter);
 	return hipGetLastError();
 }
 

@@ -15,6 +15,9 @@
 #pragma clang fp contract(off)
 
 #define RT_DEV __device__ __forceinline__
+#ifndef RT_STAT_UNIT_SLOW
+#define RT_STAT_UNIT_SLOW do {} while (0)
+#endif
 
 struct V3 { float x, y, z; };
 
@@ -117,6 +120,7 @@ RT_DEV V3 unit3_fast(V3 v)
 		const float r = rcp_refined(len);
 		return mk3(div_by_refined(v.x, len, r), div_by_refined(v.y, len, r), div_by_refined(v.z, len, r));
 	}
+	RT_STAT_UNIT_SLOW;
 	return mk3(v.x / len, v.y / len, v.z / len);
 }
 

@@ -3,6 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ray_tracing_amd as rt
+if os.environ.get('RT_LIB'): rt.LIB_PATH = os.path.join(os.path.dirname(rt.LIB_PATH), os.environ['RT_LIB'])
 
 def main():
     kernel = int(sys.argv[1]) if len(sys.argv) > 1 else 0
