@@ -101,6 +101,25 @@ RT_API int rt_deinterleave_device(rt_context *ctx, const void *d_strips, void *d
 
 RT_API int rt_synchronize(rt_context *ctx);
 
+/* ---- progressive accumulation: the reference's interactive protocol ----------------------------
+ * worker() renders passes of 1 sample per (low-resolution) pixel, starting at 1/init_scale resolution
+ * and doubling it after every published pass; each pass is added into `accum` with weight 1/scale^2
+ * and update_frame() shows accum / sum-of-weights (main.c:354-408, 450-482).  A camera move calls
+ * invalidate_accumulation() (main.c:115-124).  Here the same protocol, one pass per call:
+ *
+ *   rt_progressive_begin(ctx, w, h, init_scale, max_bounces, seed);   // realloc_frame_buffer()
+ *   for (;;) { rt_progressive_pass(ctx, &weight);                     // one worker iteration
+ *              rt_progressive_resolve(ctx, frame);                    // update_frame()
+ *              if (camera moved) { rt_set_camera(...); rt_progressive_invalidate(ctx); } }
+ *
+ * Pass number p (since the last invalidation) seeds the path of low-resolution pixel (i, j) at scale s
+ * with rt_path_seed(seed, (j*s)*w + i*s, p).  init_scale must be 1, 2, 4, 8 or 16 (main.c:611-621). */
+RT_API int rt_progressive_begin(rt_context *ctx, int width, int height, int init_scale, int max_bounces, uint64_t seed);
+RT_API int rt_progressive_pass(rt_context *ctx, float *weight_out);
+RT_API int rt_progressive_resolve(rt_context *ctx, Vector3 *frame_out);
+RT_API int rt_progressive_invalidate(rt_context *ctx);
+RT_API int rt_progressive_state(rt_context *ctx, int *next_scale, float *count, uint32_t *generation, int *passes);
+
 /* ---- measurement --------------------------------------------------------------------------- */
 /* When enabled, every rt_render_device()/rt_render() brackets its trace kernel with hipEvents on
  * the launch stream; rt_profile_collect() synchronises and returns the summed kernel time and the

@@ -142,19 +142,29 @@ REF_API void ref_pixel(float u, float v, float aspect, float out[3])
  * (main.c:363,377,387-396) for `passes` passes, then update_frame()'s resolve (main.c:476).
  * The RNG is whatever the calling thread's state is (the reference never seeds it: 0).
  */
+REF_API void ref_render_stream_scaled(int W, int H, int passes, int first_scale, float *frame_out, float *accum_out);
+
 REF_API void ref_render_stream(int W, int H, int passes, float *frame_out, float *accum_out)
 {
-	num_columns = 1; init_scale = 1; frame_w = W; frame_h = H;
+	ref_render_stream_scaled(W, H, passes, 1, frame_out, accum_out);
+}
+
+/* worker() with num_columns = 1 and the scale ladder: init_scale, then halved after every publish
+ * (main.c:354,377,387-403) */
+REF_API void ref_render_stream_scaled(int W, int H, int passes, int first_scale, float *frame_out, float *accum_out)
+{
+	num_columns = 1; init_scale = first_scale; frame_w = W; frame_h = H;
 	size_t n = (size_t) W * H;
-	Vector3 *col = malloc(sizeof(Vector3) * n);
+	Vector3 *col = calloc(n, sizeof(Vector3));
 	Vector3 *acc = calloc(n, sizeof(Vector3));
 	float count = 0;
-	int scale = 1;
+	int scale = first_scale;
 	for (int p = 0; p < passes; p++) {
 		float w = render_column(col, scale, W, 0, W, H, atomic_load(&accum_generation));
 		for (size_t k = 0; k < n; k++)
 			acc[k] = combine(acc[k], col[k], 1, 1.0f / (scale * scale));
 		count += w;
+		if (scale > 1) scale >>= 1;
 	}
 	if (accum_out) memcpy(accum_out, acc, sizeof(Vector3) * n);
 	if (frame_out)

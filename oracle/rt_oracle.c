@@ -464,9 +464,12 @@ void  orc_random_direction(uint64_t *state, float out[3])
 /* frame drivers                                                                               */
 /* ------------------------------------------------------------------------------------------ */
 
-/* main.c:274-322 at a given scale for one column; returns the pass weight 1/scale^2 */
+/* main.c:274-322 at a given scale for one column; returns the pass weight 1/scale^2.
+ * `state` != NULL: the reference's sequential stream.  `state` == NULL: counter mode, the path of
+ * low-resolution pixel (i, j) of pass `pass` starts from path_seed(seed, index of the tile's first
+ * full-resolution pixel, pass). */
 static float column_pass(V3 *data, int scale_, int column_w, int column_i, int W, int H,
-                         int max_bounces, uint64_t *state)
+                         int max_bounces, uint64_t *state, uint64_t seed, uint32_t pass)
 {
 	float weight = 1.0f / (scale_ * scale_);
 	int column_x = column_w * column_i;
@@ -483,12 +486,46 @@ static float column_pass(V3 *data, int scale_, int column_w, int column_i, int W
 			v = 1 - v;
 			int tw = scale_, th = scale_;
 			if (tw > column_w - i * scale_) tw = column_w - i * scale_;
-			V3 c = shade_path(u, v, aspect, max_bounces, state);
+			uint64_t local;
+			uint64_t *st = state;
+			if (!st) {
+				local = orc_path_seed(seed, (uint32_t) ((j * scale_) * W + (lcx + i) * scale_), pass);
+				st = &local;
+			}
+			V3 c = shade_path(u, v, aspect, max_bounces, st);
 			for (int g = 0; g < th; g++)
 				for (int t = 0; t < tw; t++)
 					data[(j * scale_ + g) * column_w + (i * scale_ + t)] = c;
 		}
 	return weight;
+}
+
+/* Progressive accumulation in counter mode: worker()'s publish step (main.c:387-408) for one pass.
+ * accum += column * (1/scale^2); *count += weight; returns the scale of the NEXT pass. */
+int orc_progressive_pass(int W, int H, int scale_, int pass, int max_bounces, uint64_t seed,
+                         float *accum, float *count)
+{
+	size_t n = (size_t) W * H;
+	V3 *col = calloc(n, sizeof(V3));
+	float w = column_pass(col, scale_, W, 0, W, H, max_bounces, NULL, seed, (uint32_t) pass);
+	float k = 1.0f / (scale_ * scale_);
+	V3 *acc = (V3*) accum;
+	for (size_t q = 0; q < n; q++)
+		acc[q] = lin2(acc[q], col[q], 1, k);                             /* main.c:394 */
+	*count += w;                                                         /* main.c:396 */
+	free(col);
+	flush_counters();
+	return scale_ > 1 ? scale_ >> 1 : scale_;                            /* main.c:402-403 */
+}
+
+/* update_frame()'s resolve, main.c:467-477 */
+void orc_resolve(int W, int H, const float *accum, float count, float *frame_out)
+{
+	const V3 *acc = (const V3*) accum;
+	for (size_t q = 0; q < (size_t) W * H; q++) {
+		V3 f = scale(acc[q], 1.0f / count);
+		frame_out[3*q] = f.x; frame_out[3*q+1] = f.y; frame_out[3*q+2] = f.z;
+	}
 }
 
 void orc_render_stream(int W, int H, int passes, int init_scale, int max_bounces,
@@ -501,7 +538,7 @@ void orc_render_stream(int W, int H, int passes, int init_scale, int max_bounces
 	float count = 0;
 	int s = init_scale;
 	for (int p = 0; p < passes; p++) {
-		float w = column_pass(col, s, W, 0, W, H, max_bounces, state);
+		float w = column_pass(col, s, W, 0, W, H, max_bounces, state, 0, 0);
 		float k = 1.0f / (s * s);
 		for (size_t q = 0; q < n; q++)
 			acc[q] = lin2(acc[q], col[q], 1, k);                     /* main.c:394 */
@@ -577,7 +614,7 @@ static void *column_worker(void *arg)
 	V3 *col = malloc(sizeof(V3) * (size_t) job->column_w * job->H);
 	uint64_t state = 0;                                              /* every reference thread starts at 0 */
 	for (int p = 0; p < job->passes; p++)
-		column_pass(col, 1, job->column_w, job->column_i, job->W, job->H, job->max_bounces, &state);
+		column_pass(col, 1, job->column_w, job->column_i, job->W, job->H, job->max_bounces, &state, 0, 0);
 	free(col);
 	flush_counters();
 	return NULL;

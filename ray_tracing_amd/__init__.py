@@ -56,7 +56,8 @@ class MouseState(C.Structure):
 EXPORTS = [
     "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
     "rt_set_camera", "rt_render", "rt_render_device", "rt_strip_rows", "rt_deinterleave_device",
-    "rt_synchronize", "rt_selftest", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
+    "rt_synchronize", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
+    "rt_progressive_invalidate", "rt_progressive_state", "rt_selftest", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
     "rt_parse_scene_string", "rt_load_cubemap", "rt_free_cubemap", "rt_decode_jpeg_file",
     "rt_camera_default", "rt_camera_basis_for", "rt_mouse_state_default", "rt_move_camera",
     "rt_rotate_camera", "rt_path_seed", "rt_set_frame_sink", "rt_move_frame_to_the_gpu", "rt_write_ppm",
@@ -94,6 +95,11 @@ def lib():
     L.rt_strip_rows.argtypes = [C.c_int, C.c_int, C.c_int]
     L.rt_deinterleave_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
     L.rt_synchronize.argtypes = [C.c_void_p]
+    L.rt_progressive_begin.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
+    L.rt_progressive_pass.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.rt_progressive_resolve.argtypes = [C.c_void_p, C.c_void_p]
+    L.rt_progressive_invalidate.argtypes = [C.c_void_p]
+    L.rt_progressive_state.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
     L.rt_selftest.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
     L.rt_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.rt_profile_collect.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -254,6 +260,29 @@ class Renderer:
         _check(lib().rt_deinterleave_device(self._ctx, C.c_void_p(strips_ptr), C.c_void_p(frame_ptr), width, height,
                                             row_block, world, C.c_void_p(stream) if stream else None),
                "rt_deinterleave_device")
+
+    # -- progressive accumulation (reference worker()/update_frame() protocol)
+    def progressive_begin(self, width, height, init_scale=8, max_bounces=10, seed=0):
+        _check(lib().rt_progressive_begin(self._ctx, width, height, init_scale, max_bounces, seed), "rt_progressive_begin")
+        self._prog_shape = (height, width, 3)
+
+    def progressive_pass(self):
+        w = C.c_float()
+        _check(lib().rt_progressive_pass(self._ctx, C.byref(w)), "rt_progressive_pass")
+        return w.value
+
+    def progressive_resolve(self):
+        out = np.empty(self._prog_shape, dtype=np.float32)
+        _check(lib().rt_progressive_resolve(self._ctx, out.ctypes.data_as(C.c_void_p)), "rt_progressive_resolve")
+        return out
+
+    def progressive_invalidate(self):
+        _check(lib().rt_progressive_invalidate(self._ctx), "rt_progressive_invalidate")
+
+    def progressive_state(self):
+        s, c, g, n = C.c_int(), C.c_float(), C.c_uint32(), C.c_int()
+        _check(lib().rt_progressive_state(self._ctx, C.byref(s), C.byref(c), C.byref(g), C.byref(n)), "rt_progressive_state")
+        return dict(next_scale=s.value, count=c.value, generation=g.value, passes=n.value)
 
     def selftest(self, which, seed=1, blocks=4096, iters=256):
         out = (C.c_ulonglong * 8)()

@@ -69,6 +69,17 @@ struct rt_context {
 	float       *d_frame = nullptr;      /* scratch for rt_render() */
 	size_t       frame_bytes = 0;
 
+	/* progressive accumulation (rt_progressive_*) */
+	struct {
+		bool     active = false;
+		int      width = 0, height = 0, init_scale = 1, scale = 1, max_bounces = 10, passes = 0;
+		uint64_t seed = 0;
+		float    count = 0;
+		uint32_t generation = 0;
+		float   *d_accum = nullptr, *d_low = nullptr, *d_out = nullptr;
+		size_t   accum_bytes = 0, low_bytes = 0;
+	} prog;
+
 	bool         profiling = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 	std::vector<hipEvent_t> event_pool;
@@ -122,6 +133,7 @@ void rt_destroy(rt_context *ctx)
 	for (auto &e : ctx->event_pool) (void) hipEventDestroy(e);
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
 	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame); (void) hipFree(ctx->d_counter);
+	(void) hipFree(ctx->prog.d_accum); (void) hipFree(ctx->prog.d_low); (void) hipFree(ctx->prog.d_out);
 	(void) hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -297,6 +309,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	L.num_objects = ctx->num_objects;
 	L.width = p->width; L.height = p->height;
 	L.spp = p->spp; L.max_bounces = p->max_bounces; L.seed = p->seed;
+	L.u_den = p->width - 1; L.v_den = p->height - 1; L.pix_scale = 1; L.pix_width = p->width; L.sample_base = 0;
 	L.row_block = p->row_block; L.rank = p->rank; L.world = p->world;
 	/* rows this rank owns: blocks rank, rank+world, ... ; the last one may be partial or absent */
 	{
@@ -350,6 +363,109 @@ int rt_deinterleave_device(rt_context *ctx, const void *d_strips, void *d_frame,
 	hipStream_t stream = hip_stream ? (hipStream_t) hip_stream : ctx->stream;
 	HIP_TRY(rt_launch_deinterleave((const float*) d_strips, (float*) d_frame, width, height, row_block, world,
 	                               rt_strip_rows(height, row_block, world), stream));
+	return RT_OK;
+}
+
+/* ---- progressive accumulation: worker() scale ladder + update_frame() (main.c:354-408, 450-482) ---- */
+
+int rt_progressive_begin(rt_context *ctx, int width, int height, int init_scale, int max_bounces, uint64_t seed)
+{
+	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_progressive_begin: NULL context");
+	if (init_scale != 1 && init_scale != 2 && init_scale != 4 && init_scale != 8 && init_scale != 16)
+		return fail(RT_ERR_ARGUMENT, "rt_progressive_begin: init_scale %d not in {1,2,4,8,16}", init_scale);   /* main.c:611-621 */
+	if (width / init_scale < 2 || height / init_scale < 2 || (int64_t) width * height > (int64_t) 1 << 30)
+		return fail(RT_ERR_ARGUMENT, "rt_progressive_begin: frame %dx%d too small for scale %d (or too large)", width, height, init_scale);
+	if (max_bounces < 1) return fail(RT_ERR_ARGUMENT, "rt_progressive_begin: max_bounces %d < 1", max_bounces);
+	HIP_TRY(hipSetDevice(ctx->device));
+	auto &g = ctx->prog;
+	const size_t accum_bytes = (size_t) width * height * 3 * sizeof(float);
+	const size_t low_bytes = (size_t) (width + 1) * height * 3 * sizeof(float);
+	if (accum_bytes != g.accum_bytes) {
+		(void) hipFree(g.d_accum); (void) hipFree(g.d_out); g.d_accum = g.d_out = nullptr; g.accum_bytes = 0;
+		HIP_TRY(hipMalloc((void**) &g.d_accum, accum_bytes));
+		HIP_TRY(hipMalloc((void**) &g.d_out, accum_bytes));
+		g.accum_bytes = accum_bytes;
+	}
+	if (low_bytes != g.low_bytes) {
+		(void) hipFree(g.d_low); g.d_low = nullptr; g.low_bytes = 0;
+		HIP_TRY(hipMalloc((void**) &g.d_low, low_bytes));
+		g.low_bytes = low_bytes;
+	}
+	g.width = width; g.height = height; g.init_scale = init_scale; g.max_bounces = max_bounces; g.seed = seed;
+	g.active = true;
+	return rt_progressive_invalidate(ctx);
+}
+
+/* invalidate_accumulation() (main.c:115-124): counts to zero, generation + 1, buffers cleared; the next
+ * pass starts again at init_scale (main.c:405-408). */
+int rt_progressive_invalidate(rt_context *ctx)
+{
+	if (!ctx || !ctx->prog.active) return fail(RT_ERR_STATE, "rt_progressive_invalidate: call rt_progressive_begin first");
+	HIP_TRY(hipSetDevice(ctx->device));
+	auto &g = ctx->prog;
+	HIP_TRY(hipMemsetAsync(g.d_accum, 0, g.accum_bytes, ctx->stream));
+	g.count = 0; g.passes = 0; g.scale = g.init_scale; g.generation++;
+	return RT_OK;
+}
+
+int rt_progressive_pass(rt_context *ctx, float *weight_out)
+{
+	if (!ctx || !ctx->prog.active) return fail(RT_ERR_STATE, "rt_progressive_pass: call rt_progressive_begin first");
+	if (!ctx->have_scene) return fail(RT_ERR_STATE, "render: no scene set (rt_set_scene)");
+	if (!ctx->have_sky)   return fail(RT_ERR_STATE, "render: no skybox set (rt_set_skybox)");
+	HIP_TRY(hipSetDevice(ctx->device));
+	auto &g = ctx->prog;
+	const int s = g.scale;
+	const int lw = g.width / s, lh = g.height / s, lcw = g.width / s + 1;     /* main.c:284-286 */
+
+	rt_launch L;
+	memset(&L, 0, sizeof(L));
+	rt_camera_basis basis;
+	rt_camera_basis_for(&ctx->camera, (float) g.width / g.height, &basis);      /* main.c:281: full-size aspect */
+	const Vector3 *src[4] = { &basis.pos, &basis.lower_left_corner, &basis.horizontal, &basis.vertical };
+	float *dst[4] = { L.pos, L.llc, L.horiz, L.vert };
+	for (int k = 0; k < 4; k++) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; }
+	L.light_index = ctx->light_index;
+	memcpy(L.light_pos, ctx->light_pos, sizeof(L.light_pos));
+	L.num_objects = ctx->num_objects;
+	L.width = lcw; L.height = lh; L.local_rows = lh;
+	L.spp = 1; L.max_bounces = g.max_bounces; L.seed = g.seed;
+	L.u_den = lw - 1; L.v_den = lh - 1; L.pix_scale = s; L.pix_width = g.width; L.sample_base = g.passes;
+	L.row_block = 8; L.rank = 0; L.world = 1;
+	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h;
+	L.frame = g.d_low;
+	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
+	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->d_counter, ctx->num_cus, ctx->stream));
+	const float weight = 1.0f / (s * s);                                         /* main.c:278 */
+	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), ctx->stream));
+	g.count += weight;                                                           /* main.c:396 */
+	g.passes++;
+	if (g.scale > 1) g.scale >>= 1;                                              /* main.c:402-403 */
+	if (weight_out) *weight_out = weight;
+	return RT_OK;
+}
+
+int rt_progressive_resolve(rt_context *ctx, Vector3 *frame_out)
+{
+	if (!ctx || !ctx->prog.active) return fail(RT_ERR_STATE, "rt_progressive_resolve: call rt_progressive_begin first");
+	if (!frame_out) return fail(RT_ERR_ARGUMENT, "rt_progressive_resolve: frame_out is NULL");
+	auto &g = ctx->prog;
+	if (g.count < 0.0001)                                                        /* update_frame() waits for this, main.c:462 */
+		return fail(RT_ERR_STATE, "rt_progressive_resolve: nothing accumulated yet");
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(rt_launch_resolve(g.d_accum, g.d_out, (size_t) g.width * g.height * 3, 1.0f / g.count, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(frame_out, g.d_out, g.accum_bytes, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return RT_OK;
+}
+
+int rt_progressive_state(rt_context *ctx, int *next_scale, float *count, uint32_t *generation, int *passes)
+{
+	if (!ctx || !ctx->prog.active) return fail(RT_ERR_STATE, "rt_progressive_state: call rt_progressive_begin first");
+	if (next_scale) *next_scale = ctx->prog.scale;
+	if (count) *count = ctx->prog.count;
+	if (generation) *generation = ctx->prog.generation;
+	if (passes) *passes = ctx->prog.passes;
 	return RT_OK;
 }
 

@@ -47,6 +47,11 @@ typedef struct {
 	int   width, height;       /* full frame                                   */
 	int   spp, max_bounces;
 	uint64_t seed;
+	/* pixel (i, j) of this launch: u = i / u_den, v = j / v_den (main.c:293-294: lowres_frame_w - 1,
+	 * lowres_frame_h - 1); its paths are seeded with pixel index (j*pix_scale)*pix_width + i*pix_scale
+	 * and sample index sample_base + s.  Full-resolution frame: u_den = width-1, v_den = height-1,
+	 * pix_scale = 1, pix_width = width, sample_base = 0. */
+	int   u_den, v_den, pix_scale, pix_width, sample_base;
 
 	/* interleaved row-block partition: local row r -> global row
 	 * ((r / row_block) * world + rank) * row_block + r % row_block          */

@@ -232,7 +232,7 @@ RT_DEV bool ball_entry_fast(V3 o, V3 d, const RayPrep &rp, V3 center, float r2, 
 	return true;
 }
 
-RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d)
+RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d, bool want_normal = true)
 {
 	const RayPrep rp = prepare_ray(d);
 	float best_t = 3.402823466e+38f;
@@ -248,7 +248,7 @@ RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d)
 		if (hit && t >= 0 && t < best_t) { best_t = t; best_obj = i; best_axis = axis; }
 	}
 	Hit best; best.t = best_t; best.obj = best_obj; best.n = mk3(0, 0, 0);
-	if (best_obj >= 0) {
+	if (best_obj >= 0 && want_normal) {   /* shadow taps only need the object (main.c:201-204) */
 		const float4 g0 = sc.geom[2 * best_obj], g1 = sc.geom[2 * best_obj + 1];
 		if (__float_as_int(g1.z) == RT_GEOM_CUBE) {
 			const float dc = best_axis == 0 ? d.x : (best_axis == 1 ? d.y : d.z);
@@ -329,18 +329,18 @@ rt_trace_simple(const rt_launch L)
 	if (j >= L.height) return;
 
 	/* main.c:293-296 at scale 1 */
-	float u = (float) i / (float) (L.width - 1);
-	float v = (float) j / (float) (L.height - 1);
+	float u = (float) i / (float) L.u_den;
+	float v = (float) j / (float) L.v_den;
 	u = 1.0f - u;
 	v = 1.0f - v;
 	const V3 cam = ld3(L.pos);
 	const V3 dir0 = primary_dir(L, u, v);
-	const uint32_t pixel_index = (uint32_t) (j * L.width + i);
+	const uint32_t pixel_index = (uint32_t) ((j * L.pix_scale) * L.pix_width + i * L.pix_scale);
 	const V3 light_pos = ld3(L.light_pos);
 
 	V3 sum = mk3(0, 0, 0);
 	for (int s = 0; s < L.spp; s++) {
-		uint64_t rng = path_seed(L.seed, pixel_index, (uint32_t) s);
+		uint64_t rng = path_seed(L.seed, pixel_index, (uint32_t) (L.sample_base + s));
 		V3 ro = cam, rd = dir0;
 		V3 carry = mk3(1, 1, 1), radiance = mk3(0, 0, 0);
 
@@ -519,9 +519,9 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 				const int j = global_row(L, lr);
 				if (i < L.width && lr < L.local_rows && j < L.height) {
 					px_i = i; px_lr = lr;
-					pixel_index = (uint32_t) (j * L.width + i);
-					float u = (float) i / (float) (L.width - 1);       /* main.c:293-296 */
-					float v = (float) j / (float) (L.height - 1);
+					pixel_index = (uint32_t) ((j * L.pix_scale) * L.pix_width + i * L.pix_scale);
+					float u = (float) i / (float) L.u_den;             /* main.c:293-296 */
+					float v = (float) j / (float) L.v_den;
 					u = 1.0f - u;
 					v = 1.0f - v;
 					prim_dir = primary_dir(L, u, v);
@@ -624,7 +624,7 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 					const V3 dn = unit3_sel<FAST>(mk3(W.q[3][slot], W.q[4][slot], W.q[5][slot]));   /* scene.c:158 */
 					const int meta = __float_as_int(W.q[6][slot]);
 					const int owner = meta & 255, rkind = meta >> 8;
-					const Hit hit = FAST ? nearest_hit_fast(sc, n, o, dn) : nearest_hit(sc, n, o, dn);
+					const Hit hit = FAST ? nearest_hit_fast(sc, n, o, dn, rkind == WF_KIND_MAIN) : nearest_hit(sc, n, o, dn);
 					if (rkind != WF_KIND_MAIN) {
 						W.tap[rkind - 1][owner] = hit.obj;
 					} else {
@@ -698,7 +698,7 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 			if (sample_done && !pixel_done) {
 				sample++;
 				if (sample < L.spp) {
-					rng = path_seed(L.seed, pixel_index, (uint32_t) sample);
+					rng = path_seed(L.seed, pixel_index, (uint32_t) (L.sample_base + sample));
 					carry = mk3(1, 1, 1); rad = mk3(0, 0, 0); bounce = 0;
 					hp = mk3(W.cache[0][lane], W.cache[1][lane], W.cache[2][lane]);
 					hn = mk3(W.cache[3][lane], W.cache[4][lane], W.cache[5][lane]);
@@ -717,6 +717,29 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 		}
 		wave_fence();
 	}
+}
+
+/* ---- progressive accumulation: worker()'s publish step (main.c:387-396) and update_frame()'s
+ * resolve (main.c:467-477) ------------------------------------------------------------------ */
+extern "C" __global__ void __launch_bounds__(RT_BLOCK)
+rt_accumulate(float *accum, const float *lowres, int width, int height, int scale, int low_w, int low_h, float k)
+{
+	const size_t total = (size_t) width * height;
+	for (size_t p = (size_t) blockIdx.x * RT_BLOCK + threadIdx.x; p < total; p += (size_t) gridDim.x * RT_BLOCK) {
+		const int y = (int) (p / (size_t) width), x = (int) (p % (size_t) width);
+		const int j = y / scale, i = x / scale;
+		if (j >= low_h) continue;             /* rows the low-resolution pass did not paint */
+		const float *c = lowres + ((size_t) j * low_w + i) * 3;
+		float *a = accum + p * 3;
+		a[0] = a[0] + c[0] * k; a[1] = a[1] + c[1] * k; a[2] = a[2] + c[2] * k;
+	}
+}
+
+extern "C" __global__ void __launch_bounds__(RT_BLOCK)
+rt_resolve(const float *accum, float *frame, size_t floats, float inv_count)
+{
+	for (size_t p = (size_t) blockIdx.x * RT_BLOCK + threadIdx.x; p < floats; p += (size_t) gridDim.x * RT_BLOCK)
+		frame[p] = accum[p] * inv_count;
 }
 
 /* ---- de-interleave: gathered per-rank strips -> full frame (multi-GPU root) ------------------- */
@@ -808,6 +831,19 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 		}
 	}
 	if (bad) atomicAdd(&out[0], bad);
+}
+
+hipError_t rt_launch_accumulate(float *accum, const float *lowres, int width, int height, int scale,
+                                int low_w, int low_h, float k, hipStream_t stream)
+{
+	hipLaunchKernelGGL(rt_accumulate, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, lowres, width, height, scale, low_w, low_h, k);
+	return hipGetLastError();
+}
+
+hipError_t rt_launch_resolve(const float *accum, float *frame, size_t floats, float inv_count, hipStream_t stream)
+{
+	hipLaunchKernelGGL(rt_resolve, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, frame, floats, inv_count);
+	return hipGetLastError();
 }
 
 hipError_t rt_launch_selftest(int which, uint64_t seed, int blocks, int iters, unsigned long long *d_out, hipStream_t stream)

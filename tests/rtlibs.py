@@ -401,3 +401,19 @@ class Ref:
 
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def oracle_progressive(o, W, H, init_scale, passes, max_bounces, seed):
+    """Drive Oracle.progressive passes like worker(): returns (frame, accum, count, next_scale)."""
+    import ctypes as C
+    o.L.orc_progressive_pass.restype = C.c_int
+    o.L.orc_progressive_pass.argtypes = [C.c_int] * 5 + [C.c_uint64, C.c_void_p, C.POINTER(C.c_float)]
+    o.L.orc_resolve.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]
+    accum = np.zeros((H, W, 3), np.float32)
+    count = C.c_float(0)
+    s = init_scale
+    for p in range(passes):
+        s = o.L.orc_progressive_pass(W, H, s, p, max_bounces, seed, accum.ctypes.data_as(C.c_void_p), C.byref(count))
+    frame = np.zeros((H, W, 3), np.float32)
+    o.L.orc_resolve(W, H, accum.ctypes.data_as(C.c_void_p), count, frame.ctypes.data_as(C.c_void_p))
+    return frame, accum, count.value, s

@@ -1,0 +1,62 @@
+"""Progressive accumulation (the reference's worker()/update_frame() protocol, main.c:354-408,450-482)
+on the GPU against the oracle's restatement of the same protocol; the oracle's scale ladder itself is
+pinned to the compiled reference in tests/test_oracle_vs_ref.py."""
+import numpy as np
+import pytest
+
+import ray_tracing_amd as rt
+from rtlibs import bits, oracle_progressive, synthetic_skybox
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("W,H,init_scale,passes", [(64, 32, 8, 6), (96, 48, 4, 5), (50, 30, 4, 4), (40, 24, 1, 3), (128, 64, 16, 7)])
+def test_progressive_matches_oracle(oracle, scene_paths, W, H, init_scale, passes):
+    sky = synthetic_skybox(32, seed=7)
+    g = rt.Renderer(0)
+    g.set_skybox(sky); oracle.set_skybox(sky)
+    for si in (0, 1):
+        g.set_scene(scene_paths[si]); oracle.load_scene(scene_paths[si])
+        g.progressive_begin(W, H, init_scale=init_scale, max_bounces=10, seed=5)
+        weights = [g.progressive_pass() for _ in range(passes)]
+        frame = g.progressive_resolve()
+        want, _, count, next_scale = oracle_progressive(oracle, W, H, init_scale, passes, 10, 5)
+        st = g.progressive_state()
+        assert st["passes"] == passes and st["next_scale"] == next_scale
+        assert np.float32(st["count"]) == np.float32(count) == np.float32(sum(np.float32(w) for w in weights))
+        assert (bits(frame) == bits(want)).all(), (si, W, H, init_scale)
+    g.close()
+
+
+def test_invalidate_restarts_the_ladder(oracle, scene_paths):
+    sky = synthetic_skybox(32, seed=7)
+    g = rt.Renderer(0)
+    g.set_skybox(sky); g.set_scene(scene_paths[0]); oracle.set_skybox(sky); oracle.load_scene(scene_paths[0])
+    g.progressive_begin(64, 32, init_scale=8, max_bounces=4, seed=1)
+    gen0 = g.progressive_state()["generation"]
+    for _ in range(5):
+        g.progressive_pass()
+    cam = dict(pos=(2, 3, 9), front=(0.1, -0.3, -1), up=(0, 1, 0), fov=30.0)
+    g.set_camera(**cam); oracle.set_camera(**cam)
+    g.progressive_invalidate()                      # invalidate_accumulation(), main.c:115-124
+    st = g.progressive_state()
+    assert st == dict(next_scale=8, count=0.0, generation=gen0 + 1, passes=0)
+    with pytest.raises(rt.RtError):                 # update_frame() would wait for a pass (main.c:462)
+        g.progressive_resolve()
+    for _ in range(3):
+        g.progressive_pass()
+    want, _, _, _ = oracle_progressive(oracle, 64, 32, 8, 3, 4, 1)
+    assert (bits(g.progressive_resolve()) == bits(want)).all()
+    oracle.set_camera(); g.close()
+
+
+def test_full_resolution_passes_equal_rt_render(scene_paths):
+    """With init_scale 1 the accumulated passes are the samples of rt_render(): same frame, bit for bit."""
+    sky = synthetic_skybox(32, seed=7)
+    g = rt.Renderer(0)
+    g.set_skybox(sky); g.set_scene(scene_paths[0])
+    g.progressive_begin(160, 90, init_scale=1, max_bounces=4, seed=9)
+    for _ in range(6):
+        g.progressive_pass()
+    assert (bits(g.progressive_resolve()) == bits(g.render(160, 90, 6, 4, seed=9))).all()
+    g.close()
