@@ -167,6 +167,10 @@ RT_API void rt_set_frame_sink(rt_frame_sink sink, void *user);
 RT_API void rt_move_frame_to_the_gpu(int w, int h, Vector3 *data);
 /* screenshot() main.c:637-681: float -> u8 by truncating *255, vertical flip; written as binary PPM */
 RT_API int  rt_write_ppm(const char *file, int w, int h, const Vector3 *data);
+/* the same conversion into an RGB8 PNG (what screenshot() produces through stb_image_write), and
+ * screenshot() itself: first free "screenshot_<n>.png" in the working directory (main.c:642-659) */
+RT_API int  rt_write_png(const char *file, int w, int h, const Vector3 *data);
+RT_API int  rt_screenshot(int w, int h, const Vector3 *data, char *name_out, size_t name_cap);
 
 #ifdef __cplusplus
 }

@@ -60,7 +60,7 @@ EXPORTS = [
     "rt_progressive_invalidate", "rt_progressive_state", "rt_selftest", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
     "rt_parse_scene_string", "rt_load_cubemap", "rt_free_cubemap", "rt_decode_jpeg_file",
     "rt_camera_default", "rt_camera_basis_for", "rt_mouse_state_default", "rt_move_camera",
-    "rt_rotate_camera", "rt_path_seed", "rt_set_frame_sink", "rt_move_frame_to_the_gpu", "rt_write_ppm",
+    "rt_rotate_camera", "rt_path_seed", "rt_set_frame_sink", "rt_move_frame_to_the_gpu", "rt_write_ppm", "rt_write_png", "rt_screenshot",
 ]
 
 _lib = None
@@ -117,6 +117,8 @@ def lib():
     L.rt_path_seed.restype = C.c_uint64
     L.rt_path_seed.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
     L.rt_write_ppm.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+    L.rt_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+    L.rt_screenshot.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_size_t]
     _lib = L
     return L
 

@@ -401,3 +401,112 @@ int rt_write_ppm(const char *file, int w, int h, const Vector3 *data)
 	fclose(fp);
 	return RT_OK;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* PNG sink -- screenshot() main.c:637-681                                                     */
+/* ------------------------------------------------------------------------------------------ */
+/* The reference hands an RGB8 buffer to stbi_write_png with a vertical flip.  The container here
+ * is a plain PNG with stored (uncompressed) deflate blocks: every decoder yields the same pixels
+ * stb's compressed stream would. */
+
+static uint32_t crc_table[256];
+
+static void crc_init(void)
+{
+	for (uint32_t n = 0; n < 256; n++) {
+		uint32_t c = n;
+		for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+		crc_table[n] = c;
+	}
+}
+
+static uint32_t crc_update(uint32_t c, const unsigned char *p, size_t n)
+{
+	for (size_t i = 0; i < n; i++) c = crc_table[(c ^ p[i]) & 0xff] ^ (c >> 8);
+	return c;
+}
+
+static void put32(unsigned char *p, uint32_t v) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; }
+
+static int chunk(FILE *fp, const char *tag, const unsigned char *data, size_t n)
+{
+	unsigned char head[8];
+	put32(head, (uint32_t) n);
+	memcpy(head + 4, tag, 4);
+	uint32_t c = crc_update(0xffffffffu, head + 4, 4);
+	c = crc_update(c, data, n) ^ 0xffffffffu;
+	unsigned char tail[4];
+	put32(tail, c);
+	return fwrite(head, 1, 8, fp) == 8 && fwrite(data, 1, n, fp) == n && fwrite(tail, 1, 4, fp) == 4;
+}
+
+int rt_write_png(const char *file, int w, int h, const Vector3 *data)
+{
+	if (!file || !data || w < 1 || h < 1) return RT_ERR_ARGUMENT;
+	if (!crc_table[1]) crc_init();
+	const size_t stride = (size_t) w * 3 + 1, raw_n = stride * (size_t) h;
+	unsigned char *raw = malloc(raw_n);
+	if (!raw) return RT_ERR_MEMORY;
+	for (int row = 0; row < h; row++) {
+		unsigned char *dst = raw + stride * (size_t) row;
+		const Vector3 *src = data + (size_t) (h - 1 - row) * w;        /* stbi_flip_vertically_on_write(1) */
+		*dst++ = 0;                                                    /* filter: none */
+		for (int i = 0; i < w; i++) {
+			*dst++ = (unsigned char) (src[i].x * 255);                 /* main.c:662-664: truncation */
+			*dst++ = (unsigned char) (src[i].y * 255);
+			*dst++ = (unsigned char) (src[i].z * 255);
+		}
+	}
+	/* zlib stream of stored blocks */
+	const size_t blocks = (raw_n + 65534) / 65535;
+	const size_t z_n = 2 + raw_n + 5 * blocks + 4;
+	unsigned char *z = malloc(z_n);
+	if (!z) { free(raw); return RT_ERR_MEMORY; }
+	size_t o = 0;
+	z[o++] = 0x78; z[o++] = 0x01;
+	uint32_t a = 1, b = 0;
+	for (size_t off = 0; off < raw_n; off += 65535) {
+		const size_t n = raw_n - off < 65535 ? raw_n - off : 65535;
+		z[o++] = off + n == raw_n;                                     /* BFINAL, BTYPE = 00 */
+		z[o++] = n & 0xff; z[o++] = n >> 8; z[o++] = ~n & 0xff; z[o++] = (~n >> 8) & 0xff;
+		memcpy(z + o, raw + off, n);
+		o += n;
+		for (size_t i = 0; i < n; i++) { a = (a + raw[off + i]) % 65521u; b = (b + a) % 65521u; }
+	}
+	put32(z + o, (b << 16) | a);
+	o += 4;
+
+	FILE *fp = fopen(file, "wb");
+	int ok = fp != NULL;
+	if (ok) {
+		static const unsigned char sig[8] = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n' };
+		unsigned char ihdr[13];
+		put32(ihdr, (uint32_t) w); put32(ihdr + 4, (uint32_t) h);
+		ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+		ok = fwrite(sig, 1, 8, fp) == 8 && chunk(fp, "IHDR", ihdr, 13) && chunk(fp, "IDAT", z, o) && chunk(fp, "IEND", NULL, 0);
+		ok = (fclose(fp) == 0) && ok;
+	}
+	free(raw); free(z);
+	return ok ? RT_OK : RT_ERR_IO;
+}
+
+/* main.c:642-659: first free "screenshot_<n>.png", n in [0, 1000) */
+int rt_screenshot(int w, int h, const Vector3 *data, char *name_out, size_t name_cap)
+{
+	char file[64];
+	int i = 0;
+	for (; i < 1000; i++) {
+		snprintf(file, sizeof(file), "screenshot_%d.png", i);
+		FILE *probe = fopen(file, "rb");
+		if (!probe) break;
+		fclose(probe);
+	}
+	if (i == 1000) return RT_ERR_IO;
+	int rc = rt_write_png(file, w, h, data);
+	if (rc == RT_OK) {
+		fprintf(stderr, "Took screenshot! (%s)\n", file);
+		if (name_out && name_cap) snprintf(name_out, name_cap, "%s", file);
+	} else
+		fprintf(stderr, "Could not take screenshot (write error)\n");
+	return rc;
+}

@@ -13,7 +13,7 @@
  *   --seed <n>           counter-mode seed
  *   --skybox <dir>       directory with {right,left,top,bottom,front,back}.jpg (default assets/skybox)
  *   --device <n>         GPU index
- *   --out <file.ppm>     where the presenter hook writes the frame (default frame.ppm)
+ *   --out <file>         where the presenter hook writes the frame: .png or .ppm (default frame.ppm)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -27,7 +27,9 @@ static const char *out_file = "frame.ppm";
 static void write_frame(int w, int h, Vector3 *data, void *user)
 {
 	(void) user;
-	int rc = rt_write_ppm(out_file, w, h, data);
+	size_t n = strlen(out_file);
+	int png = n > 4 && strcmp(out_file + n - 4, ".png") == 0;
+	int rc = png ? rt_write_png(out_file, w, h, data) : rt_write_ppm(out_file, w, h, data);
 	if (rc != RT_OK) fprintf(stderr, "Could not write %s (%d)\n", out_file, rc);
 	else             fprintf(stderr, "Wrote %s (%dx%d)\n", out_file, w, h);
 }

@@ -227,3 +227,54 @@ def test_frame_sink_and_ppm(tmp_path):
     px = np.frombuffer(raw[len(head):], np.uint8).reshape(H, W, 3)
     want = (frame * np.float32(255)).astype(np.uint8)[::-1]          # truncation + vertical flip (main.c:662-672)
     assert (px == want).all()
+
+
+def test_png_sink_and_screenshot_naming(tmp_path, monkeypatch):
+    from PIL import Image
+    L = rt.lib()
+    W, H = 37, 21                                  # > 64 KiB is exercised by the second image
+    rng = np.random.default_rng(0)
+    for (w, h) in ((W, H), (300, 200)):
+        frame = rng.random((h, w, 3), dtype=np.float32)
+        frame[0, 0] = (1.0, 0.0, 0.999999)
+        out = tmp_path / f"f{w}.png"
+        assert L.rt_write_png(str(out).encode(), w, h, frame.ctypes.data_as(C.c_void_p)) == 0
+        got = np.asarray(Image.open(out).convert("RGB"))
+        want = (frame * np.float32(255)).astype(np.uint8)[::-1]      # main.c:662-672
+        assert got.shape == want.shape and (got == want).all()
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "screenshot_0.png").write_bytes(b"taken")
+    name = C.create_string_buffer(64)
+    frame = np.zeros((4, 4, 3), np.float32)
+    assert L.rt_screenshot(4, 4, frame.ctypes.data_as(C.c_void_p), name, 64) == 0
+    assert name.value == b"screenshot_1.png" and (tmp_path / "screenshot_1.png").exists()
+
+
+def test_camera_interaction_matches_reference():
+    """rt_move_camera / rt_rotate_camera vs camera.c:42-88 of the compiled reference."""
+    from rtlibs import Ref, ref_available
+    if not ref_available():
+        pytest.skip("oracle/_ref not built here")
+    ref = Ref()
+    ref.L.ref_move_camera.argtypes = [C.c_int, C.c_float]
+    ref.L.ref_rotate_camera.argtypes = [C.c_double, C.c_double]
+    ref.L.ref_get_camera.argtypes = [C.c_void_p]
+    ref.set_camera(); ref.L.ref_reset_mouse()
+    L = rt.lib()
+    cam = rt.default_camera()
+    mouse = rt.MouseState()
+    L.rt_mouse_state_default(C.byref(mouse))
+    rng = np.random.default_rng(1)
+    x, y = 400.0, 300.0
+    for step in range(200):
+        if step % 3 == 0:
+            x += float(rng.normal() * 40); y += float(rng.normal() * 40)
+            ref.L.ref_rotate_camera(x, y); L.rt_rotate_camera(C.byref(cam), C.byref(mouse), x, y)
+        else:
+            d = int(rng.integers(4)); sp = float(np.float32(rng.uniform(0.01, 0.5)))
+            ref.L.ref_move_camera(d, sp); L.rt_move_camera(C.byref(cam), d, sp)
+        want = np.zeros(9, np.float32)
+        ref.L.ref_get_camera(want.ctypes.data_as(C.c_void_p))
+        got = np.array([cam.pos.x, cam.pos.y, cam.pos.z, cam.front.x, cam.front.y, cam.front.z, cam.up.x, cam.up.y, cam.up.z], np.float32)
+        assert (bits(got) == bits(want)).all(), step
+    ref.set_camera()
