@@ -52,6 +52,7 @@ struct rt_context {
 	int          num_objects = 0;
 	int          capacity = 0;
 	bool         have_scene = false;
+	bool         scene_fast_ok = false;  /* every cube has 0 <= size and all coordinates are finite, |x| <= 2^29 */
 	int          light_index = -1;
 	float        light_pos[3] = {0, 0, 0};
 
@@ -150,6 +151,8 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 	memset(geom.data(), 0, geom.size() * sizeof(rt_geom));
 	memset(shade.data(), 0, shade.size() * sizeof(rt_shade));
 	int light = -1;
+	bool fast_ok = true;
+	auto bounded = [](float x) { return x >= -0x1p+29f && x <= 0x1p+29f; };   /* false for NaN */
 	for (int i = 0; i < n; i++) {
 		const Object &o = scene->objects[i];
 		const Material &m = o.material;
@@ -160,10 +163,14 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 			g.b0 = o.cube.origin.x * 1.0f + o.cube.size.x * 1.0f;
 			g.b1 = o.cube.origin.y * 1.0f + o.cube.size.y * 1.0f;
 			g.b2 = o.cube.origin.z * 1.0f + o.cube.size.z * 1.0f;
+			/* the tuned slab test assumes lo <= hi (the loader enforces size >= 0, scene.c:593) */
+			fast_ok = fast_ok && g.a[0] <= g.b0 && g.a[1] <= g.b1 && g.a[2] <= g.b2 &&
+			          bounded(g.a[0]) && bounded(g.a[1]) && bounded(g.a[2]) && bounded(g.b0) && bounded(g.b1) && bounded(g.b2);
 		} else if (o.type == OBJECT_SPHERE) {
 			g.type = RT_GEOM_SPHERE;
 			g.a[0] = o.sphere.center.x; g.a[1] = o.sphere.center.y; g.a[2] = o.sphere.center.z;
 			g.b0 = o.sphere.radius * o.sphere.radius;
+			fast_ok = fast_ok && bounded(g.a[0]) && bounded(g.a[1]) && bounded(g.a[2]) && bounded(g.b0);
 		} else {
 			g.type = -1;   /* intersect_object() returns false for unknown types (scene.c:153) */
 		}
@@ -184,6 +191,7 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 		if (light < 0 && m.emission_power > 0) light = i;
 	}
 	ctx->light_index = light;
+	ctx->scene_fast_ok = fast_ok;
 	if (light >= 0) {
 		const Object &o = scene->objects[light];
 		if (o.type == OBJECT_SPHERE) {
@@ -326,7 +334,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (ctx->profiling) { e0 = take_event(ctx); e1 = take_event(ctx); HIP_TRY(hipEventRecord(e0, stream)); }
-	HIP_TRY(rt_launch_trace(L, p->kernel, ctx->d_counter, ctx->num_cus, stream));
+	HIP_TRY(rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->d_counter, ctx->num_cus, stream));
 	if (ctx->profiling) { HIP_TRY(hipEventRecord(e1, stream)); ctx->events.emplace_back(e0, e1); }
 	return RT_OK;
 }
@@ -435,7 +443,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h;
 	L.frame = g.d_low;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
-	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->d_counter, ctx->num_cus, ctx->stream));
+	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->d_counter, ctx->num_cus, ctx->stream));
 	const float weight = 1.0f / (s * s);                                         /* main.c:278 */
 	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), ctx->stream));
 	g.count += weight;                                                           /* main.c:396 */

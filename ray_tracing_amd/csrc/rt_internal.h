@@ -7,7 +7,7 @@
 
 size_t     rt_scene_lds_bytes(int num_objects);
 size_t     rt_wavefront_lds_bytes(int num_objects);
-hipError_t rt_launch_trace(const rt_launch &L, int variant, unsigned int *block_counter, int num_cus, hipStream_t stream);
+hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, unsigned int *block_counter, int num_cus, hipStream_t stream);
 hipError_t rt_launch_deinterleave(const float *strips, float *frame, int width, int height,
                                   int row_block, int world, int rows_per_rank, hipStream_t stream);
 

@@ -145,10 +145,11 @@ struct RayPrep {
 	bool   den_ok;
 };
 
-RT_DEV RayPrep prepare_ray(V3 d)
+RT_DEV RayPrep prepare_ray(V3 o, V3 d)
 {
 	RayPrep p;
-	p.inv_ok = den_in_window(d.x) && den_in_window(d.y) && den_in_window(d.z);
+	const float omax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z));
+	p.inv_ok = den_in_window(d.x) && den_in_window(d.y) && den_in_window(d.z) && omax <= 0x1p+29f;
 	p.inv = mk3(rcp_refined(d.x), rcp_refined(d.y), rcp_refined(d.z));
 	p.dd = dot3(d, d);
 	p.den = (double) (2.0f * p.dd);
@@ -162,29 +163,31 @@ RT_DEV bool wave_all(bool ok) { return __ballot(!ok) == 0ull; }
 RT_DEV bool box_entry_fast(V3 o, V3 d, const RayPrep &rp, V3 lo, V3 hi, float &t_entry, int &axis_out)
 {
 	const float n0 = lo.x - o.x, n1 = hi.x - o.x, n2 = lo.y - o.y, n3 = hi.y - o.y, n4 = lo.z - o.z, n5 = hi.z - o.z;
-	const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(n0), __builtin_fabsf(n1)),
-	                                                   __builtin_fmaxf(__builtin_fabsf(n2), __builtin_fabsf(n3))),
-	                                   __builtin_fmaxf(__builtin_fabsf(n4), __builtin_fabsf(n5)));
 	const float amin = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fabsf(n0), __builtin_fabsf(n1)),
 	                                                   __builtin_fminf(__builtin_fabsf(n2), __builtin_fabsf(n3))),
 	                                   __builtin_fminf(__builtin_fabsf(n4), __builtin_fabsf(n5)));
-	float ax, bx, ay, by, az, bz;
 	STAT(1);
-#ifdef RT_STATS
-	if (!wave_all(rp.inv_ok)) STAT(18);
-	if (!wave_all(amin >= 0x1p-100f)) STAT(19);
-	if (!wave_all(amax <= 0x1p+30f)) STAT(20);
-	if (!wave_all(amin > 0.0f)) STAT(21);
-	if (!(amin > 0.0f) && rt_stats[50] < 40) { unsigned long long k = atomicAdd(&rt_stats[50], 1ull); if (k < 4) { unsigned long long *p = &rt_stats[51 + 3 * k]; p[0] = ((unsigned long long) __float_as_uint(o.x) << 32) | __float_as_uint(o.y); p[1] = ((unsigned long long) __float_as_uint(o.z) << 32) | __float_as_uint(lo.x); p[2] = ((unsigned long long) __float_as_uint(lo.y) << 32) | __float_as_uint(hi.y); } }
-#endif
-	if (wave_all(rp.inv_ok && amin >= 0x1p-100f && amax <= 0x1p+30f)) {
-		ax = div_by_refined(n0, d.x, rp.inv.x); bx = div_by_refined(n1, d.x, rp.inv.x);
-		ay = div_by_refined(n2, d.y, rp.inv.y); by = div_by_refined(n3, d.y, rp.inv.y);
-		az = div_by_refined(n4, d.z, rp.inv.z); bz = div_by_refined(n5, d.z, rp.inv.z);
-	} else {
-		STAT(2);
-		ax = n0 / d.x; bx = n1 / d.x; ay = n2 / d.y; by = n3 / d.y; az = n4 / d.z; bz = n5 / d.z;
+	/* |numerators| <= 2^30 is guaranteed per ray (origin checked in prepare_ray) and per scene (plane
+	 * coordinates checked by rt_set_scene); zero / tiny numerators are what is left to test here. */
+	if (wave_all(rp.inv_ok && amin >= 0x1p-100f)) {
+		const float ax = div_by_refined(n0, d.x, rp.inv.x), bx = div_by_refined(n1, d.x, rp.inv.x);
+		const float ay = div_by_refined(n2, d.y, rp.inv.y), by = div_by_refined(n3, d.y, rp.inv.y);
+		const float az = div_by_refined(n4, d.z, rp.inv.z), bz = div_by_refined(n5, d.z, rp.inv.z);
+		/* All six quotients are finite here, and lo <= hi (checked by rt_set_scene), so the reference's
+		 * sign-ordered pairs (scene.c:31-59) are (min, max) and its two overlap tests (scene.c:47,61) are
+		 * "the three parameter intervals intersect": max of the entries <= min of the exits. */
+		const float nx = __builtin_fminf(ax, bx), fx = __builtin_fmaxf(ax, bx);
+		const float ny = __builtin_fminf(ay, by), fy = __builtin_fmaxf(ay, by);
+		const float nz = __builtin_fminf(az, bz), fz = __builtin_fmaxf(az, bz);
+		const float nxy = __builtin_fmaxf(nx, ny);
+		const float tn = __builtin_fmaxf(nxy, nz);
+		const float tf = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+		axis_out = nz > nxy ? 2 : (ny > nx ? 1 : 0);         /* strict: ties keep the earlier axis (scene.c:50,64) */
+		t_entry = tn;
+		return tn <= tf;
 	}
+	STAT(2);
+	const float ax = n0 / d.x, bx = n1 / d.x, ay = n2 / d.y, by = n3 / d.y, az = n4 / d.z, bz = n5 / d.z;
 	const float nx = d.x >= 0 ? ax : bx, fx = d.x >= 0 ? bx : ax;
 	const float ny = d.y >= 0 ? ay : by, fy = d.y >= 0 ? by : ay;
 	const float nz = d.z >= 0 ? az : bz, fz = d.z >= 0 ? bz : az;
@@ -234,7 +237,7 @@ RT_DEV bool ball_entry_fast(V3 o, V3 d, const RayPrep &rp, V3 center, float r2, 
 
 RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d, bool want_normal = true)
 {
-	const RayPrep rp = prepare_ray(d);
+	const RayPrep rp = prepare_ray(o, d);
 	float best_t = 3.402823466e+38f;
 	int best_obj = -1, best_axis = 0;
 	for (int i = 0; i < n; i++) {
@@ -871,7 +874,7 @@ size_t rt_scene_lds_bytes(int num_objects) { return (size_t) num_objects * (size
 
 size_t rt_wavefront_lds_bytes(int num_objects) { return rt_scene_lds_bytes(num_objects) + (RT_BLOCK / 64) * sizeof(WaveLDS); }
 
-hipError_t rt_launch_trace(const rt_launch &L, int variant, unsigned int *block_counter, int num_cus, hipStream_t stream)
+hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, unsigned int *block_counter, int num_cus, hipStream_t stream)
 {
 	if (L.local_rows <= 0 || L.width <= 0) return hipSuccess;
 	const bool simple = variant == 1 /* RT_KERNEL_SIMPLE */ || L.max_bounces < 1;
@@ -894,7 +897,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, unsigned int *block_
 	if (grid < 1) grid = 1;
 	hipError_t e = hipMemsetAsync(block_counter, 0, sizeof(unsigned int), stream);
 	if (e != hipSuccess) return e;
-	if (variant == 2 /* RT_KERNEL_WAVEFRONT: same schedule, plain IEEE operations */)
+	if (variant == 2 /* RT_KERNEL_WAVEFRONT: same schedule, plain IEEE operations */ || !scene_fast_ok)
 		hipLaunchKernelGGL(rt_trace_wavefront<false>, dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, L, block_counter);
 	else
 		hipLaunchKernelGGL(rt_trace_wavefront<true>, dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, L, block_counter);

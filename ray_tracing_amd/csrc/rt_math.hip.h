@@ -126,7 +126,18 @@ RT_DEV V3 unit3_fast(V3 v)
 
 /* ---- RNG: utils.c:60-75 ---------------------------------------------------------------- */
 
-RT_DEV uint64_t fold_mul(uint64_t a, uint64_t b) { return __umul64hi(a, b) ^ (a * b); }
+/* hi64(a*b) ^ lo64(a*b) with the four 32x32 partial products formed once (each line is one
+ * v_mad_u64_u32); written out because `__umul64hi(a,b) ^ (a*b)` makes the compiler form them twice */
+RT_DEV uint64_t fold_mul(uint64_t a, uint64_t b)
+{
+	const uint32_t a0 = (uint32_t) a, a1 = (uint32_t) (a >> 32), b0 = (uint32_t) b, b1 = (uint32_t) (b >> 32);
+	const uint64_t p0 = (uint64_t) a0 * b0;
+	const uint64_t p1 = (uint64_t) a0 * b1 + (p0 >> 32);
+	const uint64_t p2 = (uint64_t) a1 * b0 + (uint32_t) p1;
+	const uint64_t hi = (uint64_t) a1 * b1 + (p1 >> 32) + (p2 >> 32);
+	const uint64_t lo = (uint64_t) (uint32_t) p0 | (p2 << 32);
+	return hi ^ lo;
+}
 
 RT_DEV float rng_draw(uint64_t &state)
 {
