@@ -449,13 +449,15 @@ rt_trace_simple(const rt_launch L)
  * ============================================================================================= */
 
 #define WF_QUEUE   128                 /* ring: at most 63 left over + 64 pushed at a time */
-#define WF_KIND_MAIN 0                 /* kinds 1..3 = shadow tap k-1 */
+#define WF_KIND_PRIMARY 0              /* camera ray of pixel `owner` of the wave's current 8x8 block */
+#define WF_KIND_MAIN    1              /* next bounce ray of lane `owner`; kinds 2..4 = its shadow tap 0..2 */
 
 struct WaveLDS {
 	float q[7][WF_QUEUE];              /* ray queue SoA: o.xyz, d.xyz (un-normalised), meta         */
-	float res[7][64];                  /* bounce/primary result per owner lane: xyz, nxyz, obj      */
+	float res[7][64];                  /* bounce-ray result per owner lane: xyz, nxyz, obj          */
 	int   tap[3][64];                  /* shadow tap results per owner lane: object index or -1     */
-	float cache[10][64];               /* per-lane primary hit: point, normal, obj, primary dir     */
+	float blk[7][64];                  /* primary hits of the current pixel block, by pixel in block */
+	float cache[7][64];                /* per-lane copy of its pixel's primary hit                  */
 };
 
 RT_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
@@ -480,9 +482,12 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 	const bool have_light = L.light_index >= 0;
 	const float inv_spp = 1.0f / (float) L.spp;
 
-	/* wave-uniform pixel supply */
+	/* wave-uniform pixel supply: the wave owns one 8x8 pixel block at a time.  When it takes a new
+	 * block it traces all 64 camera rays at once (one full, homogeneous batch) into W.blk; lanes then
+	 * take pixels of the block as they become free and start from the stored hit. */
 	unsigned int cur_block = 0xffffffffu;   /* block being handed out */
-	int cur_next = 64;                      /* next pixel of cur_block to hand out (64 = none left) */
+	int  cur_next = 64;                     /* next pixel of cur_block to hand out (64 = none left) */
+	bool blk_ready = false;                 /* W.blk holds cur_block's primary hits */
 	bool exhausted = false;
 
 	/* per-lane path state */
@@ -491,58 +496,92 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 	int   sample = 0, bounce = 0;
 	bool  has_hit = false;
 	V3    sum = mk3(0, 0, 0), carry = mk3(1, 1, 1), rad = mk3(0, 0, 0);
-	V3    hp = mk3(0, 0, 0), hn = mk3(0, 0, 0), hdir = mk3(0, 0, 0);
+	V3    hp = mk3(0, 0, 0), hn = mk3(0, 0, 0), hdir = mk3(0, 0, 0), pdir = mk3(0, 0, 0);
 	int   hobj = -1;
 	uint64_t rng = 0;
 
 	for (;;) {
-		/* ---- 1. hand pixels to idle lanes ----------------------------------------------- */
-		bool want = px_lr < 0;
-		bool primary = false;
-		V3 prim_dir = mk3(0, 0, 0);
-		for (int attempt = 0; attempt < 2; attempt++) {
+		/* ---- 1. pixel supply --------------------------------------------------------------- */
+		bool fetched = false;                   /* a block was taken this round: trace its camera rays */
+		bool prim_on = false;
+		V3   prim_d = mk3(0, 0, 0);
+		for (int attempt = 0; attempt < 4; attempt++) {
+			const bool want = px_lr < 0;
 			const unsigned long long wmask = __ballot(want);
 			if (wmask == 0ull) break;
 			if (cur_next >= 64) {
-				if (exhausted) break;
+				if (exhausted || fetched) break;
 				unsigned int b = 0;
 				if (lane == 0) b = atomicAdd(block_counter, 1u);
 				b = (unsigned int) __builtin_amdgcn_readfirstlane((int) b);
 				if (b >= num_blocks) { exhausted = true; break; }
-				cur_block = b; cur_next = 0;
+				cur_block = b; cur_next = 0; blk_ready = false; fetched = true;
+				const int i = (int) (cur_block % (unsigned int) tiles_x) * 8 + (lane & 7);
+				const int lr = (int) (cur_block / (unsigned int) tiles_x) * 8 + (lane >> 3);
+				const int j = global_row(L, lr);
+				prim_on = i < L.width && lr < L.local_rows && j < L.height;
+				if (prim_on) {
+					float u = (float) i / (float) L.u_den;                 /* main.c:293-296 */
+					float v = (float) j / (float) L.v_den;
+					u = 1.0f - u;
+					v = 1.0f - v;
+					prim_d = primary_dir(L, u, v);
+				} else
+					W.blk[6][lane] = __int_as_float(-2);                   /* outside the frame */
 			}
+			if (!blk_ready) break;                                         /* hits arrive with this round's trace */
 			const int rank_in = __builtin_amdgcn_mbcnt_hi((unsigned int) (wmask >> 32),
 			                    __builtin_amdgcn_mbcnt_lo((unsigned int) wmask, 0u));
 			const int avail = 64 - cur_next;
 			if (want && rank_in < avail) {
 				const int q = cur_next + rank_in;
-				const int i = (int) (cur_block % (unsigned int) tiles_x) * 8 + (q & 7);
-				const int lr = (int) (cur_block / (unsigned int) tiles_x) * 8 + (q >> 3);
-				want = false;
-				const int j = global_row(L, lr);
-				if (i < L.width && lr < L.local_rows && j < L.height) {
-					px_i = i; px_lr = lr;
-					pixel_index = (uint32_t) ((j * L.pix_scale) * L.pix_width + i * L.pix_scale);
-					float u = (float) i / (float) L.u_den;             /* main.c:293-296 */
-					float v = (float) j / (float) L.v_den;
-					u = 1.0f - u;
-					v = 1.0f - v;
-					prim_dir = primary_dir(L, u, v);
-					primary = true;
+				const int obj = __float_as_int(W.blk[6][q]);
+				if (obj != -2) {
+					const int i = (int) (cur_block % (unsigned int) tiles_x) * 8 + (q & 7);
+					const int lr = (int) (cur_block / (unsigned int) tiles_x) * 8 + (q >> 3);
+					const V3 a = mk3(W.blk[0][q], W.blk[1][q], W.blk[2][q]);
+					if (obj < 0) {
+						/* sky-only pixel: every sample is clamp(0 + sky * 1) (main.c:171,267-269), summed
+						 * in sample order and resolved (main.c:394,476) */
+						const V3 c = mk3(clamp01(a.x), clamp01(a.y), clamp01(a.z));
+						V3 acc = mk3(0, 0, 0);
+						for (int k = 0; k < L.spp; k++) acc = add3(acc, c);
+						const V3 res = scale3(acc, inv_spp);
+						float *dst = L.frame + ((size_t) lr * L.width + i) * 3;
+						dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+					} else {
+						const int j = global_row(L, lr);
+						px_i = i; px_lr = lr;
+						pixel_index = (uint32_t) ((j * L.pix_scale) * L.pix_width + i * L.pix_scale);
+						float u = (float) i / (float) L.u_den;
+						float v = (float) j / (float) L.v_den;
+						u = 1.0f - u;
+						v = 1.0f - v;
+						pdir = primary_dir(L, u, v);
+						const V3 nn = mk3(W.blk[3][q], W.blk[4][q], W.blk[5][q]);
+						W.cache[0][lane] = a.x;  W.cache[1][lane] = a.y;  W.cache[2][lane] = a.z;
+						W.cache[3][lane] = nn.x; W.cache[4][lane] = nn.y; W.cache[5][lane] = nn.z;
+						W.cache[6][lane] = __int_as_float(obj);
+						sample = 0; bounce = 0; sum = mk3(0, 0, 0);
+						rng = path_seed(L.seed, pixel_index, (uint32_t) L.sample_base);
+						carry = mk3(1, 1, 1); rad = mk3(0, 0, 0);
+						hp = a; hn = nn; hobj = obj; hdir = pdir;
+						has_hit = true;
+					}
 				}
 			}
 			const int taken = __popcll(wmask);
 			cur_next += taken < avail ? taken : avail;
 		}
-		if (__ballot(px_lr >= 0) == 0ull) {
-			if (exhausted) break;
-			continue;                      /* e.g. a block of out-of-frame pixels: fetch again */
+		if (!fetched && __ballot(px_lr >= 0) == 0ull) {
+			if (exhausted && cur_next >= 64) break;
+			continue;                          /* sky / out-of-frame pixels only so far: hand out more */
 		}
 
 		/* ---- 2. shade the pending hit of every live path (main.c:180-261) ------------------- */
 		int  tapmask = 0;
-		bool emit_main = primary;
-		V3   ray_o = cam, ray_d = prim_dir;
+		bool emit_main = false;
+		V3   ray_o = cam, ray_d = prim_d;
 		V3   tap_d0 = mk3(0, 0, 0), tap_d1 = mk3(0, 0, 0), tap_d2 = mk3(0, 0, 0);
 		STAT(7);
 		if (has_hit) {
@@ -597,13 +636,15 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 		 * waves); the remainder is flushed after the last kind -------------------------------------- */
 		int q_head = 0, q_tail = 0;
 #pragma unroll 1
-		for (int kind = 0; kind < 5; kind++) {
-			if (kind < 4) {
+		for (int kind = 0; kind < 6; kind++) {
+			if (kind < 5) {
 				bool on = emit_main;
 				V3 qo = ray_o, qd = ray_d;
-				if (kind > 0) {
-					on = (tapmask >> (kind - 1)) & 1;
-					qd = kind == 1 ? tap_d0 : (kind == 2 ? tap_d1 : tap_d2);
+				if (kind == WF_KIND_PRIMARY) {
+					on = prim_on; qo = cam; qd = prim_d;
+				} else if (kind > WF_KIND_MAIN) {
+					on = (tapmask >> (kind - 2)) & 1;
+					qd = kind == 2 ? tap_d0 : (kind == 3 ? tap_d1 : tap_d2);
 					qo = madd3(hp, qd, 0.001f);                                      /* main.c:198 */
 				}
 				const unsigned long long m = __ballot(on);
@@ -617,7 +658,7 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 				q_tail += __popcll(m);
 				wave_fence();
 			}
-			while (q_tail - q_head >= 64 || (kind == 4 && q_tail > q_head)) {
+			while (q_tail - q_head >= 64 || (kind == 5 && q_tail > q_head)) {
 				const int count = q_tail - q_head < 64 ? q_tail - q_head : 64;
 				STAT(12);
 				if (lane < count) {
@@ -627,16 +668,17 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 					const V3 dn = unit3_sel<FAST>(mk3(W.q[3][slot], W.q[4][slot], W.q[5][slot]));   /* scene.c:158 */
 					const int meta = __float_as_int(W.q[6][slot]);
 					const int owner = meta & 255, rkind = meta >> 8;
-					const Hit hit = FAST ? nearest_hit_fast(sc, n, o, dn, rkind == WF_KIND_MAIN) : nearest_hit(sc, n, o, dn);
-					if (rkind != WF_KIND_MAIN) {
-						W.tap[rkind - 1][owner] = hit.obj;
+					const Hit hit = FAST ? nearest_hit_fast(sc, n, o, dn, rkind <= WF_KIND_MAIN) : nearest_hit(sc, n, o, dn);
+					if (rkind > WF_KIND_MAIN) {
+						W.tap[rkind - 2][owner] = hit.obj;
 					} else {
 						V3 a, b = hit.n;
 						if (hit.obj >= 0) a = madd3(o, dn, hit.t);                   /* scene.c:186 */
 						else            { STAT(14); a = sky_lookup(L, dn); }         /* main.c:170  */
-						W.res[0][owner] = a.x; W.res[1][owner] = a.y; W.res[2][owner] = a.z;
-						W.res[3][owner] = b.x; W.res[4][owner] = b.y; W.res[5][owner] = b.z;
-						W.res[6][owner] = __int_as_float(hit.obj);
+						float (*dst)[64] = rkind == WF_KIND_PRIMARY ? W.blk : W.res;
+						dst[0][owner] = a.x; dst[1][owner] = a.y; dst[2][owner] = a.z;
+						dst[3][owner] = b.x; dst[4][owner] = b.y; dst[5][owner] = b.z;
+						dst[6][owner] = __int_as_float(hit.obj);
 					}
 				}
 				q_head += count;
@@ -645,60 +687,42 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 		}
 
 		/* ---- 5. consume results ------------------------------------------------------------- */
+		if (fetched) blk_ready = true;
 		STAT(16);
 		if (px_lr >= 0) {
 			STAT(17);
-			bool sample_done = false, pixel_done = false;
-			if (primary) {
+			bool sample_done = false;
+			if (tapmask) {
+				V3 lit = mk3(0, 0, 0);
+				int taps = 0;
+#pragma unroll
+				for (int k = 0; k < 3; k++)
+					if ((tapmask >> k) & 1) {
+						const int obj = W.tap[k][lane];
+						if (obj >= 0) { const float4 e = sc.shade[4 * obj + 3]; lit = add3(lit, mk3(e.x, e.y, e.z)); }
+						taps++;
+					}
+				lit = scale3(lit, 1.0f / (float) taps);                          /* main.c:208-209 */
+				if (!(tiny_f(lit.x) && tiny_f(lit.y) && tiny_f(lit.z))) {        /* main.c:257-261 */
+					const float w = 0.05f;
+					rad = madd3(rad, had3(lit, carry), w);
+					carry = scale3(carry, 1.0f - w);
+				}
+			}
+			if (emit_main) {
 				const int obj = __float_as_int(W.res[6][lane]);
 				const V3 a = mk3(W.res[0][lane], W.res[1][lane], W.res[2][lane]);
 				if (obj < 0) {
-					/* sky-only pixel: every sample is clamp(0 + sky * 1) (main.c:171,267-269) */
-					const V3 c = mk3(clamp01(a.x), clamp01(a.y), clamp01(a.z));
-					for (int s = 0; s < L.spp; s++) sum = add3(sum, c);
-					pixel_done = true;
+					rad = add3(rad, had3(a, carry));                             /* main.c:171 */
+					sample_done = true;
 				} else {
-					W.cache[0][lane] = a.x; W.cache[1][lane] = a.y; W.cache[2][lane] = a.z;
-					W.cache[3][lane] = W.res[3][lane]; W.cache[4][lane] = W.res[4][lane]; W.cache[5][lane] = W.res[5][lane];
-					W.cache[6][lane] = __int_as_float(obj);
-					W.cache[7][lane] = prim_dir.x; W.cache[8][lane] = prim_dir.y; W.cache[9][lane] = prim_dir.z;
-					sample = -1;
-					sample_done = true;            /* falls into "start next sample" with sample 0 */
+					hp = a; hn = mk3(W.res[3][lane], W.res[4][lane], W.res[5][lane]); hobj = obj;
+					has_hit = true;
 				}
-			} else {
-				if (tapmask) {
-					V3 lit = mk3(0, 0, 0);
-					int taps = 0;
-#pragma unroll
-					for (int k = 0; k < 3; k++)
-						if ((tapmask >> k) & 1) {
-							const int obj = W.tap[k][lane];
-							if (obj >= 0) { const float4 e = sc.shade[4 * obj + 3]; lit = add3(lit, mk3(e.x, e.y, e.z)); }
-							taps++;
-						}
-					lit = scale3(lit, 1.0f / (float) taps);                          /* main.c:208-209 */
-					if (!(tiny_f(lit.x) && tiny_f(lit.y) && tiny_f(lit.z))) {        /* main.c:257-261 */
-						const float w = 0.05f;
-						rad = madd3(rad, had3(lit, carry), w);
-						carry = scale3(carry, 1.0f - w);
-					}
-				}
-				if (emit_main) {
-					const int obj = __float_as_int(W.res[6][lane]);
-					const V3 a = mk3(W.res[0][lane], W.res[1][lane], W.res[2][lane]);
-					if (obj < 0) {
-						rad = add3(rad, had3(a, carry));                             /* main.c:171 */
-						sample_done = true;
-					} else {
-						hp = a; hn = mk3(W.res[3][lane], W.res[4][lane], W.res[5][lane]); hobj = obj;
-						has_hit = true;
-					}
-				} else
-					sample_done = true;            /* bounce limit (main.c:158) */
-				if (sample_done)
-					sum = add3(sum, mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z)));   /* main.c:267-269,394 */
-			}
-			if (sample_done && !pixel_done) {
+			} else
+				sample_done = true;                /* bounce limit (main.c:158) */
+			if (sample_done) {
+				sum = add3(sum, mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z)));   /* main.c:267-269,394 */
 				sample++;
 				if (sample < L.spp) {
 					rng = path_seed(L.seed, pixel_index, (uint32_t) (L.sample_base + sample));
@@ -706,16 +730,14 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 					hp = mk3(W.cache[0][lane], W.cache[1][lane], W.cache[2][lane]);
 					hn = mk3(W.cache[3][lane], W.cache[4][lane], W.cache[5][lane]);
 					hobj = __float_as_int(W.cache[6][lane]);
-					hdir = mk3(W.cache[7][lane], W.cache[8][lane], W.cache[9][lane]);
+					hdir = pdir;
 					has_hit = true;
-				} else
-					pixel_done = true;
-			}
-			if (pixel_done) {
-				const V3 res = scale3(sum, inv_spp);                                 /* main.c:476 */
-				float *dst = L.frame + ((size_t) px_lr * L.width + px_i) * 3;
-				dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
-				px_lr = -1; sum = mk3(0, 0, 0); has_hit = false;
+				} else {
+					const V3 res = scale3(sum, inv_spp);                         /* main.c:476 */
+					float *dst = L.frame + ((size_t) px_lr * L.width + px_i) * 3;
+					dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+					px_lr = -1; has_hit = false;
+				}
 			}
 		}
 		wave_fence();
