@@ -202,6 +202,23 @@ RT_DEV bool box_entry_fast(V3 o, V3 d, const RayPrep &rp, V3 lo, V3 hi, float &t
 	return !(miss_xy || miss_z);
 }
 
+/* sqrt of a double that came from a positive float (>= 2^-149, <= 2^128): the rsq-seeded Goldschmidt/
+ * Newton sequence hipcc emits for an IEEE fp64 sqrt, without the input rescaling and class checks it
+ * needs for arguments near the ends of the double range.  Same operations in the same order, so the same
+ * (correctly rounded) result; rt_selftest(3) compares it with __builtin_sqrt on 10^9 arguments. */
+RT_DEV double sqrt_of_float64(double x)
+{
+	const double y = __builtin_amdgcn_rsq(x);
+	double g = x * y;
+	double h = 0.5 * y;
+	const double r = __builtin_fma(-h, g, 0.5);
+	g = __builtin_fma(g, r, g);
+	h = __builtin_fma(h, r, h);
+	g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+	g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+	return g;
+}
+
 RT_DEV bool ball_entry_fast(V3 o, V3 d, const RayPrep &rp, V3 center, float r2, float &t_entry)
 {
 	const V3 oc = sub3(center, o);
@@ -211,24 +228,31 @@ RT_DEV bool ball_entry_fast(V3 o, V3 d, const RayPrep &rp, V3 center, float r2, 
 	STAT(3);
 	if (!(discr > 0)) return false;
 	STAT(4);
-	const double root = __builtin_sqrt((double) discr);
 	const double nb = (double) -b;
-	const double num_lo = nb - root, num_hi = nb + root;
-	const double alo = __builtin_fabs(num_lo), ahi = __builtin_fabs(num_hi);
-	float r_small, r_large;
-	if (wave_all(rp.den_ok && alo >= 0x1p-300 && alo <= 0x1p+300 && ahi >= 0x1p-300 && ahi <= 0x1p+300)) {
-		r_small = (float) div_by_refined64(num_lo, rp.den, rp.rden);
-		if (r_small >= 0) { t_entry = r_small; return true; }
-		STAT(5);
-		r_large = (float) div_by_refined64(num_hi, rp.den, rp.rden);
-		if (r_large < 0) return false;
-		t_entry = r_large;
-		return true;
+	/* The two numerators.  Each is +0 or at least 2^-127 in magnitude (a float minus a double of similar
+	 * size), far inside the window where div_by_refined64 is exact, and 2a > 0, so the smaller root is the
+	 * one with `- root` and its sign is the numerator's: the reference's sort-then-pick (scene.c:119-127)
+	 * reduces to "the small root if it is >= 0, else the large one if that is >= 0".  Only one quotient is
+	 * formed.  (A negative numerator above -2^-100 -- whose quotient could round to -0.0f, which the
+	 * reference would accept -- is left to the reference-order path, like an out-of-window 2a.) */
+	if (wave_all(rp.den_ok && discr <= 0x1p+120f)) {
+		const double root = sqrt_of_float64((double) discr);
+		const double num_lo = nb - root;
+		if (wave_all(num_lo >= 0.0 || num_lo <= -0x1p-100)) {
+			const bool small_ok = num_lo >= 0.0;
+			const double num = small_ok ? num_lo : nb + root;
+			const float t = (float) div_by_refined64(num, rp.den, rp.rden);
+			if (!small_ok) STAT(5);
+			if (!small_ok && t < 0) return false;
+			t_entry = t;
+			return true;
+		}
 	}
 	/* reference order, scene.c:117-127 */
 	STAT(6);
-	float r0 = (float) (num_hi / rp.den);
-	float r1 = (float) (num_lo / rp.den);
+	const double root = __builtin_sqrt((double) discr);
+	float r0 = (float) ((nb + root) / rp.den);
+	float r1 = (float) ((nb - root) / rp.den);
 	if (r0 > r1) { const float tmp = r0; r0 = r1; r1 = tmp; }
 	if (r0 < 0) { r0 = r1; if (r0 < 0) return false; }
 	t_entry = r0;
@@ -786,6 +810,7 @@ rt_deinterleave(const float *strips, float *frame, int width, int height, int ro
  * which = 0: div_by_refined   vs `/`   on floats,  numerator in [2^-100, 2^30], denominator in [2^-30, 2^30]
  *         1: div_by_refined64 vs `/`   on doubles, numerator in [2^-300, 2^300], denominator (double) 2a, a in [2^-20, 2^20]
  *         2: unit3_fast       vs unit3 on vectors of every magnitude (incl. zero / tiny / huge components)
+ *         3: sqrt_of_float64  vs __builtin_sqrt on doubles converted from positive floats (incl. denormals, squares)
  * out[0] = number of mismatching results, out[1..] = operands of one mismatch. */
 RT_DEV uint64_t st_next(uint64_t &s)
 {
@@ -836,6 +861,18 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 				bad++;
 				out[1] = (unsigned long long) __double_as_longlong(num); out[2] = (unsigned long long) __double_as_longlong(den);
 				out[3] = (unsigned long long) __double_as_longlong(want); out[4] = (unsigned long long) __double_as_longlong(got);
+			}
+		} else if (which == 3) {
+			const uint64_t r0 = st_next(s);
+			float f = __builtin_fabsf(st_float(r0, -149 + 23, 120));
+			if ((r0 >> 60) == 0) f = __uint_as_float((uint32_t) (r0 >> 8) & 0x007fffffu);                     /* denormal floats */
+			if ((r0 >> 60) == 1) { const float k = st_float(r0, -20, 20); f = k * k; }                         /* exact squares   */
+			if (!(f > 0.0f)) continue;
+			const double want = __builtin_sqrt((double) f);
+			const double got = sqrt_of_float64((double) f);
+			if (__double_as_longlong(want) != __double_as_longlong(got)) {
+				bad++;
+				out[1] = __float_as_uint(f); out[3] = (unsigned long long) __double_as_longlong(want); out[4] = (unsigned long long) __double_as_longlong(got);
 			}
 		} else {
 			const uint64_t r0 = st_next(s), r1 = st_next(s), r2 = st_next(s), r3 = st_next(s);

@@ -1,0 +1,43 @@
+"""Interleaved A/B timing of two builds of librt_hip.so in ONE process on ONE device (device-to-device
+clock differences on this pool are larger than most kernel deltas).  usage: ab.py libA.so libB.so [rounds]"""
+import ctypes as C, os, sys, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # one HIP runtime for both libraries
+import numpy as np
+import ray_tracing_amd as rt
+
+def load(path):
+    rt._lib = None
+    rt.LIB_PATH = os.path.abspath(path)
+    L = rt.lib()
+    r = rt.Renderer(0)
+    r._L = L
+    return r
+
+cfgs = [("C1", 0, 1920, 1080, 64, 4), ("C2", 1, 1920, 1080, 256, 8)]
+libs = sys.argv[1:3]
+rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 7
+sky = None
+rs = []
+for p in libs:
+    r = load(p)
+    if sky is None:
+        sky = rt.load_skybox()
+    r.set_skybox(sky); r.profile(True)
+    rs.append(r)
+for name, scene, W, H, spp, nb in cfgs:
+    times = [[], []]
+    for k, r in enumerate(rs):
+        rt._lib = r._L
+        r.set_scene(f"{rt.DATA_DIR}/scene_{scene}.txt")
+    frames = [None, None]
+    for it in range(rounds + 1):
+        for k, r in enumerate(rs):
+            rt._lib = r._L
+            frames[k] = r.render(W, H, spp, nb)
+            ms, n = r.profile_collect()
+            if it:
+                times[k].append(ms)
+    same = bool((frames[0].view(np.uint32) == frames[1].view(np.uint32)).all())
+    a, b = statistics.median(times[0]), statistics.median(times[1])
+    print(f"{name}: A {a:.3f} ms (min {min(times[0]):.3f})   B {b:.3f} ms (min {min(times[1]):.3f})   B/A {b / a:.4f}   identical={same}", flush=True)
