@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--kernel", type=int, default=rt.KERNEL_AUTO)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-jit", action="store_true", help="do not specialise the trace kernel for the scene")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,6 +110,14 @@ def main():
     gpu.set_scene(os.path.join(rt.DATA_DIR, w["scene"]))
     gpu.set_skybox(sky)
     gpu.set_camera()
+    # scene "compilation" (hiprtc, ~1 s, outside the timed region): same frames, fewer instructions
+    compiled = False
+    if args.kernel == rt.KERNEL_AUTO and not args.no_jit:
+        try:
+            gpu.compile_scene()
+            compiled = True
+        except rt.RtError as e:
+            print(f"[bench] scene not specialised, using the generic kernel: {e}", file=sys.stderr)
 
     from ray_tracing_amd.multi_gpu import TiledFrame
     tiled = TiledFrame(gpu, W, H, spp, nb, seed=seed, row_block=ROW_BLOCK, rank=rank, world=world,
@@ -151,7 +160,8 @@ def main():
                                    f"counter-mode RNG seed {seed}, shipped skybox (6x2048x2048)",
                        "partition": f"interleaved blocks of {ROW_BLOCK} rows over {world} GPU(s)"
                                     + ("; one RCCL gather of the strips + de-interleave on rank 0" if world > 1 else ""),
-                       "kernel": {0: "auto", 1: "simple", 2: "wavefront"}.get(args.kernel, str(args.kernel))},
+                       "kernel": {0: "wavefront" + ("+scene-specialised (hiprtc)" if compiled else ""), 1: "simple",
+                                  2: "wavefront, plain IEEE ops"}.get(args.kernel, str(args.kernel))},
         }
         # ---- roofline of the dominant kernel (rank 0's launches; every rank runs the same kernel on 1/N of the rows)
         from rtlibs import Oracle
@@ -172,7 +182,7 @@ def main():
             out["roofline"] = {
                 "bound": "valu", "achieved": round(achieved, 3), "peak": round(PEAK_VALU_NOFMA_TFLOPS, 2),
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_VALU_NOFMA_TFLOPS, 4), "traffic": None,
-                "kernel": "rt_trace", "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
+                "kernel": "rt_trace_spec" if compiled else "rt_trace_wavefront", "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
                 "flops_per_sample": round(work["flops"], 1), "rays_per_sample": round(work["rays"], 3),
                 "object_tests_per_sample": round(work["object_tests"], 2),
                 "rng_draws_per_sample": round(work["rng_draws"], 2),

@@ -77,6 +77,12 @@ RT_API const char *rt_last_error(void);
 
 /* ---- inputs: replaces the globals of main.c:54-55 and the statics of camera.c:28,33-35 ------ */
 RT_API int rt_set_scene(rt_context *ctx, const Scene *scene);
+/* Optional: compile a trace kernel specialised for the scene that is set (in-process, hiprtc; about
+ * a second).  Frames are bit-identical with and without it; it only removes work (shared slab planes are
+ * divided once, no geometry loads).  The compiled kernel is dropped by the next rt_set_scene().  Scenes of
+ * 1..64 objects; returns an error -- and leaves the generic kernels in use -- if hiprtc is unavailable. */
+RT_API int rt_compile_scene(rt_context *ctx);
+RT_API int rt_scene_is_compiled(rt_context *ctx);
 /* chan must be 3 or 4 (what stb_image returns for the shipped JPEGs is 3); all faces w x h */
 RT_API int rt_set_skybox(rt_context *ctx, const Cubemap *skybox);
 RT_API int rt_set_camera(rt_context *ctx, const rt_camera *camera);

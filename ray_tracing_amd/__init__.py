@@ -55,7 +55,7 @@ class MouseState(C.Structure):
 # every symbol include/rt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
-    "rt_set_camera", "rt_render", "rt_render_device", "rt_strip_rows", "rt_deinterleave_device",
+    "rt_set_camera", "rt_compile_scene", "rt_scene_is_compiled", "rt_render", "rt_render_device", "rt_strip_rows", "rt_deinterleave_device",
     "rt_synchronize", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
     "rt_progressive_invalidate", "rt_progressive_state", "rt_selftest", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
     "rt_parse_scene_string", "rt_load_cubemap", "rt_free_cubemap", "rt_decode_jpeg_file",
@@ -89,6 +89,8 @@ def lib():
     L.rt_set_scene.argtypes = [C.c_void_p, C.c_void_p]
     L.rt_set_skybox.argtypes = [C.c_void_p, C.POINTER(Cubemap)]
     L.rt_set_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
+    L.rt_compile_scene.argtypes = [C.c_void_p]
+    L.rt_scene_is_compiled.argtypes = [C.c_void_p]
     L.rt_default_params.argtypes = [C.POINTER(RenderParams), C.c_int, C.c_int, C.c_int, C.c_int]
     L.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p]
     L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p]
@@ -217,6 +219,13 @@ class Renderer:
             assert buf.nbytes == SCENE_BYTES
         _check(lib().rt_set_scene(self._ctx, buf.ctypes.data_as(C.c_void_p)), "rt_set_scene")
         return buf
+
+    def compile_scene(self):
+        """JIT a trace kernel specialised for the current scene (rt_compile_scene); raises RtError if it cannot."""
+        _check(lib().rt_compile_scene(self._ctx), "rt_compile_scene")
+
+    def scene_is_compiled(self):
+        return bool(lib().rt_scene_is_compiled(self._ctx))
 
     def set_skybox(self, faces):
         """faces: uint8 (6, h, w, chan) in CubeFace order."""

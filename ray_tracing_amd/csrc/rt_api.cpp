@@ -52,6 +52,9 @@ struct rt_context {
 	int          num_objects = 0;
 	int          capacity = 0;
 	bool         have_scene = false;
+	std::vector<rt_geom> h_geom;         /* host copy of the packed geometry (rt_compile_scene) */
+	hipModule_t  spec_module = nullptr;  /* scene-specialised kernel, valid until the scene changes */
+	hipFunction_t spec_fn = nullptr;
 	bool         scene_fast_ok = false;  /* every cube has 0 <= size and all coordinates are finite, |x| <= 2^29 */
 	int          light_index = -1;
 	float        light_pos[3] = {0, 0, 0};
@@ -132,6 +135,7 @@ void rt_destroy(rt_context *ctx)
 	(void) hipStreamSynchronize(ctx->stream);
 	for (auto &p : ctx->events) { (void) hipEventDestroy(p.first); (void) hipEventDestroy(p.second); }
 	for (auto &e : ctx->event_pool) (void) hipEventDestroy(e);
+	if (ctx->spec_module) (void) hipModuleUnload(ctx->spec_module);
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
 	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame); (void) hipFree(ctx->d_counter);
 	(void) hipFree(ctx->prog.d_accum); (void) hipFree(ctx->prog.d_low); (void) hipFree(ctx->prog.d_out);
@@ -192,6 +196,8 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 	}
 	ctx->light_index = light;
 	ctx->scene_fast_ok = fast_ok;
+	ctx->h_geom.assign(geom.begin(), geom.begin() + n);
+	if (ctx->spec_module) { (void) hipModuleUnload(ctx->spec_module); ctx->spec_module = nullptr; ctx->spec_fn = nullptr; }
 	if (light >= 0) {
 		const Object &o = scene->objects[light];
 		if (o.type == OBJECT_SPHERE) {
@@ -219,6 +225,25 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 	ctx->have_scene = true;
 	return RT_OK;
 }
+
+/* Scene "compilation": see rt_jit.cpp.  Optional; everything works without it. */
+int rt_compile_scene(rt_context *ctx)
+{
+	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_compile_scene: NULL context");
+	if (!ctx->have_scene) return fail(RT_ERR_STATE, "rt_compile_scene: no scene set (rt_set_scene)");
+	if (ctx->spec_fn) return RT_OK;
+	const int n = ctx->num_objects;
+	if (n < 1 || n > 64) return fail(RT_ERR_ARGUMENT, "rt_compile_scene: %d objects; only scenes of 1..64 objects are specialised", n);
+	if (!ctx->scene_fast_ok) return fail(RT_ERR_ARGUMENT, "rt_compile_scene: scene has a box with negative size or out-of-range coordinates");
+	if (getenv("RT_NO_JIT")) return fail(RT_ERR_STATE, "rt_compile_scene: disabled by RT_NO_JIT");
+	HIP_TRY(hipSetDevice(ctx->device));
+	std::string message;
+	const int rc = rt_jit_build(ctx->h_geom.data(), n, &ctx->spec_module, &ctx->spec_fn, message);
+	if (rc != RT_OK) { ctx->spec_module = nullptr; ctx->spec_fn = nullptr; return fail(rc, "rt_compile_scene: %s", message.c_str()); }
+	return RT_OK;
+}
+
+int rt_scene_is_compiled(rt_context *ctx) { return ctx && ctx->spec_fn ? 1 : 0; }
 
 int rt_set_skybox(rt_context *ctx, const Cubemap *sky)
 {
@@ -334,7 +359,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (ctx->profiling) { e0 = take_event(ctx); e1 = take_event(ctx); HIP_TRY(hipEventRecord(e0, stream)); }
-	HIP_TRY(rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->d_counter, ctx->num_cus, stream));
+	HIP_TRY(rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, stream));
 	if (ctx->profiling) { HIP_TRY(hipEventRecord(e1, stream)); ctx->events.emplace_back(e0, e1); }
 	return RT_OK;
 }
@@ -443,7 +468,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h;
 	L.frame = g.d_low;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
-	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->d_counter, ctx->num_cus, ctx->stream));
+	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->stream));
 	const float weight = 1.0f / (s * s);                                         /* main.c:278 */
 	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), ctx->stream));
 	g.count += weight;                                                           /* main.c:396 */

@@ -10,7 +10,15 @@
 #ifndef RT_DEVICE_H
 #define RT_DEVICE_H
 
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#else   /* hiprtc (rt_compile_scene): no host headers */
+#ifndef RT_RTC_STDINT
+#define RT_RTC_STDINT
+typedef unsigned int uint32_t;
+typedef unsigned long long uint64_t;
+#endif
+#endif
 
 #define RT_GEOM_CUBE   0
 #define RT_GEOM_SPHERE 1

@@ -3,11 +3,15 @@
 #define RT_INTERNAL_H
 
 #include <hip/hip_runtime_api.h>
+#include <string>
 #include "rt_device.h"
 
 size_t     rt_scene_lds_bytes(int num_objects);
 size_t     rt_wavefront_lds_bytes(int num_objects);
-hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, unsigned int *block_counter, int num_cus, hipStream_t stream);
+/* spec_fn: kernel compiled by rt_compile_scene for the current scene, or nullptr */
+hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, hipFunction_t spec_fn,
+                           unsigned int *block_counter, int num_cus, hipStream_t stream);
+int        rt_jit_build(const rt_geom *geom, int n, hipModule_t *module, hipFunction_t *function, std::string &message);
 hipError_t rt_launch_deinterleave(const float *strips, float *frame, int width, int height,
                                   int row_block, int world, int rows_per_rank, hipStream_t stream);
 

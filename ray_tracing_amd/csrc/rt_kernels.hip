@@ -11,8 +11,10 @@
  * (broadcast) ds_read_b128.  The skybox stays in HBM / Infinity Cache as RGBA8 (one dword per
  * fetch).  No MFMA: there is no contraction in this workload.
  */
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#endif
 #include "rt_device.h"
 #include "rt_math.hip.h"
 
@@ -287,6 +289,63 @@ RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d, bool want_nor
 	return best;
 }
 
+/* ---- scene-specialised trace (experiment: `make spec`) -------------------------------------------
+ * With the geometry known at compile time the object loop unrolls, boxes that share slab planes share
+ * their quotients (common-subexpression elimination of identical exact chains), geometry needs no LDS
+ * reads and the zero-numerator test is done once per ray. */
+#ifdef RT_SPEC_HEADER
+#include RT_SPEC_HEADER
+RT_DEV Hit nearest_hit_spec(const SceneLDS &sc, int n, V3 o, V3 d, bool want_normal)
+{
+	const RayPrep rp = prepare_ray(o, d);
+	float amin = 3.402823466e+38f;
+#pragma unroll
+	for (int i = 0; i < SPEC_N; i++)
+		if (SPEC_T[i] == RT_GEOM_CUBE) {
+			amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(SPEC_G[i][0] - o.x), __builtin_fabsf(SPEC_G[i][3] - o.x)));
+			amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(SPEC_G[i][1] - o.y), __builtin_fabsf(SPEC_G[i][4] - o.y)));
+			amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(SPEC_G[i][2] - o.z), __builtin_fabsf(SPEC_G[i][5] - o.z)));
+		}
+	if (!wave_all(rp.inv_ok && amin >= 0x1p-100f))
+		return nearest_hit_fast(sc, n, o, d, want_normal);
+	float best_t = 3.402823466e+38f;
+	int best_obj = -1, best_axis = 0;
+#pragma unroll
+	for (int i = 0; i < SPEC_N; i++) {
+		float t = 0.0f; int axis = 0; bool hit = false;
+		if (SPEC_T[i] == RT_GEOM_CUBE) {
+			const float ax = div_by_refined(SPEC_G[i][0] - o.x, d.x, rp.inv.x), bx = div_by_refined(SPEC_G[i][3] - o.x, d.x, rp.inv.x);
+			const float ay = div_by_refined(SPEC_G[i][1] - o.y, d.y, rp.inv.y), by = div_by_refined(SPEC_G[i][4] - o.y, d.y, rp.inv.y);
+			const float az = div_by_refined(SPEC_G[i][2] - o.z, d.z, rp.inv.z), bz = div_by_refined(SPEC_G[i][5] - o.z, d.z, rp.inv.z);
+			const float nx = __builtin_fminf(ax, bx), fx = __builtin_fmaxf(ax, bx);
+			const float ny = __builtin_fminf(ay, by), fy = __builtin_fmaxf(ay, by);
+			const float nz = __builtin_fminf(az, bz), fz = __builtin_fmaxf(az, bz);
+			const float nxy = __builtin_fmaxf(nx, ny);
+			t = __builtin_fmaxf(nxy, nz);
+			const float tf = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+			axis = nz > nxy ? 2 : (ny > nx ? 1 : 0);
+			hit = t <= tf;
+		} else if (SPEC_T[i] == RT_GEOM_SPHERE)
+			hit = ball_entry_fast(o, d, rp, mk3(SPEC_G[i][0], SPEC_G[i][1], SPEC_G[i][2]), SPEC_G[i][3], t);
+		if (hit && t >= 0 && t < best_t) { best_t = t; best_obj = i; best_axis = axis; }
+	}
+	Hit best; best.t = best_t; best.obj = best_obj; best.n = mk3(0, 0, 0);
+	if (best_obj >= 0 && want_normal) {
+		const float4 g0 = sc.geom[2 * best_obj], g1 = sc.geom[2 * best_obj + 1];
+		if (__float_as_int(g1.z) == RT_GEOM_CUBE) {
+			const float dc = best_axis == 0 ? d.x : (best_axis == 1 ? d.y : d.z);
+			const float s = dc > 0 ? -1.0f : 1.0f;
+			best.n = mk3(best_axis == 0 ? s : 0.0f, best_axis == 1 ? s : 0.0f, best_axis == 2 ? s : 0.0f);
+		} else
+			best.n = unit3_fast(sub3(madd3(o, d, best_t), mk3(g0.x, g0.y, g0.z)));
+	}
+	return best;
+}
+#define NEAREST_HIT_TUNED nearest_hit_spec
+#else
+#define NEAREST_HIT_TUNED nearest_hit_fast
+#endif
+
 /* ---- skybox: gpu_and_windowing.c:42-112 ---------------------------------------------------- */
 
 RT_DEV V3 sky_lookup(const rt_launch &L, V3 dir)
@@ -335,6 +394,7 @@ RT_DEV V3 primary_dir(const rt_launch &L, float px, float py)
 	           L.llc[2] + L.horiz[2] * px + L.vert[2] * py - L.pos[2]);
 }
 
+#ifndef RT_SPEC_ONLY
 /* =============================================================================================
  * rt_trace_simple: the path loop in the reference's own order (main.c:131-272), one lane per pixel.
  * Kept as the in-GPU cross-check for the tuned kernel (tests compare the two at full frame sizes).
@@ -449,6 +509,8 @@ rt_trace_simple(const rt_launch L)
 	dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
 }
 
+#endif /* RT_SPEC_ONLY */
+
 /* =============================================================================================
  * rt_trace_wavefront: the tuned kernel.  Same arithmetic as rt_trace_simple, different schedule.
  *
@@ -489,8 +551,7 @@ RT_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 template <bool FAST> RT_DEV V3 unit3_sel(V3 v) { return FAST ? unit3_fast(v) : unit3(v); }
 
 template <bool FAST>
-__global__ void __launch_bounds__(RT_BLOCK, 4)
-rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
+RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 {
 	extern __shared__ float4 lds[];
 	const int n = L.num_objects;
@@ -692,7 +753,7 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 					const V3 dn = unit3_sel<FAST>(mk3(W.q[3][slot], W.q[4][slot], W.q[5][slot]));   /* scene.c:158 */
 					const int meta = __float_as_int(W.q[6][slot]);
 					const int owner = meta & 255, rkind = meta >> 8;
-					const Hit hit = FAST ? nearest_hit_fast(sc, n, o, dn, rkind <= WF_KIND_MAIN) : nearest_hit(sc, n, o, dn);
+					const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, n, o, dn, rkind <= WF_KIND_MAIN) : nearest_hit(sc, n, o, dn);
 					if (rkind > WF_KIND_MAIN) {
 						W.tap[rkind - 2][owner] = hit.obj;
 					} else {
@@ -768,6 +829,25 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 	}
 }
 
+#ifndef RT_SPEC_ONLY
+template <bool FAST>
+__global__ void __launch_bounds__(RT_BLOCK, 4)
+rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
+{
+	wavefront_body<FAST>(L, block_counter);
+}
+#endif
+
+#ifdef RT_SPEC_HEADER
+/* the same kernel with the trace loop specialised for one scene (rt_compile_scene, JIT) */
+extern "C" __global__ void __launch_bounds__(RT_BLOCK, 4)
+rt_trace_spec(const rt_launch L, unsigned int *block_counter)
+{
+	wavefront_body<true>(L, block_counter);
+}
+#endif
+
+#ifndef RT_SPEC_ONLY
 /* ---- progressive accumulation: worker()'s publish step (main.c:387-396) and update_frame()'s
  * resolve (main.c:467-477) ------------------------------------------------------------------ */
 extern "C" __global__ void __launch_bounds__(RT_BLOCK)
@@ -933,7 +1013,8 @@ size_t rt_scene_lds_bytes(int num_objects) { return (size_t) num_objects * (size
 
 size_t rt_wavefront_lds_bytes(int num_objects) { return rt_scene_lds_bytes(num_objects) + (RT_BLOCK / 64) * sizeof(WaveLDS); }
 
-hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, unsigned int *block_counter, int num_cus, hipStream_t stream)
+hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, hipFunction_t spec_fn,
+                           unsigned int *block_counter, int num_cus, hipStream_t stream)
 {
 	if (L.local_rows <= 0 || L.width <= 0) return hipSuccess;
 	const bool simple = variant == 1 /* RT_KERNEL_SIMPLE */ || L.max_bounces < 1;
@@ -956,6 +1037,13 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	if (grid < 1) grid = 1;
 	hipError_t e = hipMemsetAsync(block_counter, 0, sizeof(unsigned int), stream);
 	if (e != hipSuccess) return e;
+	if (variant == 0 /* RT_KERNEL_AUTO */ && scene_fast_ok && spec_fn) {
+		/* same kernel, trace loop specialised for this scene by rt_compile_scene() */
+		rt_launch Lc = L;
+		unsigned int *counter = block_counter;
+		void *args[] = { &Lc, &counter };
+		return hipModuleLaunchKernel(spec_fn, (unsigned int) grid, 1, 1, RT_BLOCK, 1, 1, (unsigned int) lds, stream, args, nullptr);
+	}
 	if (variant == 2 /* RT_KERNEL_WAVEFRONT: same schedule, plain IEEE operations */ || !scene_fast_ok)
 		hipLaunchKernelGGL(rt_trace_wavefront<false>, dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, L, block_counter);
 	else
@@ -970,3 +1058,4 @@ hipError_t rt_launch_deinterleave(const float *strips, float *frame, int width, 
 	                   strips, frame, width, height, row_block, world, rows_per_rank);
 	return hipGetLastError();
 }
+#endif /* RT_SPEC_ONLY */

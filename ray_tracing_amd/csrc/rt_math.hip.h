@@ -9,8 +9,18 @@
 #ifndef RT_MATH_HIP_H
 #define RT_MATH_HIP_H
 
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#else   /* hiprtc (rt_compile_scene): no host headers */
+#ifndef RT_RTC_STDINT
+#define RT_RTC_STDINT
+typedef unsigned int uint32_t;
+typedef unsigned long long uint64_t;
+#endif
+#endif
 
 #pragma clang fp contract(off)
 

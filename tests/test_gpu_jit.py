@@ -1,0 +1,103 @@
+"""rt_compile_scene(): the scene-specialised (hiprtc-compiled) trace kernel must produce the same bits as
+the generic kernels and the oracle, must be dropped when the scene changes, and must refuse what it
+cannot specialise while leaving rendering intact."""
+import numpy as np
+import pytest
+
+import ray_tracing_amd as rt
+from rtlibs import bits, make_scene, synthetic_skybox
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    r = rt.Renderer(0)
+    yield r
+    r.close()
+
+
+@pytest.mark.parametrize("scene_i,bounces", [(0, 4), (0, 10), (1, 8), (2, 8)])
+def test_compiled_scene_is_bit_identical(gpu, oracle, scene_paths, scene_i, bounces):
+    sky = rt.load_skybox()
+    gpu.set_skybox(sky); oracle.set_skybox(sky)
+    gpu.set_scene(scene_paths[scene_i]); oracle.load_scene(scene_paths[scene_i])
+    gpu.set_camera(); oracle.set_camera()
+    assert not gpu.scene_is_compiled()
+    generic = gpu.render(192, 108, 6, bounces, seed=4)
+    gpu.compile_scene()
+    assert gpu.scene_is_compiled()
+    compiled = gpu.render(192, 108, 6, bounces, seed=4)
+    want = oracle.render_counter(192, 108, 6, bounces, seed=4)
+    assert (bits(compiled) == bits(generic)).all()
+    assert (bits(compiled) == bits(want)).all()
+
+
+def test_compiled_scene_full_size_and_strips(gpu, scene_paths):
+    import torch
+    sky = rt.load_skybox()
+    gpu.set_skybox(sky); gpu.set_scene(scene_paths[0]); gpu.set_camera()
+    W, H, spp, nb = 1920, 1080, 4, 4
+    generic = gpu.render(W, H, spp, nb, seed=0)
+    gpu.compile_scene()
+    compiled = gpu.render(W, H, spp, nb, seed=0)
+    assert (bits(compiled) == bits(generic)).all()
+    world, rb = 4, 8
+    rows = rt.strip_rows(H, rb, world)
+    strips = torch.zeros((world, rows, W, 3), dtype=torch.float32, device="cuda:0")
+    for rank in range(world):
+        gpu.render_device(gpu.params(W, H, spp, nb, seed=0, row_block=rb, rank=rank, world=world), strips[rank].data_ptr())
+    gpu.synchronize()
+    frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda:0")
+    gpu.deinterleave_device(strips.data_ptr(), frame.data_ptr(), W, H, rb, world)
+    gpu.synchronize()
+    assert (bits(frame.cpu().numpy()) == bits(generic)).all()
+
+
+def test_set_scene_drops_the_compiled_kernel(gpu, oracle, scene_paths):
+    sky = synthetic_skybox(32, seed=7)
+    gpu.set_skybox(sky); oracle.set_skybox(sky)
+    gpu.set_scene(scene_paths[0]); gpu.compile_scene()
+    assert gpu.scene_is_compiled()
+    gpu.set_scene(scene_paths[1]); oracle.load_scene(scene_paths[1])
+    assert not gpu.scene_is_compiled()
+    assert (bits(gpu.render(96, 54, 3, 6, seed=2)) == bits(oracle.render_counter(96, 54, 3, 6, seed=2))).all()
+
+
+def test_random_scene_and_edge_geometry(gpu, oracle):
+    """Random boxes/spheres sharing many planes (grid-aligned), an emissive cube, camera on a slab plane."""
+    sky = synthetic_skybox(32, seed=5)
+    rng = np.random.default_rng(9)
+    objs = []
+    for k in range(40):
+        if k % 4 == 3:
+            objs.append(dict(type="sphere", center=rng.integers(-3, 6, 3).astype(float), radius=float(rng.choice([0.5, 1.0])),
+                             albedo=rng.uniform(0, 1, 3), roughness=rng.uniform(0, 1), metallic=float(k % 8 == 3)))
+        else:
+            objs.append(dict(type="cube", origin=rng.integers(-4, 6, 3).astype(float), size=rng.choice([0.0, 0.5, 1.0, 2.0], 3),
+                             albedo=rng.uniform(0, 1, 3), roughness=rng.uniform(0, 1), reflectance=rng.uniform(0, 1),
+                             metallic=float(k % 5 == 0), emission_power=4.0 if k == 6 else 0.0))
+    scene = make_scene(objs)
+    cam = dict(pos=(6, 4, 8), front=(-0.6, -0.35, -1), up=(0, 1, 0), fov=1.0)     # pos components sit on slab planes
+    for r in (gpu, oracle):
+        r.set_skybox(sky); r.set_scene(scene); r.set_camera(**cam)
+    gpu.compile_scene()
+    g = gpu.render(131, 77, 3, 7, seed=13)
+    c = oracle.render_counter(131, 77, 3, 7, seed=13)
+    assert (bits(g) == bits(c)).all()
+    gpu.set_camera(); oracle.set_camera()
+
+
+def test_refuses_what_it_cannot_specialise(gpu, oracle):
+    sky = synthetic_skybox(16, seed=1)
+    gpu.set_skybox(sky); oracle.set_skybox(sky)
+    big = make_scene([dict(type="sphere", center=(i % 10, i // 10, 0), radius=0.3) for i in range(65)])
+    gpu.set_scene(big); oracle.set_scene(big)
+    with pytest.raises(rt.RtError):
+        gpu.compile_scene()
+    assert not gpu.scene_is_compiled()
+    assert (bits(gpu.render(40, 30, 2, 3, seed=1)) == bits(oracle.render_counter(40, 30, 2, 3, seed=1))).all()
+    empty = make_scene([])
+    gpu.set_scene(empty)
+    with pytest.raises(rt.RtError):
+        gpu.compile_scene()
