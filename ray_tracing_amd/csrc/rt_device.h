@@ -71,6 +71,12 @@ typedef struct {
 	int   sky_w, sky_h;
 
 	float *frame;              /* local_rows x width x 3 floats, resolved      */
+	/* sample chunking (few pixels per GPU): a pixel's spp samples are split into num_chunks work
+	 * items of chunk_spp samples so that more lanes than pixels can be busy; each clamped sample is
+	 * stored to samples[s][pixel][3] and rt_sum_samples adds them in sample order (main.c:394).
+	 * num_chunks == 1: the lane sums its pixel itself and writes `frame`. */
+	int    num_chunks, chunk_spp;
+	float *samples;
 	const rt_geom  *geom;      /* num_objects records (global; staged to LDS)  */
 	const rt_shade *shade;
 } rt_launch;

@@ -561,7 +561,9 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 
 	const int tiles_x = (L.width + 7) >> 3;
 	const int tiles_y = (L.local_rows + 7) >> 3;
-	const unsigned int num_blocks = (unsigned int) (tiles_x * tiles_y);
+	const bool chunked = L.num_chunks > 1;
+	const unsigned int num_blocks = (unsigned int) (tiles_x * tiles_y) * (unsigned int) L.num_chunks;
+	const size_t sample_stride = (size_t) L.local_rows * L.width * 3;      /* floats per sample plane */
 	const V3 cam = ld3(L.pos);
 	const V3 light_pos = ld3(L.light_pos);
 	const bool have_light = L.light_index >= 0;
@@ -570,7 +572,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	/* wave-uniform pixel supply: the wave owns one 8x8 pixel block at a time.  When it takes a new
 	 * block it traces all 64 camera rays at once (one full, homogeneous batch) into W.blk; lanes then
 	 * take pixels of the block as they become free and start from the stored hit. */
-	unsigned int cur_block = 0xffffffffu;   /* block being handed out */
+	unsigned int cur_block = 0xffffffffu;   /* pixel block being handed out */
+	int  cur_s0 = 0, cur_s1 = L.spp;        /* its sample range (one chunk of the pixels' samples) */
 	int  cur_next = 64;                     /* next pixel of cur_block to hand out (64 = none left) */
 	bool blk_ready = false;                 /* W.blk holds cur_block's primary hits */
 	bool exhausted = false;
@@ -578,7 +581,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	/* per-lane path state */
 	int   px_i = 0, px_lr = -1;             /* px_lr < 0: lane has no pixel */
 	uint32_t pixel_index = 0;
-	int   sample = 0, bounce = 0;
+	int   sample = 0, sample_end = 0, bounce = 0;
 	bool  has_hit = false;
 	V3    sum = mk3(0, 0, 0), carry = mk3(1, 1, 1), rad = mk3(0, 0, 0);
 	V3    hp = mk3(0, 0, 0), hn = mk3(0, 0, 0), hdir = mk3(0, 0, 0), pdir = mk3(0, 0, 0);
@@ -600,7 +603,9 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				if (lane == 0) b = atomicAdd(block_counter, 1u);
 				b = (unsigned int) __builtin_amdgcn_readfirstlane((int) b);
 				if (b >= num_blocks) { exhausted = true; break; }
-				cur_block = b; cur_next = 0; blk_ready = false; fetched = true;
+				cur_block = b / (unsigned int) L.num_chunks; cur_next = 0; blk_ready = false; fetched = true;
+				cur_s0 = (int) (b % (unsigned int) L.num_chunks) * L.chunk_spp;
+				cur_s1 = cur_s0 + L.chunk_spp < L.spp ? cur_s0 + L.chunk_spp : L.spp;
 				const int i = (int) (cur_block % (unsigned int) tiles_x) * 8 + (lane & 7);
 				const int lr = (int) (cur_block / (unsigned int) tiles_x) * 8 + (lane >> 3);
 				const int j = global_row(L, lr);
@@ -629,11 +634,18 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 						/* sky-only pixel: every sample is clamp(0 + sky * 1) (main.c:171,267-269), summed
 						 * in sample order and resolved (main.c:394,476) */
 						const V3 c = mk3(clamp01(a.x), clamp01(a.y), clamp01(a.z));
-						V3 acc = mk3(0, 0, 0);
-						for (int k = 0; k < L.spp; k++) acc = add3(acc, c);
-						const V3 res = scale3(acc, inv_spp);
-						float *dst = L.frame + ((size_t) lr * L.width + i) * 3;
-						dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+						if (chunked) {
+							for (int k = cur_s0; k < cur_s1; k++) {
+								float *dst = L.samples + (size_t) k * sample_stride + ((size_t) lr * L.width + i) * 3;
+								dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
+							}
+						} else {
+							V3 acc = mk3(0, 0, 0);
+							for (int k = 0; k < L.spp; k++) acc = add3(acc, c);
+							const V3 res = scale3(acc, inv_spp);
+							float *dst = L.frame + ((size_t) lr * L.width + i) * 3;
+							dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+						}
 					} else {
 						const int j = global_row(L, lr);
 						px_i = i; px_lr = lr;
@@ -647,8 +659,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 						W.cache[0][lane] = a.x;  W.cache[1][lane] = a.y;  W.cache[2][lane] = a.z;
 						W.cache[3][lane] = nn.x; W.cache[4][lane] = nn.y; W.cache[5][lane] = nn.z;
 						W.cache[6][lane] = __int_as_float(obj);
-						sample = 0; bounce = 0; sum = mk3(0, 0, 0);
-						rng = path_seed(L.seed, pixel_index, (uint32_t) L.sample_base);
+						sample = cur_s0; sample_end = cur_s1; bounce = 0; sum = mk3(0, 0, 0);
+						rng = path_seed(L.seed, pixel_index, (uint32_t) (L.sample_base + sample));
 						carry = mk3(1, 1, 1); rad = mk3(0, 0, 0);
 						hp = a; hn = nn; hobj = obj; hdir = pdir;
 						has_hit = true;
@@ -807,9 +819,14 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			} else
 				sample_done = true;                /* bounce limit (main.c:158) */
 			if (sample_done) {
-				sum = add3(sum, mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z)));   /* main.c:267-269,394 */
+				const V3 col = mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z));     /* main.c:267-269 */
+				if (chunked) {
+					float *dst = L.samples + (size_t) sample * sample_stride + ((size_t) px_lr * L.width + px_i) * 3;
+					dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
+				} else
+					sum = add3(sum, col);                                                /* main.c:394 */
 				sample++;
-				if (sample < L.spp) {
+				if (sample < sample_end) {
 					rng = path_seed(L.seed, pixel_index, (uint32_t) (L.sample_base + sample));
 					carry = mk3(1, 1, 1); rad = mk3(0, 0, 0); bounce = 0;
 					hp = mk3(W.cache[0][lane], W.cache[1][lane], W.cache[2][lane]);
@@ -818,9 +835,11 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					hdir = pdir;
 					has_hit = true;
 				} else {
-					const V3 res = scale3(sum, inv_spp);                         /* main.c:476 */
-					float *dst = L.frame + ((size_t) px_lr * L.width + px_i) * 3;
-					dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+					if (!chunked) {
+						const V3 res = scale3(sum, inv_spp);                     /* main.c:476 */
+						float *dst = L.frame + ((size_t) px_lr * L.width + px_i) * 3;
+						dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+					}
 					px_lr = -1; has_hit = false;
 				}
 			}
@@ -861,6 +880,27 @@ rt_accumulate(float *accum, const float *lowres, int width, int height, int scal
 		const float *c = lowres + ((size_t) j * low_w + i) * 3;
 		float *a = accum + p * 3;
 		a[0] = a[0] + c[0] * k; a[1] = a[1] + c[1] * k; a[2] = a[2] + c[2] * k;
+	}
+}
+
+/* chunked mode: add a pixel's stored samples in sample order and resolve (main.c:394,476) */
+extern "C" __global__ void __launch_bounds__(RT_BLOCK)
+rt_sum_samples(const float *samples, float *frame, size_t plane_floats, int spp, float inv_spp)
+{
+	/* 16 B per lane: four independent sequential sums per thread, coalesced across the wave */
+	const size_t quads = plane_floats / 4;
+	for (size_t q = (size_t) blockIdx.x * RT_BLOCK + threadIdx.x; q < quads; q += (size_t) gridDim.x * RT_BLOCK) {
+		float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		for (int s = 0; s < spp; s++) {
+			const float4 v = *reinterpret_cast<const float4*>(samples + (size_t) s * plane_floats + 4 * q);
+			acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
+		}
+		*reinterpret_cast<float4*>(frame + 4 * q) = make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp);
+	}
+	for (size_t p = quads * 4 + (size_t) blockIdx.x * RT_BLOCK + threadIdx.x; p < plane_floats; p += (size_t) gridDim.x * RT_BLOCK) {
+		float acc = 0.0f;
+		for (int s = 0; s < spp; s++) acc = acc + samples[(size_t) s * plane_floats + p];
+		frame[p] = acc * inv_spp;
 	}
 }
 
@@ -982,6 +1022,12 @@ hipError_t rt_launch_accumulate(float *accum, const float *lowres, int width, in
 	return hipGetLastError();
 }
 
+hipError_t rt_launch_sum_samples(const float *samples, float *frame, size_t plane_floats, int spp, hipStream_t stream)
+{
+	hipLaunchKernelGGL(rt_sum_samples, dim3(4096), dim3(RT_BLOCK), 0, stream, samples, frame, plane_floats, spp, 1.0f / (float) spp);
+	return hipGetLastError();
+}
+
 hipError_t rt_launch_resolve(const float *accum, float *frame, size_t floats, float inv_count, hipStream_t stream)
 {
 	hipLaunchKernelGGL(rt_resolve, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, frame, floats, inv_count);
@@ -1030,7 +1076,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	if (per_cu < 1) per_cu = 1;
 	if (per_cu > 4) per_cu = 4;
 	if (const char *e = getenv("RT_WF_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }   /* tuning aid */
-	const long long blocks = (long long) ((L.width + 7) / 8) * ((L.local_rows + 7) / 8);
+	const long long blocks = (long long) ((L.width + 7) / 8) * ((L.local_rows + 7) / 8) * (L.num_chunks > 1 ? L.num_chunks : 1);
 	long long grid = (long long) num_cus * per_cu;
 	const long long useful = (blocks + (RT_BLOCK / 64) - 1) / (RT_BLOCK / 64);
 	if (grid > useful) grid = useful;
