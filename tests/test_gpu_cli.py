@@ -1,0 +1,42 @@
+"""The plain-C host (rt_cli = rt_main.c linked against librt_hip.so, no Python, no torch in the process):
+flags of the reference's main() plus the explicit spp/bounces/size, frame handed to the presenter-shaped
+sink.  Its image must equal the library's frame after the reference's screenshot conversion."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ray_tracing_amd as rt
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(os.path.dirname(rt.LIB_PATH), "rt_cli")
+
+
+def test_cli_renders_the_same_frame(tmp_path, scene_paths):
+    out = tmp_path / "frame.ppm"
+    W, H, spp, nb, seed = 96, 54, 4, 4, 7
+    cmd = [CLI, "--scene", scene_paths[0], "--threads", "8", "--init-scale", "8", "--skybox", os.path.join(rt.DATA_DIR, "skybox"),
+           "--width", str(W), "--height", str(H), "--spp", str(spp), "--bounces", str(nb), "--seed", str(seed), "--out", str(out)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "Scene parsed (9 objects)" in p.stderr and "Cubemap loaded (2048x2048x3)" in p.stderr
+    raw = out.read_bytes()
+    head = f"P6\n{W} {H}\n255\n".encode()
+    assert raw.startswith(head)
+    img = np.frombuffer(raw[len(head):], np.uint8).reshape(H, W, 3)
+    g = rt.Renderer(0)
+    g.set_scene(scene_paths[0]); g.set_skybox(rt.load_skybox()); g.set_camera()
+    frame = g.render(W, H, spp, nb, seed=seed)
+    g.close()
+    want = (frame * np.float32(255)).astype(np.uint8)[::-1]          # main.c:662-672
+    assert (img == want).all()
+
+
+def test_cli_reports_errors_like_the_reference(tmp_path):
+    p = subprocess.run([CLI, "--threads", "4"], capture_output=True, text=True, timeout=60)
+    assert p.returncode != 0 and "Missing --scene" in p.stderr
+    bad = tmp_path / "bad.txt"
+    bad.write_text("sphere radius x")
+    p = subprocess.run([CLI, "--scene", str(bad)], capture_output=True, text=True, timeout=60)
+    assert p.returncode != 0 and "Couldn't parse scene" in p.stderr and "Missing number after property name (line 1)" in p.stderr
