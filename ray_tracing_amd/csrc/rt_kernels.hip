@@ -289,7 +289,7 @@ RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d, bool want_nor
 	return best;
 }
 
-/* ---- scene-specialised trace (experiment: `make spec`) -------------------------------------------
+/* ---- scene-specialised trace (rt_compile_scene, rt_jit.cpp) ----------------------------------------
  * With the geometry known at compile time the object loop unrolls, boxes that share slab planes share
  * their quotients (common-subexpression elimination of identical exact chains), geometry needs no LDS
  * reads and the zero-numerator test is done once per ray. */

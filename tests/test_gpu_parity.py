@@ -237,3 +237,22 @@ def test_baseline_config_geometries(gpu, real_sky, scene_paths, name, scene_i, W
     gpu.deinterleave_device(strips.data_ptr(), frame.data_ptr(), W, H, rb, world)
     gpu.synchronize()
     assert (bits(frame.cpu().numpy()) == bits(a)).all(), name
+
+
+def test_c1_exact_benchmark_config(gpu, real_sky, scene_paths):
+    """BASELINE config C1 exactly as bench.py runs it (1920x1080, 64 spp, 4 bounces, seed 0): generic tuned
+    kernel == scene-compiled kernel == reference-order kernel, and oracle rows."""
+    from rtlibs import Oracle
+    W, H, spp, nb = 1920, 1080, 64, 4
+    gpu.set_skybox(real_sky); gpu.set_scene(scene_paths[0]); gpu.set_camera()
+    a = gpu.render(W, H, spp, nb, seed=0)
+    s = gpu.render(W, H, spp, nb, seed=0, kernel=rt.KERNEL_SIMPLE)
+    gpu.compile_scene()
+    j = gpu.render(W, H, spp, nb, seed=0)
+    gpu.set_scene(scene_paths[0])                       # drop the compiled kernel for the tests that follow
+    assert (bits(a) == bits(s)).all() and (bits(a) == bits(j)).all()
+    o = Oracle(); o.set_skybox(real_sky); o.load_scene(scene_paths[0])
+    for r0 in (200, 700):
+        c = o.render_counter(W, H, spp, nb, seed=0, rows=(r0, r0 + 1))
+        assert (bits(c[r0]) == bits(a[r0])).all(), r0
+    print(f"C1 frame mean {a.mean():.6f}")
