@@ -135,7 +135,7 @@ RT_API int rt_profile_collect(rt_context *ctx, double *kernel_ms_total, int *lau
 
 /* On-GPU self-test of the exact-arithmetic shortcuts the tuned kernel uses (shared-reciprocal
  * division, vector normalisation): compares them bit-for-bit with the plain IEEE forms on
- * blocks*256*iters random operand sets.  which = 0 (f32 divide), 1 (f64 divide), 2 (normalize), 3 (f64 sqrt of a float).
+ * blocks*256*iters random operand sets.  which = 0 (f32 divide), 1 (f64 divide), 2 (normalize), 3 (f64 sqrt of a float), 4 (|x| < 0.0001 threshold).
  * out[0] = mismatches (must be 0); out[1..7] = operands of one mismatch, for diagnosis. */
 RT_API int rt_selftest(rt_context *ctx, int which, uint64_t seed, int blocks, int iters, unsigned long long out[8]);
 

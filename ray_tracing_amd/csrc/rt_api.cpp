@@ -67,6 +67,7 @@ struct rt_context {
 	rt_camera    camera;
 	bool         have_camera = false;
 
+	float        *d_byte_lut = nullptr;  /* b / 255 for b = 0..255 */
 	unsigned int *d_counter = nullptr;   /* pixel-block counter of the persistent kernel */
 	int          num_cus = 256;
 
@@ -123,7 +124,10 @@ int rt_create(rt_context **out, int device_id)
 		if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
 			ctx->num_cus = prop.multiProcessorCount;
 		e = hipMalloc((void**) &ctx->d_counter, 64);
-		if (e != hipSuccess) { (void) hipStreamDestroy(ctx->stream); delete ctx; return fail(RT_ERR_DEVICE, "hipMalloc: %s", hipGetErrorString(e)); }
+		if (e == hipSuccess) e = hipMalloc((void**) &ctx->d_byte_lut, 256 * sizeof(float));
+		if (e == hipSuccess) e = rt_launch_fill_byte_lut(ctx->d_byte_lut, ctx->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+		if (e != hipSuccess) { (void) hipStreamDestroy(ctx->stream); delete ctx; return fail(RT_ERR_DEVICE, "rt_create: %s", hipGetErrorString(e)); }
 	}
 	rt_camera_default(&ctx->camera);
 	ctx->have_camera = true;     /* the reference starts from its default pose too (camera.c:33-35) */
@@ -140,7 +144,7 @@ void rt_destroy(rt_context *ctx)
 	for (auto &e : ctx->event_pool) (void) hipEventDestroy(e);
 	if (ctx->spec_module) (void) hipModuleUnload(ctx->spec_module);
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
-	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame); (void) hipFree(ctx->d_counter); (void) hipFree(ctx->d_samples);
+	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame); (void) hipFree(ctx->d_counter); (void) hipFree(ctx->d_samples); (void) hipFree(ctx->d_byte_lut);
 	(void) hipFree(ctx->prog.d_accum); (void) hipFree(ctx->prog.d_low); (void) hipFree(ctx->prog.d_out);
 	(void) hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -353,7 +357,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 		const int mine = blocks > p->rank ? (blocks - p->rank + p->world - 1) / p->world : 0;
 		L.local_rows = mine * p->row_block;
 	}
-	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h;
+	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.byte_lut = ctx->d_byte_lut;
 	L.frame = (float*) d_strip;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
 	L.num_chunks = 1; L.chunk_spp = p->spp; L.samples = nullptr;
@@ -497,7 +501,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	L.spp = 1; L.max_bounces = g.max_bounces; L.seed = g.seed;
 	L.u_den = lw - 1; L.v_den = lh - 1; L.pix_scale = s; L.pix_width = g.width; L.sample_base = g.passes;
 	L.row_block = 8; L.rank = 0; L.world = 1;
-	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h;
+	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.byte_lut = ctx->d_byte_lut;
 	L.frame = g.d_low;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
 	L.num_chunks = 1; L.chunk_spp = 1; L.samples = nullptr;
@@ -537,7 +541,7 @@ int rt_progressive_state(rt_context *ctx, int *next_scale, float *count, uint32_
 
 int rt_selftest(rt_context *ctx, int which, uint64_t seed, int blocks, int iters, unsigned long long out[8])
 {
-	if (!ctx || !out || which < 0 || which > 3 || blocks < 1 || iters < 1)
+	if (!ctx || !out || which < 0 || which > 4 || blocks < 1 || iters < 1)
 		return fail(RT_ERR_ARGUMENT, "rt_selftest: bad argument");
 	HIP_TRY(hipSetDevice(ctx->device));
 	unsigned long long *d = nullptr;

@@ -348,24 +348,35 @@ RT_DEV Hit nearest_hit_spec(const SceneLDS &sc, int n, V3 o, V3 d, bool want_nor
 
 /* ---- skybox: gpu_and_windowing.c:42-112 ---------------------------------------------------- */
 
+template <bool FAST = false>
 RT_DEV V3 sky_lookup(const rt_launch &L, V3 dir)
 {
 	float ax = dir.x < 0 ? -dir.x : dir.x;
 	float ay = dir.y < 0 ? -dir.y : dir.y;
 	float az = dir.z < 0 ? -dir.z : dir.z;
-	int face; float u, v;
+	int face; float nu, nv, m;                     /* u = nu / m, v = nv / m */
 	if (ax > ay && ax > az) {
-		float m = ax + 0.0f;
-		if (dir.x > 0) { face = 3; u = -dir.z / m; v = -dir.y / m; }   /* CF_RIGHT  */
-		else           { face = 2; u =  dir.z / m; v = -dir.y / m; }   /* CF_LEFT   */
+		m = ax + 0.0f;
+		if (dir.x > 0) { face = 3; nu = -dir.z; nv = -dir.y; }          /* CF_RIGHT  */
+		else           { face = 2; nu =  dir.z; nv = -dir.y; }          /* CF_LEFT   */
 	} else if (ay > ax && ay > az) {
-		float m = ay + 0.0f;
-		if (dir.y > 0) { face = 4; u = dir.x / m; v =  dir.z / m; }    /* CF_TOP    */
-		else           { face = 5; u = dir.x / m; v = -dir.z / m; }    /* CF_BOTTOM */
+		m = ay + 0.0f;
+		if (dir.y > 0) { face = 4; nu = dir.x; nv =  dir.z; }           /* CF_TOP    */
+		else           { face = 5; nu = dir.x; nv = -dir.z; }           /* CF_BOTTOM */
 	} else {
-		float m = az + 0.0f;
-		if (dir.z > 0) { face = 0; u =  dir.x / m; v = -dir.y / m; }   /* CF_FRONT  */
-		else           { face = 1; u = -dir.x / m; v = -dir.y / m; }   /* CF_BACK   */
+		m = az + 0.0f;
+		if (dir.z > 0) { face = 0; nu =  dir.x; nv = -dir.y; }          /* CF_FRONT  */
+		else           { face = 1; nu = -dir.x; nv = -dir.y; }          /* CF_BACK   */
+	}
+	float u, v;
+	const float lo = __builtin_fminf(__builtin_fabsf(nu), __builtin_fabsf(nv));
+	if (FAST && wave_all(m >= 0x1p-30f && m <= 0x1p+30f && lo >= 0x1p-100f && __builtin_fmaxf(__builtin_fabsf(nu), __builtin_fabsf(nv)) <= 0x1p+30f)) {
+		const float r = rcp_refined(m);             /* both quotients share the reciprocal (rt_math.hip.h) */
+		u = div_by_refined(nu, m, r);
+		v = div_by_refined(nv, m, r);
+	} else {
+		u = nu / m;
+		v = nv / m;
 	}
 	u = clamp11(u);
 	v = clamp11(v);
@@ -374,6 +385,8 @@ RT_DEV V3 sky_lookup(const rt_launch &L, V3 dir)
 	int x = (int) (u * (float) (L.sky_w - 1));
 	int y = (int) (v * (float) (L.sky_h - 1));
 	uint32_t texel = L.sky[((size_t) face * L.sky_h + y) * L.sky_w + x];
+	if (FAST && L.byte_lut)                         /* byte_lut[b] = (float) b / 255, built on this device */
+		return mk3(L.byte_lut[texel & 255u], L.byte_lut[(texel >> 8) & 255u], L.byte_lut[(texel >> 16) & 255u]);
 	return mk3((float) (texel & 255u) / 255.0f,
 	           (float) ((texel >> 8) & 255u) / 255.0f,
 	           (float) ((texel >> 16) & 255u) / 255.0f);
@@ -435,7 +448,7 @@ rt_trace_simple(const rt_launch L)
 			const V3 dn = unit3(rd);
 			const Hit hit = nearest_hit(sc, n, ro, dn);
 			if (hit.obj < 0) {
-				radiance = add3(radiance, had3(sky_lookup(L, dn), carry));   /* main.c:170-171 */
+				radiance = add3(radiance, had3(sky_lookup<false>(L, dn), carry));   /* main.c:170-171 */
 				break;
 			}
 			const V3 point = madd3(ro, dn, hit.t);                           /* scene.c:186 */
@@ -771,7 +784,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					} else {
 						V3 a, b = hit.n;
 						if (hit.obj >= 0) a = madd3(o, dn, hit.t);                   /* scene.c:186 */
-						else            { STAT(14); a = sky_lookup(L, dn); }         /* main.c:170  */
+						else            { STAT(14); a = sky_lookup<FAST>(L, dn); }         /* main.c:170  */
 						float (*dst)[64] = rkind == WF_KIND_PRIMARY ? W.blk : W.res;
 						dst[0][owner] = a.x; dst[1][owner] = a.y; dst[2][owner] = a.z;
 						dst[3][owner] = b.x; dst[4][owner] = b.y; dst[5][owner] = b.z;
@@ -800,7 +813,9 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 						taps++;
 					}
 				lit = scale3(lit, 1.0f / (float) taps);                          /* main.c:208-209 */
-				if (!(tiny_f(lit.x) && tiny_f(lit.y) && tiny_f(lit.z))) {        /* main.c:257-261 */
+				const bool dark = FAST ? (tiny_f_fast(lit.x) && tiny_f_fast(lit.y) && tiny_f_fast(lit.z))
+				                       : (tiny_f(lit.x) && tiny_f(lit.y) && tiny_f(lit.z));
+				if (!dark) {                                                      /* main.c:257-261 */
 					const float w = 0.05f;
 					rad = madd3(rad, had3(lit, carry), w);
 					carry = scale3(carry, 1.0f - w);
@@ -883,6 +898,13 @@ rt_accumulate(float *accum, const float *lowres, int width, int height, int scal
 	}
 }
 
+/* byte_lut[b] = (float) b / 255 -- the reference's texel conversion (gpu_and_windowing.c:108-110),
+ * evaluated once per context on the device so the table holds exactly what the kernels would compute */
+extern "C" __global__ void rt_fill_byte_lut(float *lut)
+{
+	lut[threadIdx.x] = (float) threadIdx.x / 255.0f;
+}
+
 /* chunked mode: add a pixel's stored samples in sample order and resolve (main.c:394,476) */
 extern "C" __global__ void __launch_bounds__(RT_BLOCK)
 rt_sum_samples(const float *samples, float *frame, size_t plane_floats, int spp, float inv_spp)
@@ -930,6 +952,7 @@ rt_deinterleave(const float *strips, float *frame, int width, int height, int ro
  * which = 0: div_by_refined   vs `/`   on floats,  numerator in [2^-100, 2^30], denominator in [2^-30, 2^30]
  *         1: div_by_refined64 vs `/`   on doubles, numerator in [2^-300, 2^300], denominator (double) 2a, a in [2^-20, 2^20]
  *         2: unit3_fast       vs unit3 on vectors of every magnitude (incl. zero / tiny / huge components)
+ *         4: tiny_f_fast      vs tiny_f (the |x| < 0.0001 test of vector.c:79 without fp64)
  *         3: sqrt_of_float64  vs __builtin_sqrt on doubles converted from positive floats (incl. denormals, squares)
  * out[0] = number of mismatching results, out[1..] = operands of one mismatch. */
 RT_DEV uint64_t st_next(uint64_t &s)
@@ -982,6 +1005,14 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 				out[1] = (unsigned long long) __double_as_longlong(num); out[2] = (unsigned long long) __double_as_longlong(den);
 				out[3] = (unsigned long long) __double_as_longlong(want); out[4] = (unsigned long long) __double_as_longlong(got);
 			}
+		} else if (which == 4) {
+			const uint64_t r0 = st_next(s);
+			float f = st_float(r0, -16, -10);                                  /* around 1e-4 = 2^-13.3 */
+			if ((r0 >> 60) == 0) f = __uint_as_float(0x38D1B717u + (uint32_t) ((r0 >> 8) & 7) - 3u);
+			if ((r0 >> 60) == 1) f = -__uint_as_float(0x38D1B717u + (uint32_t) ((r0 >> 8) & 7) - 3u);
+			if ((r0 >> 60) == 2) f = st_float(r0, -126, 127);
+			if ((r0 >> 56) == 0x30) f = __uint_as_float(0x7fc00000u);
+			if (tiny_f(f) != tiny_f_fast(f)) { bad++; out[1] = __float_as_uint(f); }
 		} else if (which == 3) {
 			const uint64_t r0 = st_next(s);
 			float f = __builtin_fabsf(st_float(r0, -149 + 23, 120));
@@ -1019,6 +1050,12 @@ hipError_t rt_launch_accumulate(float *accum, const float *lowres, int width, in
                                 int low_w, int low_h, float k, hipStream_t stream)
 {
 	hipLaunchKernelGGL(rt_accumulate, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, lowres, width, height, scale, low_w, low_h, k);
+	return hipGetLastError();
+}
+
+hipError_t rt_launch_fill_byte_lut(float *lut, hipStream_t stream)
+{
+	hipLaunchKernelGGL(rt_fill_byte_lut, dim3(1), dim3(256), 0, stream, lut);
 	return hipGetLastError();
 }
 

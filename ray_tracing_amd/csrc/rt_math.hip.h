@@ -62,6 +62,8 @@ RT_DEV V3 unit3(V3 v)
 RT_DEV float clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }   /* vector.c:52 */
 RT_DEV float clamp11(float x) { return x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x); }
 RT_DEV bool  tiny_f(float f) { return (double) f < 0.0001 && (double) f > -0.0001; } /* vector.c:79 */
+/* the same predicate without fp64: the largest float below the double 0.0001 is 0x38D1B717 (NaN -> false) */
+RT_DEV bool  tiny_f_fast(float f) { return __builtin_fabsf(f) <= __uint_as_float(0x38D1B717u); }
 
 
 /* ---- exact division with a shared reciprocal ---------------------------------------------------

@@ -24,12 +24,14 @@ for p in libs:
     if sky is None:
         sky = rt.load_skybox()
     r.set_skybox(sky); r.profile(True)
+    r._jit = bool(os.environ.get("AB_JIT"))
     rs.append(r)
 for name, scene, W, H, spp, nb in cfgs:
     times = [[], []]
     for k, r in enumerate(rs):
         rt._lib = r._L
         r.set_scene(f"{rt.DATA_DIR}/scene_{scene}.txt")
+        if r._jit: r.compile_scene()
     frames = [None, None]
     for it in range(rounds + 1):
         for k, r in enumerate(rs):
