@@ -21,6 +21,9 @@
 #pragma clang fp contract(off)
 
 #define RT_BLOCK    256
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 4     /* register budget of the wavefront kernels: 512 / 4 = 128 VGPRs */
+#endif
 #define RT_TILE_W   32     /* workgroup tile: 32 x 8 pixels = four 8x8 wave tiles side by side */
 #define RT_TILE_H   8
 
@@ -874,7 +877,7 @@ rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 
 #ifdef RT_SPEC_HEADER
 /* the same kernel with the trace loop specialised for one scene (rt_compile_scene, JIT) */
-extern "C" __global__ void __launch_bounds__(RT_BLOCK, 4)
+extern "C" __global__ void __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD)
 rt_trace_spec(const rt_launch L, unsigned int *block_counter)
 {
 	wavefront_body<true>(L, block_counter);
