@@ -5,11 +5,16 @@
  *   render_column() -> pixel() -> trace_ray()/sample_cubemap() -> accumulate -> resolve
  *   (main.c:274-322, 131-272, 387-396, 467-477; scene.c:10-190; gpu_and_windowing.c:42-112).
  *
- * One wavefront lane per pixel; the spp loop runs inside the lane so the per-pixel float sum is
- * formed in sample order exactly as the reference accumulates passes (main.c:394).  Scene
- * geometry and shading records are staged once per workgroup into LDS and read with wave-uniform
- * (broadcast) ds_read_b128.  The skybox stays in HBM / Infinity Cache as RGBA8 (one dword per
- * fetch).  No MFMA: there is no contraction in this workload.
+ * Kernels:
+ *   rt_trace_simple      the path loop in the reference's own order, one lane per pixel (cross-check)
+ *   rt_trace_wavefront   the tuned schedule: persistent waves, per-wave LDS ray queue, exact shortcuts
+ *   rt_trace_spec        the same, recompiled by hiprtc with the scene as constants (rt_compile_scene)
+ *   rt_sum_samples       sums chunked samples in sample order; rt_accumulate / rt_resolve (progressive
+ *                        passes); rt_deinterleave (multi-GPU root); rt_selftest_kernel
+ * One lane owns one path at a time and the samples of a pixel are always added in sample order
+ * (main.c:394), whichever kernel runs.  Scene geometry and shading records are staged once per
+ * workgroup into LDS and read with wave-uniform (broadcast) ds_read_b128; the skybox stays in HBM /
+ * Infinity Cache as RGBA8 (one dword per fetch).  No MFMA: there is no contraction in this workload.
  */
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
@@ -545,7 +550,10 @@ rt_trace_simple(const rt_launch L)
  *     gets them -- trace_ray() runs on (nearly) full waves;
  *   - the primary hit is traced once per pixel and re-used by all samples (the reference has no
  *     sub-pixel jitter, main.c:293-296, so bounce 0 of every sample is the same ray): bit-exact;
- *   - sky-only pixels cost one ray in total.
+ *     the 64 camera rays of a block are traced together as one batch when the wave takes the block,
+ *     and a sky-only pixel is finished on the spot;
+ *   - when a launch has few pixels per wave (multi-GPU strips) a pixel's samples are split into
+ *     chunks that different lanes take; samples are then stored and summed by rt_sum_samples.
  * The per-pixel sample sum is still formed in sample order (main.c:394), so results are
  * bit-identical to rt_trace_simple and to the CPU oracle.
  * ============================================================================================= */
