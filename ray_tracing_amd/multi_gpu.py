@@ -34,17 +34,31 @@ def frame_index(height, row_block, world):
     return (blk % world) * n + (blk // world) * row_block + j % row_block
 
 
+_use_all_gather = False      # set if the backend in use has no gather (then every rank receives all strips)
+
+
 def gather_strips(strip, rank, world, dst=0, out=None):
-    """One gather of equally-sized strips to `dst`.  Returns [world, rows, W, 3] on dst, None elsewhere."""
+    """One gather of equally-sized strips to `dst`.  Returns [world, rows, W, 3] on dst, None elsewhere.
+    Backends without a gather primitive fall back to one all-gather (same traffic pattern per link on a
+    fully connected xGMI node, 7x more bytes overall)."""
+    global _use_all_gather
     if world == 1:
         return strip.unsqueeze(0)
-    if rank == dst:
-        if out is None:
-            out = torch.empty((world,) + tuple(strip.shape), dtype=strip.dtype, device=strip.device)
-        dist.gather(strip, list(out.unbind(0)), dst=dst)
-        return out
-    dist.gather(strip, None, dst=dst)
-    return None
+    if not _use_all_gather:
+        try:
+            if rank == dst:
+                if out is None:
+                    out = torch.empty((world,) + tuple(strip.shape), dtype=strip.dtype, device=strip.device)
+                dist.gather(strip, list(out.unbind(0)), dst=dst)
+                return out
+            dist.gather(strip, None, dst=dst)
+            return None
+        except (RuntimeError, NotImplementedError):
+            _use_all_gather = True       # every rank takes this branch on the same call
+    if out is None:
+        out = torch.empty((world,) + tuple(strip.shape), dtype=strip.dtype, device=strip.device)
+    dist.all_gather_into_tensor(out, strip)
+    return out if rank == dst else None
 
 
 def assemble(strips, height, row_block, world, renderer=None, out=None):
