@@ -278,3 +278,72 @@ def test_camera_interaction_matches_reference():
         got = np.array([cam.pos.x, cam.pos.y, cam.pos.z, cam.front.x, cam.front.y, cam.front.z, cam.up.x, cam.up.y, cam.up.z], np.float32)
         assert (bits(got) == bits(want)).all(), step
     ref.set_camera()
+
+
+def _random_scene_text(rng):
+    """Grammar-driven text with deliberate damage: the loader must agree with the reference on every one."""
+    props_sphere = ["radius", "center"]
+    props_cube = ["origin", "size"]
+    props_mat = ["albedo", "roughness", "reflectance", "metallic", "emission_power", "emission_color"]
+    vec_props = {"center", "origin", "size", "albedo", "emission_color"}
+
+    def num():
+        k = rng.integers(8)
+        if k == 0:
+            return str(int(rng.integers(0, 3)))
+        if k == 1:
+            return f"-{rng.uniform(0, 9):.{int(rng.integers(1, 8))}f}"
+        if k == 2:
+            return f"{rng.uniform(0, 1):.{int(rng.integers(1, 9))}f}"
+        if k == 3:
+            return str(int(rng.integers(0, 200)))
+        if k == 4:
+            return f"{rng.uniform(0, 1):.3f}"
+        if k == 5:
+            return rng.choice(["1.", ".5", "+1", "1e3", "-", "0.0.1", "0x10", "1,5"])
+        return f"{rng.uniform(0, 2):.2f}"
+
+    out = []
+    for _ in range(int(rng.integers(0, 6))):
+        kind = rng.choice(["sphere", "cube", "sphere", "cube", "Sphere", "cub"])
+        out.append(kind)
+        pool = props_mat + (props_sphere if kind == "sphere" else props_cube)
+        if rng.integers(6) == 0:
+            pool = pool + props_sphere + props_cube
+        for _ in range(int(rng.integers(0, 7))):
+            p = rng.choice(pool)
+            sep = rng.choice(["   ", "    ", "\t\t\t", " ", "\n   ", "      "])
+            if p in vec_props:
+                vals = " ".join(num() for _ in range(int(rng.choice([3, 3, 3, 3, 2, 4]))))
+                brace = rng.choice(["{%s}", "{%s}", "{ %s }", "{%s", "%s}", "{\n%s\n}"])
+                out.append(f"\n\t{p}{sep}{brace % vals}")
+            else:
+                out.append(f"\n\t{p}{sep}{num()}")
+        out.append(rng.choice(["\n\n", "\n", "  ", "\r\n"]))
+    return "".join(out) + "    \n   "          # padding: keeps the reference's 9/11-character skips inside the buffer
+
+
+def test_scene_loader_fuzz_against_oracle_and_reference(oracle, capfd, tmp_path):
+    from rtlibs import Ref, ref_available
+    ref = Ref() if ref_available() else None
+    rng = np.random.default_rng(2024)
+    n_ok = 0
+    for k in range(400):
+        text = _random_scene_text(rng)
+        rc, buf = rt.parse_scene_string(text)
+        err = capfd.readouterr().err
+        rc_o, buf_o = oracle.parse_scene_string(text)
+        err_o = capfd.readouterr().err
+        assert (rc == 0) == (rc_o == 0) and err == err_o, repr(text)
+        if rc == 0:
+            n_ok += 1
+            assert scene_signature(buf) == scene_signature(buf_o), repr(text)
+        if ref is not None:
+            f = tmp_path / "s.txt"
+            f.write_text(text, newline="")
+            rc_r, buf_r = ref.parse_scene_file(str(f))
+            err_r = capfd.readouterr().err
+            assert (rc_r == 0) == (rc == 0) and err_r == err, repr(text)
+            if rc == 0:
+                assert scene_signature(buf) == scene_signature(buf_r), repr(text)
+    assert 40 < n_ok < 360          # the generator produces both accepted and rejected files
