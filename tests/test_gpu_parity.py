@@ -256,3 +256,25 @@ def test_c1_exact_benchmark_config(gpu, real_sky, scene_paths):
         c = o.render_counter(W, H, spp, nb, seed=0, rows=(r0, r0 + 1))
         assert (bits(c[r0]) == bits(a[r0])).all(), r0
     print(f"C1 frame mean {a.mean():.6f}")
+
+
+def test_parameter_sweep_small_frames(gpu, oracle, scene_paths):
+    """Odd sizes, extreme spp / bounce limits, every chunking regime (RT_CHUNKS override), seeds near 2^64."""
+    sky = synthetic_skybox(24, seed=2)
+    gpu.set_skybox(sky); oracle.set_skybox(sky)
+    gpu.set_camera(); oracle.set_camera()
+    cases = [(0, 2, 2, 1, 1, 0), (0, 3, 2, 5, 1, 1), (1, 9, 7, 130, 3, 2**64 - 1), (2, 17, 5, 64, 50, 2**63),
+             (0, 64, 8, 1024, 4, 77), (1, 8, 64, 33, 16, 5), (0, 13, 11, 7, 0, 3)]
+    for (si, W, H, spp, nb, seed) in cases:
+        gpu.set_scene(scene_paths[si]); oracle.load_scene(scene_paths[si])
+        want = oracle.render_counter(W, H, spp, nb, seed=seed)
+        for chunks in (None, "1", "3", "1000"):
+            if chunks is None:
+                os.environ.pop("RT_CHUNKS", None)
+            else:
+                os.environ["RT_CHUNKS"] = chunks
+            try:
+                got = gpu.render(W, H, spp, nb, seed=seed)
+            finally:
+                os.environ.pop("RT_CHUNKS", None)
+            assert (bits(got) == bits(want)).all(), (si, W, H, spp, nb, seed, chunks)
