@@ -156,6 +156,7 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 	const int n = scene->num_objects;
 	if (n < 0 || n > MAX_OBJECTS) return fail(RT_ERR_ARGUMENT, "rt_set_scene: num_objects %d not in [0,%d]", n, MAX_OBJECTS);
 	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipDeviceSynchronize());     /* frames still in flight (rt_render_device) read the old scene / compiled kernel */
 
 	std::vector<rt_geom>  geom((size_t) n > 0 ? n : 1);
 	std::vector<rt_shade> shade((size_t) n > 0 ? n : 1);
@@ -261,6 +262,7 @@ int rt_set_skybox(rt_context *ctx, const Cubemap *sky)
 	for (int f = 0; f < 6; f++)
 		if (!sky->data[f]) return fail(RT_ERR_ARGUMENT, "rt_set_skybox: face %d is NULL", f);
 	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipDeviceSynchronize());     /* frames still in flight read the old texels */
 
 	/* RGBA8 repack: one aligned dword per texel for the kernel's gather (sample_cubemap reads
 	 * bytes [0..2] of a `chan`-strided texel, gpu_and_windowing.c:106-111) */
