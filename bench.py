@@ -192,6 +192,22 @@ def main():
                 "note": "no MFMA/HBM bound applies (SURVEY.md 8d): peak = fp32 VALU issue rate without FMA "
                         "(parity forbids contraction) = 157.3/2 TFLOP/s; flops counted as written in the reference",
             }
+        if "roofline" in out:
+            # HBM-side traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot
+            # collect PMC counters itself): FETCH_SIZE + WRITE_SIZE in bytes per launch, N = 1 only.
+            prof = os.path.join(ROOT, "profiles", "r01", "v6_final_summary.txt")
+            if world == 1 and compiled and os.path.exists(prof):
+                vals = {}
+                for line in open(prof):
+                    parts = line.split()
+                    if len(parts) == 2 and parts[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+                        vals[parts[0]] = float(parts[1]) * 1024.0
+                if len(vals) == 2:
+                    out["roofline"]["traffic"] = round(vals["FETCH_SIZE"] + vals["WRITE_SIZE"])
+                    out["roofline"]["traffic_note"] = ("bytes per launch from profiles/r01/v6_final_summary.txt (rocprofv3 --pmc "
+                                                       "FETCH_SIZE / WRITE_SIZE in separate passes); reads are scattered 4-byte "
+                                                       "skybox gathers (one 32-64 B sector each, served by the 256 MiB Infinity "
+                                                       "Cache that holds the whole 100 MB skybox), so no x2 streaming correction is applied")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(w, sky)
