@@ -71,8 +71,10 @@ struct rt_context {
 	unsigned int *d_counter = nullptr;   /* pixel-block counter of the persistent kernel */
 	int          num_cus = 256;
 
-	float       *d_samples = nullptr;    /* per-sample colours of the chunked mode (few pixels per GPU) */
+	float       *d_samples = nullptr;    /* per-sample colours of the chunked mode */
 	size_t       samples_bytes = 0;
+	unsigned char *d_direct = nullptr;   /* per-pixel "written directly" flags of the chunked mode */
+	size_t       direct_bytes = 0;
 
 	float       *d_frame = nullptr;      /* scratch for rt_render() */
 	size_t       frame_bytes = 0;
@@ -123,7 +125,7 @@ int rt_create(rt_context **out, int device_id)
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
 			ctx->num_cus = prop.multiProcessorCount;
-		e = hipMalloc((void**) &ctx->d_counter, 64);
+		e = hipMalloc((void**) &ctx->d_counter, rt_counter_bytes());
 		if (e == hipSuccess) e = hipMalloc((void**) &ctx->d_byte_lut, 256 * sizeof(float));
 		if (e == hipSuccess) e = rt_launch_fill_byte_lut(ctx->d_byte_lut, ctx->stream);
 		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -144,7 +146,7 @@ void rt_destroy(rt_context *ctx)
 	for (auto &e : ctx->event_pool) (void) hipEventDestroy(e);
 	if (ctx->spec_module) (void) hipModuleUnload(ctx->spec_module);
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
-	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame); (void) hipFree(ctx->d_counter); (void) hipFree(ctx->d_samples); (void) hipFree(ctx->d_byte_lut);
+	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame); (void) hipFree(ctx->d_counter); (void) hipFree(ctx->d_samples); (void) hipFree(ctx->d_direct); (void) hipFree(ctx->d_byte_lut);
 	(void) hipFree(ctx->prog.d_accum); (void) hipFree(ctx->prog.d_low); (void) hipFree(ctx->prog.d_out);
 	(void) hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -362,43 +364,53 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.byte_lut = ctx->d_byte_lut;
 	L.frame = (float*) d_strip;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
-	L.num_chunks = 1; L.chunk_spp = p->spp; L.samples = nullptr;
+	L.num_chunks = 1; L.chunk_spp = p->spp; L.samples = nullptr; L.direct = nullptr;
+	L.num_shards = 1;
 	/* Few pixels per GPU (multi-GPU strips, small frames): one lane per pixel cannot fill the chip, so a
 	 * pixel's samples are split over several lanes and summed afterwards in sample order. */
 	if (p->kernel != RT_KERNEL_SIMPLE && p->max_bounces >= 1 && p->spp > 1) {
 		const long long pixel_blocks = (long long) ((p->width + 7) / 8) * ((L.local_rows + 7) / 8);
-		/* measured on C1 strips (scripts/chunk_sweep.py): ~24 work blocks per resident wave balance the
-		 * persistent waves' tails; more than 16 chunks costs more in repeated camera rays than it gains */
+		/* Work items are (8x8 pixel block, chunk of samples).  Measured (scripts/chunk_sweep*.py): items of
+		 * about 16 samples balance the persistent waves' tails on full frames, and a launch wants about 24
+		 * items per resident wave; more than 16 chunks costs more in repeated camera rays than it gains. */
 		const long long want_blocks = (long long) ctx->num_cus * 16 * 24;
-		int chunks = 1;
+		int chunks = (p->spp + 15) / 16;
+		if (pixel_blocks > 0 && pixel_blocks * chunks < want_blocks) chunks = (int) ((want_blocks + pixel_blocks - 1) / pixel_blocks);
+		if (chunks > 16) chunks = 16;
 		if (const char *e = getenv("RT_CHUNKS")) chunks = atoi(e);               /* tuning / test override */
-		else if (pixel_blocks > 0 && pixel_blocks < want_blocks) chunks = (int) ((want_blocks + pixel_blocks - 1) / pixel_blocks);
-		if (chunks > 16 && !getenv("RT_CHUNKS")) chunks = 16;
 		if (chunks > p->spp) chunks = p->spp;
 		if (chunks > 1) {
 			const int chunk_spp = (p->spp + chunks - 1) / chunks;
 			chunks = (p->spp + chunk_spp - 1) / chunk_spp;
-			const size_t need = (size_t) p->spp * L.local_rows * p->width * 3 * sizeof(float);
+			const size_t pixels = (size_t) L.local_rows * p->width;
+			const size_t need = (size_t) p->spp * pixels * 3 * sizeof(float);
 			if (chunks > 1 && need <= ((size_t) 8 << 30)) {
 				if (need > ctx->samples_bytes) {
 					(void) hipFree(ctx->d_samples); ctx->d_samples = nullptr; ctx->samples_bytes = 0;
 					HIP_TRY(hipMalloc((void**) &ctx->d_samples, need));
 					ctx->samples_bytes = need;
 				}
-				L.num_chunks = chunks; L.chunk_spp = chunk_spp; L.samples = ctx->d_samples;
+				if (pixels > ctx->direct_bytes) {
+					(void) hipFree(ctx->d_direct); ctx->d_direct = nullptr; ctx->direct_bytes = 0;
+					HIP_TRY(hipMalloc((void**) &ctx->d_direct, pixels));
+					ctx->direct_bytes = pixels;
+				}
+				HIP_TRY(hipMemsetAsync(ctx->d_direct, 0, pixels, stream));
+				L.num_chunks = chunks; L.chunk_spp = chunk_spp; L.samples = ctx->d_samples; L.direct = ctx->d_direct;
 			}
 		}
 	}
 
-	if (rt_wavefront_lds_bytes(L.num_objects) > 160 * 1024)
-		return fail(RT_ERR_ARGUMENT, "render: scene needs %zu B of LDS (> 160 KiB)", rt_wavefront_lds_bytes(L.num_objects));
+	/* 4K-class frames can be dominated by cheap (sky) work items: give them 64 dequeue counters */
+	if ((long long) ((p->width + 7) / 8) * ((L.local_rows + 7) / 8) >= 100000 && ctx->num_cus >= 64) L.num_shards = 64;
+	if (const char *e = getenv("RT_SHARDS")) { const int v = atoi(e); if (v == 1 || v == 64) L.num_shards = v; }   /* tuning aid */
 
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (ctx->profiling) { e0 = take_event(ctx); e1 = take_event(ctx); HIP_TRY(hipEventRecord(e0, stream)); }
 	HIP_TRY(rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, stream));
 	if (ctx->profiling) { HIP_TRY(hipEventRecord(e1, stream)); ctx->events.emplace_back(e0, e1); }
 	if (L.num_chunks > 1)
-		HIP_TRY(rt_launch_sum_samples(L.samples, L.frame, (size_t) L.local_rows * L.width * 3, L.spp, stream));
+		HIP_TRY(rt_launch_sum_samples(L.samples, L.direct, L.frame, (size_t) L.local_rows * L.width * 3, L.spp, stream));
 	return RT_OK;
 }
 
@@ -506,7 +518,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.byte_lut = ctx->d_byte_lut;
 	L.frame = g.d_low;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
-	L.num_chunks = 1; L.chunk_spp = 1; L.samples = nullptr;
+	L.num_chunks = 1; L.chunk_spp = 1; L.samples = nullptr; L.direct = nullptr; L.num_shards = 1;
 	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->stream));
 	const float weight = 1.0f / (s * s);                                         /* main.c:278 */
 	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), ctx->stream));

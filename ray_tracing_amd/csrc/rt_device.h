@@ -76,8 +76,10 @@ typedef struct {
 	 * items of chunk_spp samples so that more lanes than pixels can be busy; each clamped sample is
 	 * stored to samples[s][pixel][3] and rt_sum_samples adds them in sample order (main.c:394).
 	 * num_chunks == 1: the lane sums its pixel itself and writes `frame`. */
+	int    num_shards;         /* work-item queues in use (1 or 64), see wavefront_body */
 	int    num_chunks, chunk_spp;
 	float *samples;
+	unsigned char *direct;     /* per local pixel: 1 = written directly by the trace kernel (sky-only), zeroed per launch */
 	const rt_geom  *geom;      /* num_objects records (global; staged to LDS)  */
 	const rt_shade *shade;
 } rt_launch;

@@ -19,6 +19,7 @@
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstring>
 #endif
 #include "rt_device.h"
 #include "rt_math.hip.h"
@@ -558,6 +559,8 @@ rt_trace_simple(const rt_launch L)
  * bit-identical to rt_trace_simple and to the CPU oracle.
  * ============================================================================================= */
 
+#define RT_COUNTER_BYTES (64 * 128)     /* WF_SHARDS counters, one per 128-byte line */
+#define WF_SHARDS  64                  /* work-item queues (counters 128 B apart), see wavefront_body */
 #define WF_QUEUE   128                 /* ring: at most 63 left over + 64 pushed at a time */
 #define WF_KIND_PRIMARY 0              /* camera ray of pixel `owner` of the wave's current 8x8 block */
 #define WF_KIND_MAIN    1              /* next bounce ray of lane `owner`; kinds 2..4 = its shadow tap 0..2 */
@@ -623,9 +626,15 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			if (wmask == 0ull) break;
 			if (cur_next >= 64) {
 				if (exhausted || fetched) break;
+				/* Work items are dealt from `num_shards` interleaved queues (item = shard + num_shards * k), each
+				 * with its own counter on its own 128-byte line: one counter saturates at ~88 dequeues/us
+				 * (MI355X_MICROARCH.md), which a sky-dominated 4K frame exceeds (C3: 2.1 -> 1.3 ms).  A wave pulls
+				 * only from the queue of its workgroup; the queues hold equal, interleaved shares of the frame.
+				 * The host uses one queue unless the frame has >= 100k pixel blocks. */
 				unsigned int b = 0;
-				if (lane == 0) b = atomicAdd(block_counter, 1u);
+				if (lane == 0) b = atomicAdd(block_counter + (blockIdx.x % (unsigned int) L.num_shards) * 32u, 1u);
 				b = (unsigned int) __builtin_amdgcn_readfirstlane((int) b);
+				b = blockIdx.x % (unsigned int) L.num_shards + (unsigned int) L.num_shards * b;
 				if (b >= num_blocks) { exhausted = true; break; }
 				cur_block = b / (unsigned int) L.num_chunks; cur_next = 0; blk_ready = false; fetched = true;
 				cur_s0 = (int) (b % (unsigned int) L.num_chunks) * L.chunk_spp;
@@ -658,12 +667,10 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 						/* sky-only pixel: every sample is clamp(0 + sky * 1) (main.c:171,267-269), summed
 						 * in sample order and resolved (main.c:394,476) */
 						const V3 c = mk3(clamp01(a.x), clamp01(a.y), clamp01(a.z));
-						if (chunked) {
-							for (int k = cur_s0; k < cur_s1; k++) {
-								float *dst = L.samples + (size_t) k * sample_stride + ((size_t) lr * L.width + i) * 3;
-								dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
-							}
+						if (chunked && cur_s0 != 0) {
+							/* another chunk of a sky-only pixel: the lane that has chunk 0 writes the pixel */
 						} else {
+							if (chunked) L.direct[(size_t) lr * L.width + i] = 1;     /* rt_sum_samples skips it */
 							V3 acc = mk3(0, 0, 0);
 							for (int k = 0; k < L.spp; k++) acc = add3(acc, c);
 							const V3 res = scale3(acc, inv_spp);
@@ -916,21 +923,33 @@ extern "C" __global__ void rt_fill_byte_lut(float *lut)
 	lut[threadIdx.x] = (float) threadIdx.x / 255.0f;
 }
 
-/* chunked mode: add a pixel's stored samples in sample order and resolve (main.c:394,476) */
+/* chunked mode: add a pixel's stored samples in sample order and resolve (main.c:394,476).  Pixels
+ * flagged in `direct` (sky-only pixels) were written by the trace kernel itself and are skipped. */
 extern "C" __global__ void __launch_bounds__(RT_BLOCK)
-rt_sum_samples(const float *samples, float *frame, size_t plane_floats, int spp, float inv_spp)
+rt_sum_samples(const float *samples, const unsigned char *direct, float *frame, size_t plane_floats, int spp, float inv_spp)
 {
 	/* 16 B per lane: four independent sequential sums per thread, coalesced across the wave */
 	const size_t quads = plane_floats / 4;
 	for (size_t q = (size_t) blockIdx.x * RT_BLOCK + threadIdx.x; q < quads; q += (size_t) gridDim.x * RT_BLOCK) {
+		const size_t p0 = (4 * q) / 3, p1 = (4 * q + 3) / 3;          /* the (at most two) pixels these four floats belong to */
+		const bool d0 = direct[p0] != 0, d1 = direct[p1] != 0;
+		if (d0 && d1) continue;
 		float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		for (int s = 0; s < spp; s++) {
 			const float4 v = *reinterpret_cast<const float4*>(samples + (size_t) s * plane_floats + 4 * q);
 			acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
 		}
-		*reinterpret_cast<float4*>(frame + 4 * q) = make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp);
+		float *dst = frame + 4 * q;
+		if (!d0 && !d1)
+			*reinterpret_cast<float4*>(dst) = make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp);
+		else {
+			const float r[4] = { acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp };
+			for (int k = 0; k < 4; k++)
+				if (!direct[(4 * q + k) / 3]) dst[k] = r[k];
+		}
 	}
 	for (size_t p = quads * 4 + (size_t) blockIdx.x * RT_BLOCK + threadIdx.x; p < plane_floats; p += (size_t) gridDim.x * RT_BLOCK) {
+		if (direct[p / 3]) continue;
 		float acc = 0.0f;
 		for (int s = 0; s < spp; s++) acc = acc + samples[(size_t) s * plane_floats + p];
 		frame[p] = acc * inv_spp;
@@ -1070,9 +1089,9 @@ hipError_t rt_launch_fill_byte_lut(float *lut, hipStream_t stream)
 	return hipGetLastError();
 }
 
-hipError_t rt_launch_sum_samples(const float *samples, float *frame, size_t plane_floats, int spp, hipStream_t stream)
+hipError_t rt_launch_sum_samples(const float *samples, const unsigned char *direct, float *frame, size_t plane_floats, int spp, hipStream_t stream)
 {
-	hipLaunchKernelGGL(rt_sum_samples, dim3(4096), dim3(RT_BLOCK), 0, stream, samples, frame, plane_floats, spp, 1.0f / (float) spp);
+	hipLaunchKernelGGL(rt_sum_samples, dim3(4096), dim3(RT_BLOCK), 0, stream, samples, direct, frame, plane_floats, spp, 1.0f / (float) spp);
 	return hipGetLastError();
 }
 
@@ -1103,6 +1122,8 @@ extern "C" __attribute__((visibility("default"))) int rt_stats_read(unsigned lon
 
 /* ---- host-callable launchers (C++ linkage inside the library; the C ABI lives in rt_api.cpp) -- */
 
+size_t rt_counter_bytes() { return RT_COUNTER_BYTES; }
+
 size_t rt_scene_lds_bytes(int num_objects) { return (size_t) num_objects * (sizeof(rt_geom) + sizeof(rt_shade)); }
 
 size_t rt_wavefront_lds_bytes(int num_objects) { return rt_scene_lds_bytes(num_objects) + (RT_BLOCK / 64) * sizeof(WaveLDS); }
@@ -1129,7 +1150,8 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	const long long useful = (blocks + (RT_BLOCK / 64) - 1) / (RT_BLOCK / 64);
 	if (grid > useful) grid = useful;
 	if (grid < 1) grid = 1;
-	hipError_t e = hipMemsetAsync(block_counter, 0, sizeof(unsigned int), stream);
+	if (grid < L.num_shards) return hipErrorInvalidValue;      /* every queue needs a workgroup (rt_api.cpp picks num_shards) */
+	hipError_t e = hipMemsetAsync(block_counter, 0, RT_COUNTER_BYTES, stream);
 	if (e != hipSuccess) return e;
 	if (variant == 0 /* RT_KERNEL_AUTO */ && scene_fast_ok && spec_fn) {
 		/* same kernel, trace loop specialised for this scene by rt_compile_scene() */
