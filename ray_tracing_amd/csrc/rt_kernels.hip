@@ -379,7 +379,7 @@ RT_DEV V3 sky_lookup(const rt_launch &L, V3 dir)
 	}
 	float u, v;
 	const float lo = __builtin_fminf(__builtin_fabsf(nu), __builtin_fabsf(nv));
-	if (FAST && wave_all(m >= 0x1p-30f && m <= 0x1p+30f && lo >= 0x1p-100f && __builtin_fmaxf(__builtin_fabsf(nu), __builtin_fabsf(nv)) <= 0x1p+30f)) {
+	if (FAST && wave_all(m >= 0x1p-30f && m <= 0x1p+20f && lo >= 0x1p-100f && __builtin_fmaxf(__builtin_fabsf(nu), __builtin_fabsf(nv)) <= 0x1p+30f)) {
 		const float r = rcp_refined(m);             /* both quotients share the reciprocal (rt_math.hip.h) */
 		u = div_by_refined(nu, m, r);
 		v = div_by_refined(nv, m, r);
@@ -984,6 +984,9 @@ rt_deinterleave(const float *strips, float *frame, int width, int height, int ro
  *         2: unit3_fast       vs unit3 on vectors of every magnitude (incl. zero / tiny / huge components)
  *         4: tiny_f_fast      vs tiny_f (the |x| < 0.0001 test of vector.c:79 without fp64)
  *         3: sqrt_of_float64  vs __builtin_sqrt on doubles converted from positive floats (incl. denormals, squares)
+ *         5: EXHAUSTIVE: rcp_refined vs 1/d for all 2^23 significands; div_by_refined vs `/` for every d significand x
+ *            `iters` n significands (iters = 2^23 = all 2^46 pairs, 52 s; `seed` picks the first numerator)
+ *         6: EXHAUSTIVE: sqrt_in_window vs sqrtf (+ the refined reciprocal of the root) for every float in [2^-30, 2^60]
  * out[0] = number of mismatching results, out[1..] = operands of one mismatch. */
 RT_DEV uint64_t st_next(uint64_t &s)
 {
@@ -1007,10 +1010,45 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 {
 	uint64_t s = seed + 0x1000003ull * (uint64_t) (blockIdx.x * RT_BLOCK + threadIdx.x);
 	unsigned long long bad = 0;
+	if (which == 5) {
+		/* every denominator significand x `iters` numerator significands (iters = 2^23: all pairs).  The
+		 * sequences are invariant under power-of-two scaling inside the window, so [1,2) x [1,2) is enough. */
+		const uint32_t step = 0x9E3779B1u & 0x7fffffu, offset = (uint32_t) seed & 0x7fffffu;      /* odd: a bijection mod 2^23 */
+		for (uint32_t md = blockIdx.x * RT_BLOCK + threadIdx.x; md < (1u << 23); md += gridDim.x * RT_BLOCK) {
+			const float d = __uint_as_float(0x3f800000u | md);
+			const float r = rcp_refined(d);
+			if (__float_as_uint(r) != __float_as_uint(1.0f / d)) { bad++; out[1] = __float_as_uint(d); out[3] = __float_as_uint(1.0f / d); out[4] = __float_as_uint(r); }
+			uint32_t mn = offset;
+			for (int it = 0; it < iters; it++, mn = (mn + step) & 0x7fffffu) {
+				const float n = __uint_as_float(0x3f800000u | mn);
+				const float want = n / d, got = div_by_refined(n, d, r);
+				if (__float_as_uint(want) != __float_as_uint(got)) {
+					bad++;
+					out[1] = __float_as_uint(n); out[2] = __float_as_uint(d); out[3] = __float_as_uint(want); out[4] = __float_as_uint(got);
+				}
+			}
+		}
+		if (bad) atomicAdd(&out[0], bad);
+		return;
+	}
+	if (which == 6) {
+		/* every float in [2^-30, 2^60]: sqrt_in_window vs sqrtf, and the refined reciprocal of the root */
+		const uint32_t first = 0x3f800000u - (30u << 23), count = (90u << 23) + 1u;
+		for (uint32_t k = blockIdx.x * RT_BLOCK + threadIdx.x; k < count; k += gridDim.x * RT_BLOCK) {
+			const float x = __uint_as_float(first + k);
+			const float want = __builtin_sqrtf(x), got = sqrt_in_window(x);
+			if (__float_as_uint(want) != __float_as_uint(got) || __float_as_uint(rcp_refined(want)) != __float_as_uint(1.0f / want)) {
+				bad++;
+				out[1] = __float_as_uint(x); out[3] = __float_as_uint(want); out[4] = __float_as_uint(got);
+			}
+		}
+		if (bad) atomicAdd(&out[0], bad);
+		return;
+	}
 	for (int it = 0; it < iters; it++) {
 		if (which == 0) {
 			const uint64_t r0 = st_next(s), r1 = st_next(s);
-			float n = st_float(r0, -100, 30), d = st_float(r1, -30, 30);
+			float n = st_float(r0, -100, 30), d = st_float(r1, -30, 20);
 			if ((r0 >> 60) == 0) d = __uint_as_float((__float_as_uint(d) & 0xff800000u) | ((uint32_t) (r1 >> 40) & 0x3u));   /* near powers of two */
 			if ((r1 >> 60) == 1) n = d * st_float(r0, -2, 2);                        /* correlated operands */
 			const float want = n / d;
@@ -1057,13 +1095,16 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 			}
 		} else {
 			const uint64_t r0 = st_next(s), r1 = st_next(s), r2 = st_next(s), r3 = st_next(s);
-			int lo = -20, hi = 20;
-			switch (r3 & 7) { case 0: lo = -126; hi = 127; break; case 1: lo = -30; hi = -10; break; case 2: lo = 20; hi = 64; break; default: break; }
+			/* unit3_fast decides per WAVE: even iterations keep a whole wave inside the tuned form's window,
+			 * odd ones mix magnitudes and special values so that single lanes push their wave out of it */
+			int lo = -14, hi = 29;
+			const bool mixed = (it & 1) != 0;
+			if (mixed) switch (r3 & 7) { case 0: lo = -126; hi = 127; break; case 1: lo = -30; hi = -10; break; case 2: lo = 20; hi = 64; break; default: lo = -20; hi = 20; break; }
 			V3 v = mk3(st_float(r0, lo, hi), st_float(r1, lo, hi), st_float(r2, lo, hi));
-			if (((r3 >> 8) & 15) == 0) v.x = 0.0f;
-			if (((r3 >> 12) & 15) == 0) v.y = -0.0f;
-			if (((r3 >> 16) & 31) == 0) v.z = __uint_as_float((uint32_t) r2 & 0x807fffffu);   /* denormal */
-			if (((r3 >> 24) & 63) == 0) { const float k = 0.00001f / __builtin_sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); v = scale3(v, k); }
+			if (mixed && ((r3 >> 8) & 15) == 0) v.x = 0.0f;
+			if (mixed && ((r3 >> 12) & 15) == 0) v.y = -0.0f;
+			if (mixed && ((r3 >> 16) & 31) == 0) v.z = __uint_as_float((uint32_t) r2 & 0x807fffffu);   /* denormal */
+			if (mixed && ((r3 >> 24) & 63) == 0) { const float k = 0.00001f / __builtin_sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); v = scale3(v, k); }
 			const V3 want = unit3(v), got = unit3_fast(v);
 			if (__float_as_uint(want.x) != __float_as_uint(got.x) || __float_as_uint(want.y) != __float_as_uint(got.y) ||
 			    __float_as_uint(want.z) != __float_as_uint(got.z)) {

@@ -67,17 +67,19 @@ RT_DEV bool  tiny_f_fast(float f) { return __builtin_fabsf(f) <= __uint_as_float
 
 
 /* ---- exact division with a shared reciprocal ---------------------------------------------------
- * hipcc lowers an IEEE `n / d` to  v_div_scale x2, v_rcp, two Newton steps on the reciprocal, a
- * product, two residual corrections (the last inside v_div_fmas) and v_div_fixup.  When neither
- * operand needs rescaling -- both comfortably inside the normal range and their ratio too (the
- * conditions of V_DIV_SCALE_F32 in the CDNA ISA guide) -- the scale/fixup instructions are
- * identities and the quotient is exactly
- *     r = rcp(d); r += r*(1 - d*r);  q = n*r;  q += r*(n - d*q);  q += r*(n - d*q)
- * evaluated with fused multiply-adds.  The reciprocal part depends on d only, so a ray that
- * divides many numerators by the same three direction components (the slab test, scene.c:31-59),
- * or a vector divided by its length (vector.c:134-136), pays for it once.  The result is the same
- * correctly rounded quotient, bit for bit; rt_selftest() (tests/test_gpu_selftest.py) checks that
- * against `/` on 10^9 operand pairs.  Operands outside the safe window take the ordinary `/`.
+ * hipcc lowers an IEEE `n / d` to  v_div_scale x2, v_rcp, a Newton step on the reciprocal, a product,
+ * two residual corrections (the last inside v_div_fmas) and v_div_fixup.  When neither operand needs
+ * rescaling -- both inside the exponent window below, so that every intermediate is a normal number and
+ * the sequence is invariant under scaling by powers of two -- much less is needed on gfx950:
+ *     r = rcp(d); r += r*(1 - d*r);          is RN(1/d) for EVERY significand of d, and
+ *     q = n*r;    q += r*(n - d*q)           is RN(n/d) for EVERY pair of significands (n, d)
+ * (fused multiply-adds).  Both statements are verified exhaustively on the device -- all 2^23
+ * reciprocals, all 2^46 significand pairs, against `/` -- by rt_selftest(5) (tests/test_gpu_selftest.py
+ * runs a stratified subset on every run, the full sweep takes 52 s; scripts/ubench/div_exhaustive.hip).
+ * The reciprocal depends on d only, so a ray that divides many numerators by the same three direction
+ * components (the slab test, scene.c:31-59), or a vector divided by its length (vector.c:134-136),
+ * pays for it once and each quotient costs three instructions.  Operands outside the window (zeros,
+ * denormals, infinities, NaN included) take the ordinary `/`.
  */
 RT_DEV float rcp_refined(float d)
 {
@@ -88,21 +90,32 @@ RT_DEV float rcp_refined(float d)
 
 RT_DEV float div_by_refined(float n, float d, float r)
 {
-	float q = n * r;
-	q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
-	q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
-	return q;
+	const float q = n * r;
+	return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
 }
 
-/* |x| in [2^-30, 2^30]: a denominator for which rcp_refined/div_by_refined are exact (with a
- * numerator accepted by num_in_window) */
+/* |x| in [2^-30, 2^20]: a denominator for which rcp_refined/div_by_refined are exact (with a numerator
+ * accepted by num_in_window: quotient >= 2^-120 and residual granularity >= 2^-147, all normal/exact) */
 RT_DEV bool den_in_window(float x)
 {
 	const float a = __builtin_fabsf(x);
-	return a >= 0x1p-30f && a <= 0x1p+30f;
+	return a >= 0x1p-30f && a <= 0x1p+20f;
 }
 /* |x| in [2^-60, 2^30]; zero, NaN and infinities are outside */
 RT_DEV bool num_in_window(float lo_abs, float hi_abs) { return lo_abs >= 0x1p-60f && hi_abs <= 0x1p+30f; }
+
+/* sqrtf for x in [2^-30, 2^60]: rsq-seeded coupled (Goldschmidt) step + one residual correction.  Equal
+ * to the correctly rounded sqrtf for every float in that range (exhaustive: rt_selftest(6)); hipcc's own
+ * expansion spends twice the instructions on input scaling, +-1 ulp selection and class fix-ups. */
+RT_DEV float sqrt_in_window(float x)
+{
+	const float y = __builtin_amdgcn_rsqf(x);
+	float g = x * y, h = 0.5f * y;
+	const float e = __builtin_fmaf(-h, g, 0.5f);
+	g = __builtin_fmaf(g, e, g);
+	h = __builtin_fmaf(h, e, h);
+	return __builtin_fmaf(__builtin_fmaf(-g, g, x), h, g);
+}
 
 RT_DEV double rcp_refined64(double d)
 {
@@ -118,21 +131,23 @@ RT_DEV double div_by_refined64(double n, double d, double r)
 	return __builtin_fma(__builtin_fma(-d, q, n), r, q);
 }
 
-/* vector.c:129-138 with the three divisions sharing one reciprocal.  `len < 0.00001` compared in
- * double is `len <= 0x3727C5AC` in float (the largest float below the double 0.00001). */
+/* vector.c:129-138 with the three divisions sharing one reciprocal.  The tuned form needs the squared
+ * length in [2^-30, 2^60] (so the length is >= 2^-15 > 0.00001: the reference's epsilon branch is not
+ * taken) and every component at least 2^-60 in magnitude (a +-0 / denormal numerator keeps its sign and
+ * rounding only through `/`); one lane outside sends its wave through the reference-order form. */
 RT_DEV V3 unit3_fast(V3 v)
 {
-	const float len = __builtin_sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
-	if (len <= __uint_as_float(0x3727C5ACu))
-		return v;
-	const float ax = __builtin_fabsf(v.x), ay = __builtin_fabsf(v.y), az = __builtin_fabsf(v.z);
-	const float lo = __builtin_fminf(__builtin_fminf(ax, ay), az);
-	const float hi = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az);
-	if (__builtin_expect(len <= 0x1p+30f && num_in_window(lo, hi), 1)) {
+	const float s2 = v.x * v.x + v.y * v.y + v.z * v.z;
+	const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z));
+	if (__ballot(!(s2 >= 0x1p-30f && s2 <= 0x1p+60f && lo >= 0x1p-60f)) == 0ull) {
+		const float len = sqrt_in_window(s2);
 		const float r = rcp_refined(len);
 		return mk3(div_by_refined(v.x, len, r), div_by_refined(v.y, len, r), div_by_refined(v.z, len, r));
 	}
 	RT_STAT_UNIT_SLOW;
+	const float len = __builtin_sqrtf(s2);
+	if (len <= __uint_as_float(0x3727C5ACu))      /* `(double) len < 0.00001`: 0x3727C5AC is the largest float below it */
+		return v;
 	return mk3(v.x / len, v.y / len, v.z / len);
 }
 

@@ -9,7 +9,7 @@
 #define REP64(x) REP8(REP8(x))
 
 template <int WHICH>
-__global__ void __launch_bounds__(256) k(float *out, int iters, float seed)
+__global__ void __launch_bounds__(256) k(float *out, int iters, float seed, int lanes = 64)
 {
 	float a0 = seed + threadIdx.x, a1 = a0 * 1.1f, a2 = a0 * 1.2f, a3 = a0 * 1.3f, a4 = a0 * 1.4f, a5 = a0 * 1.5f, a6 = a0 * 1.6f, a7 = a0 * 1.7f;
 	float b = seed * 0.999f, c = seed * 0.001f;
@@ -18,6 +18,7 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float seed)
 	unsigned long long l0 = u0, l1 = u1, l2 = u2, l3 = u3;
 	typedef float float2v __attribute__((ext_vector_type(2)));
 	float2v p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pb = {b, b}, pc = {c, c};
+	if ((int) (threadIdx.x & 63) < lanes)      /* EXEC mask: does a half-empty wave issue faster? */
 	for (int i = 0; i < iters; i++) {
 		if (WHICH == 0) { REP8(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));) }
 		if (WHICH == 1) { REP8(asm volatile("v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_add_f32 %2, %2, %5\n v_add_f32 %3, %3, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));) }
@@ -38,14 +39,14 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float seed)
 	out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + (float) (d0 + d1 + d2 + d3) + (float) (u0 ^ u1 ^ u2 ^ u3) + (float) (l0 ^ l1 ^ l2 ^ l3) + p0.x + p1.y + p2.x + p3.y;
 }
 
-template <int W> double run(const char *name, float *d_out, int cus)
+template <int W> double run(const char *name, float *d_out, int cus, int lanes = 64)
 {
 	const int iters = 2000, blocks = cus * 4;    // 4 blocks of 256 = 16 waves/CU = 4 waves/SIMD
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-	hipLaunchKernelGGL(k<W>, dim3(blocks), dim3(256), 0, 0, d_out, 10, 1.0f);
+	hipLaunchKernelGGL(k<W>, dim3(blocks), dim3(256), 0, 0, d_out, 10, 1.0f, lanes);
 	hipDeviceSynchronize();
 	hipEventRecord(e0);
-	hipLaunchKernelGGL(k<W>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 1.0f);
+	hipLaunchKernelGGL(k<W>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 1.0f, lanes);
 	hipEventRecord(e1); hipEventSynchronize(e1);
 	float ms; hipEventElapsedTime(&ms, e0, e1);
 	// instructions per SIMD: 4 waves * iters * 32 instrs
@@ -76,5 +77,10 @@ int main()
 	run<12>("div_scale/fixup/fmas/max3", d, cus);
 	run<13>("cvt f64<->f32", d, cus);
 	run<14>("u24 mul family", d, cus);
+	run<0>("v_fma_f32, lanes 0-31 only", d, cus, 32);
+	run<0>("v_fma_f32, lanes 0-15 only", d, cus, 16);
+	run<4>("v_fma_f64, lanes 0-31 only", d, cus, 32);
+	run<6>("v_mad_u64_u32, lanes 0-31 only", d, cus, 32);
+	run<8>("v_rcp/sqrt_f32, lanes 0-31 only", d, cus, 32);
 	return 0;
 }

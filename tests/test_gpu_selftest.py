@@ -19,3 +19,26 @@ def test_shortcuts_are_bit_exact(which, name):
         assert out[0] == 0, f"{name}: {out[0]} mismatches, e.g. operands {[hex(x) for x in out[1:6]]}"
     g.close()
     print(f"{name}: {total:.2e} cases, 0 mismatches")
+
+
+def test_exact_division_every_significand():
+    """rcp_refined == RN(1/d) for all 2^23 significands, and the 3-instruction quotient == `/` for every
+    denominator significand x 4 x 2048 numerator significands (6.9e10 pairs here; the sweep over ALL 2^46
+    pairs -- iters=1<<23, about a minute, 0 mismatches -- runs with RT_FULL_SWEEP=1)."""
+    import os
+    g = rt.Renderer(0)
+    if os.environ.get("RT_FULL_SWEEP"):
+        out = g.selftest(5, seed=0, blocks=8192, iters=1 << 23)
+        assert out[0] == 0, f"{out[0]} mismatches, e.g. {[hex(x) for x in out[1:6]]}"
+    else:
+        for seed in (0, 1234567, 4242424, 8000001):
+            out = g.selftest(5, seed=seed, blocks=8192, iters=2048)
+            assert out[0] == 0, f"{out[0]} mismatches, e.g. {[hex(x) for x in out[1:6]]}"
+    g.close()
+
+
+def test_tuned_sqrt_every_float_in_window():
+    g = rt.Renderer(0)
+    out = g.selftest(6, blocks=8192, iters=1)
+    assert out[0] == 0, f"{out[0]} mismatches, e.g. x={hex(out[1])} want={hex(out[3])} got={hex(out[4])}"
+    g.close()
