@@ -213,21 +213,20 @@ RT_DEV bool box_entry_fast(V3 o, V3 d, const RayPrep &rp, V3 lo, V3 hi, float &t
 	return !(miss_xy || miss_z);
 }
 
-/* sqrt of a double that came from a positive float (>= 2^-149, <= 2^128): the rsq-seeded Goldschmidt/
- * Newton sequence hipcc emits for an IEEE fp64 sqrt, without the input rescaling and class checks it
- * needs for arguments near the ends of the double range.  Same operations in the same order, so the same
- * (correctly rounded) result; rt_selftest(3) compares it with __builtin_sqrt on 10^9 arguments. */
-RT_DEV double sqrt_of_float64(double x)
+/* sqrt((double) x) for a normal float x <= 2^120: the rsq-seeded coupled (Goldschmidt) step hipcc emits for
+ * an IEEE fp64 sqrt, seeded with the cheaper fp32 v_rsq and with ONE residual correction, without the input
+ * rescaling and class checks a general double argument needs.  Equal to the correctly rounded fp64 sqrt for
+ * every one of the 2.06e9 floats in that range: rt_selftest(3) sweeps them all. */
+RT_DEV double sqrt_of_float64(float xf)
 {
-	const double y = __builtin_amdgcn_rsq(x);
+	const double x = (double) xf;
+	const double y = (double) __builtin_amdgcn_rsqf(xf);
 	double g = x * y;
 	double h = 0.5 * y;
 	const double r = __builtin_fma(-h, g, 0.5);
 	g = __builtin_fma(g, r, g);
 	h = __builtin_fma(h, r, h);
-	g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
-	g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
-	return g;
+	return __builtin_fma(__builtin_fma(-g, g, x), h, g);
 }
 
 RT_DEV bool ball_entry_fast(V3 o, V3 d, const RayPrep &rp, V3 center, float r2, float &t_entry)
@@ -246,8 +245,8 @@ RT_DEV bool ball_entry_fast(V3 o, V3 d, const RayPrep &rp, V3 center, float r2, 
 	 * reduces to "the small root if it is >= 0, else the large one if that is >= 0".  Only one quotient is
 	 * formed.  (A negative numerator above -2^-100 -- whose quotient could round to -0.0f, which the
 	 * reference would accept -- is left to the reference-order path, like an out-of-window 2a.) */
-	if (wave_all(rp.den_ok && discr <= 0x1p+120f)) {
-		const double root = sqrt_of_float64((double) discr);
+	if (wave_all(rp.den_ok && discr >= 0x1p-126f && discr <= 0x1p+120f)) {
+		const double root = sqrt_of_float64(discr);
 		const double num_lo = nb - root;
 		if (wave_all(num_lo >= 0.0 || num_lo <= -0x1p-100)) {
 			const bool small_ok = num_lo >= 0.0;
@@ -983,7 +982,7 @@ rt_deinterleave(const float *strips, float *frame, int width, int height, int ro
  *         1: div_by_refined64 vs `/`   on doubles, numerator in [2^-300, 2^300], denominator (double) 2a, a in [2^-20, 2^20]
  *         2: unit3_fast       vs unit3 on vectors of every magnitude (incl. zero / tiny / huge components)
  *         4: tiny_f_fast      vs tiny_f (the |x| < 0.0001 test of vector.c:79 without fp64)
- *         3: sqrt_of_float64  vs __builtin_sqrt on doubles converted from positive floats (incl. denormals, squares)
+ *         3: EXHAUSTIVE: sqrt_of_float64 vs the IEEE fp64 sqrt for every normal float up to 2^120 (`iters` ignored)
  *         5: EXHAUSTIVE: rcp_refined vs 1/d for all 2^23 significands; div_by_refined vs `/` for every d significand x
  *            `iters` n significands (iters = 2^23 = all 2^46 pairs, 52 s; `seed` picks the first numerator)
  *         6: EXHAUSTIVE: sqrt_in_window vs sqrtf (+ the refined reciprocal of the root) for every float in [2^-30, 2^60]
@@ -1026,6 +1025,20 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 					bad++;
 					out[1] = __float_as_uint(n); out[2] = __float_as_uint(d); out[3] = __float_as_uint(want); out[4] = __float_as_uint(got);
 				}
+			}
+		}
+		if (bad) atomicAdd(&out[0], bad);
+		return;
+	}
+	if (which == 3) {
+		/* every normal float up to 2^120: sqrt_of_float64 vs the IEEE fp64 sqrt */
+		const uint32_t first = 0x00800000u, count = 0x3f800000u + (120u << 23) - first + 1u;
+		for (uint32_t k = blockIdx.x * RT_BLOCK + threadIdx.x; k < count; k += gridDim.x * RT_BLOCK) {
+			const float f = __uint_as_float(first + k);
+			const double want = __builtin_sqrt((double) f), got = sqrt_of_float64(f);
+			if (__double_as_longlong(want) != __double_as_longlong(got)) {
+				bad++;
+				out[1] = __float_as_uint(f); out[3] = (unsigned long long) __double_as_longlong(want); out[4] = (unsigned long long) __double_as_longlong(got);
 			}
 		}
 		if (bad) atomicAdd(&out[0], bad);
@@ -1081,18 +1094,6 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 			if ((r0 >> 60) == 2) f = st_float(r0, -126, 127);
 			if ((r0 >> 56) == 0x30) f = __uint_as_float(0x7fc00000u);
 			if (tiny_f(f) != tiny_f_fast(f)) { bad++; out[1] = __float_as_uint(f); }
-		} else if (which == 3) {
-			const uint64_t r0 = st_next(s);
-			float f = __builtin_fabsf(st_float(r0, -149 + 23, 120));
-			if ((r0 >> 60) == 0) f = __uint_as_float((uint32_t) (r0 >> 8) & 0x007fffffu);                     /* denormal floats */
-			if ((r0 >> 60) == 1) { const float k = st_float(r0, -20, 20); f = k * k; }                         /* exact squares   */
-			if (!(f > 0.0f)) continue;
-			const double want = __builtin_sqrt((double) f);
-			const double got = sqrt_of_float64((double) f);
-			if (__double_as_longlong(want) != __double_as_longlong(got)) {
-				bad++;
-				out[1] = __float_as_uint(f); out[3] = (unsigned long long) __double_as_longlong(want); out[4] = (unsigned long long) __double_as_longlong(got);
-			}
 		} else {
 			const uint64_t r0 = st_next(s), r1 = st_next(s), r2 = st_next(s), r3 = st_next(s);
 			/* unit3_fast decides per WAVE: even iterations keep a whole wave inside the tuned form's window,
