@@ -15,6 +15,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdarg>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -55,7 +56,7 @@ struct rt_context {
 	std::vector<rt_geom> h_geom;         /* host copy of the packed geometry (rt_compile_scene) */
 	hipModule_t  spec_module = nullptr;  /* scene-specialised kernel, valid until the scene changes */
 	hipFunction_t spec_fn = nullptr;
-	bool         scene_fast_ok = false;  /* every cube has 0 <= size and all coordinates are finite, |x| <= 2^29 */
+	bool         scene_fast_ok = false;  /* every cube has 0 <= size, plane coordinates +0 or 2^-76 <= |x| <= 2^29, sphere data |x| <= 2^29 */
 	int          light_index = -1;
 	float        light_pos[3] = {0, 0, 0};
 
@@ -167,6 +168,9 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 	int light = -1;
 	bool fast_ok = true;
 	auto bounded = [](float x) { return x >= -0x1p+29f && x <= 0x1p+29f; };   /* false for NaN */
+	/* a slab plane coordinate the tuned slab test accepts: +0, or 2^-76 <= |x| <= 2^29 (then `plane - origin`
+	 * is exactly +0 or at least 2^-100 in magnitude unless the origin itself is tiny; see prepare_ray) */
+	auto plane_ok = [](float x) { return (x == 0.0f && !std::signbit(x)) || (std::fabs(x) >= 0x1p-76f && std::fabs(x) <= 0x1p+29f); };
 	for (int i = 0; i < n; i++) {
 		const Object &o = scene->objects[i];
 		const Material &m = o.material;
@@ -179,7 +183,7 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 			g.b2 = o.cube.origin.z * 1.0f + o.cube.size.z * 1.0f;
 			/* the tuned slab test assumes lo <= hi (the loader enforces size >= 0, scene.c:593) */
 			fast_ok = fast_ok && g.a[0] <= g.b0 && g.a[1] <= g.b1 && g.a[2] <= g.b2 &&
-			          bounded(g.a[0]) && bounded(g.a[1]) && bounded(g.a[2]) && bounded(g.b0) && bounded(g.b1) && bounded(g.b2);
+			          plane_ok(g.a[0]) && plane_ok(g.a[1]) && plane_ok(g.a[2]) && plane_ok(g.b0) && plane_ok(g.b1) && plane_ok(g.b2);
 		} else if (o.type == OBJECT_SPHERE) {
 			g.type = RT_GEOM_SPHERE;
 			g.a[0] = o.sphere.center.x; g.a[1] = o.sphere.center.y; g.a[2] = o.sphere.center.z;

@@ -156,11 +156,18 @@ struct RayPrep {
 	bool   den_ok;
 };
 
+RT_DEV uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; }
+
+template <bool ORIGIN_CHECK>
 RT_DEV RayPrep prepare_ray(V3 o, V3 d)
 {
 	RayPrep p;
 	const float omax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z));
-	p.inv_ok = den_in_window(d.x) && den_in_window(d.y) && den_in_window(d.z) && omax <= 0x1p+29f;
+	/* slab numerators `plane - o`: with the plane coordinates rt_set_scene accepts they are exactly +0 (fine:
+	 * div_by_refined(+0, d, r) is the IEEE +-0) or at least 2^-100 in magnitude, unless o itself is a non-zero
+	 * number below 2^-100 facing a plane at 0.  (bits - 1 as unsigned: 0 -> 0xffffffff, so zero passes.) */
+	const uint32_t otiny = umin3((__float_as_uint(o.x) & 0x7fffffffu) - 1u, (__float_as_uint(o.y) & 0x7fffffffu) - 1u, (__float_as_uint(o.z) & 0x7fffffffu) - 1u);
+	p.inv_ok = den_in_window(d.x) && den_in_window(d.y) && den_in_window(d.z) && omax <= 0x1p+29f && (!ORIGIN_CHECK || otiny >= 0x0d800000u - 1u);
 	p.inv = mk3(rcp_refined(d.x), rcp_refined(d.y), rcp_refined(d.z));
 	p.dd = dot3(d, d);
 	p.den = (double) (2.0f * p.dd);
@@ -171,29 +178,30 @@ RT_DEV RayPrep prepare_ray(V3 o, V3 d)
 
 RT_DEV bool wave_all(bool ok) { return __ballot(!ok) == 0ull; }
 
-RT_DEV bool box_entry_fast(V3 o, V3 d, const RayPrep &rp, V3 lo, V3 hi, float &t_entry, int &axis_out)
+RT_DEV bool box_entry_fast(V3 o, V3 d, const RayPrep &rp, bool ray_ok, V3 lo, V3 hi, float &t_entry, int &axis_out)
 {
 	const float n0 = lo.x - o.x, n1 = hi.x - o.x, n2 = lo.y - o.y, n3 = hi.y - o.y, n4 = lo.z - o.z, n5 = hi.z - o.z;
-	const float amin = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fabsf(n0), __builtin_fabsf(n1)),
-	                                                   __builtin_fminf(__builtin_fabsf(n2), __builtin_fabsf(n3))),
-	                                   __builtin_fminf(__builtin_fabsf(n4), __builtin_fabsf(n5)));
 	STAT(1);
-	/* |numerators| <= 2^30 is guaranteed per ray (origin checked in prepare_ray) and per scene (plane
-	 * coordinates checked by rt_set_scene); zero / tiny numerators are what is left to test here. */
-	if (wave_all(rp.inv_ok && amin >= 0x1p-100f)) {
+	/* ray_ok (wave-uniform, prepare_ray): every lane's direction is inside the window of the shared-reciprocal
+	 * division and every numerator is +0 or in [2^-100, 2^30] in magnitude */
+	if (ray_ok) {
 		const float ax = div_by_refined(n0, d.x, rp.inv.x), bx = div_by_refined(n1, d.x, rp.inv.x);
 		const float ay = div_by_refined(n2, d.y, rp.inv.y), by = div_by_refined(n3, d.y, rp.inv.y);
 		const float az = div_by_refined(n4, d.z, rp.inv.z), bz = div_by_refined(n5, d.z, rp.inv.z);
 		/* All six quotients are finite here, and lo <= hi (checked by rt_set_scene), so the reference's
 		 * sign-ordered pairs (scene.c:31-59) are (min, max) and its two overlap tests (scene.c:47,61) are
-		 * "the three parameter intervals intersect": max of the entries <= min of the exits. */
+		 * "the three parameter intervals intersect": max of the entries <= min of the exits.  The entry is
+		 * selected with the reference's own strict compares (scene.c:50,64: ties -- two zero quotients of
+		 * opposite sign included -- keep the earlier axis), not with v_max. */
 		const float nx = __builtin_fminf(ax, bx), fx = __builtin_fmaxf(ax, bx);
 		const float ny = __builtin_fminf(ay, by), fy = __builtin_fmaxf(ay, by);
 		const float nz = __builtin_fminf(az, bz), fz = __builtin_fmaxf(az, bz);
-		const float nxy = __builtin_fmaxf(nx, ny);
-		const float tn = __builtin_fmaxf(nxy, nz);
+		const bool y_in = ny > nx;
+		const float nxy = y_in ? ny : nx;
+		const bool z_in = nz > nxy;
+		const float tn = z_in ? nz : nxy;
 		const float tf = __builtin_fminf(__builtin_fminf(fx, fy), fz);
-		axis_out = nz > nxy ? 2 : (ny > nx ? 1 : 0);         /* strict: ties keep the earlier axis (scene.c:50,64) */
+		axis_out = z_in ? 2 : (y_in ? 1 : 0);
 		t_entry = tn;
 		return tn <= tf;
 	}
@@ -271,7 +279,8 @@ RT_DEV bool ball_entry_fast(V3 o, V3 d, const RayPrep &rp, V3 center, float r2, 
 
 RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d, bool want_normal = true)
 {
-	const RayPrep rp = prepare_ray(o, d);
+	const RayPrep rp = prepare_ray<true>(o, d);
+	const bool ray_ok = wave_all(rp.inv_ok);
 	float best_t = 3.402823466e+38f;
 	int best_obj = -1, best_axis = 0;
 	for (int i = 0; i < n; i++) {
@@ -279,7 +288,7 @@ RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d, bool want_nor
 		const int type = __float_as_int(g1.z);
 		float t = 0.0f; int axis = 0; bool hit = false;
 		if (type == RT_GEOM_CUBE)
-			hit = box_entry_fast(o, d, rp, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), t, axis);
+			hit = box_entry_fast(o, d, rp, ray_ok, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), t, axis);
 		else if (type == RT_GEOM_SPHERE)
 			hit = ball_entry_fast(o, d, rp, mk3(g0.x, g0.y, g0.z), g0.w, t);
 		if (hit && t >= 0 && t < best_t) { best_t = t; best_obj = i; best_axis = axis; }
@@ -300,12 +309,15 @@ RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d, bool want_nor
 /* ---- scene-specialised trace (rt_compile_scene, rt_jit.cpp) ----------------------------------------
  * With the geometry known at compile time the object loop unrolls, boxes that share slab planes share
  * their quotients (common-subexpression elimination of identical exact chains), geometry needs no LDS
- * reads and the zero-numerator test is done once per ray. */
+ * reads. */
 #ifdef RT_SPEC_HEADER
 #include RT_SPEC_HEADER
 RT_DEV Hit nearest_hit_spec(const SceneLDS &sc, int n, V3 o, V3 d, bool want_normal)
 {
-	const RayPrep rp = prepare_ray(o, d);
+	/* (the specialised loop keeps the per-ray test "no slab numerator below 2^-100, zero included" and v_max for
+	 * the entry parameter: with the planes as literals the compare-and-select form of box_entry_fast costs more
+	 * scalar registers than this kernel has left) */
+	const RayPrep rp = prepare_ray<false>(o, d);
 	float amin = 3.402823466e+38f;
 #pragma unroll
 	for (int i = 0; i < SPEC_N; i++)
@@ -1064,6 +1076,7 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 			float n = st_float(r0, -100, 30), d = st_float(r1, -30, 20);
 			if ((r0 >> 60) == 0) d = __uint_as_float((__float_as_uint(d) & 0xff800000u) | ((uint32_t) (r1 >> 40) & 0x3u));   /* near powers of two */
 			if ((r1 >> 60) == 1) n = d * st_float(r0, -2, 2);                        /* correlated operands */
+			if ((r1 >> 56) == 0x2f) n = 0.0f;                                      /* +0 numerator: a ray origin on a slab plane */
 			const float want = n / d;
 			const float got = div_by_refined(n, d, rcp_refined(d));
 			if (__float_as_uint(want) != __float_as_uint(got)) {
