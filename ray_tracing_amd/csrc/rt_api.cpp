@@ -252,7 +252,7 @@ int rt_compile_scene(rt_context *ctx)
 	if (getenv("RT_NO_JIT")) return fail(RT_ERR_STATE, "rt_compile_scene: disabled by RT_NO_JIT");
 	HIP_TRY(hipSetDevice(ctx->device));
 	std::string message;
-	const int rc = rt_jit_build(ctx->h_geom.data(), n, &ctx->spec_module, &ctx->spec_fn, message);
+	const int rc = rt_jit_build(ctx->h_geom.data(), n, ctx->light_index, ctx->light_pos, &ctx->spec_module, &ctx->spec_fn, message);
 	if (rc != RT_OK) { ctx->spec_module = nullptr; ctx->spec_fn = nullptr; return fail(rc, "rt_compile_scene: %s", message.c_str()); }
 	return RT_OK;
 }

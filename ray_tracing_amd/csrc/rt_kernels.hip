@@ -582,6 +582,11 @@ struct WaveLDS {
 	int   tap[3][64];                  /* shadow tap results per owner lane: object index or -1     */
 	float blk[7][64];                  /* primary hits of the current pixel block, by pixel in block */
 	float cache[7][64];                /* per-lane copy of its pixel's primary hit                  */
+	/* per-block tables written when the block is taken, so that handing a pixel to a lane is a few LDS reads */
+	float colv[3][8];                  /* llc + horiz*u for the block's 8 columns (camera.c:121, left to right) */
+	float rowv[3][8];                  /* vert*v for its 8 rows                                      */
+	int   rowpart[8];                  /* (j*pix_scale)*pix_width: row part of the RNG pixel index   */
+	unsigned char list[64];            /* the block's object pixels (index in block), compacted      */
 };
 
 RT_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
@@ -603,17 +608,25 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	const unsigned int num_blocks = (unsigned int) (tiles_x * tiles_y) * (unsigned int) L.num_chunks;
 	const size_t sample_stride = (size_t) L.local_rows * L.width * 3;      /* floats per sample plane */
 	const V3 cam = ld3(L.pos);
+#ifdef RT_SPEC_HEADER
+	const bool have_light = SPEC_LIGHT >= 0;               /* the compiled scene's emitter: literals, no scalar registers */
+	const V3 light_pos = mk3(SPEC_LIGHT_POS[0], SPEC_LIGHT_POS[1], SPEC_LIGHT_POS[2]);
+#else
 	const V3 light_pos = ld3(L.light_pos);
 	const bool have_light = L.light_index >= 0;
+#endif
 	const float inv_spp = 1.0f / (float) L.spp;
 
 	/* wave-uniform pixel supply: the wave owns one 8x8 pixel block at a time.  When it takes a new
-	 * block it traces all 64 camera rays at once (one full, homogeneous batch) into W.blk; lanes then
-	 * take pixels of the block as they become free and start from the stored hit. */
-	unsigned int cur_block = 0xffffffffu;   /* pixel block being handed out */
+	 * block it traces all 64 camera rays at once (one full, homogeneous batch) into W.blk and fills the
+	 * block's column/row tables; one round later all lanes together write the block's sky-only pixels and
+	 * list its object pixels (W.list); lanes then take listed pixels as they become free. */
+	int  tile_i0 = 0, tile_lr0 = 0;         /* frame column / strip row of the block's first pixel */
 	int  cur_s0 = 0, cur_s1 = L.spp;        /* its sample range (one chunk of the pixels' samples) */
-	int  cur_next = 64;                     /* next pixel of cur_block to hand out (64 = none left) */
-	bool blk_ready = false;                 /* W.blk holds cur_block's primary hits */
+	int  cur_next = 0, cur_count = 0;       /* next entry of W.list to hand out, entries in it */
+	bool blk_done = true;                   /* nothing left to hand out: take another block */
+	bool blk_ready = false;                 /* W.blk holds the block's primary hits */
+	bool blk_listed = false;                /* W.list is built, sky pixels are written */
 	bool exhausted = false;
 
 	/* per-lane path state */
@@ -635,7 +648,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			const bool want = px_lr < 0;
 			const unsigned long long wmask = __ballot(want);
 			if (wmask == 0ull) break;
-			if (cur_next >= 64) {
+			if (blk_done) {
 				if (exhausted || fetched) break;
 				/* Work items are dealt from `num_shards` interleaved queues (item = shard + num_shards * k), each
 				 * with its own counter on its own 128-byte line: one counter saturates at ~88 dequeues/us
@@ -647,73 +660,82 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				b = (unsigned int) __builtin_amdgcn_readfirstlane((int) b);
 				b = blockIdx.x % (unsigned int) L.num_shards + (unsigned int) L.num_shards * b;
 				if (b >= num_blocks) { exhausted = true; break; }
-				cur_block = b / (unsigned int) L.num_chunks; cur_next = 0; blk_ready = false; fetched = true;
+				const unsigned int blk = b / (unsigned int) L.num_chunks;
+				blk_done = false; blk_ready = false; blk_listed = false; fetched = true; cur_next = cur_count = 0;
 				cur_s0 = (int) (b % (unsigned int) L.num_chunks) * L.chunk_spp;
 				cur_s1 = cur_s0 + L.chunk_spp < L.spp ? cur_s0 + L.chunk_spp : L.spp;
-				const int i = (int) (cur_block % (unsigned int) tiles_x) * 8 + (lane & 7);
-				const int lr = (int) (cur_block / (unsigned int) tiles_x) * 8 + (lane >> 3);
+				tile_i0 = (int) (blk % (unsigned int) tiles_x) * 8;
+				tile_lr0 = (int) (blk / (unsigned int) tiles_x) * 8;
+				const int i = tile_i0 + (lane & 7), lr = tile_lr0 + (lane >> 3);
 				const int j = global_row(L, lr);
+				float u = (float) i / (float) L.u_den;                     /* main.c:293-296 */
+				float v = (float) j / (float) L.v_den;
+				u = 1.0f - u;
+				v = 1.0f - v;
+				/* camera.c:121: ((llc + horiz*u) + vert*v) - pos, split into its column and row parts */
+				const V3 cv = mk3(L.llc[0] + L.horiz[0] * u, L.llc[1] + L.horiz[1] * u, L.llc[2] + L.horiz[2] * u);
+				const V3 rv = mk3(L.vert[0] * v, L.vert[1] * v, L.vert[2] * v);
 				prim_on = i < L.width && lr < L.local_rows && j < L.height;
-				if (prim_on) {
-					float u = (float) i / (float) L.u_den;                 /* main.c:293-296 */
-					float v = (float) j / (float) L.v_den;
-					u = 1.0f - u;
-					v = 1.0f - v;
-					prim_d = primary_dir(L, u, v);
-				} else
-					W.blk[6][lane] = __int_as_float(-2);                   /* outside the frame */
+				prim_d = sub3(add3(cv, rv), cam);
+				if (lane < 8) { W.colv[0][lane] = cv.x; W.colv[1][lane] = cv.y; W.colv[2][lane] = cv.z; }
+				if ((lane & 7) == 0) {
+					const int r = lane >> 3;
+					W.rowv[0][r] = rv.x; W.rowv[1][r] = rv.y; W.rowv[2][r] = rv.z;
+					W.rowpart[r] = (j * L.pix_scale) * L.pix_width;
+				}
+				if (!prim_on) W.blk[6][lane] = __int_as_float(-2);         /* outside the frame */
 			}
 			if (!blk_ready) break;                                         /* hits arrive with this round's trace */
+			if (!blk_listed) {
+				/* once per block, all lanes: lane q looks at pixel q of the block */
+				const int obj = __float_as_int(W.blk[6][lane]);
+				if (obj == -1 && (!chunked || cur_s0 == 0)) {
+					/* sky-only pixel: every sample is clamp(0 + sky * 1) (main.c:171,267-269), summed in sample
+					 * order and resolved (main.c:394,476).  With chunks, the item that holds chunk 0 writes it. */
+					const int i = tile_i0 + (lane & 7), lr = tile_lr0 + (lane >> 3);
+					const V3 c = mk3(clamp01(W.blk[0][lane]), clamp01(W.blk[1][lane]), clamp01(W.blk[2][lane]));
+					if (chunked) L.direct[(size_t) lr * L.width + i] = 1;         /* rt_sum_samples skips it */
+					V3 acc = mk3(0, 0, 0);
+					for (int k = 0; k < L.spp; k++) acc = add3(acc, c);
+					const V3 res = scale3(acc, inv_spp);
+					float *dst = L.frame + ((size_t) lr * L.width + i) * 3;
+					dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+				}
+				const unsigned long long om = __ballot(obj >= 0);
+				if (obj >= 0)
+					W.list[__builtin_amdgcn_mbcnt_hi((unsigned int) (om >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) om, 0u))] = (unsigned char) lane;
+				cur_count = __popcll(om);
+				blk_listed = true;
+				wave_fence();
+				if (cur_count == 0) { blk_done = true; continue; }
+			}
 			const int rank_in = __builtin_amdgcn_mbcnt_hi((unsigned int) (wmask >> 32),
 			                    __builtin_amdgcn_mbcnt_lo((unsigned int) wmask, 0u));
-			const int avail = 64 - cur_next;
+			const int avail = cur_count - cur_next;
 			if (want && rank_in < avail) {
-				const int q = cur_next + rank_in;
+				const int q = W.list[cur_next + rank_in];
+				const int c = q & 7, r = q >> 3;
+				px_i = tile_i0 + c; px_lr = tile_lr0 + r;
+				pixel_index = (uint32_t) (W.rowpart[r] + px_i * L.pix_scale);
+				pdir = sub3(add3(mk3(W.colv[0][c], W.colv[1][c], W.colv[2][c]), mk3(W.rowv[0][r], W.rowv[1][r], W.rowv[2][r])), cam);
+				const V3 a = mk3(W.blk[0][q], W.blk[1][q], W.blk[2][q]);
+				const V3 nn = mk3(W.blk[3][q], W.blk[4][q], W.blk[5][q]);
 				const int obj = __float_as_int(W.blk[6][q]);
-				if (obj != -2) {
-					const int i = (int) (cur_block % (unsigned int) tiles_x) * 8 + (q & 7);
-					const int lr = (int) (cur_block / (unsigned int) tiles_x) * 8 + (q >> 3);
-					const V3 a = mk3(W.blk[0][q], W.blk[1][q], W.blk[2][q]);
-					if (obj < 0) {
-						/* sky-only pixel: every sample is clamp(0 + sky * 1) (main.c:171,267-269), summed
-						 * in sample order and resolved (main.c:394,476) */
-						const V3 c = mk3(clamp01(a.x), clamp01(a.y), clamp01(a.z));
-						if (chunked && cur_s0 != 0) {
-							/* another chunk of a sky-only pixel: the lane that has chunk 0 writes the pixel */
-						} else {
-							if (chunked) L.direct[(size_t) lr * L.width + i] = 1;     /* rt_sum_samples skips it */
-							V3 acc = mk3(0, 0, 0);
-							for (int k = 0; k < L.spp; k++) acc = add3(acc, c);
-							const V3 res = scale3(acc, inv_spp);
-							float *dst = L.frame + ((size_t) lr * L.width + i) * 3;
-							dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
-						}
-					} else {
-						const int j = global_row(L, lr);
-						px_i = i; px_lr = lr;
-						pixel_index = (uint32_t) ((j * L.pix_scale) * L.pix_width + i * L.pix_scale);
-						float u = (float) i / (float) L.u_den;
-						float v = (float) j / (float) L.v_den;
-						u = 1.0f - u;
-						v = 1.0f - v;
-						pdir = primary_dir(L, u, v);
-						const V3 nn = mk3(W.blk[3][q], W.blk[4][q], W.blk[5][q]);
-						W.cache[0][lane] = a.x;  W.cache[1][lane] = a.y;  W.cache[2][lane] = a.z;
-						W.cache[3][lane] = nn.x; W.cache[4][lane] = nn.y; W.cache[5][lane] = nn.z;
-						W.cache[6][lane] = __int_as_float(obj);
-						sample = cur_s0; sample_end = cur_s1; bounce = 0; sum = mk3(0, 0, 0);
-						rng = path_seed(L.seed, pixel_index, (uint32_t) (L.sample_base + sample));
-						carry = mk3(1, 1, 1); rad = mk3(0, 0, 0);
-						hp = a; hn = nn; hobj = obj; hdir = pdir;
-						has_hit = true;
-					}
-				}
+				W.cache[0][lane] = a.x;  W.cache[1][lane] = a.y;  W.cache[2][lane] = a.z;
+				W.cache[3][lane] = nn.x; W.cache[4][lane] = nn.y; W.cache[5][lane] = nn.z;
+				W.cache[6][lane] = __int_as_float(obj);
+				sample = cur_s0; sample_end = cur_s1; bounce = 0; sum = mk3(0, 0, 0);
+				rng = path_seed(L.seed, pixel_index, (uint32_t) (L.sample_base + sample));
+				carry = mk3(1, 1, 1); rad = mk3(0, 0, 0);
+				hp = a; hn = nn; hobj = obj; hdir = pdir;
+				has_hit = true;
 			}
 			const int taken = __popcll(wmask);
 			cur_next += taken < avail ? taken : avail;
+			if (cur_next >= cur_count) blk_done = true;
 		}
 		if (!fetched && __ballot(px_lr >= 0) == 0ull) {
-			if (exhausted && cur_next >= 64) break;
+			if (exhausted && blk_done) break;
 			continue;                          /* sky / out-of-frame pixels only so far: hand out more */
 		}
 

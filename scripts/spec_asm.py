@@ -20,7 +20,17 @@ def header(scene_path):
             G.append([g[0], g[1], g[2]] + [f(f(g[k] * f(1)) + f(g[3 + k] * f(1))) for k in range(3)]); T.append(0)
         else:              # sphere: center, radius (vector.h:58-61)
             G.append([g[0], g[1], g[2], f(g[3] * g[3]), f(0), f(0)]); T.append(1)
-    h = "#define SPEC_N %d\nstatic constexpr int SPEC_T[SPEC_N] = {%s};\nstatic constexpr float SPEC_G[SPEC_N][6] = {\n" % (n, ", ".join(map(str, T)))
+    # first emitter and its origin_of() (main.c:140-146, scene.c:10-15)
+    light, lpos = -1, [f(0)] * 3
+    for i in range(n):
+        rec = buf[68 * i: 68 * i + 68]
+        epow = rec[28 + 24: 28 + 28].view(np.float32)[0]
+        if light < 0 and epow > 0:
+            light = i
+            g = rec[4:28].view(np.float32)
+            lpos = [g[0], g[1], g[2]] if T[i] == 1 else [f(f(g[k] * f(1)) + f(g[3 + k] * f(0.5))) for k in range(3)]
+    h0 = "#define SPEC_LIGHT %d\nstatic constexpr float SPEC_LIGHT_POS[3] = {%s};\n" % (light, ", ".join(float(v).hex() + "f" for v in lpos))
+    h = h0 + "#define SPEC_N %d\nstatic constexpr int SPEC_T[SPEC_N] = {%s};\nstatic constexpr float SPEC_G[SPEC_N][6] = {\n" % (n, ", ".join(map(str, T)))
     h += ",\n".join("\t{" + ", ".join(float(v).hex() + "f" for v in g) + "}" for g in G) + "\n};\n"
     return h
 
