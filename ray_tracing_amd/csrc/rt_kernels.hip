@@ -743,18 +743,16 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		int  tapmask = 0;
 		bool emit_main = false;
 		V3   ray_o = cam, ray_d = prim_d;
-		V3   tap_d0 = mk3(0, 0, 0), tap_d1 = mk3(0, 0, 0), tap_d2 = mk3(0, 0, 0);
+		V3   tap_j0 = mk3(0, 0, 0), tap_j1 = mk3(0, 0, 0), tap_j2 = mk3(0, 0, 0);   /* accepted rand_dir of each tap (main.c:193) */
 		STAT(7);
 		if (has_hit) {
 			STAT(8);
 			if (have_light) {
-				const V3 to_light = sub3(light_pos, hp);
-				{ const V3 jit = rng_direction<FAST>(rng);
-				  if (dot3(jit, hn) > 0) { STAT(9); tap_d0 = unit3_sel<FAST>(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 1; } }
-				{ const V3 jit = rng_direction<FAST>(rng);
-				  if (dot3(jit, hn) > 0) { STAT(10); tap_d1 = unit3_sel<FAST>(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 2; } }
-				{ const V3 jit = rng_direction<FAST>(rng);
-				  if (dot3(jit, hn) > 0) { STAT(11); tap_d2 = unit3_sel<FAST>(lin2(jit, to_light, 0.5f, 1.0f)); tapmask |= 4; } }
+				/* main.c:191-195: three rand_dir draws, a tap is skipped when it points into the surface.  The
+				 * tap's direction and origin (main.c:197-198) are formed where it is traced, on a full batch. */
+				tap_j0 = rng_direction<FAST>(rng); if (dot3(tap_j0, hn) > 0) tapmask |= 1;
+				tap_j1 = rng_direction<FAST>(rng); if (dot3(tap_j1, hn) > 0) tapmask |= 2;
+				tap_j2 = rng_direction<FAST>(rng); if (dot3(tap_j2, hn) > 0) tapmask |= 4;
 			}
 			const float4 m0 = sc.shade[4 * hobj], m1 = sc.shade[4 * hobj + 1];
 			const float4 m2 = sc.shade[4 * hobj + 2], m3 = sc.shade[4 * hobj + 3];
@@ -796,28 +794,28 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		 * kind at a time, and trace full batches of 64 as soon as they exist (scene.c:156-190 on full
 		 * waves); the remainder is flushed after the last kind -------------------------------------- */
 		int q_head = 0, q_tail = 0;
+		/* one ray of kind `k` per lane with `on` set, appended to the ring in lane order */
+		auto push = [&](bool on, V3 qo, V3 qd, int k) {
+			const unsigned long long m = __ballot(on);
+			if (on) {
+				const int slot = (q_tail + (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32),
+				                  __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u))) & (WF_QUEUE - 1);
+				W.q[0][slot] = qo.x; W.q[1][slot] = qo.y; W.q[2][slot] = qo.z;
+				W.q[3][slot] = qd.x; W.q[4][slot] = qd.y; W.q[5][slot] = qd.z;
+				W.q[6][slot] = __int_as_float(lane | (k << 8));
+			}
+			q_tail += __popcll(m);
+			wave_fence();
+		};
 #pragma unroll 1
 		for (int kind = 0; kind < 6; kind++) {
-			if (kind < 5) {
-				bool on = emit_main;
-				V3 qo = ray_o, qd = ray_d;
-				if (kind == WF_KIND_PRIMARY) {
-					on = prim_on; qo = cam; qd = prim_d;
-				} else if (kind > WF_KIND_MAIN) {
-					on = (tapmask >> (kind - 2)) & 1;
-					qd = kind == 2 ? tap_d0 : (kind == 3 ? tap_d1 : tap_d2);
-					qo = madd3(hp, qd, 0.001f);                                      /* main.c:198 */
-				}
-				const unsigned long long m = __ballot(on);
-				if (on) {
-					const int slot = (q_tail + (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32),
-					                  __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u))) & (WF_QUEUE - 1);
-					W.q[0][slot] = qo.x; W.q[1][slot] = qo.y; W.q[2][slot] = qo.z;
-					W.q[3][slot] = qd.x; W.q[4][slot] = qd.y; W.q[5][slot] = qd.z;
-					W.q[6][slot] = __int_as_float(lane | (kind << 8));
-				}
-				q_tail += __popcll(m);
-				wave_fence();
+			switch (kind) {                 /* a tap is queued as (hit point, rand_dir) */
+			case WF_KIND_PRIMARY: push(prim_on, cam, prim_d, WF_KIND_PRIMARY); break;
+			case WF_KIND_MAIN:    push(emit_main, ray_o, ray_d, WF_KIND_MAIN); break;
+			case 2:               push((tapmask & 1) != 0, hp, tap_j0, 2); break;
+			case 3:               push((tapmask & 2) != 0, hp, tap_j1, 3); break;
+			case 4:               push((tapmask & 4) != 0, hp, tap_j2, 4); break;
+			default: break;
 			}
 			while (q_tail - q_head >= 64 || (kind == 5 && q_tail > q_head)) {
 				const int count = q_tail - q_head < 64 ? q_tail - q_head : 64;
@@ -825,10 +823,15 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				if (lane < count) {
 					STAT(13);
 					const int slot = (q_head + lane) & (WF_QUEUE - 1);
-					const V3 o = mk3(W.q[0][slot], W.q[1][slot], W.q[2][slot]);
-					const V3 dn = unit3_sel<FAST>(mk3(W.q[3][slot], W.q[4][slot], W.q[5][slot]));   /* scene.c:158 */
+					V3 o = mk3(W.q[0][slot], W.q[1][slot], W.q[2][slot]);
+					V3 d = mk3(W.q[3][slot], W.q[4][slot], W.q[5][slot]);
 					const int meta = __float_as_int(W.q[6][slot]);
 					const int owner = meta & 255, rkind = meta >> 8;
+					if (rkind > WF_KIND_MAIN) {                                                   /* main.c:186,197-198 */
+						d = unit3_sel<FAST>(lin2(d, sub3(light_pos, o), 0.5f, 1.0f));
+						o = madd3(o, d, 0.001f);
+					}
+					const V3 dn = unit3_sel<FAST>(d);                                             /* scene.c:158 */
 					const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, n, o, dn, rkind <= WF_KIND_MAIN) : nearest_hit(sc, n, o, dn);
 					if (rkind > WF_KIND_MAIN) {
 						W.tap[rkind - 2][owner] = hit.obj;
