@@ -414,10 +414,11 @@ RT_DEV V3 sky_lookup(const rt_launch &L, V3 dir)
 
 /* ---- pixel mapping --------------------------------------------------------------------------- */
 
-RT_DEV int global_row(const rt_launch &L, int local_row)
+RT_DEV int global_row(int row_block, int rank, int world, int local_row)
 {
-	return ((local_row / L.row_block) * L.world + L.rank) * L.row_block + local_row % L.row_block;
+	return ((local_row / row_block) * world + rank) * row_block + local_row % row_block;
 }
+RT_DEV int global_row(const rt_launch &L, int local_row) { return global_row(L.row_block, L.rank, L.world, local_row); }
 
 /* camera.c:121 with the frame constants of camera.c:99-118 hoisted to the host */
 RT_DEV V3 primary_dir(const rt_launch &L, float px, float py)
@@ -589,6 +590,19 @@ struct WaveLDS {
 	unsigned char list[64];            /* the block's object pixels (index in block), compacted      */
 };
 
+/* The launch record as the code that takes a new pixel block reads it.  Kernel arguments are invariant, so the
+ * compiler loads every field once at kernel entry and keeps it in a scalar register for the whole kernel --
+ * far more than the 102 there are, and the spill/reload traffic lands in the per-round code.  The fields only
+ * a block hand-out needs are read through a pointer whose origin is hidden, i.e. from memory when used. */
+typedef const __attribute__((address_space(1))) rt_launch *rt_launch_cold;
+RT_DEV rt_launch_cold cold_view()
+{
+	/* the launch record is the first kernel argument of every trace kernel: offset 0 of the kernarg segment */
+	unsigned long long a = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(a));
+	return (rt_launch_cold) a;
+}
+
 RT_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 template <bool FAST> RT_DEV V3 unit3_sel(V3 v) { return FAST ? unit3_fast(v) : unit3(v); }
@@ -644,6 +658,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		bool fetched = false;                   /* a block was taken this round: trace its camera rays */
 		bool prim_on = false;
 		V3   prim_d = mk3(0, 0, 0);
+#pragma unroll 1
 		for (int attempt = 0; attempt < 4; attempt++) {
 			const bool want = px_lr < 0;
 			const unsigned long long wmask = __ballot(want);
@@ -655,33 +670,36 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				 * (MI355X_MICROARCH.md), which a sky-dominated 4K frame exceeds (C3: 2.1 -> 1.3 ms).  A wave pulls
 				 * only from the queue of its workgroup; the queues hold equal, interleaved shares of the frame.
 				 * The host uses one queue unless the frame has >= 100k pixel blocks. */
+				const rt_launch_cold C = cold_view();
+				const unsigned int shards = (unsigned int) C->num_shards, chunks = (unsigned int) C->num_chunks;
 				unsigned int b = 0;
-				if (lane == 0) b = atomicAdd(block_counter + (blockIdx.x % (unsigned int) L.num_shards) * 32u, 1u);
+				if (lane == 0) b = atomicAdd(block_counter + (blockIdx.x % shards) * 32u, 1u);
 				b = (unsigned int) __builtin_amdgcn_readfirstlane((int) b);
-				b = blockIdx.x % (unsigned int) L.num_shards + (unsigned int) L.num_shards * b;
+				b = blockIdx.x % shards + shards * b;
 				if (b >= num_blocks) { exhausted = true; break; }
-				const unsigned int blk = b / (unsigned int) L.num_chunks;
+				const unsigned int blk = b / chunks;
 				blk_done = false; blk_ready = false; blk_listed = false; fetched = true; cur_next = cur_count = 0;
-				cur_s0 = (int) (b % (unsigned int) L.num_chunks) * L.chunk_spp;
-				cur_s1 = cur_s0 + L.chunk_spp < L.spp ? cur_s0 + L.chunk_spp : L.spp;
+				const int chunk_spp = C->chunk_spp, spp = C->spp;
+				cur_s0 = (int) (b % chunks) * chunk_spp;
+				cur_s1 = cur_s0 + chunk_spp < spp ? cur_s0 + chunk_spp : spp;
 				tile_i0 = (int) (blk % (unsigned int) tiles_x) * 8;
 				tile_lr0 = (int) (blk / (unsigned int) tiles_x) * 8;
 				const int i = tile_i0 + (lane & 7), lr = tile_lr0 + (lane >> 3);
-				const int j = global_row(L, lr);
-				float u = (float) i / (float) L.u_den;                     /* main.c:293-296 */
-				float v = (float) j / (float) L.v_den;
+				const int j = global_row(C->row_block, C->rank, C->world, lr);
+				float u = (float) i / (float) C->u_den;                     /* main.c:293-296 */
+				float v = (float) j / (float) C->v_den;
 				u = 1.0f - u;
 				v = 1.0f - v;
 				/* camera.c:121: ((llc + horiz*u) + vert*v) - pos, split into its column and row parts */
-				const V3 cv = mk3(L.llc[0] + L.horiz[0] * u, L.llc[1] + L.horiz[1] * u, L.llc[2] + L.horiz[2] * u);
-				const V3 rv = mk3(L.vert[0] * v, L.vert[1] * v, L.vert[2] * v);
-				prim_on = i < L.width && lr < L.local_rows && j < L.height;
+				const V3 cv = mk3(C->llc[0] + C->horiz[0] * u, C->llc[1] + C->horiz[1] * u, C->llc[2] + C->horiz[2] * u);
+				const V3 rv = mk3(C->vert[0] * v, C->vert[1] * v, C->vert[2] * v);
+				prim_on = i < C->width && lr < C->local_rows && j < C->height;
 				prim_d = sub3(add3(cv, rv), cam);
 				if (lane < 8) { W.colv[0][lane] = cv.x; W.colv[1][lane] = cv.y; W.colv[2][lane] = cv.z; }
 				if ((lane & 7) == 0) {
 					const int r = lane >> 3;
 					W.rowv[0][r] = rv.x; W.rowv[1][r] = rv.y; W.rowv[2][r] = rv.z;
-					W.rowpart[r] = (j * L.pix_scale) * L.pix_width;
+					W.rowpart[r] = (j * C->pix_scale) * C->pix_width;
 				}
 				if (!prim_on) W.blk[6][lane] = __int_as_float(-2);         /* outside the frame */
 			}
