@@ -710,13 +710,14 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				if (obj == -1 && (!chunked || cur_s0 == 0)) {
 					/* sky-only pixel: every sample is clamp(0 + sky * 1) (main.c:171,267-269), summed in sample
 					 * order and resolved (main.c:394,476).  With chunks, the item that holds chunk 0 writes it. */
-					const int i = tile_i0 + (lane & 7), lr = tile_lr0 + (lane >> 3);
+					const rt_launch_cold C = cold_view();
+					const int i = tile_i0 + (lane & 7), lr = tile_lr0 + (lane >> 3), width = C->width, spp = C->spp;
 					const V3 c = mk3(clamp01(W.blk[0][lane]), clamp01(W.blk[1][lane]), clamp01(W.blk[2][lane]));
-					if (chunked) L.direct[(size_t) lr * L.width + i] = 1;         /* rt_sum_samples skips it */
+					if (chunked) C->direct[(size_t) lr * width + i] = 1;           /* rt_sum_samples skips it */
 					V3 acc = mk3(0, 0, 0);
-					for (int k = 0; k < L.spp; k++) acc = add3(acc, c);
+					for (int k = 0; k < spp; k++) acc = add3(acc, c);
 					const V3 res = scale3(acc, inv_spp);
-					float *dst = L.frame + ((size_t) lr * L.width + i) * 3;
+					float *dst = C->frame + ((size_t) lr * width + i) * 3;
 					dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
 				}
 				const unsigned long long om = __ballot(obj >= 0);
