@@ -101,3 +101,42 @@ def test_refuses_what_it_cannot_specialise(gpu, oracle):
     gpu.set_scene(empty)
     with pytest.raises(rt.RtError):
         gpu.compile_scene()
+
+
+def test_slab_planes_outside_the_tuned_window(gpu, oracle):
+    """Plane coordinates the shared-reciprocal slab test does not accept -- a non-zero coordinate below 2^-76
+    and a negative zero -- must send the scene through the reference-order kernel (still bit-exact) and make
+    rt_compile_scene refuse it."""
+    sky = synthetic_skybox(16, seed=3)
+    for origin in ((1e-30, 0.0, 0.0), (-0.0, 0.0, 0.0)):
+        scene = make_scene([dict(type="cube", origin=origin, size=(2.0, 1.0, 2.0), roughness=0.5),
+                            dict(type="cube", origin=(-3, -0.1, -3), size=(9, 0.1, 9), roughness=1.0),
+                            dict(type="sphere", center=(1.0, 3.0, 1.0), radius=0.7, emission_power=3.0)])
+        cam = dict(pos=(0.0, 2.0, 5.0), front=(0.1, -0.3, -1.0), up=(0, 1, 0), fov=1.0)    # pos.x on the plane x = +-0
+        for r in (gpu, oracle):
+            r.set_skybox(sky); r.set_scene(scene); r.set_camera(**cam)
+        with pytest.raises(rt.RtError):
+            gpu.compile_scene()
+        g = gpu.render(64, 48, 3, 5, seed=21)
+        c = oracle.render_counter(64, 48, 3, 5, seed=21)
+        assert (bits(g) == bits(c)).all()
+    gpu.set_camera(); oracle.set_camera()
+
+
+def test_ray_origins_on_slab_planes_stay_exact(gpu, oracle):
+    """Camera exactly on several slab planes of the scene (numerators +0 for every primary ray), including two
+    planes of one box whose entry parameters are zeros of opposite sign."""
+    sky = synthetic_skybox(16, seed=4)
+    scene = make_scene([dict(type="cube", origin=(1.0, 0.0, -2.0), size=(1.0, 1.0, 1.0), roughness=0.3),       # x in [1,2], z in [-2,-1]
+                        dict(type="cube", origin=(0.0, -0.5, -4.0), size=(1.0, 1.0, 3.0), metallic=1.0),       # hi.x = 1, hi.z = -1
+                        dict(type="cube", origin=(-4, -0.6, -6), size=(9, 0.1, 9), roughness=1.0),
+                        dict(type="sphere", center=(1.5, 3.0, -1.5), radius=0.6, emission_power=4.0)])
+    for pos, front in (((1.0, 0.5, -1.0), (0.3, -0.1, -1.0)), ((1.0, 0.5, -1.0), (-0.3, 0.1, 1.0)), ((2.0, 1.0, 1.0), (-0.4, -0.3, -1.0))):
+        for r in (gpu, oracle):
+            r.set_skybox(sky); r.set_scene(scene); r.set_camera(pos=pos, front=front, up=(0, 1, 0), fov=1.2)
+        generic = gpu.render(80, 60, 3, 6, seed=8)
+        c = oracle.render_counter(80, 60, 3, 6, seed=8)
+        assert (bits(generic) == bits(c)).all()
+        gpu.compile_scene()
+        assert (bits(gpu.render(80, 60, 3, 6, seed=8)) == bits(c)).all()
+    gpu.set_camera(); oracle.set_camera()
