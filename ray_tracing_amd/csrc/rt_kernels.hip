@@ -580,7 +580,7 @@ rt_trace_simple(const rt_launch L)
 struct WaveLDS {
 	float q[7][WF_QUEUE];              /* ray queue SoA: o.xyz, d.xyz (un-normalised), meta         */
 	float res[7][64];                  /* bounce-ray result per owner lane: xyz, nxyz, obj          */
-	int   tap[3][64];                  /* shadow tap results per owner lane: object index or -1     */
+	short tap[3][64];                  /* shadow tap results per owner lane: object index (< 1024) or -1 */
 	float blk[7][64];                  /* primary hits of the current pixel block, by pixel in block */
 	float cache[7][64];                /* per-lane copy of its pixel's primary hit                  */
 	/* per-block tables written when the block is taken, so that handing a pixel to a lane is a few LDS reads */
@@ -853,7 +853,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					const V3 dn = unit3_sel<FAST>(d);                                             /* scene.c:158 */
 					const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, n, o, dn, rkind <= WF_KIND_MAIN) : nearest_hit(sc, n, o, dn);
 					if (rkind > WF_KIND_MAIN) {
-						W.tap[rkind - 2][owner] = hit.obj;
+						W.tap[rkind - 2][owner] = (short) hit.obj;
 					} else {
 						V3 a, b = hit.n;
 						if (hit.obj >= 0) a = madd3(o, dn, hit.t);                   /* scene.c:186 */
