@@ -10,7 +10,7 @@ for world in (1, 2, 4, 8):
     strip = torch.empty((rows, W, 3), dtype=torch.float32, device="cuda:0")
     p = g.params(W, H, spp, nb, row_block=8, rank=0, world=world)
     out = []
-    for chunks in (1, 2, 3, 4, 6, 8):
+    for chunks in (1, 2, 3, 4, 6, 8, 11, 16):
         os.environ["RT_CHUNKS"] = str(chunks)
         best = 1e9
         for it in range(5):
