@@ -644,8 +644,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	bool exhausted = false;
 
 	/* per-lane path state */
-	int   px_i = 0, px_lr = -1;             /* px_lr < 0: lane has no pixel */
-	uint32_t pixel_index = 0;
+	int   px_off = -1;                      /* the lane's pixel: row * width + column inside the strip; < 0: none */
+	uint32_t pixel_index = 0;               /* its index for the RNG seed (main.c:286 order) */
 	int   sample = 0, sample_end = 0, bounce = 0;
 	bool  has_hit = false;
 	V3    sum = mk3(0, 0, 0), carry = mk3(1, 1, 1), rad = mk3(0, 0, 0);
@@ -660,7 +660,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		V3   prim_d = mk3(0, 0, 0);
 #pragma unroll 1
 		for (int attempt = 0; attempt < 4; attempt++) {
-			const bool want = px_lr < 0;
+			const bool want = px_off < 0;
 			const unsigned long long wmask = __ballot(want);
 			if (wmask == 0ull) break;
 			if (blk_done) {
@@ -734,8 +734,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			if (want && rank_in < avail) {
 				const int q = W.list[cur_next + rank_in];
 				const int c = q & 7, r = q >> 3;
-				px_i = tile_i0 + c; px_lr = tile_lr0 + r;
-				pixel_index = (uint32_t) (W.rowpart[r] + px_i * L.pix_scale);
+				px_off = (tile_lr0 + r) * L.width + tile_i0 + c;
+				pixel_index = (uint32_t) (W.rowpart[r] + (tile_i0 + c) * L.pix_scale);
 				pdir = sub3(add3(mk3(W.colv[0][c], W.colv[1][c], W.colv[2][c]), mk3(W.rowv[0][r], W.rowv[1][r], W.rowv[2][r])), cam);
 				const V3 a = mk3(W.blk[0][q], W.blk[1][q], W.blk[2][q]);
 				const V3 nn = mk3(W.blk[3][q], W.blk[4][q], W.blk[5][q]);
@@ -753,7 +753,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			cur_next += taken < avail ? taken : avail;
 			if (cur_next >= cur_count) blk_done = true;
 		}
-		if (!fetched && __ballot(px_lr >= 0) == 0ull) {
+		if (!fetched && __ballot(px_off >= 0) == 0ull) {
 			if (exhausted && blk_done) break;
 			continue;                          /* sky / out-of-frame pixels only so far: hand out more */
 		}
@@ -872,7 +872,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		/* ---- 5. consume results ------------------------------------------------------------- */
 		if (fetched) blk_ready = true;
 		STAT(16);
-		if (px_lr >= 0) {
+		if (px_off >= 0) {
 			STAT(17);
 			bool sample_done = false;
 			if (tapmask) {
@@ -909,7 +909,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			if (sample_done) {
 				const V3 col = mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z));     /* main.c:267-269 */
 				if (chunked) {
-					float *dst = L.samples + (size_t) sample * sample_stride + ((size_t) px_lr * L.width + px_i) * 3;
+					float *dst = L.samples + (size_t) sample * sample_stride + (size_t) px_off * 3;
 					dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
 				} else
 					sum = add3(sum, col);                                                /* main.c:394 */
@@ -925,10 +925,10 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				} else {
 					if (!chunked) {
 						const V3 res = scale3(sum, inv_spp);                     /* main.c:476 */
-						float *dst = L.frame + ((size_t) px_lr * L.width + px_i) * 3;
+						float *dst = L.frame + (size_t) px_off * 3;
 						dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
 					}
-					px_lr = -1; has_hit = false;
+					px_off = -1; has_hit = false;
 				}
 			}
 		}
