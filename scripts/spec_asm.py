@@ -40,7 +40,7 @@ if __name__ == "__main__":
     hdr = os.path.join(ROOT, "build_variants", "rt_scene_spec.h")
     os.makedirs(os.path.dirname(hdr), exist_ok=True)
     open(hdr, "w").write(header(scene))
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-DRT_SPEC_ONLY",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-DRT_SPEC_ONLY",
            "-DRT_SPEC_HEADER=\"rt_scene_spec.h\"", "-DRT_WAVES_PER_SIMD=4", "-I", os.path.dirname(hdr), "-I", csrc,
            "--cuda-device-only", "-S", "-Rpass-analysis=kernel-resource-usage", os.path.join(csrc, "rt_kernels.hip"), "-o", out] + sys.argv[3:]
     print(" ".join(cmd)); sys.exit(subprocess.call(cmd))
