@@ -314,19 +314,8 @@ RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d, bool want_nor
 #include RT_SPEC_HEADER
 RT_DEV Hit nearest_hit_spec(const SceneLDS &sc, int n, V3 o, V3 d, bool want_normal)
 {
-	/* (the specialised loop keeps the per-ray test "no slab numerator below 2^-100, zero included" and v_max for
-	 * the entry parameter: with the planes as literals the compare-and-select form of box_entry_fast costs more
-	 * scalar registers than this kernel has left) */
-	const RayPrep rp = prepare_ray<false>(o, d);
-	float amin = 3.402823466e+38f;
-#pragma unroll
-	for (int i = 0; i < SPEC_N; i++)
-		if (SPEC_T[i] == RT_GEOM_CUBE) {
-			amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(SPEC_G[i][0] - o.x), __builtin_fabsf(SPEC_G[i][3] - o.x)));
-			amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(SPEC_G[i][1] - o.y), __builtin_fabsf(SPEC_G[i][4] - o.y)));
-			amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(SPEC_G[i][2] - o.z), __builtin_fabsf(SPEC_G[i][5] - o.z)));
-		}
-	if (!wave_all(rp.inv_ok && amin >= 0x1p-100f))
+	const RayPrep rp = prepare_ray<true>(o, d);
+	if (!wave_all(rp.inv_ok))
 		return nearest_hit_fast(sc, n, o, d, want_normal);
 	float best_t = 3.402823466e+38f;
 	int best_obj = -1, best_axis = 0;
@@ -340,10 +329,12 @@ RT_DEV Hit nearest_hit_spec(const SceneLDS &sc, int n, V3 o, V3 d, bool want_nor
 			const float nx = __builtin_fminf(ax, bx), fx = __builtin_fmaxf(ax, bx);
 			const float ny = __builtin_fminf(ay, by), fy = __builtin_fmaxf(ay, by);
 			const float nz = __builtin_fminf(az, bz), fz = __builtin_fmaxf(az, bz);
-			const float nxy = __builtin_fmaxf(nx, ny);
-			t = __builtin_fmaxf(nxy, nz);
+			const bool y_in = ny > nx;                      /* scene.c:50,64: strict, ties (and zeros of either sign) keep the earlier axis */
+			const float nxy = y_in ? ny : nx;
+			const bool z_in = nz > nxy;
+			t = z_in ? nz : nxy;
 			const float tf = __builtin_fminf(__builtin_fminf(fx, fy), fz);
-			axis = nz > nxy ? 2 : (ny > nx ? 1 : 0);
+			axis = z_in ? 2 : (y_in ? 1 : 0);
 			hit = t <= tf;
 		} else if (SPEC_T[i] == RT_GEOM_SPHERE)
 			hit = ball_entry_fast(o, d, rp, mk3(SPEC_G[i][0], SPEC_G[i][1], SPEC_G[i][2]), SPEC_G[i][3], t);
