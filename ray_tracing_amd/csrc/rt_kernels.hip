@@ -781,7 +781,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 
 			bool specular = __float_as_int(m1.w) != 0;
 			if (!specular)
-				specular = rng_draw(rng) <= (fresnel.x + fresnel.y + fresnel.z) / 3.0f;
+				specular = rng_draw(rng) <= (FAST ? third_of(fresnel.x + fresnel.y + fresnel.z) : (fresnel.x + fresnel.y + fresnel.z) / 3.0f);
 			V3 out_dir;
 			if (specular) {
 				STAT(15);
@@ -876,7 +876,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 						if (obj >= 0) { const float4 e = sc.shade[4 * obj + 3]; lit = add3(lit, mk3(e.x, e.y, e.z)); }
 						taps++;
 					}
-				lit = scale3(lit, 1.0f / (float) taps);                          /* main.c:208-209 */
+				/* main.c:208-209: 1.0f / num_samples, num_samples in 1..3 (the quotients as literals; RN(1/3) = 0x3eaaaaab) */
+				lit = scale3(lit, FAST ? (taps == 1 ? 1.0f : (taps == 2 ? 0.5f : __uint_as_float(0x3eaaaaabu))) : 1.0f / (float) taps);
 				const bool dark = FAST ? (tiny_f_fast(lit.x) && tiny_f_fast(lit.y) && tiny_f_fast(lit.z))
 				                       : (tiny_f(lit.x) && tiny_f(lit.y) && tiny_f(lit.z));
 				if (!dark) {                                                      /* main.c:257-261 */
@@ -1117,6 +1118,16 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 			if (__float_as_uint(want) != __float_as_uint(got)) {
 				bad++;
 				out[1] = __float_as_uint(n); out[2] = __float_as_uint(d); out[3] = __float_as_uint(want); out[4] = __float_as_uint(got);
+			}
+			/* avgv()'s division by 3 (mixed with -0, denormal and huge numerators, which take the wave's `/` path) */
+			float m = n;
+			if ((r0 >> 56) == 0x11) m = -0.0f;
+			if ((r0 >> 56) == 0x12) m = __uint_as_float((uint32_t) r1 & 0x807fffffu);
+			if ((r0 >> 56) == 0x13) m = st_float(r1, 30, 127);
+			const float want3 = m / 3.0f, got3 = third_of(m);
+			if (__float_as_uint(want3) != __float_as_uint(got3)) {
+				bad++;
+				out[1] = __float_as_uint(m); out[2] = __float_as_uint(3.0f); out[3] = __float_as_uint(want3); out[4] = __float_as_uint(got3);
 			}
 		} else if (which == 1) {
 			const uint64_t r0 = st_next(s), r1 = st_next(s), r2 = st_next(s);

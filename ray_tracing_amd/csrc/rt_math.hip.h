@@ -131,6 +131,15 @@ RT_DEV double div_by_refined64(double n, double d, double r)
 	return __builtin_fma(__builtin_fma(-d, q, n), r, q);
 }
 
+/* avgv(): x / 3.0f (vector.c:89-92) as div_by_refined with the reciprocal RN(1/3) as a literal; +0 is exact
+ * too (see rt_kernels.hip prepare_ray); anything else outside the numerator window takes the wave through `/` */
+RT_DEV float third_of(float x)
+{
+	if (__ballot(!(x == 0.0f ? !__builtin_signbit(x) : (__builtin_fabsf(x) >= 0x1p-100f && __builtin_fabsf(x) <= 0x1p+30f))) == 0ull)
+		return div_by_refined(x, 3.0f, __uint_as_float(0x3eaaaaabu));
+	return x / 3.0f;
+}
+
 /* vector.c:129-138 with the three divisions sharing one reciprocal.  The tuned form needs the squared
  * length in [2^-30, 2^60] (so the length is >= 2^-15 > 0.00001: the reference's epsilon branch is not
  * taken) and every component at least 2^-60 in magnitude (a +-0 / denormal numerator keeps its sign and
