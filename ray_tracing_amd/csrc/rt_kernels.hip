@@ -171,8 +171,8 @@ RT_DEV RayPrep prepare_ray(V3 o, V3 d)
 	p.inv = mk3(rcp_refined(d.x), rcp_refined(d.y), rcp_refined(d.z));
 	p.dd = dot3(d, d);
 	p.den = (double) (2.0f * p.dd);
-	p.den_ok = p.dd >= 0x1p-20f && p.dd <= 0x1p+20f;
-	p.rden = rcp_refined64(p.den);
+	p.den_ok = near_one(p.dd);
+	p.rden = rcp_twice_near_one(p.dd);
 	return p;
 }
 
@@ -1027,7 +1027,8 @@ rt_deinterleave(const float *strips, float *frame, int width, int height, int ro
 
 /* ---- self-test of the exact-arithmetic shortcuts (tests/test_gpu_selftest.py) -------------------
  * which = 0: div_by_refined   vs `/`   on floats,  numerator in [2^-100, 2^30], denominator in [2^-30, 2^30]
- *         1: div_by_refined64 vs `/`   on doubles, numerator in [2^-300, 2^300], denominator (double) 2a, a in [2^-20, 2^20]
+ *         1: div_by_refined64 vs `/`   on doubles, numerator in [2^-300, 2^300], denominator (double) 2a for every float a with
+ *            |a - 1| <= 2^-18 (dot(d,d) of a normalised direction), and its series reciprocal vs 1.0 / den
  *         2: unit3_fast       vs unit3 on vectors of every magnitude (incl. zero / tiny / huge components)
  *         4: tiny_f_fast      vs tiny_f (the |x| < 0.0001 test of vector.c:79 without fp64)
  *         3: EXHAUSTIVE: sqrt_of_float64 vs the IEEE fp64 sqrt for every normal float up to 2^120 (`iters` ignored)
@@ -1131,15 +1132,16 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 			}
 		} else if (which == 1) {
 			const uint64_t r0 = st_next(s), r1 = st_next(s), r2 = st_next(s);
-			const float a = st_float(r0, -20, 20);
-			const double den = (double) (2.0f * __builtin_fabsf(a));
+			const float a = __uint_as_float(0x3f800000u - 64u + (uint32_t) (r0 % 97ull));      /* every float with |a - 1| <= 2^-18 */
+			const double den = (double) (2.0f * a);
 			const int e = -300 + (int) (r1 % 600ull);
 			double num = __builtin_ldexp(1.0 + (double) (r2 >> 12) * 0x1p-52, e);
 			if (r1 >> 63) num = -num;
 			if ((r1 >> 58 & 15) == 0) num = (double) st_float(r2, -60, 30) - __builtin_sqrt((double) __builtin_fabsf(st_float(r1, -60, 30)));
 			if (!(__builtin_fabs(num) >= 0x1p-300 && __builtin_fabs(num) <= 0x1p+300)) continue;
 			const double want = num / den;
-			const double got = div_by_refined64(num, den, rcp_refined64(den));
+			const double got = div_by_refined64(num, den, rcp_twice_near_one(a));
+			if (!near_one(a) || __double_as_longlong(rcp_twice_near_one(a)) != __double_as_longlong(1.0 / den)) { bad++; out[1] = __float_as_uint(a); }
 			if (__double_as_longlong(want) != __double_as_longlong(got)) {
 				bad++;
 				out[1] = (unsigned long long) __double_as_longlong(num); out[2] = (unsigned long long) __double_as_longlong(den);

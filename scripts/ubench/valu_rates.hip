@@ -35,13 +35,21 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float seed, int 
 		if (WHICH == 12) { REP8(asm volatile("v_div_scale_f32 %0, vcc, %0, %4, %0\n v_div_fixup_f32 %1, %1, %4, %5\n v_div_fmas_f32 %2, %2, %4, %5\n v_max3_f32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");) }
 		if (WHICH == 13) { REP8(asm volatile("v_cvt_f64_f32 %0, %4\n v_cvt_f32_f64 %2, %1\n v_cvt_f64_f32 %1, %5\n v_cvt_f32_f64 %3, %0" : "+v"(d0), "+v"(d1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));) }
 		if (WHICH == 14) { REP8(asm volatile("v_mul_u32_u24 %0, %0, %4\n v_mul_hi_u32_u24 %1, %1, %4\n v_mad_u32_u24 %2, %2, %4, %3\n v_mul_u32_u24 %3, %3, %4" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(0x9E3779u));) }
+		if (WHICH == 15) { REP8(asm volatile("v_lshlrev_b64 %0, %4, %0\n v_lshlrev_b64 %1, %4, %1\n v_lshlrev_b64 %2, %4, %2\n v_lshlrev_b64 %3, %4, %3" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3) : "v"(u0));) }
+		if (WHICH == 16) { REP8(asm volatile("v_ffbh_u32 %0, %0\n v_ffbh_u32 %1, %1\n v_ffbh_u32 %2, %2\n v_ffbh_u32 %3, %3" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));) }
+		if (WHICH == 17) { REP8(asm volatile("v_ldexp_f32 %0, %0, %4\n v_ldexp_f32 %1, %1, %4\n v_ldexp_f32 %2, %2, %4\n v_ldexp_f32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(u0));) }
+		if (WHICH == 18) { REP8(asm volatile("v_cvt_f32_u32 %0, %4\n v_cvt_f32_u32 %1, %5\n v_cvt_f32_u32 %2, %4\n v_cvt_f32_u32 %3, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(u0), "v"(u1));) }
+		if (WHICH == 19) { REP8(asm volatile("v_lshl_add_u64 %0, %0, 0, %1\n v_lshl_add_u64 %1, %1, 0, %2\n v_lshl_add_u64 %2, %2, 0, %3\n v_lshl_add_u64 %3, %3, 0, %0" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));) }
+		if (WHICH == 20) { REP8(asm volatile("v_alignbit_b32 %0, %0, %1, %4\n v_alignbit_b32 %1, %1, %2, %4\n v_min_u32 %2, %2, %4\n v_min3_f32 %3, %3, %3, %3" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(a3) : "v"(u3));) }
+		if (WHICH == 21) { REP8(asm volatile("v_lshrrev_b64 %0, 30, %0\n v_lshrrev_b64 %1, 27, %1\n v_lshrrev_b64 %2, 31, %2\n v_lshrrev_b64 %3, 5, %3" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));) }
+		if (WHICH == 22) { REP8(asm volatile("v_cvt_f64_u32 %0, %4\n v_cvt_f64_u32 %1, %5\n v_cvt_f64_u32 %2, %4\n v_cvt_f64_u32 %3, %5" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(u0), "v"(u1));) }
 	}
 	out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + (float) (d0 + d1 + d2 + d3) + (float) (u0 ^ u1 ^ u2 ^ u3) + (float) (l0 ^ l1 ^ l2 ^ l3) + p0.x + p1.y + p2.x + p3.y;
 }
 
 template <int W> double run(const char *name, float *d_out, int cus, int lanes = 64)
 {
-	const int iters = 2000, blocks = cus * 4;    // 4 blocks of 256 = 16 waves/CU = 4 waves/SIMD
+	const int iters = 20000, blocks = cus * 4;    // 4 blocks of 256 = 16 waves/CU = 4 waves/SIMD
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
 	hipLaunchKernelGGL(k<W>, dim3(blocks), dim3(256), 0, 0, d_out, 10, 1.0f, lanes);
 	hipDeviceSynchronize();
@@ -77,6 +85,14 @@ int main()
 	run<12>("div_scale/fixup/fmas/max3", d, cus);
 	run<13>("cvt f64<->f32", d, cus);
 	run<14>("u24 mul family", d, cus);
+	run<15>("v_lshlrev_b64 (variable)", d, cus);
+	run<16>("v_ffbh_u32", d, cus);
+	run<17>("v_ldexp_f32", d, cus);
+	run<18>("v_cvt_f32_u32", d, cus);
+	run<19>("v_lshl_add_u64", d, cus);
+	run<20>("alignbit/alignbit/min_u32/min3_f32", d, cus);
+	run<21>("v_lshrrev_b64 (constant)", d, cus);
+	run<22>("v_cvt_f64_u32", d, cus);
 	run<0>("v_fma_f32, lanes 0-31 only", d, cus, 32);
 	run<0>("v_fma_f32, lanes 0-15 only", d, cus, 16);
 	run<4>("v_fma_f64, lanes 0-31 only", d, cus, 32);
