@@ -68,7 +68,6 @@ struct rt_context {
 	rt_camera    camera;
 	bool         have_camera = false;
 
-	float        *d_byte_lut = nullptr;  /* b / 255 for b = 0..255 */
 	unsigned int *d_counter = nullptr;   /* pixel-block counter of the persistent kernel */
 	int          num_cus = 256;
 
@@ -127,8 +126,6 @@ int rt_create(rt_context **out, int device_id)
 		if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
 			ctx->num_cus = prop.multiProcessorCount;
 		e = hipMalloc((void**) &ctx->d_counter, rt_counter_bytes());
-		if (e == hipSuccess) e = hipMalloc((void**) &ctx->d_byte_lut, 256 * sizeof(float));
-		if (e == hipSuccess) e = rt_launch_fill_byte_lut(ctx->d_byte_lut, ctx->stream);
 		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 		if (e != hipSuccess) { (void) hipStreamDestroy(ctx->stream); delete ctx; return fail(RT_ERR_DEVICE, "rt_create: %s", hipGetErrorString(e)); }
 	}
@@ -147,7 +144,7 @@ void rt_destroy(rt_context *ctx)
 	for (auto &e : ctx->event_pool) (void) hipEventDestroy(e);
 	if (ctx->spec_module) (void) hipModuleUnload(ctx->spec_module);
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
-	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame); (void) hipFree(ctx->d_counter); (void) hipFree(ctx->d_samples); (void) hipFree(ctx->d_direct); (void) hipFree(ctx->d_byte_lut);
+	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame); (void) hipFree(ctx->d_counter); (void) hipFree(ctx->d_samples); (void) hipFree(ctx->d_direct);
 	(void) hipFree(ctx->prog.d_accum); (void) hipFree(ctx->prog.d_low); (void) hipFree(ctx->prog.d_out);
 	(void) hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -365,7 +362,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 		const int mine = blocks > p->rank ? (blocks - p->rank + p->world - 1) / p->world : 0;
 		L.local_rows = mine * p->row_block;
 	}
-	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.byte_lut = ctx->d_byte_lut;
+	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h;
 	L.frame = (float*) d_strip;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
 	L.num_chunks = 1; L.chunk_spp = p->spp; L.samples = nullptr; L.direct = nullptr;
@@ -519,7 +516,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	L.spp = 1; L.max_bounces = g.max_bounces; L.seed = g.seed;
 	L.u_den = lw - 1; L.v_den = lh - 1; L.pix_scale = s; L.pix_width = g.width; L.sample_base = g.passes;
 	L.row_block = 8; L.rank = 0; L.world = 1;
-	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.byte_lut = ctx->d_byte_lut;
+	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h;
 	L.frame = g.d_low;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
 	L.num_chunks = 1; L.chunk_spp = 1; L.samples = nullptr; L.direct = nullptr; L.num_shards = 1;

@@ -69,7 +69,6 @@ typedef struct {
 	/* skybox: 6 faces of RGBA8 texels, face-major                            */
 	const uint32_t *sky;
 	int   sky_w, sky_h;
-	const float *byte_lut;     /* 256 floats: b / 255 (may be NULL: divide)                      */
 
 	float *frame;              /* local_rows x width x 3 floats, resolved      */
 	/* sample chunking (few pixels per GPU): a pixel's spp samples are split into num_chunks work

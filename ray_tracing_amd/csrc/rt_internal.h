@@ -18,7 +18,6 @@ hipError_t rt_launch_deinterleave(const float *strips, float *frame, int width, 
 
 hipError_t rt_launch_accumulate(float *accum, const float *lowres, int width, int height, int scale,
                                 int low_w, int low_h, float k, hipStream_t stream);
-hipError_t rt_launch_fill_byte_lut(float *lut, hipStream_t stream);
 hipError_t rt_launch_sum_samples(const float *samples, const unsigned char *direct, float *frame, size_t plane_floats, int spp, hipStream_t stream);
 hipError_t rt_launch_resolve(const float *accum, float *frame, size_t floats, float inv_count, hipStream_t stream);
 hipError_t rt_launch_selftest(int which, uint64_t seed, int blocks, int iters, unsigned long long *d_out, hipStream_t stream);

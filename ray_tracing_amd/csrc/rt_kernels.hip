@@ -396,8 +396,12 @@ RT_DEV V3 sky_lookup(const rt_launch &L, V3 dir)
 	int x = (int) (u * (float) (L.sky_w - 1));
 	int y = (int) (v * (float) (L.sky_h - 1));
 	uint32_t texel = L.sky[((size_t) face * L.sky_h + y) * L.sky_w + x];
-	if (FAST && L.byte_lut)                         /* byte_lut[b] = (float) b / 255, built on this device */
-		return mk3(L.byte_lut[texel & 255u], L.byte_lut[(texel >> 8) & 255u], L.byte_lut[(texel >> 16) & 255u]);
+	if (FAST) {                                     /* (float) b / 255 (gpu_and_windowing.c:108-110) with the literal RN(1/255):
+	                                                 * exact for the 256 possible numerators, rt_selftest(4) */
+		const float r255 = __uint_as_float(0x3b808081u);
+		return mk3(div_by_refined((float) (texel & 255u), 255.0f, r255), div_by_refined((float) ((texel >> 8) & 255u), 255.0f, r255),
+		           div_by_refined((float) ((texel >> 16) & 255u), 255.0f, r255));
+	}
 	return mk3((float) (texel & 255u) / 255.0f,
 	           (float) ((texel >> 8) & 255u) / 255.0f,
 	           (float) ((texel >> 16) & 255u) / 255.0f);
@@ -963,13 +967,6 @@ rt_accumulate(float *accum, const float *lowres, int width, int height, int scal
 	}
 }
 
-/* byte_lut[b] = (float) b / 255 -- the reference's texel conversion (gpu_and_windowing.c:108-110),
- * evaluated once per context on the device so the table holds exactly what the kernels would compute */
-extern "C" __global__ void rt_fill_byte_lut(float *lut)
-{
-	lut[threadIdx.x] = (float) threadIdx.x / 255.0f;
-}
-
 /* chunked mode: add a pixel's stored samples in sample order and resolve (main.c:394,476).  Pixels
  * flagged in `direct` (sky-only pixels) were written by the trace kernel itself and are skipped. */
 extern "C" __global__ void __launch_bounds__(RT_BLOCK)
@@ -1155,6 +1152,8 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 			if ((r0 >> 60) == 2) f = st_float(r0, -126, 127);
 			if ((r0 >> 56) == 0x30) f = __uint_as_float(0x7fc00000u);
 			if (tiny_f(f) != tiny_f_fast(f)) { bad++; out[1] = __float_as_uint(f); }
+			const float byte = (float) (uint32_t) (r0 & 255u);                 /* and the sky texel channels: b / 255 */
+			if (__float_as_uint(byte / 255.0f) != __float_as_uint(div_by_refined(byte, 255.0f, __uint_as_float(0x3b808081u)))) { bad++; out[1] = __float_as_uint(byte); }
 		} else {
 			const uint64_t r0 = st_next(s), r1 = st_next(s), r2 = st_next(s), r3 = st_next(s);
 			/* unit3_fast decides per WAVE: even iterations keep a whole wave inside the tuned form's window,
@@ -1183,12 +1182,6 @@ hipError_t rt_launch_accumulate(float *accum, const float *lowres, int width, in
                                 int low_w, int low_h, float k, hipStream_t stream)
 {
 	hipLaunchKernelGGL(rt_accumulate, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, lowres, width, height, scale, low_w, low_h, k);
-	return hipGetLastError();
-}
-
-hipError_t rt_launch_fill_byte_lut(float *lut, hipStream_t stream)
-{
-	hipLaunchKernelGGL(rt_fill_byte_lut, dim3(1), dim3(256), 0, stream, lut);
 	return hipGetLastError();
 }
 
