@@ -247,24 +247,23 @@ RT_DEV bool ball_entry_fast(V3 o, V3 d, const RayPrep &rp, V3 center, float r2, 
 	if (!(discr > 0)) return false;
 	STAT(4);
 	const double nb = (double) -b;
-	/* The two numerators.  Each is +0 or at least 2^-127 in magnitude (a float minus a double of similar
-	 * size), far inside the window where div_by_refined64 is exact, and 2a > 0, so the smaller root is the
-	 * one with `- root` and its sign is the numerator's: the reference's sort-then-pick (scene.c:119-127)
-	 * reduces to "the small root if it is >= 0, else the large one if that is >= 0".  Only one quotient is
-	 * formed.  (A negative numerator above -2^-100 -- whose quotient could round to -0.0f, which the
-	 * reference would accept -- is left to the reference-order path, like an out-of-window 2a.) */
-	if (wave_all(rp.den_ok && discr >= 0x1p-126f && discr <= 0x1p+120f)) {
+	/* 2a > 0, so the smaller root is the one with `- root` and its sign is its numerator's: the reference's
+	 * sort-then-pick (scene.c:119-127) reduces to "the small root if it is >= 0, else the large one if that is
+	 * >= 0", and only one quotient is formed.  The one way the float results could disagree with those signs
+	 * is a negative quotient so small that it rounds to -0.0f (which `r0 < 0` lets through).  It cannot happen
+	 * when |b| >= 2^-90: -b and D = discr are floats, so (-b)^2 and D are equal or differ by at least
+	 * 2^-47 (-b)^2, hence |-b - sqrt(D)| is 0 or at least 2^-49 |b| >= 2^-139, and so is the numerator after
+	 * rounding the root.  (b == 0, tiny b and an out-of-window 2a or D take the reference-order path.) */
+	if (wave_all(rp.den_ok && discr >= 0x1p-126f && discr <= 0x1p+120f && __builtin_fabsf(b) >= 0x1p-90f)) {
 		const double root = sqrt_of_float64(discr);
 		const double num_lo = nb - root;
-		if (wave_all(num_lo >= 0.0 || num_lo <= -0x1p-100)) {
-			const bool small_ok = num_lo >= 0.0;
-			const double num = small_ok ? num_lo : nb + root;
-			const float t = (float) div_by_refined64(num, rp.den, rp.rden);
-			if (!small_ok) STAT(5);
-			if (!small_ok && t < 0) return false;
-			t_entry = t;
-			return true;
-		}
+		const bool small_ok = num_lo >= 0.0;
+		const double num = small_ok ? num_lo : nb + root;
+		const float t = (float) div_by_refined64(num, rp.den, rp.rden);
+		if (!small_ok) STAT(5);
+		if (!small_ok && t < 0) return false;
+		t_entry = t;
+		return true;
 	}
 	/* reference order, scene.c:117-127 */
 	STAT(6);
