@@ -260,6 +260,8 @@ int rt_set_skybox(rt_context *ctx, const Cubemap *sky)
 {
 	if (!ctx || !sky) return fail(RT_ERR_ARGUMENT, "rt_set_skybox: NULL argument");
 	if (sky->w <= 0 || sky->h <= 0) return fail(RT_ERR_ARGUMENT, "rt_set_skybox: bad size %dx%d", sky->w, sky->h);
+	if ((long long) sky->w * sky->h * 6 > 0x7fffffffLL)     /* the kernels index texels with the reference's int arithmetic */
+		return fail(RT_ERR_ARGUMENT, "rt_set_skybox: %dx%d faces are too large", sky->w, sky->h);
 	if (sky->chan != 3 && sky->chan != 4)
 		return fail(RT_ERR_ARGUMENT, "rt_set_skybox: %d channels unsupported (need 3 or 4)", sky->chan);
 	for (int f = 0; f < 6; f++)
@@ -362,7 +364,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 		const int mine = blocks > p->rank ? (blocks - p->rank + p->world - 1) / p->world : 0;
 		L.local_rows = mine * p->row_block;
 	}
-	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h;
+	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.sky_wm1 = (float) (ctx->sky_w - 1); L.sky_hm1 = (float) (ctx->sky_h - 1);
 	L.frame = (float*) d_strip;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
 	L.num_chunks = 1; L.chunk_spp = p->spp; L.samples = nullptr; L.direct = nullptr;
@@ -516,7 +518,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	L.spp = 1; L.max_bounces = g.max_bounces; L.seed = g.seed;
 	L.u_den = lw - 1; L.v_den = lh - 1; L.pix_scale = s; L.pix_width = g.width; L.sample_base = g.passes;
 	L.row_block = 8; L.rank = 0; L.world = 1;
-	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h;
+	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.sky_wm1 = (float) (ctx->sky_w - 1); L.sky_hm1 = (float) (ctx->sky_h - 1);
 	L.frame = g.d_low;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
 	L.num_chunks = 1; L.chunk_spp = 1; L.samples = nullptr; L.direct = nullptr; L.num_shards = 1;

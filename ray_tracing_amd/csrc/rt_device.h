@@ -69,6 +69,7 @@ typedef struct {
 	/* skybox: 6 faces of RGBA8 texels, face-major                            */
 	const uint32_t *sky;
 	int   sky_w, sky_h;
+	float sky_wm1, sky_hm1;    /* (float)(w - 1), (float)(h - 1): the texel scale of gpu_and_windowing.c:103-104 */
 
 	float *frame;              /* local_rows x width x 3 floats, resolved      */
 	/* sample chunking (few pixels per GPU): a pixel's spp samples are split into num_chunks work

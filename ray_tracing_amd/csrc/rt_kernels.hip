@@ -361,9 +361,11 @@ RT_DEV Hit nearest_hit_spec(const SceneLDS &sc, int n, V3 o, V3 d, bool want_nor
 template <bool FAST = false>
 RT_DEV V3 sky_lookup(const rt_launch &L, V3 dir)
 {
-	float ax = dir.x < 0 ? -dir.x : dir.x;
-	float ay = dir.y < 0 ? -dir.y : dir.y;
-	float az = dir.z < 0 ? -dir.z : dir.z;
+	/* absf() (utils.c): x < 0 ? -x : x keeps -0, and `abs + eps` with eps = 0 (gpu_and_windowing.c:51-58) turns
+	 * it into +0; |x| gives the same compares and the same sums */
+	const float ax = FAST ? __builtin_fabsf(dir.x) : (dir.x < 0 ? -dir.x : dir.x);
+	const float ay = FAST ? __builtin_fabsf(dir.y) : (dir.y < 0 ? -dir.y : dir.y);
+	const float az = FAST ? __builtin_fabsf(dir.z) : (dir.z < 0 ? -dir.z : dir.z);
 	int face; float nu, nv, m;                     /* u = nu / m, v = nv / m */
 	if (ax > ay && ax > az) {
 		m = ax + 0.0f;
@@ -379,22 +381,22 @@ RT_DEV V3 sky_lookup(const rt_launch &L, V3 dir)
 		else           { face = 1; nu = -dir.x; nv = -dir.y; }          /* CF_BACK   */
 	}
 	float u, v;
-	const float lo = __builtin_fminf(__builtin_fabsf(nu), __builtin_fabsf(nv));
-	if (FAST && wave_all(m >= 0x1p-30f && m <= 0x1p+20f && lo >= 0x1p-100f && __builtin_fmaxf(__builtin_fabsf(nu), __builtin_fabsf(nv)) <= 0x1p+30f)) {
-		const float r = rcp_refined(m);             /* both quotients share the reciprocal (rt_math.hip.h) */
-		u = div_by_refined(nu, m, r);
-		v = div_by_refined(nv, m, r);
+	/* Shared-reciprocal quotients (rt_math.hip.h).  A numerator below the window (zero, -0, tiny) needs no care
+	 * here: its quotient is below 2^-25 in magnitude either way and u + 1.0f below rounds it away. */
+	if (FAST && wave_all(m >= 0x1p-30f && __builtin_fmaxf(__builtin_fmaxf(ax, ay), az) <= 0x1p+20f)) {
+		const float r = rcp_refined(m);             /* (finite quotients: clamp(x, -1, 1) is the median of the three) */
+		u = __builtin_amdgcn_fmed3f(div_by_refined(nu, m, r), -1.0f, 1.0f);
+		v = __builtin_amdgcn_fmed3f(div_by_refined(nv, m, r), -1.0f, 1.0f);
 	} else {
-		u = nu / m;
-		v = nv / m;
+		u = clamp11(nu / m);
+		v = clamp11(nv / m);
 	}
-	u = clamp11(u);
-	v = clamp11(v);
 	u = 0.5f * (u + 1.0f);
 	v = 0.5f * (v + 1.0f);
-	int x = (int) (u * (float) (L.sky_w - 1));
-	int y = (int) (v * (float) (L.sky_h - 1));
-	uint32_t texel = L.sky[((size_t) face * L.sky_h + y) * L.sky_w + x];
+	const int x = (int) (u * L.sky_wm1);           /* int x = u * (c->w - 1)  (gpu_and_windowing.c:103-104) */
+	const int y = (int) (v * L.sky_hm1);
+	/* texel index in the reference's own int arithmetic (:106); rt_set_skybox bounds 6*w*h below 2^31 */
+	const uint32_t texel = L.sky[(uint32_t) ((face * L.sky_h + y) * L.sky_w + x)];
 	if (FAST) {                                     /* (float) b / 255 (gpu_and_windowing.c:108-110) with the literal RN(1/255):
 	                                                 * exact for the 256 possible numerators, rt_selftest(4) */
 		const float r255 = __uint_as_float(0x3b808081u);
