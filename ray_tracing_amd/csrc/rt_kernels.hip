@@ -556,11 +556,15 @@ rt_trace_simple(const rt_launch L)
  *     up to three shadow taps, all known right after shading because the taps only feed the
  *     light term that is added afterwards, main.c:257-261) are compacted into a per-wave LDS
  *     queue with ballot/mbcnt prefix sums and traced in full batches of 64 by whichever lane
- *     gets them -- trace_ray() runs on (nearly) full waves;
+ *     gets them -- trace_ray() runs on full waves;
+ *   - the radiance arithmetic of a bounce (emission, albedo, light term: main.c:232,248,257-261) needs
+ *     the bounce's tap results but nothing else does, so it runs one round behind the ray generation
+ *     (the "back" and the "front" of a lane): taps that do not fill a batch simply wait in the queue
+ *     for the next round's rays, and 99 % of the traced batches are full;
  *   - the primary hit is traced once per pixel and re-used by all samples (the reference has no
  *     sub-pixel jitter, main.c:293-296, so bounce 0 of every sample is the same ray): bit-exact;
  *     the 64 camera rays of a block are traced together as one batch when the wave takes the block,
- *     and a sky-only pixel is finished on the spot;
+ *     and the block's sky-only pixels are written by all lanes together;
  *   - when a launch has few pixels per wave (multi-GPU strips) a pixel's samples are split into
  *     chunks that different lanes take; samples are then stored and summed by rt_sum_samples.
  * The per-pixel sample sum is still formed in sample order (main.c:394), so results are
@@ -569,14 +573,18 @@ rt_trace_simple(const rt_launch L)
 
 #define RT_COUNTER_BYTES (64 * 128)     /* WF_SHARDS counters, one per 128-byte line */
 #define WF_SHARDS  64                  /* work-item queues (counters 128 B apart), see wavefront_body */
-#define WF_QUEUE   128                 /* ring: at most 63 left over + 64 pushed at a time */
+#define WF_QUEUE   128                 /* ring: at most 63 waiting + 64 pushed at a time */
 #define WF_KIND_PRIMARY 0              /* camera ray of pixel `owner` of the wave's current 8x8 block */
+#define REC_VALID    1                /* per-bounce record handed from the front to the back (wavefront_body) */
+#define REC_SPECULAR 2
+#define REC_LAST     4                /* the path ends after this bounce ...               */
+#define REC_SKY      8                /* ... because its bounce ray left the scene (end_sky) */
 #define WF_KIND_MAIN    1              /* next bounce ray of lane `owner`; kinds 2..4 = its shadow tap 0..2 */
 
 struct WaveLDS {
 	float q[7][WF_QUEUE];              /* ray queue SoA: o.xyz, d.xyz (un-normalised), meta         */
 	float res[7][64];                  /* bounce-ray result per owner lane: xyz, nxyz, obj          */
-	short tap[3][64];                  /* shadow tap results per owner lane: object index (< 1024) or -1 */
+	short tap[2][3][64];               /* shadow tap results per owner lane (object index < 1024 or -1), by parity of the round that queued them */
 	float blk[7][64];                  /* primary hits of the current pixel block, by pixel in block */
 	float cache[7][64];                /* per-lane copy of its pixel's primary hit                  */
 	/* per-block tables written when the block is taken, so that handing a pixel to a lane is a few LDS reads */
@@ -640,23 +648,32 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	bool exhausted = false;
 
 	/* per-lane path state */
-	int   px_off = -1;                      /* the lane's pixel: row * width + column inside the strip; < 0: none */
+	int   px_off = -1;                      /* the back's pixel: row * width + column inside the strip; < 0: none */
+	int   f_off = -1, f_end = 0;            /* the front's pixel and the end of its sample range */
 	uint32_t pixel_index = 0;               /* its index for the RNG seed (main.c:286 order) */
-	int   sample = 0, sample_end = 0, bounce = 0;
+	/* A path is worked on at two places one round apart.  The FRONT (section 2) turns the pending hit into the
+	 * next rays: it owns rng, bounce, fsample and the hit.  The BACK (section 5) does the radiance arithmetic
+	 * of a bounce (main.c:232,248,257-261) one round later, when its shadow taps are certainly traced: it owns
+	 * rad, carry, sum, sample.  `prev` is the record of the bounce the front shaded in the previous round. */
+	int   sample = 0, fsample = 0, sample_end = 0, bounce = 0;
 	bool  has_hit = false;
 	V3    sum = mk3(0, 0, 0), carry = mk3(1, 1, 1), rad = mk3(0, 0, 0);
 	V3    hp = mk3(0, 0, 0), hn = mk3(0, 0, 0), hdir = mk3(0, 0, 0), pdir = mk3(0, 0, 0);
+	V3    end_sky = mk3(0, 0, 0);           /* sky colour that ends the sample of `prev` (REC_SKY) */
 	int   hobj = -1;
+	int   prev = 0;                         /* REC_* | tapmask << 4 | object << 8 */
 	uint64_t rng = 0;
+	/* the ray queue persists across rounds: taps that do not fill a batch wait for the next round's rays */
+	unsigned int q_head = 0, q_tail = 0, parity = 0;
 
-	for (;;) {
+	for (;; parity ^= 1u) {
 		/* ---- 1. pixel supply --------------------------------------------------------------- */
 		bool fetched = false;                   /* a block was taken this round: trace its camera rays */
 		bool prim_on = false;
 		V3   prim_d = mk3(0, 0, 0);
 #pragma unroll 1
 		for (int attempt = 0; attempt < 4; attempt++) {
-			const bool want = px_off < 0;
+			const bool want = f_off < 0 && (chunked || px_off < 0);
 			const unsigned long long wmask = __ballot(want);
 			if (wmask == 0ull) break;
 			if (blk_done) {
@@ -708,7 +725,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					 * order and resolved (main.c:394,476).  With chunks, the item that holds chunk 0 writes it. */
 					const rt_launch_cold C = cold_view();
 					const int i = tile_i0 + (lane & 7), lr = tile_lr0 + (lane >> 3), width = C->width, spp = C->spp;
-					const V3 c = mk3(clamp01(W.blk[0][lane]), clamp01(W.blk[1][lane]), clamp01(W.blk[2][lane]));
+					const V3 sky = sky_lookup<FAST>(L, mk3(W.blk[0][lane], W.blk[1][lane], W.blk[2][lane]));
+					const V3 c = mk3(clamp01(sky.x), clamp01(sky.y), clamp01(sky.z));
 					if (chunked) C->direct[(size_t) lr * width + i] = 1;           /* rt_sum_samples skips it */
 					V3 acc = mk3(0, 0, 0);
 					for (int k = 0; k < spp; k++) acc = add3(acc, c);
@@ -730,7 +748,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			if (want && rank_in < avail) {
 				const int q = W.list[cur_next + rank_in];
 				const int c = q & 7, r = q >> 3;
-				px_off = (tile_lr0 + r) * L.width + tile_i0 + c;
+				f_off = (tile_lr0 + r) * L.width + tile_i0 + c;
 				pixel_index = (uint32_t) (W.rowpart[r] + (tile_i0 + c) * L.pix_scale);
 				pdir = sub3(add3(mk3(W.colv[0][c], W.colv[1][c], W.colv[2][c]), mk3(W.rowv[0][r], W.rowv[1][r], W.rowv[2][r])), cam);
 				const V3 a = mk3(W.blk[0][q], W.blk[1][q], W.blk[2][q]);
@@ -739,9 +757,12 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				W.cache[0][lane] = a.x;  W.cache[1][lane] = a.y;  W.cache[2][lane] = a.z;
 				W.cache[3][lane] = nn.x; W.cache[4][lane] = nn.y; W.cache[5][lane] = nn.z;
 				W.cache[6][lane] = __int_as_float(obj);
-				sample = cur_s0; sample_end = cur_s1; bounce = 0; sum = mk3(0, 0, 0);
-				rng = path_seed(L.seed, pixel_index, (uint32_t) (L.sample_base + sample));
-				carry = mk3(1, 1, 1); rad = mk3(0, 0, 0);
+				fsample = cur_s0; f_end = cur_s1; bounce = 0;
+				rng = path_seed(L.seed, pixel_index, (uint32_t) (L.sample_base + fsample));
+				if (px_off < 0) {                   /* the back is idle: it follows at once */
+					px_off = f_off; sample = fsample; sample_end = f_end; sum = mk3(0, 0, 0);
+					carry = mk3(1, 1, 1); rad = mk3(0, 0, 0); prev = 0;
+				}
 				hp = a; hn = nn; hobj = obj; hdir = pdir;
 				has_hit = true;
 			}
@@ -749,13 +770,13 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			cur_next += taken < avail ? taken : avail;
 			if (cur_next >= cur_count) blk_done = true;
 		}
-		if (!fetched && __ballot(px_off >= 0) == 0ull) {
+		if (!fetched && __ballot(px_off >= 0 || f_off >= 0) == 0ull) {
 			if (exhausted && blk_done) break;
 			continue;                          /* sky / out-of-frame pixels only so far: hand out more */
 		}
 
 		/* ---- 2. shade the pending hit of every live path (main.c:180-261) ------------------- */
-		int  tapmask = 0;
+		int  tapmask = 0, cur = 0;
 		bool emit_main = false;
 		V3   ray_o = cam, ray_d = prim_d;
 		V3   tap_j0 = mk3(0, 0, 0), tap_j1 = mk3(0, 0, 0), tap_j2 = mk3(0, 0, 0);   /* accepted rand_dir of each tap (main.c:193) */
@@ -770,7 +791,6 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				tap_j2 = rng_direction<FAST>(rng); if (dot3(tap_j2, hn) > 0) tapmask |= 4;
 			}
 			const float4 m0 = sc.shade[4 * hobj], m1 = sc.shade[4 * hobj + 1];
-			const float4 m2 = sc.shade[4 * hobj + 2], m3 = sc.shade[4 * hobj + 3];
 			const V3 f0 = mk3(m0.x, m0.y, m0.z), omf0 = mk3(m1.x, m1.y, m1.z);
 
 			const float n_dot_v = clamp01(dot3(hn, neg3(hdir)));
@@ -782,8 +802,6 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			V3 scatter = rng_direction<FAST>(rng);
 			if (dot3(scatter, hn) < 0) scatter = neg3(scatter);
 
-			rad = add3(rad, had3(mk3(m3.x, m3.y, m3.z), carry));
-
 			bool specular = __float_as_int(m1.w) != 0;
 			if (!specular)
 				specular = rng_draw(rng) <= (FAST ? third_of(fresnel.x + fresnel.y + fresnel.z) : (fresnel.x + fresnel.y + fresnel.z) / 3.0f);
@@ -793,33 +811,33 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				const V3 nneg = neg3(hn);
 				const float f = -2.0f * dot3(nneg, hdir);
 				out_dir = unit3_sel<FAST>(lin2(scatter, madd3(hdir, nneg, f), m0.w, 1.0f));
-			} else {
+			} else
 				out_dir = scatter;
-				carry = had3(carry, mk3(m2.x, m2.y, m2.z));
-			}
 			bounce++;
 			emit_main = bounce < L.max_bounces;
 			ray_o = madd3(hp, out_dir, 0.001f);
 			ray_d = out_dir;
 			hdir = out_dir;
 			has_hit = false;
+			cur = REC_VALID | (specular ? REC_SPECULAR : 0) | (emit_main ? 0 : REC_LAST) | (tapmask << 4) | (hobj << 8);
 		}
 
 		/* ---- 3+4. compact this round's rays into the wave's ring queue (ballot + mbcnt prefix), one
 		 * kind at a time, and trace full batches of 64 as soon as they exist (scene.c:156-190 on full
 		 * waves); the remainder is flushed after the last kind -------------------------------------- */
-		int q_head = 0, q_tail = 0;
+		unsigned int must = q_tail;            /* rays up to here are needed by the end of this round */
 		/* one ray of kind `k` per lane with `on` set, appended to the ring in lane order */
 		auto push = [&](bool on, V3 qo, V3 qd, int k) {
 			const unsigned long long m = __ballot(on);
 			if (on) {
-				const int slot = (q_tail + (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32),
-				                  __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u))) & (WF_QUEUE - 1);
+				const unsigned int slot = (q_tail + __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32),
+				                           __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u))) & (WF_QUEUE - 1);
 				W.q[0][slot] = qo.x; W.q[1][slot] = qo.y; W.q[2][slot] = qo.z;
 				W.q[3][slot] = qd.x; W.q[4][slot] = qd.y; W.q[5][slot] = qd.z;
-				W.q[6][slot] = __int_as_float(lane | (k << 8));
+				W.q[6][slot] = __int_as_float(lane | (k << 8) | (int) (parity << 12));
 			}
-			q_tail += __popcll(m);
+			q_tail += (unsigned int) __popcll(m);
+			if (k <= WF_KIND_MAIN) must = q_tail;        /* camera and bounce rays: their lanes wait for the hit */
 			wave_fence();
 		};
 #pragma unroll 1
@@ -832,16 +850,16 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			case 4:               push((tapmask & 4) != 0, hp, tap_j2, 4); break;
 			default: break;
 			}
-			while (q_tail - q_head >= 64 || (kind == 5 && q_tail > q_head)) {
-				const int count = q_tail - q_head < 64 ? q_tail - q_head : 64;
+			while (q_tail - q_head >= 64u || (kind == 5 && (int) (must - q_head) > 0)) {
+				const int count = q_tail - q_head < 64u ? (int) (q_tail - q_head) : 64;
 				STAT(12);
 				if (lane < count) {
 					STAT(13);
-					const int slot = (q_head + lane) & (WF_QUEUE - 1);
+					const unsigned int slot = (q_head + (unsigned int) lane) & (WF_QUEUE - 1);
 					V3 o = mk3(W.q[0][slot], W.q[1][slot], W.q[2][slot]);
 					V3 d = mk3(W.q[3][slot], W.q[4][slot], W.q[5][slot]);
 					const int meta = __float_as_int(W.q[6][slot]);
-					const int owner = meta & 255, rkind = meta >> 8;
+					const int owner = meta & 255, rkind = (meta >> 8) & 15;
 					if (rkind > WF_KIND_MAIN) {                                                   /* main.c:186,197-198 */
 						d = unit3_sel<FAST>(lin2(d, sub3(light_pos, o), 0.5f, 1.0f));
 						o = madd3(o, d, 0.001f);
@@ -849,83 +867,102 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					const V3 dn = unit3_sel<FAST>(d);                                             /* scene.c:158 */
 					const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, n, o, dn, rkind <= WF_KIND_MAIN) : nearest_hit(sc, n, o, dn);
 					if (rkind > WF_KIND_MAIN) {
-						W.tap[rkind - 2][owner] = (short) hit.obj;
+						W.tap[meta >> 12][rkind - 2][owner] = (short) hit.obj;
 					} else {
 						V3 a, b = hit.n;
 						if (hit.obj >= 0) a = madd3(o, dn, hit.t);                   /* scene.c:186 */
-						else            { STAT(14); a = sky_lookup<FAST>(L, dn); }         /* main.c:170  */
+						else              a = dn;       /* left the scene: the owner looks the sky up (main.c:170), once per round */
 						float (*dst)[64] = rkind == WF_KIND_PRIMARY ? W.blk : W.res;
 						dst[0][owner] = a.x; dst[1][owner] = a.y; dst[2][owner] = a.z;
 						dst[3][owner] = b.x; dst[4][owner] = b.y; dst[5][owner] = b.z;
 						dst[6][owner] = __int_as_float(hit.obj);
 					}
 				}
-				q_head += count;
+				q_head += (unsigned int) count;
 				wave_fence();
 			}
 		}
 
-		/* ---- 5. consume results ------------------------------------------------------------- */
+		/* ---- 5. back: retire the bounce shaded one round ago (its taps are traced by now), take this round's
+		 * bounce-ray result, and move the front to the next sample when the path has ended ------------------ */
 		if (fetched) blk_ready = true;
 		STAT(16);
 		if (px_off >= 0) {
 			STAT(17);
-			bool sample_done = false;
-			if (tapmask) {
-				V3 lit = mk3(0, 0, 0);
-				int taps = 0;
+			if (prev & REC_VALID) {
+				const int pobj = prev >> 8, ptaps = (prev >> 4) & 7;
+				const float4 m2 = sc.shade[4 * pobj + 2], m3 = sc.shade[4 * pobj + 3];
+				rad = add3(rad, had3(mk3(m3.x, m3.y, m3.z), carry));                    /* main.c:232 */
+				if (!(prev & REC_SPECULAR)) carry = had3(carry, mk3(m2.x, m2.y, m2.z));  /* main.c:248 */
+				if (ptaps) {
+					V3 lit = mk3(0, 0, 0);
+					int taps = 0;
 #pragma unroll
-				for (int k = 0; k < 3; k++)
-					if ((tapmask >> k) & 1) {
-						const int obj = W.tap[k][lane];
-						if (obj >= 0) { const float4 e = sc.shade[4 * obj + 3]; lit = add3(lit, mk3(e.x, e.y, e.z)); }
-						taps++;
+					for (int k = 0; k < 3; k++)
+						if ((ptaps >> k) & 1) {
+							const int obj = W.tap[parity ^ 1u][k][lane];
+							if (obj >= 0) { const float4 e = sc.shade[4 * obj + 3]; lit = add3(lit, mk3(e.x, e.y, e.z)); }
+							taps++;
+						}
+					/* main.c:208-209: 1.0f / num_samples, num_samples in 1..3 (the quotients as literals; RN(1/3) = 0x3eaaaaab) */
+					lit = scale3(lit, FAST ? (taps == 1 ? 1.0f : (taps == 2 ? 0.5f : __uint_as_float(0x3eaaaaabu))) : 1.0f / (float) taps);
+					const bool dark = FAST ? (tiny_f_fast(lit.x) && tiny_f_fast(lit.y) && tiny_f_fast(lit.z))
+					                       : (tiny_f(lit.x) && tiny_f(lit.y) && tiny_f(lit.z));
+					if (!dark) {                                                      /* main.c:257-261 */
+						const float w = 0.05f;
+						rad = madd3(rad, had3(lit, carry), w);
+						carry = scale3(carry, 1.0f - w);
 					}
-				/* main.c:208-209: 1.0f / num_samples, num_samples in 1..3 (the quotients as literals; RN(1/3) = 0x3eaaaaab) */
-				lit = scale3(lit, FAST ? (taps == 1 ? 1.0f : (taps == 2 ? 0.5f : __uint_as_float(0x3eaaaaabu))) : 1.0f / (float) taps);
-				const bool dark = FAST ? (tiny_f_fast(lit.x) && tiny_f_fast(lit.y) && tiny_f_fast(lit.z))
-				                       : (tiny_f(lit.x) && tiny_f(lit.y) && tiny_f(lit.z));
-				if (!dark) {                                                      /* main.c:257-261 */
-					const float w = 0.05f;
-					rad = madd3(rad, had3(lit, carry), w);
-					carry = scale3(carry, 1.0f - w);
+				}
+				if (prev & REC_LAST) {              /* the path ended with that bounce: sky (main.c:171) or bounce limit (main.c:158) */
+					if (prev & REC_SKY) rad = add3(rad, had3(end_sky, carry));
+					const V3 col = mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z));     /* main.c:267-269 */
+					if (chunked) {
+						float *dst = L.samples + (size_t) sample * sample_stride + (size_t) px_off * 3;
+						dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
+					} else
+						sum = add3(sum, col);                                                /* main.c:394 */
+					sample++;
+					carry = mk3(1, 1, 1); rad = mk3(0, 0, 0);
+					if (sample >= sample_end) {
+						if (!chunked) {
+							const V3 res = scale3(sum, inv_spp);                     /* main.c:476 */
+							float *dst = L.frame + (size_t) px_off * 3;
+							dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+						}
+						px_off = -1;
+						if (f_off >= 0) {           /* the front is already on the next pixel: follow it */
+							px_off = f_off; sample = fsample; sample_end = f_end; sum = mk3(0, 0, 0);
+						}
+					}
 				}
 			}
-			if (emit_main) {
-				const int obj = __float_as_int(W.res[6][lane]);
-				const V3 a = mk3(W.res[0][lane], W.res[1][lane], W.res[2][lane]);
-				if (obj < 0) {
-					rad = add3(rad, had3(a, carry));                             /* main.c:171 */
-					sample_done = true;
-				} else {
-					hp = a; hn = mk3(W.res[3][lane], W.res[4][lane], W.res[5][lane]); hobj = obj;
-					has_hit = true;
-				}
-			} else
-				sample_done = true;                /* bounce limit (main.c:158) */
-			if (sample_done) {
-				const V3 col = mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z));     /* main.c:267-269 */
-				if (chunked) {
-					float *dst = L.samples + (size_t) sample * sample_stride + (size_t) px_off * 3;
-					dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
-				} else
-					sum = add3(sum, col);                                                /* main.c:394 */
-				sample++;
-				if (sample < sample_end) {
-					rng = path_seed(L.seed, pixel_index, (uint32_t) (L.sample_base + sample));
-					carry = mk3(1, 1, 1); rad = mk3(0, 0, 0); bounce = 0;
-					hp = mk3(W.cache[0][lane], W.cache[1][lane], W.cache[2][lane]);
-					hn = mk3(W.cache[3][lane], W.cache[4][lane], W.cache[5][lane]);
-					hobj = __float_as_int(W.cache[6][lane]);
-					hdir = pdir;
-					has_hit = true;
-				} else {
-					if (!chunked) {
-						const V3 res = scale3(sum, inv_spp);                     /* main.c:476 */
-						float *dst = L.frame + (size_t) px_off * 3;
-						dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+			prev = cur;
+			if (cur & REC_VALID) {
+				bool path_ended = true;                                  /* bounce limit (main.c:158) */
+				if (emit_main) {
+					const int obj = __float_as_int(W.res[6][lane]);
+					const V3 a = mk3(W.res[0][lane], W.res[1][lane], W.res[2][lane]);
+					if (obj < 0) {
+						STAT(14);
+						end_sky = sky_lookup<FAST>(L, a); prev |= REC_LAST | REC_SKY;             /* main.c:163-172 */
+					} else {
+						hp = a; hn = mk3(W.res[3][lane], W.res[4][lane], W.res[5][lane]); hobj = obj;
+						has_hit = true; path_ended = false;
 					}
-					px_off = -1; has_hit = false;
+				}
+				if (path_ended) {
+					fsample++;
+					if (fsample >= f_end) f_off = -1;     /* item done: the front may take another pixel */
+					else {                               /* the front starts the next sample from the pixel's primary hit */
+						rng = path_seed(L.seed, pixel_index, (uint32_t) (L.sample_base + fsample));
+						bounce = 0;
+						hp = mk3(W.cache[0][lane], W.cache[1][lane], W.cache[2][lane]);
+						hn = mk3(W.cache[3][lane], W.cache[4][lane], W.cache[5][lane]);
+						hobj = __float_as_int(W.cache[6][lane]);
+						hdir = pdir;
+						has_hit = true;
+					}
 				}
 			}
 		}
