@@ -359,7 +359,7 @@ RT_DEV Hit nearest_hit_spec(const SceneLDS &sc, int n, V3 o, V3 d, bool want_nor
 /* ---- skybox: gpu_and_windowing.c:42-112 ---------------------------------------------------- */
 
 template <bool FAST = false>
-RT_DEV V3 sky_lookup(const rt_launch &L, V3 dir)
+RT_DEV uint32_t sky_texel(const rt_launch &L, V3 dir)
 {
 	/* absf() (utils.c): x < 0 ? -x : x keeps -0, and `abs + eps` with eps = 0 (gpu_and_windowing.c:51-58) turns
 	 * it into +0; |x| gives the same compares and the same sums */
@@ -396,7 +396,13 @@ RT_DEV V3 sky_lookup(const rt_launch &L, V3 dir)
 	const int x = (int) (u * L.sky_wm1);           /* int x = u * (c->w - 1)  (gpu_and_windowing.c:103-104) */
 	const int y = (int) (v * L.sky_hm1);
 	/* texel index in the reference's own int arithmetic (:106); rt_set_skybox bounds 6*w*h below 2^31 */
-	const uint32_t texel = L.sky[(uint32_t) ((face * L.sky_h + y) * L.sky_w + x)];
+	return L.sky[(uint32_t) ((face * L.sky_h + y) * L.sky_w + x)];
+}
+
+/* the three colour channels of an RGBA8 texel: (float) color[k] / 255 (gpu_and_windowing.c:107-111) */
+template <bool FAST = false>
+RT_DEV V3 sky_colour(uint32_t texel)
+{
 	if (FAST) {                                     /* (float) b / 255 (gpu_and_windowing.c:108-110) with the literal RN(1/255):
 	                                                 * exact for the 256 possible numerators, rt_selftest(4) */
 		const float r255 = __uint_as_float(0x3b808081u);
@@ -407,6 +413,9 @@ RT_DEV V3 sky_lookup(const rt_launch &L, V3 dir)
 	           (float) ((texel >> 8) & 255u) / 255.0f,
 	           (float) ((texel >> 16) & 255u) / 255.0f);
 }
+
+template <bool FAST = false>
+RT_DEV V3 sky_lookup(const rt_launch &L, V3 dir) { return sky_colour<FAST>(sky_texel<FAST>(L, dir)); }
 
 /* ---- pixel mapping --------------------------------------------------------------------------- */
 
@@ -659,7 +668,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	bool  has_hit = false;
 	V3    sum = mk3(0, 0, 0), carry = mk3(1, 1, 1), rad = mk3(0, 0, 0);
 	V3    hp = mk3(0, 0, 0), hn = mk3(0, 0, 0), hdir = mk3(0, 0, 0), pdir = mk3(0, 0, 0);
-	V3    end_sky = mk3(0, 0, 0);           /* sky colour that ends the sample of `prev` (REC_SKY) */
+	uint32_t end_sky = 0;                   /* sky texel that ends the sample of `prev` (REC_SKY): fetched when the bounce ray
+	                                         * is found to have left the scene, converted a round later when it is used */
 	int   hobj = -1;
 	int   prev = 0;                         /* REC_* | tapmask << 4 | object << 8 */
 	uint64_t rng = 0;
@@ -915,7 +925,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					}
 				}
 				if (prev & REC_LAST) {              /* the path ended with that bounce: sky (main.c:171) or bounce limit (main.c:158) */
-					if (prev & REC_SKY) rad = add3(rad, had3(end_sky, carry));
+					if (prev & REC_SKY) rad = add3(rad, had3(sky_colour<FAST>(end_sky), carry));
 					const V3 col = mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z));     /* main.c:267-269 */
 					if (chunked) {
 						float *dst = L.samples + (size_t) sample * sample_stride + (size_t) px_off * 3;
@@ -945,7 +955,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					const V3 a = mk3(W.res[0][lane], W.res[1][lane], W.res[2][lane]);
 					if (obj < 0) {
 						STAT(14);
-						end_sky = sky_lookup<FAST>(L, a); prev |= REC_LAST | REC_SKY;             /* main.c:163-172 */
+						end_sky = sky_texel<FAST>(L, a); prev |= REC_LAST | REC_SKY;               /* main.c:163-172 */
 					} else {
 						hp = a; hn = mk3(W.res[3][lane], W.res[4][lane], W.res[5][lane]); hobj = obj;
 						has_hit = true; path_ended = false;
