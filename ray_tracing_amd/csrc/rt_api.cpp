@@ -75,6 +75,11 @@ struct rt_context {
 	size_t       samples_bytes = 0;
 	unsigned char *d_direct = nullptr;   /* per-pixel "written directly" flags of the chunked mode */
 	size_t       direct_bytes = 0;
+	float       *d_blk_hits = nullptr;   /* rt_primary_pass outputs (rt_device.h) */
+	unsigned char *d_blk_list = nullptr;
+	int         *d_blk_count = nullptr;
+	unsigned int *d_obj_blocks = nullptr;
+	size_t       blk_capacity = 0;       /* pixel blocks the four buffers above hold */
 
 	float       *d_frame = nullptr;      /* scratch for rt_render() */
 	size_t       frame_bytes = 0;
@@ -144,7 +149,7 @@ void rt_destroy(rt_context *ctx)
 	for (auto &e : ctx->event_pool) (void) hipEventDestroy(e);
 	if (ctx->spec_module) (void) hipModuleUnload(ctx->spec_module);
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
-	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame); (void) hipFree(ctx->d_counter); (void) hipFree(ctx->d_samples); (void) hipFree(ctx->d_direct);
+	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame); (void) hipFree(ctx->d_counter); (void) hipFree(ctx->d_samples); (void) hipFree(ctx->d_direct); (void) hipFree(ctx->d_blk_hits); (void) hipFree(ctx->d_blk_list); (void) hipFree(ctx->d_blk_count); (void) hipFree(ctx->d_obj_blocks);
 	(void) hipFree(ctx->prog.d_accum); (void) hipFree(ctx->prog.d_low); (void) hipFree(ctx->prog.d_out);
 	(void) hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -336,6 +341,24 @@ static hipEvent_t take_event(rt_context *ctx)
 	return e;
 }
 
+/* buffers rt_primary_pass fills for the trace kernel: sized by the launch's 8x8 pixel blocks, grown on demand */
+static int attach_block_buffers(rt_context *ctx, rt_launch &L)
+{
+	const size_t blocks = (size_t) ((L.width + 7) / 8) * (size_t) ((L.local_rows + 7) / 8);
+	if (blocks > ctx->blk_capacity) {
+		(void) hipFree(ctx->d_blk_hits); (void) hipFree(ctx->d_blk_list); (void) hipFree(ctx->d_blk_count); (void) hipFree(ctx->d_obj_blocks);
+		ctx->d_blk_hits = nullptr; ctx->d_blk_list = nullptr; ctx->d_blk_count = nullptr; ctx->d_obj_blocks = nullptr; ctx->blk_capacity = 0;
+		HIP_TRY(hipMalloc((void**) &ctx->d_blk_hits, blocks * 7 * 64 * sizeof(float)));
+		HIP_TRY(hipMalloc((void**) &ctx->d_blk_list, blocks * 64));
+		HIP_TRY(hipMalloc((void**) &ctx->d_blk_count, blocks * sizeof(int)));
+		HIP_TRY(hipMalloc((void**) &ctx->d_obj_blocks, blocks * sizeof(unsigned int)));
+		ctx->blk_capacity = blocks;
+	}
+	L.blk_hits = ctx->d_blk_hits; L.blk_list = ctx->d_blk_list; L.blk_count = ctx->d_blk_count; L.obj_blocks = ctx->d_obj_blocks;
+	L.obj_block_count = ctx->d_counter + rt_counter_bytes() / sizeof(unsigned int) - 32;     /* last 128-byte line of the counter block */
+	return RT_OK;
+}
+
 int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, void *hip_stream)
 {
 	int rc = check_params(ctx, p);
@@ -373,13 +396,13 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	 * pixel's samples are split over several lanes and summed afterwards in sample order. */
 	if (p->kernel != RT_KERNEL_SIMPLE && p->max_bounces >= 1 && p->spp > 1) {
 		const long long pixel_blocks = (long long) ((p->width + 7) / 8) * ((L.local_rows + 7) / 8);
-		/* Work items are (8x8 pixel block, chunk of samples).  Measured (scripts/chunk_sweep*.py): items of
-		 * about 16 samples balance the persistent waves' tails on full frames, and a launch wants about 24
-		 * items per resident wave; more than 16 chunks costs more in repeated camera rays than it gains. */
+		/* Work items are (8x8 pixel block with object pixels, chunk of samples).  Measured (scripts/chunk_sweep.py,
+		 * scripts/ab.py with AB_CHUNKS_*): items of about 8 samples balance the persistent waves' tails best
+		 * (C1: 8 chunks, C2: 32), and a launch wants about 24 items per resident wave (multi-GPU strips). */
 		const long long want_blocks = (long long) ctx->num_cus * 16 * 24;
-		int chunks = (p->spp + 15) / 16;
+		int chunks = (p->spp + 7) / 8;
 		if (pixel_blocks > 0 && pixel_blocks * chunks < want_blocks) chunks = (int) ((want_blocks + pixel_blocks - 1) / pixel_blocks);
-		if (chunks > 16) chunks = 16;
+		if (chunks > 32) chunks = 32;
 		if (const char *e = getenv("RT_CHUNKS")) chunks = atoi(e);               /* tuning / test override */
 		if (chunks > p->spp) chunks = p->spp;
 		if (chunks > 1) {
@@ -410,6 +433,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (ctx->profiling) { e0 = take_event(ctx); e1 = take_event(ctx); HIP_TRY(hipEventRecord(e0, stream)); }
+	{ const int rc = attach_block_buffers(ctx, L); if (rc != RT_OK) return rc; }
 	HIP_TRY(rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, stream));
 	if (ctx->profiling) { HIP_TRY(hipEventRecord(e1, stream)); ctx->events.emplace_back(e0, e1); }
 	if (L.num_chunks > 1)
@@ -522,6 +546,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	L.frame = g.d_low;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
 	L.num_chunks = 1; L.chunk_spp = 1; L.samples = nullptr; L.direct = nullptr; L.num_shards = 1;
+	{ const int rc = attach_block_buffers(ctx, L); if (rc != RT_OK) return rc; }
 	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->stream));
 	const float weight = 1.0f / (s * s);                                         /* main.c:278 */
 	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), ctx->stream));

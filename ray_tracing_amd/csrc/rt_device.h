@@ -79,7 +79,13 @@ typedef struct {
 	int    num_shards;         /* work-item queues in use (1 or 64), see wavefront_body */
 	int    num_chunks, chunk_spp;
 	float *samples;
-	unsigned char *direct;     /* per local pixel: 1 = written directly by the trace kernel (sky-only), zeroed per launch */
+	unsigned char *direct;     /* per local pixel: 1 = written by rt_primary_pass (sky-only), zeroed per launch */
+	/* written by rt_primary_pass, read by the trace kernels (per 8x8 pixel block of the strip) */
+	float *blk_hits;           /* [block][7][64]: camera-ray hit of each pixel: point xyz, normal xyz, object (-1 sky, -2 outside) */
+	unsigned char *blk_list;   /* [block][64]: the block's object pixels (index in block), compacted */
+	int   *blk_count;          /* [block]: entries in blk_list */
+	unsigned int *obj_blocks;  /* blocks with at least one object pixel, in the order they were found */
+	unsigned int *obj_block_count;
 	const rt_geom  *geom;      /* num_objects records (global; staged to LDS)  */
 	const rt_shade *shade;
 } rt_launch;

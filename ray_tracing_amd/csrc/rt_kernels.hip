@@ -7,6 +7,7 @@
  *
  * Kernels:
  *   rt_trace_simple      the path loop in the reference's own order, one lane per pixel (cross-check)
+ *   rt_primary_pass      camera rays of all pixels, once per launch: sky-only pixels are finished, the rest is handed on
  *   rt_trace_wavefront   the tuned schedule: persistent waves, per-wave LDS ray queue, exact shortcuts
  *   rt_trace_spec        the same, recompiled by hiprtc with the scene as constants (rt_compile_scene)
  *   rt_sum_samples       sums chunked samples in sample order; rt_accumulate / rt_resolve (progressive
@@ -550,6 +551,87 @@ rt_trace_simple(const rt_launch L)
 
 #endif /* RT_SPEC_ONLY */
 
+#ifndef RT_SPEC_ONLY
+/* =============================================================================================
+ * rt_primary_pass: the camera ray of every pixel, once per launch.  The reference has no sub-pixel jitter
+ * (main.c:293-296), so bounce 0 of every sample of a pixel is the same ray: one wave per 8x8 pixel block traces
+ * the block's 64 camera rays, finishes its sky-only pixels on the spot -- every sample is clamp(0 + sky * 1)
+ * (main.c:171,267-269), summed in sample order and resolved (main.c:394,476) -- and leaves for the trace kernel
+ * the hits of the other pixels, their compacted list, and the list of blocks that have any.
+ * ============================================================================================= */
+template <bool FAST>
+__global__ void __launch_bounds__(RT_BLOCK)
+rt_primary_pass(const rt_launch L, int blocks_per_group)
+{
+	extern __shared__ float4 lds[];
+	const SceneLDS sc = stage_scene(L, lds);
+	const int n = L.num_objects;
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int tiles_x = (L.width + 7) >> 3, tiles_y = (L.local_rows + 7) >> 3;
+	const unsigned int total = (unsigned int) (tiles_x * tiles_y);
+	/* the workgroup's share of the blocks: blocks_per_group consecutive ones; the ones that have object pixels
+	 * are collected in LDS and appended to L.obj_blocks with ONE atomic per workgroup (a single address takes
+	 * ~88 atomics per microsecond: one per block would cost more than the camera rays) */
+	unsigned int *found = reinterpret_cast<unsigned int*>(lds + 6 * n);      /* count, blocks_per_group ids, base */
+	if (threadIdx.x == 0) found[0] = 0;
+	__syncthreads();
+	const V3 cam = ld3(L.pos);
+	const float inv_spp = 1.0f / (float) L.spp;
+	const unsigned int first = blockIdx.x * (unsigned int) blocks_per_group;
+	for (unsigned int k = (unsigned int) wave; k < (unsigned int) blocks_per_group; k += RT_BLOCK / 64) {
+		const unsigned int blk = first + k;
+		if (blk >= total) break;
+		const int i = (int) (blk % (unsigned int) tiles_x) * 8 + (lane & 7), lr = (int) (blk / (unsigned int) tiles_x) * 8 + (lane >> 3);
+		const int j = global_row(L, lr);
+		int obj = -2;                                   /* outside the frame */
+		V3 a = mk3(0, 0, 0), nn = mk3(0, 0, 0);
+		if (i < L.width && lr < L.local_rows && j < L.height) {
+			float u = (float) i / (float) L.u_den;      /* main.c:293-296 */
+			float v = (float) j / (float) L.v_den;
+			u = 1.0f - u;
+			v = 1.0f - v;
+			const V3 pd = primary_dir(L, u, v);
+			const V3 dn = FAST ? unit3_fast(pd) : unit3(pd);                           /* scene.c:158 */
+			const Hit hit = FAST ? nearest_hit_fast(sc, n, cam, dn) : nearest_hit(sc, n, cam, dn);
+			obj = hit.obj;
+			if (obj >= 0) {
+				a = madd3(cam, dn, hit.t);                                               /* scene.c:186 */
+				nn = hit.n;
+			} else {
+				const V3 sky = sky_lookup<FAST>(L, dn);                                  /* main.c:170 */
+				const V3 c = mk3(clamp01(sky.x), clamp01(sky.y), clamp01(sky.z));
+				if (L.num_chunks > 1) L.direct[(size_t) lr * L.width + i] = 1;          /* rt_sum_samples skips it */
+				V3 acc = mk3(0, 0, 0);
+				for (int s = 0; s < L.spp; s++) acc = add3(acc, c);
+				const V3 res = scale3(acc, inv_spp);
+				float *dst = L.frame + ((size_t) lr * L.width + i) * 3;
+				dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+			}
+		}
+		const unsigned long long om = __ballot(obj >= 0);
+		if (om) {                                       /* sky-only blocks leave nothing behind */
+			float *dst = L.blk_hits + (size_t) blk * (7 * 64) + lane;
+			dst[0] = a.x; dst[64] = a.y; dst[128] = a.z; dst[192] = nn.x; dst[256] = nn.y; dst[320] = nn.z; dst[384] = __int_as_float(obj);
+			if (obj >= 0)
+				L.blk_list[(size_t) blk * 64 + __builtin_amdgcn_mbcnt_hi((unsigned int) (om >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) om, 0u))] = (unsigned char) lane;
+			if (lane == 0) {
+				L.blk_count[blk] = __popcll(om);
+				found[1 + atomicAdd(&found[0], 1u)] = blk;
+			}
+		}
+	}
+	__syncthreads();
+	const unsigned int mine = found[0];
+	if (mine) {
+		unsigned int *base_slot = found + 1 + blocks_per_group;
+		if (threadIdx.x == 0) *base_slot = atomicAdd(L.obj_block_count, mine);     /* the group's range in L.obj_blocks */
+		__syncthreads();
+		const unsigned int base = *base_slot;
+		for (unsigned int k = threadIdx.x; k < mine; k += RT_BLOCK) L.obj_blocks[base + k] = found[1 + k];
+	}
+}
+#endif /* RT_SPEC_ONLY */
+
 /* =============================================================================================
  * rt_trace_wavefront: the tuned kernel.  Same arithmetic as rt_trace_simple, different schedule.
  *
@@ -570,20 +652,18 @@ rt_trace_simple(const rt_launch L)
  *     the bounce's tap results but nothing else does, so it runs one round behind the ray generation
  *     (the "back" and the "front" of a lane): taps that do not fill a batch simply wait in the queue
  *     for the next round's rays, and 99 % of the traced batches are full;
- *   - the primary hit is traced once per pixel and re-used by all samples (the reference has no
- *     sub-pixel jitter, main.c:293-296, so bounce 0 of every sample is the same ray): bit-exact;
- *     the 64 camera rays of a block are traced together as one batch when the wave takes the block,
- *     and the block's sky-only pixels are written by all lanes together;
+ *   - the primary hit is traced once per pixel, by rt_primary_pass, and re-used by all samples (the
+ *     reference has no sub-pixel jitter, main.c:293-296, so bounce 0 of every sample is the same ray):
+ *     bit-exact; sky-only pixels never reach this kernel;
  *   - when a launch has few pixels per wave (multi-GPU strips) a pixel's samples are split into
  *     chunks that different lanes take; samples are then stored and summed by rt_sum_samples.
  * The per-pixel sample sum is still formed in sample order (main.c:394), so results are
  * bit-identical to rt_trace_simple and to the CPU oracle.
  * ============================================================================================= */
 
-#define RT_COUNTER_BYTES (64 * 128)     /* WF_SHARDS counters, one per 128-byte line */
+#define RT_COUNTER_BYTES (65 * 128)     /* WF_SHARDS counters, one per 128-byte line, + rt_primary_pass's block count */
 #define WF_SHARDS  64                  /* work-item queues (counters 128 B apart), see wavefront_body */
 #define WF_QUEUE   128                 /* ring: at most 63 waiting + 64 pushed at a time */
-#define WF_KIND_PRIMARY 0              /* camera ray of pixel `owner` of the wave's current 8x8 block */
 #define REC_VALID    1                /* per-bounce record handed from the front to the back (wavefront_body) */
 #define REC_SPECULAR 2
 #define REC_LAST     4                /* the path ends after this bounce ...               */
@@ -630,10 +710,11 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + 6 * n)[wave];
 
 	const int tiles_x = (L.width + 7) >> 3;
-	const int tiles_y = (L.local_rows + 7) >> 3;
 	const bool chunked = L.num_chunks > 1;
-	const unsigned int num_blocks = (unsigned int) (tiles_x * tiles_y) * (unsigned int) L.num_chunks;
 	const size_t sample_stride = (size_t) L.local_rows * L.width * 3;      /* floats per sample plane */
+	const float inv_spp = 1.0f / (float) L.spp;
+	/* work items: (block with object pixels, chunk of samples); rt_primary_pass counted and listed the blocks */
+	const unsigned int num_blocks = (unsigned int) __builtin_amdgcn_readfirstlane((int) *L.obj_block_count) * (unsigned int) L.num_chunks;
 	const V3 cam = ld3(L.pos);
 #ifdef RT_SPEC_HEADER
 	const bool have_light = SPEC_LIGHT >= 0;               /* the compiled scene's emitter: literals, no scalar registers */
@@ -642,18 +723,15 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	const V3 light_pos = ld3(L.light_pos);
 	const bool have_light = L.light_index >= 0;
 #endif
-	const float inv_spp = 1.0f / (float) L.spp;
 
-	/* wave-uniform pixel supply: the wave owns one 8x8 pixel block at a time.  When it takes a new
-	 * block it traces all 64 camera rays at once (one full, homogeneous batch) into W.blk and fills the
-	 * block's column/row tables; one round later all lanes together write the block's sky-only pixels and
-	 * list its object pixels (W.list); lanes then take listed pixels as they become free. */
+	/* wave-uniform pixel supply: the wave owns one 8x8 pixel block (and one chunk of its samples) at a time.
+	 * When it takes a new one it loads the block's camera-ray hits and its list of object pixels (rt_primary_pass)
+	 * into W.blk / W.list and fills the block's column/row tables; lanes then take listed pixels as they become
+	 * free. */
 	int  tile_i0 = 0, tile_lr0 = 0;         /* frame column / strip row of the block's first pixel */
 	int  cur_s0 = 0, cur_s1 = L.spp;        /* its sample range (one chunk of the pixels' samples) */
 	int  cur_next = 0, cur_count = 0;       /* next entry of W.list to hand out, entries in it */
 	bool blk_done = true;                   /* nothing left to hand out: take another block */
-	bool blk_ready = false;                 /* W.blk holds the block's primary hits */
-	bool blk_listed = false;                /* W.list is built, sky pixels are written */
 	bool exhausted = false;
 
 	/* per-lane path state */
@@ -678,21 +756,18 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 
 	for (;; parity ^= 1u) {
 		/* ---- 1. pixel supply --------------------------------------------------------------- */
-		bool fetched = false;                   /* a block was taken this round: trace its camera rays */
-		bool prim_on = false;
-		V3   prim_d = mk3(0, 0, 0);
 #pragma unroll 1
 		for (int attempt = 0; attempt < 4; attempt++) {
 			const bool want = f_off < 0 && (chunked || px_off < 0);
 			const unsigned long long wmask = __ballot(want);
 			if (wmask == 0ull) break;
 			if (blk_done) {
-				if (exhausted || fetched) break;
+				if (exhausted) break;
 				/* Work items are dealt from `num_shards` interleaved queues (item = shard + num_shards * k), each
 				 * with its own counter on its own 128-byte line: one counter saturates at ~88 dequeues/us
-				 * (MI355X_MICROARCH.md), which a sky-dominated 4K frame exceeds (C3: 2.1 -> 1.3 ms).  A wave pulls
-				 * only from the queue of its workgroup; the queues hold equal, interleaved shares of the frame.
-				 * The host uses one queue unless the frame has >= 100k pixel blocks. */
+				 * (MI355X_MICROARCH.md), which a 4K frame of cheap items exceeds.  A wave pulls only from the
+				 * queue of its workgroup; the queues hold equal, interleaved shares of the items.  The host uses
+				 * one queue unless the frame has >= 100k pixel blocks. */
 				const rt_launch_cold C = cold_view();
 				const unsigned int shards = (unsigned int) C->num_shards, chunks = (unsigned int) C->num_chunks;
 				unsigned int b = 0;
@@ -700,8 +775,16 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				b = (unsigned int) __builtin_amdgcn_readfirstlane((int) b);
 				b = blockIdx.x % shards + shards * b;
 				if (b >= num_blocks) { exhausted = true; break; }
-				const unsigned int blk = b / chunks;
-				blk_done = false; blk_ready = false; blk_listed = false; fetched = true; cur_next = cur_count = 0;
+				const unsigned int blk = (unsigned int) __builtin_amdgcn_readfirstlane((int) C->obj_blocks[b / chunks]);
+				/* the block's camera-ray hits and its list of object pixels come from rt_primary_pass */
+				{
+					const float *src = C->blk_hits + (size_t) blk * (7 * 64) + lane;
+#pragma unroll
+					for (int k = 0; k < 7; k++) W.blk[k][lane] = src[k * 64];
+					W.list[lane] = C->blk_list[(size_t) blk * 64 + lane];
+				}
+				cur_count = __builtin_amdgcn_readfirstlane(C->blk_count[blk]);
+				cur_next = 0; blk_done = false;
 				const int chunk_spp = C->chunk_spp, spp = C->spp;
 				cur_s0 = (int) (b % chunks) * chunk_spp;
 				cur_s1 = cur_s0 + chunk_spp < spp ? cur_s0 + chunk_spp : spp;
@@ -716,41 +799,13 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				/* camera.c:121: ((llc + horiz*u) + vert*v) - pos, split into its column and row parts */
 				const V3 cv = mk3(C->llc[0] + C->horiz[0] * u, C->llc[1] + C->horiz[1] * u, C->llc[2] + C->horiz[2] * u);
 				const V3 rv = mk3(C->vert[0] * v, C->vert[1] * v, C->vert[2] * v);
-				prim_on = i < C->width && lr < C->local_rows && j < C->height;
-				prim_d = sub3(add3(cv, rv), cam);
 				if (lane < 8) { W.colv[0][lane] = cv.x; W.colv[1][lane] = cv.y; W.colv[2][lane] = cv.z; }
 				if ((lane & 7) == 0) {
 					const int r = lane >> 3;
 					W.rowv[0][r] = rv.x; W.rowv[1][r] = rv.y; W.rowv[2][r] = rv.z;
 					W.rowpart[r] = (j * C->pix_scale) * C->pix_width;
 				}
-				if (!prim_on) W.blk[6][lane] = __int_as_float(-2);         /* outside the frame */
-			}
-			if (!blk_ready) break;                                         /* hits arrive with this round's trace */
-			if (!blk_listed) {
-				/* once per block, all lanes: lane q looks at pixel q of the block */
-				const int obj = __float_as_int(W.blk[6][lane]);
-				if (obj == -1 && (!chunked || cur_s0 == 0)) {
-					/* sky-only pixel: every sample is clamp(0 + sky * 1) (main.c:171,267-269), summed in sample
-					 * order and resolved (main.c:394,476).  With chunks, the item that holds chunk 0 writes it. */
-					const rt_launch_cold C = cold_view();
-					const int i = tile_i0 + (lane & 7), lr = tile_lr0 + (lane >> 3), width = C->width, spp = C->spp;
-					const V3 sky = sky_lookup<FAST>(L, mk3(W.blk[0][lane], W.blk[1][lane], W.blk[2][lane]));
-					const V3 c = mk3(clamp01(sky.x), clamp01(sky.y), clamp01(sky.z));
-					if (chunked) C->direct[(size_t) lr * width + i] = 1;           /* rt_sum_samples skips it */
-					V3 acc = mk3(0, 0, 0);
-					for (int k = 0; k < spp; k++) acc = add3(acc, c);
-					const V3 res = scale3(acc, inv_spp);
-					float *dst = C->frame + ((size_t) lr * width + i) * 3;
-					dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
-				}
-				const unsigned long long om = __ballot(obj >= 0);
-				if (obj >= 0)
-					W.list[__builtin_amdgcn_mbcnt_hi((unsigned int) (om >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) om, 0u))] = (unsigned char) lane;
-				cur_count = __popcll(om);
-				blk_listed = true;
 				wave_fence();
-				if (cur_count == 0) { blk_done = true; continue; }
 			}
 			const int rank_in = __builtin_amdgcn_mbcnt_hi((unsigned int) (wmask >> 32),
 			                    __builtin_amdgcn_mbcnt_lo((unsigned int) wmask, 0u));
@@ -780,15 +835,15 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			cur_next += taken < avail ? taken : avail;
 			if (cur_next >= cur_count) blk_done = true;
 		}
-		if (!fetched && __ballot(px_off >= 0 || f_off >= 0) == 0ull) {
+		if (__ballot(px_off >= 0 || f_off >= 0) == 0ull) {
 			if (exhausted && blk_done) break;
-			continue;                          /* sky / out-of-frame pixels only so far: hand out more */
+			continue;
 		}
 
 		/* ---- 2. shade the pending hit of every live path (main.c:180-261) ------------------- */
 		int  tapmask = 0, cur = 0;
 		bool emit_main = false;
-		V3   ray_o = cam, ray_d = prim_d;
+		V3   ray_o = mk3(0, 0, 0), ray_d = mk3(0, 0, 0);
 		V3   tap_j0 = mk3(0, 0, 0), tap_j1 = mk3(0, 0, 0), tap_j2 = mk3(0, 0, 0);   /* accepted rand_dir of each tap (main.c:193) */
 		STAT(7);
 		if (has_hit) {
@@ -847,13 +902,12 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				W.q[6][slot] = __int_as_float(lane | (k << 8) | (int) (parity << 12));
 			}
 			q_tail += (unsigned int) __popcll(m);
-			if (k <= WF_KIND_MAIN) must = q_tail;        /* camera and bounce rays: their lanes wait for the hit */
+			if (k == WF_KIND_MAIN) must = q_tail;        /* bounce rays: their lanes wait for the hit */
 			wave_fence();
 		};
 #pragma unroll 1
 		for (int kind = 0; kind < 6; kind++) {
 			switch (kind) {                 /* a tap is queued as (hit point, rand_dir) */
-			case WF_KIND_PRIMARY: push(prim_on, cam, prim_d, WF_KIND_PRIMARY); break;
 			case WF_KIND_MAIN:    push(emit_main, ray_o, ray_d, WF_KIND_MAIN); break;
 			case 2:               push((tapmask & 1) != 0, hp, tap_j0, 2); break;
 			case 3:               push((tapmask & 2) != 0, hp, tap_j1, 3); break;
@@ -875,17 +929,16 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 						o = madd3(o, d, 0.001f);
 					}
 					const V3 dn = unit3_sel<FAST>(d);                                             /* scene.c:158 */
-					const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, n, o, dn, rkind <= WF_KIND_MAIN) : nearest_hit(sc, n, o, dn);
+					const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, n, o, dn, rkind == WF_KIND_MAIN) : nearest_hit(sc, n, o, dn);
 					if (rkind > WF_KIND_MAIN) {
 						W.tap[meta >> 12][rkind - 2][owner] = (short) hit.obj;
 					} else {
 						V3 a, b = hit.n;
 						if (hit.obj >= 0) a = madd3(o, dn, hit.t);                   /* scene.c:186 */
 						else              a = dn;       /* left the scene: the owner looks the sky up (main.c:170), once per round */
-						float (*dst)[64] = rkind == WF_KIND_PRIMARY ? W.blk : W.res;
-						dst[0][owner] = a.x; dst[1][owner] = a.y; dst[2][owner] = a.z;
-						dst[3][owner] = b.x; dst[4][owner] = b.y; dst[5][owner] = b.z;
-						dst[6][owner] = __int_as_float(hit.obj);
+						W.res[0][owner] = a.x; W.res[1][owner] = a.y; W.res[2][owner] = a.z;
+						W.res[3][owner] = b.x; W.res[4][owner] = b.y; W.res[5][owner] = b.z;
+						W.res[6][owner] = __int_as_float(hit.obj);
 					}
 				}
 				q_head += (unsigned int) count;
@@ -895,7 +948,6 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 
 		/* ---- 5. back: retire the bounce shaded one round ago (its taps are traced by now), take this round's
 		 * bounce-ray result, and move the front to the next sample when the path has ended ------------------ */
-		if (fetched) blk_ready = true;
 		STAT(16);
 		if (px_off >= 0) {
 			STAT(17);
@@ -1297,6 +1349,21 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	if (grid < L.num_shards) return hipErrorInvalidValue;      /* every queue needs a workgroup (rt_api.cpp picks num_shards) */
 	hipError_t e = hipMemsetAsync(block_counter, 0, RT_COUNTER_BYTES, stream);
 	if (e != hipSuccess) return e;
+	{
+		const unsigned int pixel_blocks = (unsigned int) (((L.width + 7) / 8) * ((L.local_rows + 7) / 8));
+		/* a few workgroups per CU, each with a run of consecutive blocks (at least one per wave) */
+		unsigned int groups = (unsigned int) num_cus * 8u;
+		if (groups * (RT_BLOCK / 64) > pixel_blocks) groups = (pixel_blocks + RT_BLOCK / 64 - 1) / (RT_BLOCK / 64);
+		const int per_group = (int) ((pixel_blocks + groups - 1) / groups);
+		groups = (pixel_blocks + (unsigned int) per_group - 1) / (unsigned int) per_group;
+		const size_t plds = rt_scene_lds_bytes(L.num_objects) + (size_t) (per_group + 2) * sizeof(unsigned int);
+		if (variant == 2 || !scene_fast_ok)
+			hipLaunchKernelGGL(rt_primary_pass<false>, dim3(groups), dim3(RT_BLOCK), plds, stream, L, per_group);
+		else
+			hipLaunchKernelGGL(rt_primary_pass<true>, dim3(groups), dim3(RT_BLOCK), plds, stream, L, per_group);
+		e = hipGetLastError();
+		if (e != hipSuccess) return e;
+	}
 	if (variant == 0 /* RT_KERNEL_AUTO */ && scene_fast_ok && spec_fn) {
 		/* same kernel, trace loop specialised for this scene by rt_compile_scene() */
 		rt_launch Lc = L;
