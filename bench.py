@@ -190,7 +190,8 @@ def main():
                         "frac": round(bytes_ / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 6),
                         "bytes_per_sample": round(bytes_ / samples_per_launch, 3)},
                 "note": "no MFMA/HBM bound applies (SURVEY.md 8d): peak = fp32 VALU issue rate without FMA "
-                        "(parity forbids contraction) = 157.3/2 TFLOP/s; flops counted as written in the reference",
+                        "(parity forbids contraction) = 157.3/2 TFLOP/s; flops counted as written in the reference; "
+                        "avg_kernel_ms = HIP events around rt_primary_pass (camera rays, ~0.05 ms) + the trace kernel",
             }
         if "roofline" in out:
             # HBM-side traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot
