@@ -671,7 +671,8 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 #define WF_KIND_MAIN    1              /* next bounce ray of lane `owner`; kinds 2..4 = its shadow tap 0..2 */
 
 struct WaveLDS {
-	float q[7][WF_QUEUE];              /* ray queue SoA: o.xyz, d.xyz (un-normalised), meta         */
+	float q[6][WF_QUEUE];              /* ray queue SoA: o.xyz, d.xyz (un-normalised)                */
+	unsigned short qmeta[WF_QUEUE];    /* owner lane | kind << 8 | parity << 12                      */
 	float res[7][64];                  /* bounce-ray result per owner lane: xyz, nxyz, obj          */
 	short tap[2][3][64];               /* shadow tap results per owner lane (object index < 1024 or -1), by parity of the round that queued them */
 	float blk[7][64];                  /* primary hits of the current pixel block, by pixel in block */
@@ -695,6 +696,10 @@ RT_DEV rt_launch_cold cold_view()
 	asm volatile("" : "+s"(a));
 	return (rt_launch_cold) a;
 }
+
+/* four workgroups (16 waves) per CU need 4 x (96 B x objects + 4 x sizeof(WaveLDS)) <= 160 KiB: keep room for 20
+ * objects -- one workgroup less per CU costs 15 % */
+static_assert(4 * sizeof(WaveLDS) + 96 * 20 <= 160 * 1024 / 4, "WaveLDS grew: scenes of up to 20 objects no longer fit four workgroups per CU");
 
 RT_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
@@ -899,7 +904,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				                           __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u))) & (WF_QUEUE - 1);
 				W.q[0][slot] = qo.x; W.q[1][slot] = qo.y; W.q[2][slot] = qo.z;
 				W.q[3][slot] = qd.x; W.q[4][slot] = qd.y; W.q[5][slot] = qd.z;
-				W.q[6][slot] = __int_as_float(lane | (k << 8) | (int) (parity << 12));
+				W.qmeta[slot] = (unsigned short) (lane | (k << 8) | (int) (parity << 12));
 			}
 			q_tail += (unsigned int) __popcll(m);
 			if (k == WF_KIND_MAIN) must = q_tail;        /* bounce rays: their lanes wait for the hit */
@@ -922,7 +927,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					const unsigned int slot = (q_head + (unsigned int) lane) & (WF_QUEUE - 1);
 					V3 o = mk3(W.q[0][slot], W.q[1][slot], W.q[2][slot]);
 					V3 d = mk3(W.q[3][slot], W.q[4][slot], W.q[5][slot]);
-					const int meta = __float_as_int(W.q[6][slot]);
+					const int meta = W.qmeta[slot];
 					const int owner = meta & 255, rkind = (meta >> 8) & 15;
 					if (rkind > WF_KIND_MAIN) {                                                   /* main.c:186,197-198 */
 						d = unit3_sel<FAST>(lin2(d, sub3(light_pos, o), 0.5f, 1.0f));
