@@ -421,14 +421,15 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 					HIP_TRY(hipMalloc((void**) &ctx->d_direct, pixels));
 					ctx->direct_bytes = pixels;
 				}
-				HIP_TRY(hipMemsetAsync(ctx->d_direct, 0, pixels, stream));
 				L.num_chunks = chunks; L.chunk_spp = chunk_spp; L.samples = ctx->d_samples; L.direct = ctx->d_direct;
 			}
 		}
 	}
 
-	/* 4K-class frames can be dominated by cheap (sky) work items: give them 64 dequeue counters */
-	if ((long long) ((p->width + 7) / 8) * ((L.local_rows + 7) / 8) >= 100000 && ctx->num_cus >= 64) L.num_shards = 64;
+	/* 64 dequeue counters instead of one (a single address takes ~88 atomics per microsecond: 16 K waves asking for
+	 * their first item at once already cost ~0.2 ms) unless the launch is too small to give every queue its
+	 * workgroups and a fair share of items */
+	if ((long long) ((p->width + 7) / 8) * ((L.local_rows + 7) / 8) * L.num_chunks >= 64 * 64 && ctx->num_cus >= 64) L.num_shards = 64;
 	if (const char *e = getenv("RT_SHARDS")) { const int v = atoi(e); if (v == 1 || v == 64) L.num_shards = v; }   /* tuning aid */
 
 	hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -79,7 +79,7 @@ typedef struct {
 	int    num_shards;         /* work-item queues in use (1 or 64), see wavefront_body */
 	int    num_chunks, chunk_spp;
 	float *samples;
-	unsigned char *direct;     /* per local pixel: 1 = written by rt_primary_pass (sky-only), zeroed per launch */
+	unsigned char *direct;     /* per local pixel, set by rt_primary_pass: 1 = finished there (sky-only), 0 = sum its samples */
 	/* written by rt_primary_pass, read by the trace kernels (per 8x8 pixel block of the strip) */
 	float *blk_hits;           /* [block][7][64]: camera-ray hit of each pixel: point xyz, normal xyz, object (-1 sky, -2 outside) */
 	unsigned char *blk_list;   /* [block][64]: the block's object pixels (index in block), compacted */

@@ -594,19 +594,24 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 			const V3 dn = FAST ? unit3_fast(pd) : unit3(pd);                           /* scene.c:158 */
 			const Hit hit = FAST ? nearest_hit_fast(sc, n, cam, dn) : nearest_hit(sc, n, cam, dn);
 			obj = hit.obj;
+			if (L.num_chunks > 1) L.direct[(size_t) lr * L.width + i] = obj < 0;      /* 1: finished here, rt_sum_samples skips it */
 			if (obj >= 0) {
 				a = madd3(cam, dn, hit.t);                                               /* scene.c:186 */
 				nn = hit.n;
 			} else {
 				const V3 sky = sky_lookup<FAST>(L, dn);                                  /* main.c:170 */
 				const V3 c = mk3(clamp01(sky.x), clamp01(sky.y), clamp01(sky.z));
-				if (L.num_chunks > 1) L.direct[(size_t) lr * L.width + i] = 1;          /* rt_sum_samples skips it */
 				V3 acc = mk3(0, 0, 0);
 				for (int s = 0; s < L.spp; s++) acc = add3(acc, c);
 				const V3 res = scale3(acc, inv_spp);
 				float *dst = L.frame + ((size_t) lr * L.width + i) * 3;
 				dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
 			}
+		}
+		else if (i < L.width && lr < L.local_rows) {    /* padding row of a strip (multi_gpu.py): inside the buffer, outside the frame */
+			if (L.num_chunks > 1) L.direct[(size_t) lr * L.width + i] = 1;
+			float *dst = L.frame + ((size_t) lr * L.width + i) * 3;
+			dst[0] = 0.0f; dst[1] = 0.0f; dst[2] = 0.0f;
 		}
 		const unsigned long long om = __ballot(obj >= 0);
 		if (om) {                                       /* sky-only blocks leave nothing behind */
