@@ -196,7 +196,7 @@ def main():
         if "roofline" in out:
             # HBM-side traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot
             # collect PMC counters itself): FETCH_SIZE + WRITE_SIZE in bytes per launch, N = 1 only.
-            prof = os.path.join(ROOT, "profiles", "r01", "v12_final_summary.txt")
+            prof = os.path.join(ROOT, "profiles", "r01", "v13_final_summary.txt")
             if world == 1 and compiled and os.path.exists(prof):
                 vals = {}
                 for line in open(prof):
@@ -205,7 +205,7 @@ def main():
                         vals[parts[0]] = float(parts[1]) * 1024.0
                 if len(vals) == 2:
                     out["roofline"]["traffic"] = round(vals["FETCH_SIZE"] + vals["WRITE_SIZE"])
-                    out["roofline"]["traffic_note"] = ("bytes per launch from profiles/r01/v12_final_summary.txt (rocprofv3 --pmc "
+                    out["roofline"]["traffic_note"] = ("bytes per launch from profiles/r01/v13_final_summary.txt (rocprofv3 --pmc "
                                                        "FETCH_SIZE / WRITE_SIZE in separate passes); reads are scattered 4-byte "
                                                        "skybox gathers (one 32-64 B sector each, served by the 256 MiB Infinity "
                                                        "Cache that holds the whole 100 MB skybox), so no x2 streaming correction is applied")
