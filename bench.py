@@ -2,45 +2,88 @@
 """bench.py -- headline benchmark: Msamples/s on BASELINE.json config C1
 (scene_0.txt, 1920x1080, 64 spp, 4 bounces) on N GPUs of one node.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C2|C3|C4]
 
-A step = one full frame through the hot path: every rank renders its interleaved row blocks with the
-HIP kernel (librt_hip.so, C ABI), then -- for N > 1 -- ONE RCCL gather of the finished strips to rank
-0 and a de-interleave kernel there.  Inputs (scene, skybox, camera) are resident in HBM before the
-timed region; the frame stays in HBM (the PCIe-inclusive rate is reported in DESIGN.md, not here).
-The same frame is split over N GPUs, so scaling is "strong".
+For N > 1 either form works: launched by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` (one rank per GPU, RANK/LOCAL_RANK/WORLD_SIZE
+from the environment), or plainly as `python bench.py --gpus N`: a parent that has made no GPU call then
+starts exactly that command as a child process, relays rank 0's JSON line and exits with the child's status
+(the reference fans out from its host binary the same way: start_workers(), main.c:695-706).
 
-Rank 0 prints ONE JSON line; `roofline` is computed from HIP-event kernel times measured over the
-timed region and from ALGORITHMIC flops/bytes counted by the CPU oracle's instrumented build;
-`cpu_baseline` times the reference's own column-threaded renderer (oracle/_ref, the unmodified
-reference sources) -- or the oracle port if that build is absent -- on this box's host cores.
+A step = one full frame through the hot path, ending where the reference's update_frame() ends
+(main.c:467-479): every rank renders its interleaved row blocks with the HIP kernels (librt_hip.so, C ABI),
+then -- for N > 1 -- ONE RCCL gather of the finished strips to rank 0 and a de-interleave kernel there, then
+the resolved Vector3[W*H] frame is copied to (pinned) HOST memory on rank 0.  Inputs (scene, skybox,
+camera) are resident in HBM before the timed region.  Two frames are in flight: the gather / host copy of
+frame k overlaps the render of frame k+1 (ray_tracing_amd/multi_gpu.py); `frame_latency` reports the same
+frame with nothing overlapped (first launch -> frame on the host, median of 7).  The same frame is split
+over N GPUs, so scaling is "strong".
+
+Rank 0 prints ONE JSON line; `roofline` is computed from HIP-event kernel times measured over the timed
+region and from ALGORITHMIC flops/bytes counted by the CPU oracle's instrumented build; `cpu_baseline` times
+the reference's own column-threaded renderer (oracle/_ref, the unmodified reference sources compiled by
+oracle/Makefile; the built library travels with the tree) -- or the oracle port if that build
+is absent -- on this box's host cores.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import ray_tracing_amd as rt  # noqa: E402
-
-# BASELINE.json configs[1]
-WORKLOAD = dict(name="C1", scene="scene_0.txt", width=1920, height=1080, spp=64, max_bounces=4, seed=0)
+# BASELINE.json configs[1..4]
+WORKLOADS = {
+    "C1": dict(name="C1", scene="scene_0.txt", width=1920, height=1080, spp=64, max_bounces=4, seed=0),
+    "C2": dict(name="C2", scene="scene_1.txt", width=1920, height=1080, spp=256, max_bounces=8, seed=0),
+    "C3": dict(name="C3", scene="scene_2.txt", width=3840, height=2160, spp=64, max_bounces=8, seed=0),
+    "C4": dict(name="C4", scene="scene_0.txt", width=3840, height=2160, spp=1024, max_bounces=8, seed=0),
+}
 ROW_BLOCK = 8
 
 # MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 vector counts an FMA as 2 flops at 64 flop/clk/SIMD.  The
 # parity rules forbid FMA contraction, so the applicable issue peak is one flop per lane per issue:
 PEAK_VALU_NOFMA_TFLOPS = 157.3 / 2
 PEAK_HBM_GBPS = 8000.0
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="C1")
+    ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-jit", action="store_true", help="do not specialise the trace kernel for the scene")
+    ap.add_argument("--no-extras", action="store_true", help="skip frame_latency / generic-kernel legs (profiling runs)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only prove the N-rank launch + rendezvous (no GPU work); used by the CPU tests")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: start the N ranks as a CHILD
+    process tree.  Nothing in this process has touched the GPU (torch is not even imported yet), and it is never
+    replaced by exec: it waits for the child and exits with its status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def algorithmic_work(oracle_count, W, H, max_bounces, seed):
@@ -53,76 +96,144 @@ def algorithmic_work(oracle_count, W, H, max_bounces, seed):
     return {k: c[k] / n for k in ("flops", "rays", "object_tests", "rng_draws", "sky_fetches")}
 
 
-def cpu_baseline(w, sky):
-    """Reference CPU path on this box: render_column() on one thread per column (main.c:333,363,377),
-    bounce limit patched to the workload's.  Bounded to ~10-25 s."""
+def cpu_baseline(rt, w, sky):
+    """Reference CPU path on this box: render_column() on one thread per column (main.c:333,363,377), bounce
+    limit patched to the workload's -- at all host cores (the headline baseline) and at one thread; plus the
+    oracle port with a dynamic row scheduler (counter mode).  Bounded to roughly 30 s in all."""
     from rtlibs import Oracle, Ref, ref_available
     W, H, nb = w["width"], w["height"], w["max_bounces"]
     cores = min(os.cpu_count() or 1, 32)          # MAX_COLUMNS = 32 (main.c:46)
     while W % cores and cores > 1:                # the reference never renders W % columns pixels
         cores -= 1
     scene_path = os.path.join(rt.DATA_DIR, w["scene"])
+    o = Oracle()
+    o.load_scene(scene_path); o.set_skybox(sky); o.set_camera()
     if ref_available():
         ref = Ref(bounce_patch=True)
         ref.load_scene(scene_path); ref.set_skybox(sky); ref.set_bounce_limit(nb)
-        run = lambda passes: ref.time_columns(W, H, passes, cores)   # noqa: E731
+        run = lambda passes, threads: ref.time_columns(W, H, passes, threads)   # noqa: E731
         kind = "reference"
     else:
-        o = Oracle()
-        o.load_scene(scene_path); o.set_skybox(sky)
-        run = lambda passes: o.time_columns(W, H, passes, nb, cores)  # noqa: E731
+        run = lambda passes, threads: o.time_columns(W, H, passes, nb, threads)  # noqa: E731
         kind = "port"
-    t = time.perf_counter(); run(1); one = time.perf_counter() - t
-    passes = int(max(1, min(64, 12.0 / max(one, 1e-3))))
-    t = time.perf_counter(); run(passes); dt = time.perf_counter() - t
-    return {"value": round(W * H * passes / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": kind,
-            "sample": f"{passes} full passes of {w['scene']} {W}x{H} at {nb} bounces = {W * H * passes / 1e6:.1f} Msamples, "
-                      f"static column split over {cores} threads as the reference does, {dt:.1f} s"}
+
+    def rate(threads, budget_s):
+        t = time.perf_counter(); run(1, threads); one = time.perf_counter() - t
+        passes = int(max(1, min(64, budget_s / max(one, 1e-3))))
+        t = time.perf_counter(); run(passes, threads); dt = time.perf_counter() - t
+        return W * H * passes / dt / 1e6, passes, dt
+
+    v_all, passes, dt = rate(cores, 10.0)
+    out = {"value": round(v_all, 4), "unit": "Msamples/s", "cores": cores, "kind": kind,
+           "sample": f"{passes} full passes of {w['scene']} {W}x{H} at {nb} bounces = {W * H * passes / 1e6:.1f} Msamples, "
+                     f"static column split over {cores} threads as the reference does, {dt:.1f} s",
+           "host_cpus": os.cpu_count()}
+    v1, p1, dt1 = rate(1, 4.0)
+    out["one_thread"] = {"value": round(v1, 4), "unit": "Msamples/s", "cores": 1, "kind": kind,
+                         "sample": f"{p1} full pass(es), one column = the whole frame, {dt1:.1f} s"}
+    # the oracle port, counter mode, rows dealt dynamically to all host threads (the scheduler variant of SURVEY 8d)
+    threads = os.cpu_count() or 1
+    t = time.perf_counter()
+    o.render_counter(W, H, 1, nb, seed=w["seed"], threads=threads)
+    one = time.perf_counter() - t
+    spp = int(max(1, min(16, 6.0 / max(one, 1e-3))))
+    t = time.perf_counter()
+    o.render_counter(W, H, spp, nb, seed=w["seed"], threads=threads)
+    dtd = time.perf_counter() - t
+    out["dynamic_rows"] = {"value": round(W * H * spp / dtd / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+                           "sample": f"oracle port, counter mode, {spp} spp of the same frame, rows dealt dynamically to {threads} threads, {dtd:.1f} s"}
+    return out
+
+
+def launch_check(args):
+    """Rendezvous of the N ranks and one all-reduce, nothing else (CPU boxes run it over gloo)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    backend = args.backend or "nccl"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend)
+        t = torch.tensor([rank + 1], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        total = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        total = 1
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": world, "backend": backend if world > 1 else None,
+                          "rank_sum": total, "expected": world * (world + 1) // 2}), flush=True)
+    return 0 if total == world * (world + 1) // 2 else 1
+
+
+def traffic_from_profiles(config, compiled):
+    """HBM-side traffic of the dominant kernel from the committed rocprofv3 PMC passes (bench.py cannot collect
+    PMC counters itself).  profiles/pmc_latest.json is written by scripts/summarize_pmc.py from the passes of
+    the current round: {config: {"kernel": ..., "fetch_bytes": ..., "write_bytes": ..., "source": ...}}."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    e = table.get(config + ("" if compiled else "_generic"))
+    if not e:
+        return None
+    return e
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--kernel", type=int, default=rt.KERNEL_AUTO)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-jit", action="store_true", help="do not specialise the trace kernel for the scene")
-    args = ap.parse_args()
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
+    if args.launch_check:
+        sys.exit(launch_check(args))
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
+    import ray_tracing_amd as rt
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
-        args.gpus = world
+    args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(args.backend or "nccl", device_id=dev)
 
-    w = WORKLOAD
+    w = WORKLOADS[args.config]
     W, H, spp, nb, seed = w["width"], w["height"], w["spp"], w["max_bounces"], w["seed"]
+    scene_path = os.path.join(rt.DATA_DIR, w["scene"])
     sky = rt.load_skybox()
     gpu = rt.Renderer(local_rank)
-    gpu.set_scene(os.path.join(rt.DATA_DIR, w["scene"]))
+    gpu.set_scene(scene_path)
     gpu.set_skybox(sky)
     gpu.set_camera()
     # scene "compilation" (hiprtc, ~1 s, outside the timed region): same frames, fewer instructions
-    compiled = False
+    compiled, jit_s = False, None
     if args.kernel == rt.KERNEL_AUTO and not args.no_jit:
         try:
+            t = time.perf_counter()
             gpu.compile_scene()
+            jit_s = time.perf_counter() - t
             compiled = True
         except rt.RtError as e:
             print(f"[bench] scene not specialised, using the generic kernel: {e}", file=sys.stderr)
 
     from ray_tracing_amd.multi_gpu import TiledFrame
     tiled = TiledFrame(gpu, W, H, spp, nb, seed=seed, row_block=ROW_BLOCK, rank=rank, world=world,
-                       kernel=args.kernel, device=dev)
-    step = tiled.step
+                       kernel=args.kernel, device=dev, to_host=True)
 
     def fence():
         torch.cuda.synchronize()
@@ -131,43 +242,81 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        tiled.step()
+    tiled.flush()
     fence()
     gpu.profile(True)
+    tiled.record_events = True
+    start = torch.cuda.Event(enable_timing=True)
+    start.record(tiled.stream)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        tiled.step()
+    tiled.flush()                       # every frame gathered, de-interleaved and resident in host memory
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = gpu.profile_collect()
     gpu.profile(False)
+    tiled.record_events = False
+    marks = [start] + tiled.done_events
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)) if len(marks) > 1 else []
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # ---- the same frame with nothing overlapped: first launch -> frame on the host (SURVEY.md 8d protocol)
+    latency = None
+    if not args.no_extras:
+        runs = []
+        for _ in range(7):
+            fence()
+            t1 = time.perf_counter()
+            tiled.render_now()
+            if world > 1:
+                dist.barrier()
+            runs.append((time.perf_counter() - t1) * 1e3)
+        runs.sort()
+        latency = runs[len(runs) // 2]
+
+    samples_per_step = W * H * spp
     if rank == 0:
-        samples_per_step = W * H * spp
         value = samples_per_step * args.steps / elapsed / 1e6
+        metric = "Msamples/s (rays/s) at 1920x1080x64spp scene_0; 1/2/4/8 GPU"
+        if args.config != "C1":
+            metric = f"Msamples/s at {W}x{H}x{spp}spp {w['scene'][:-4]} ({args.config})"
         out = {
-            "metric": "Msamples/s (rays/s) at 1920x1080x64spp scene_0; 1/2/4/8 GPU",
+            "metric": metric,
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{w['name']}: {w['scene']} {W}x{H}, {spp} spp, {nb} bounces, default camera, "
                                    f"counter-mode RNG seed {seed}, shipped skybox (6x2048x2048)",
+                       "timed_region": "K frames, each: strip render -> "
+                                       + ("one RCCL gather to rank 0 -> de-interleave -> " if world > 1 else "")
+                                       + "resolved frame copied to pinned host memory; two frames in flight",
                        "partition": f"interleaved blocks of {ROW_BLOCK} rows over {world} GPU(s)"
-                                    + ("; one RCCL gather of the strips + de-interleave on rank 0" if world > 1 else ""),
+                                    + (f"; collective: {tiled.primitive}" if world > 1 else ""),
                        "kernel": {0: "wavefront" + ("+scene-specialised (hiprtc)" if compiled else ""), 1: "simple",
                                   2: "wavefront, plain IEEE ops"}.get(args.kernel, str(args.kernel))},
         }
+        if step_ms:
+            med = step_ms[len(step_ms) // 2]
+            out["ms_per_step_median"] = round(med, 4)
+            out["value_at_median_step"] = round(samples_per_step / med / 1e3, 2)
+        if latency is not None:
+            out["frame_latency"] = {"median_ms": round(latency, 4), "runs": 7,
+                                    "msamples_per_s": round(samples_per_step / latency / 1e3, 2),
+                                    "region": "first launch -> gathered, resolved frame resident in host memory, nothing overlapped"}
+        if jit_s is not None:
+            out["jit_compile_s"] = round(jit_s, 3)
         # ---- roofline of the dominant kernel (rank 0's launches; every rank runs the same kernel on 1/N of the rows)
         from rtlibs import Oracle
         try:
             oc = Oracle(counters=True)
-            oc.load_scene(os.path.join(rt.DATA_DIR, w["scene"])); oc.set_skybox(sky); oc.set_camera()
+            oc.load_scene(scene_path); oc.set_skybox(sky); oc.set_camera()
             work = algorithmic_work(oc, W, H, nb, seed)
         except Exception as e:   # the oracle is a checker; the bench line must still print
             work = None
@@ -179,6 +328,7 @@ def main():
             # algorithmic bytes: 3 B per skybox fetch + 12 B per pixel written once per launch
             bytes_ = 3.0 * work["sky_fetches"] * samples_per_launch + 12.0 * (samples_per_launch / spp)
             achieved = flops / (avg_ms * 1e-3) / 1e12
+            out["rays_per_s"] = round(value * 1e6 * work["rays"], 1)
             out["roofline"] = {
                 "bound": "valu", "achieved": round(achieved, 3), "peak": round(PEAK_VALU_NOFMA_TFLOPS, 2),
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_VALU_NOFMA_TFLOPS, 4), "traffic": None,
@@ -191,27 +341,27 @@ def main():
                         "bytes_per_sample": round(bytes_ / samples_per_launch, 3)},
                 "note": "no MFMA/HBM bound applies (SURVEY.md 8d): peak = fp32 VALU issue rate without FMA "
                         "(parity forbids contraction) = 157.3/2 TFLOP/s; flops counted as written in the reference; "
-                        "avg_kernel_ms = HIP events around rt_primary_pass (camera rays, ~0.05 ms) + the trace kernel",
+                        "avg_kernel_ms = HIP events around rt_primary_pass (camera rays) + the trace kernel",
             }
-        if "roofline" in out:
-            # HBM-side traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot
-            # collect PMC counters itself): FETCH_SIZE + WRITE_SIZE in bytes per launch, N = 1 only.
-            prof = os.path.join(ROOT, "profiles", "r01", "v13_final_summary.txt")
-            if world == 1 and compiled and os.path.exists(prof):
-                vals = {}
-                for line in open(prof):
-                    parts = line.split()
-                    if len(parts) == 2 and parts[0] in ("FETCH_SIZE", "WRITE_SIZE"):
-                        vals[parts[0]] = float(parts[1]) * 1024.0
-                if len(vals) == 2:
-                    out["roofline"]["traffic"] = round(vals["FETCH_SIZE"] + vals["WRITE_SIZE"])
-                    out["roofline"]["traffic_note"] = ("bytes per launch from profiles/r01/v13_final_summary.txt (rocprofv3 --pmc "
-                                                       "FETCH_SIZE / WRITE_SIZE in separate passes); reads are scattered 4-byte "
-                                                       "skybox gathers (one 32-64 B sector each, served by the 256 MiB Infinity "
-                                                       "Cache that holds the whole 100 MB skybox), so no x2 streaming correction is applied")
+            tr = traffic_from_profiles(args.config, compiled) if world == 1 else None
+            if tr:
+                out["roofline"]["traffic"] = round(tr["fetch_bytes"] + tr["write_bytes"])
+                out["roofline"]["traffic_note"] = tr.get("source", "")
+        # ---- the generic kernel (no hiprtc): same frame, same events
+        if world == 1 and compiled and not args.no_extras:
+            gpu.set_scene(scene_path)                 # drops the compiled kernel
+            tiled.render_now()
+            gpu.profile(True)
+            for _ in range(5):
+                tiled.step()
+            tiled.flush()
+            g_ms, g_n = gpu.profile_collect()
+            gpu.profile(False)
+            if g_n:
+                out.setdefault("roofline", {})["generic_kernel_ms"] = round(g_ms / g_n, 4)
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(w, sky)
+                out["cpu_baseline"] = cpu_baseline(rt, w, sky)
                 out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
             except Exception as e:
                 out["cpu_baseline_error"] = repr(e)

@@ -70,6 +70,21 @@ typedef struct {
 
 RT_API void rt_default_params(rt_render_params *p, int width, int height, int spp, int max_bounces);
 
+/* Scheduling knobs of the trace kernels.  None of them changes a single bit of any frame (tests render with
+ * several settings and compare); they exist for measurement scripts and for tests that must reach a
+ * particular code path.  0 / NULL = let the library decide.  Set per context, read at every launch; the
+ * library never reads environment variables. */
+typedef struct {
+	int    sample_chunks;       /* work items per pixel: a pixel's spp samples are split into this many chunks
+	                             * that different lanes take (>= 1; clipped to spp) */
+	int    dequeue_shards;      /* work-item queues of the persistent waves: 1 or 64 */
+	int    workgroups_per_cu;   /* resident workgroups per CU, 1..4 */
+	size_t scratch_limit_bytes; /* launches whose per-sample scratch would exceed this run unchunked (default 8 GiB) */
+	int    jit_waves_per_simd;  /* rt_compile_scene: register budget = 512 / this many VGPRs (default 4) */
+	const char *jit_flags;      /* rt_compile_scene: extra hiprtc options, space separated (copied) */
+} rt_tuning;
+RT_API void rt_default_tuning(rt_tuning *t);
+
 /* ---- context ------------------------------------------------------------------------------ */
 RT_API int  rt_create(rt_context **out, int device_id);
 RT_API void rt_destroy(rt_context *ctx);
@@ -86,6 +101,7 @@ RT_API int rt_scene_is_compiled(rt_context *ctx);
 /* chan must be 3 or 4 (what stb_image returns for the shipped JPEGs is 3); all faces w x h */
 RT_API int rt_set_skybox(rt_context *ctx, const Cubemap *skybox);
 RT_API int rt_set_camera(rt_context *ctx, const rt_camera *camera);
+RT_API int rt_set_tuning(rt_context *ctx, const rt_tuning *tuning);
 
 /* ---- the hot path: replaces start_workers()+worker()+update_frame() ------------------------ */
 /* Renders the whole frame (world must be 1) into caller-allocated host memory: width*height
@@ -94,7 +110,13 @@ RT_API int rt_set_camera(rt_context *ctx, const rt_camera *camera);
 RT_API int rt_render(rt_context *ctx, const rt_render_params *params, Vector3 *frame_out);
 
 /* Same, but the destination is DEVICE memory (rt_strip_rows()*width*12 bytes) and the call only
- * enqueues work on `hip_stream` (a hipStream_t; NULL = the context's own stream).  No sync. */
+ * enqueues work on `hip_stream` (a hipStream_t; NULL = the context's own non-blocking stream;
+ * RT_STREAM_LEGACY = the device's legacy null stream, which a literal 0 cannot name here).  No sync.
+ * A context owns ONE set of launch scratch (work queues, primary-hit tables, sample planes): launches of one
+ * context are ordered one after another even when they are enqueued on different streams (a launch on a new
+ * stream waits for the context's previous launch through an event), and rt_set_scene / rt_set_skybox wait
+ * for the context's own launches only, not for the whole device. */
+#define RT_STREAM_LEGACY ((void *) (intptr_t) -1)
 RT_API int rt_render_device(rt_context *ctx, const rt_render_params *params, void *d_strip, void *hip_stream);
 
 /* Rows held by one rank's strip, padded so every rank has the same count (gather-friendly). */

@@ -47,6 +47,14 @@ class RenderParams(C.Structure):
                 ("kernel", C.c_int)]
 
 
+class Tuning(C.Structure):
+    _fields_ = [("sample_chunks", C.c_int), ("dequeue_shards", C.c_int), ("workgroups_per_cu", C.c_int),
+                ("scratch_limit_bytes", C.c_size_t), ("jit_waves_per_simd", C.c_int), ("jit_flags", C.c_char_p)]
+
+
+STREAM_LEGACY = C.c_void_p(-1).value      # RT_STREAM_LEGACY: the device's legacy null stream
+
+
 class MouseState(C.Structure):
     _fields_ = [("first_mouse", C.c_int), ("yaw", C.c_float), ("pitch", C.c_float),
                 ("last_x", C.c_float), ("last_y", C.c_float)]
@@ -55,7 +63,7 @@ class MouseState(C.Structure):
 # every symbol include/rt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
-    "rt_set_camera", "rt_compile_scene", "rt_scene_is_compiled", "rt_render", "rt_render_device", "rt_strip_rows", "rt_deinterleave_device",
+    "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_render", "rt_render_device", "rt_strip_rows", "rt_deinterleave_device",
     "rt_synchronize", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
     "rt_progressive_invalidate", "rt_progressive_state", "rt_selftest", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
     "rt_parse_scene_string", "rt_load_cubemap", "rt_free_cubemap", "rt_decode_jpeg_file",
@@ -89,6 +97,8 @@ def lib():
     L.rt_set_scene.argtypes = [C.c_void_p, C.c_void_p]
     L.rt_set_skybox.argtypes = [C.c_void_p, C.POINTER(Cubemap)]
     L.rt_set_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
+    L.rt_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
+    L.rt_default_tuning.argtypes = [C.POINTER(Tuning)]
     L.rt_compile_scene.argtypes = [C.c_void_p]
     L.rt_scene_is_compiled.argtypes = [C.c_void_p]
     L.rt_default_params.argtypes = [C.POINTER(RenderParams), C.c_int, C.c_int, C.c_int, C.c_int]
@@ -248,6 +258,16 @@ class Renderer:
             cam.fov = fov
         _check(lib().rt_set_camera(self._ctx, C.byref(cam)), "rt_set_camera")
 
+    def set_tuning(self, sample_chunks=0, dequeue_shards=0, workgroups_per_cu=0, scratch_limit_bytes=0,
+                   jit_waves_per_simd=0, jit_flags=None):
+        """rt_set_tuning(): scheduling knobs (0 / None = automatic).  They never change a frame."""
+        t = Tuning()
+        lib().rt_default_tuning(C.byref(t))
+        t.sample_chunks, t.dequeue_shards, t.workgroups_per_cu = sample_chunks, dequeue_shards, workgroups_per_cu
+        t.scratch_limit_bytes, t.jit_waves_per_simd = scratch_limit_bytes, jit_waves_per_simd
+        t.jit_flags = jit_flags.encode() if jit_flags else None
+        _check(lib().rt_set_tuning(self._ctx, C.byref(t)), "rt_set_tuning")
+
     @staticmethod
     def params(width, height, spp, max_bounces, seed=0, row_block=8, rank=0, world=1, kernel=KERNEL_AUTO):
         p = RenderParams()
@@ -262,14 +282,23 @@ class Renderer:
         _check(lib().rt_render(self._ctx, C.byref(p), out.ctypes.data_as(C.c_void_p)), "rt_render")
         return out
 
+    @staticmethod
+    def _stream_arg(stream):
+        """None -> the context's own stream (NULL in the C ABI); a hipStream_t handle as int otherwise, where the
+        handle 0 -- torch's default stream -- is the device's legacy null stream and is passed as RT_STREAM_LEGACY
+        (NULL already means "the context's stream")."""
+        if stream is None:
+            return None
+        return C.c_void_p(STREAM_LEGACY if stream == 0 else stream)
+
     def render_device(self, params, device_ptr, stream=None):
         """Enqueue one strip render into device memory (no sync)."""
-        _check(lib().rt_render_device(self._ctx, C.byref(params), C.c_void_p(device_ptr),
-                                      C.c_void_p(stream) if stream else None), "rt_render_device")
+        _check(lib().rt_render_device(self._ctx, C.byref(params), C.c_void_p(device_ptr), self._stream_arg(stream)),
+               "rt_render_device")
 
     def deinterleave_device(self, strips_ptr, frame_ptr, width, height, row_block, world, stream=None):
         _check(lib().rt_deinterleave_device(self._ctx, C.c_void_p(strips_ptr), C.c_void_p(frame_ptr), width, height,
-                                            row_block, world, C.c_void_p(stream) if stream else None),
+                                            row_block, world, self._stream_arg(stream)),
                "rt_deinterleave_device")
 
     # -- progressive accumulation (reference worker()/update_frame() protocol)

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/rt_hip.h"
@@ -95,14 +96,66 @@ struct rt_context {
 		size_t   accum_bytes = 0, low_bytes = 0;
 	} prog;
 
+	rt_tuning    tuning = {};
+	std::string  jit_flags;              /* owns tuning.jit_flags */
+
+	/* launches of one context share its scratch: `last_launch` is recorded after every launch, on the launch's
+	 * stream; a launch on another stream waits for it, and the setters wait for it instead of the whole device */
+	hipEvent_t   last_launch = nullptr;
+	hipStream_t  last_stream = nullptr;
+	bool         launched = false;
+
 	bool         profiling = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 	std::vector<hipEvent_t> event_pool;
 };
 
+/* Everything this context has enqueued -- on its own stream or on a caller's -- has finished. */
+static int wait_for_launches(rt_context *ctx)
+{
+	if (ctx->launched) HIP_TRY(hipEventSynchronize(ctx->last_launch));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return RT_OK;
+}
+
+/* Called before a launch is enqueued on `stream`: the context's scratch is shared, so the launch is ordered
+ * behind the context's previous one when that ran on a different stream. */
+static int order_behind_previous(rt_context *ctx, hipStream_t stream)
+{
+	if (ctx->launched && ctx->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->last_launch, 0));
+	return RT_OK;
+}
+
+static int mark_launch(rt_context *ctx, hipStream_t stream)
+{
+	HIP_TRY(hipEventRecord(ctx->last_launch, stream));
+	ctx->last_stream = stream; ctx->launched = true;
+	return RT_OK;
+}
+
+static hipStream_t pick_stream(rt_context *ctx, void *hip_stream)
+{
+	if (hip_stream == RT_STREAM_LEGACY) return nullptr;             /* the device's legacy null stream */
+	return hip_stream ? (hipStream_t) hip_stream : ctx->stream;
+}
+
 extern "C" {
 
 const char *rt_last_error(void) { return g_error; }
+
+void rt_default_tuning(rt_tuning *t) { if (t) memset(t, 0, sizeof(*t)); }
+
+int rt_set_tuning(rt_context *ctx, const rt_tuning *t)
+{
+	if (!ctx || !t) return fail(RT_ERR_ARGUMENT, "rt_set_tuning: NULL argument");
+	if (t->sample_chunks < 0 || (t->dequeue_shards != 0 && t->dequeue_shards != 1 && t->dequeue_shards != 64) ||
+	    t->workgroups_per_cu < 0 || t->workgroups_per_cu > 4 || t->jit_waves_per_simd < 0 || t->jit_waves_per_simd > 8)
+		return fail(RT_ERR_ARGUMENT, "rt_set_tuning: value out of range");
+	ctx->tuning = *t;
+	ctx->jit_flags = t->jit_flags ? t->jit_flags : "";
+	ctx->tuning.jit_flags = ctx->jit_flags.c_str();
+	return RT_OK;
+}
 
 void rt_default_params(rt_render_params *p, int width, int height, int spp, int max_bounces)
 {
@@ -131,6 +184,7 @@ int rt_create(rt_context **out, int device_id)
 		if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
 			ctx->num_cus = prop.multiProcessorCount;
 		e = hipMalloc((void**) &ctx->d_counter, rt_counter_bytes());
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->last_launch, hipEventDisableTiming);
 		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 		if (e != hipSuccess) { (void) hipStreamDestroy(ctx->stream); delete ctx; return fail(RT_ERR_DEVICE, "rt_create: %s", hipGetErrorString(e)); }
 	}
@@ -147,6 +201,8 @@ void rt_destroy(rt_context *ctx)
 	(void) hipStreamSynchronize(ctx->stream);
 	for (auto &p : ctx->events) { (void) hipEventDestroy(p.first); (void) hipEventDestroy(p.second); }
 	for (auto &e : ctx->event_pool) (void) hipEventDestroy(e);
+	if (ctx->launched) (void) hipEventSynchronize(ctx->last_launch);
+	if (ctx->last_launch) (void) hipEventDestroy(ctx->last_launch);
 	if (ctx->spec_module) (void) hipModuleUnload(ctx->spec_module);
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
 	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame); (void) hipFree(ctx->d_counter); (void) hipFree(ctx->d_samples); (void) hipFree(ctx->d_direct); (void) hipFree(ctx->d_blk_hits); (void) hipFree(ctx->d_blk_list); (void) hipFree(ctx->d_blk_count); (void) hipFree(ctx->d_obj_blocks);
@@ -161,7 +217,7 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 	const int n = scene->num_objects;
 	if (n < 0 || n > MAX_OBJECTS) return fail(RT_ERR_ARGUMENT, "rt_set_scene: num_objects %d not in [0,%d]", n, MAX_OBJECTS);
 	HIP_TRY(hipSetDevice(ctx->device));
-	HIP_TRY(hipDeviceSynchronize());     /* frames still in flight (rt_render_device) read the old scene / compiled kernel */
+	{ const int rc = wait_for_launches(ctx); if (rc != RT_OK) return rc; }   /* frames still in flight read the old scene / compiled kernel */
 
 	std::vector<rt_geom>  geom((size_t) n > 0 ? n : 1);
 	std::vector<rt_shade> shade((size_t) n > 0 ? n : 1);
@@ -251,10 +307,10 @@ int rt_compile_scene(rt_context *ctx)
 	const int n = ctx->num_objects;
 	if (n < 1 || n > 64) return fail(RT_ERR_ARGUMENT, "rt_compile_scene: %d objects; only scenes of 1..64 objects are specialised", n);
 	if (!ctx->scene_fast_ok) return fail(RT_ERR_ARGUMENT, "rt_compile_scene: scene has a box with negative size or out-of-range coordinates");
-	if (getenv("RT_NO_JIT")) return fail(RT_ERR_STATE, "rt_compile_scene: disabled by RT_NO_JIT");
 	HIP_TRY(hipSetDevice(ctx->device));
 	std::string message;
-	const int rc = rt_jit_build(ctx->h_geom.data(), n, ctx->light_index, ctx->light_pos, &ctx->spec_module, &ctx->spec_fn, message);
+	const int rc = rt_jit_build(ctx->h_geom.data(), n, ctx->light_index, ctx->light_pos, ctx->tuning.jit_waves_per_simd, ctx->jit_flags.c_str(),
+	                            &ctx->spec_module, &ctx->spec_fn, message);
 	if (rc != RT_OK) { ctx->spec_module = nullptr; ctx->spec_fn = nullptr; return fail(rc, "rt_compile_scene: %s", message.c_str()); }
 	return RT_OK;
 }
@@ -272,7 +328,7 @@ int rt_set_skybox(rt_context *ctx, const Cubemap *sky)
 	for (int f = 0; f < 6; f++)
 		if (!sky->data[f]) return fail(RT_ERR_ARGUMENT, "rt_set_skybox: face %d is NULL", f);
 	HIP_TRY(hipSetDevice(ctx->device));
-	HIP_TRY(hipDeviceSynchronize());     /* frames still in flight read the old texels */
+	{ const int rc = wait_for_launches(ctx); if (rc != RT_OK) return rc; }   /* frames still in flight read the old texels */
 
 	/* RGBA8 repack: one aligned dword per texel for the kernel's gather (sample_cubemap reads
 	 * bytes [0..2] of a `chan`-strided texel, gpu_and_windowing.c:106-111) */
@@ -337,9 +393,11 @@ static hipEvent_t take_event(rt_context *ctx)
 {
 	if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
 	hipEvent_t e = nullptr;
-	(void) hipEventCreate(&e);
+	if (hipEventCreate(&e) != hipSuccess) return nullptr;
 	return e;
 }
+
+static void give_event(rt_context *ctx, hipEvent_t e) { if (e) ctx->event_pool.push_back(e); }
 
 /* buffers rt_primary_pass fills for the trace kernel: sized by the launch's 8x8 pixel blocks, grown on demand */
 static int attach_block_buffers(rt_context *ctx, rt_launch &L)
@@ -365,7 +423,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	if (rc != RT_OK) return rc;
 	if (!d_strip) return fail(RT_ERR_ARGUMENT, "rt_render_device: d_strip is NULL");
 	HIP_TRY(hipSetDevice(ctx->device));
-	hipStream_t stream = hip_stream ? (hipStream_t) hip_stream : ctx->stream;
+	hipStream_t stream = pick_stream(ctx, hip_stream);
 
 	rt_launch L;
 	memset(&L, 0, sizeof(L));
@@ -403,14 +461,15 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 		int chunks = (p->spp + 7) / 8;
 		if (pixel_blocks > 0 && pixel_blocks * chunks < want_blocks) chunks = (int) ((want_blocks + pixel_blocks - 1) / pixel_blocks);
 		if (chunks > 32) chunks = 32;
-		if (const char *e = getenv("RT_CHUNKS")) chunks = atoi(e);               /* tuning / test override */
+		if (ctx->tuning.sample_chunks > 0) chunks = ctx->tuning.sample_chunks;    /* measurement / test override */
 		if (chunks > p->spp) chunks = p->spp;
 		if (chunks > 1) {
 			const int chunk_spp = (p->spp + chunks - 1) / chunks;
 			chunks = (p->spp + chunk_spp - 1) / chunk_spp;
 			const size_t pixels = (size_t) L.local_rows * p->width;
 			const size_t need = (size_t) p->spp * pixels * 3 * sizeof(float);
-			if (chunks > 1 && need <= ((size_t) 8 << 30)) {
+			const size_t limit = ctx->tuning.scratch_limit_bytes ? ctx->tuning.scratch_limit_bytes : (size_t) 8 << 30;
+			if (chunks > 1 && need <= limit) {
 				if (need > ctx->samples_bytes) {
 					(void) hipFree(ctx->d_samples); ctx->d_samples = nullptr; ctx->samples_bytes = 0;
 					HIP_TRY(hipMalloc((void**) &ctx->d_samples, need));
@@ -430,16 +489,27 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	 * their first item at once already cost ~0.2 ms) unless the launch is too small to give every queue its
 	 * workgroups and a fair share of items */
 	if ((long long) ((p->width + 7) / 8) * ((L.local_rows + 7) / 8) * L.num_chunks >= 64 * 64 && ctx->num_cus >= 64) L.num_shards = 64;
-	if (const char *e = getenv("RT_SHARDS")) { const int v = atoi(e); if (v == 1 || v == 64) L.num_shards = v; }   /* tuning aid */
+	if (ctx->tuning.dequeue_shards) L.num_shards = ctx->tuning.dequeue_shards;
 
-	hipEvent_t e0 = nullptr, e1 = nullptr;
-	if (ctx->profiling) { e0 = take_event(ctx); e1 = take_event(ctx); HIP_TRY(hipEventRecord(e0, stream)); }
 	{ const int rc = attach_block_buffers(ctx, L); if (rc != RT_OK) return rc; }
-	HIP_TRY(rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, stream));
-	if (ctx->profiling) { HIP_TRY(hipEventRecord(e1, stream)); ctx->events.emplace_back(e0, e1); }
+	{ const int rc = order_behind_previous(ctx, stream); if (rc != RT_OK) return rc; }
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	if (ctx->profiling) {
+		e0 = take_event(ctx); e1 = take_event(ctx);
+		if (!e0 || !e1) { give_event(ctx, e0); give_event(ctx, e1); return fail(RT_ERR_DEVICE, "rt_render_device: hipEventCreate failed"); }
+		hipError_t e = hipEventRecord(e0, stream);
+		if (e != hipSuccess) { give_event(ctx, e0); give_event(ctx, e1); return fail(RT_ERR_DEVICE, "hipEventRecord: %s", hipGetErrorString(e)); }
+	}
+	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->tuning.workgroups_per_cu, stream);
+	if (le == hipSuccess && ctx->profiling) le = hipEventRecord(e1, stream);
+	if (ctx->profiling) {
+		if (le == hipSuccess) ctx->events.emplace_back(e0, e1);
+		else { give_event(ctx, e0); give_event(ctx, e1); }                 /* a failed launch keeps no events */
+	}
+	if (le != hipSuccess) return fail(RT_ERR_DEVICE, "trace launch: %s", hipGetErrorString(le));
 	if (L.num_chunks > 1)
 		HIP_TRY(rt_launch_sum_samples(L.samples, L.direct, L.frame, (size_t) L.local_rows * L.width * 3, L.spp, stream));
-	return RT_OK;
+	return mark_launch(ctx, stream);
 }
 
 int rt_render(rt_context *ctx, const rt_render_params *p, Vector3 *frame_out)
@@ -471,7 +541,7 @@ int rt_deinterleave_device(rt_context *ctx, const void *d_strips, void *d_frame,
 	if (width < 1 || height < 1 || row_block < 1 || world < 1)
 		return fail(RT_ERR_ARGUMENT, "rt_deinterleave_device: bad geometry");
 	HIP_TRY(hipSetDevice(ctx->device));
-	hipStream_t stream = hip_stream ? (hipStream_t) hip_stream : ctx->stream;
+	hipStream_t stream = pick_stream(ctx, hip_stream);
 	HIP_TRY(rt_launch_deinterleave((const float*) d_strips, (float*) d_frame, width, height, row_block, world,
 	                               rt_strip_rows(height, row_block, world), stream));
 	return RT_OK;
@@ -548,9 +618,11 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
 	L.num_chunks = 1; L.chunk_spp = 1; L.samples = nullptr; L.direct = nullptr; L.num_shards = 1;
 	{ const int rc = attach_block_buffers(ctx, L); if (rc != RT_OK) return rc; }
-	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->stream));
+	{ const int rc = order_behind_previous(ctx, ctx->stream); if (rc != RT_OK) return rc; }
+	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream));
 	const float weight = 1.0f / (s * s);                                         /* main.c:278 */
 	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), ctx->stream));
+	{ const int rc = mark_launch(ctx, ctx->stream); if (rc != RT_OK) return rc; }
 	g.count += weight;                                                           /* main.c:396 */
 	g.passes++;
 	if (g.scale > 1) g.scale >>= 1;                                              /* main.c:402-403 */
@@ -602,8 +674,7 @@ int rt_synchronize(rt_context *ctx)
 {
 	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_synchronize: NULL context");
 	HIP_TRY(hipSetDevice(ctx->device));
-	HIP_TRY(hipStreamSynchronize(ctx->stream));
-	return RT_OK;
+	return wait_for_launches(ctx);
 }
 
 int rt_profile_enable(rt_context *ctx, int on)

@@ -259,7 +259,7 @@ int rt_parse_scene_file(const char *file, Scene *scene)
 	fclose(fp);
 	if (bad) { free(text); fprintf(stderr, "Error: Couldn't open scene file\n"); return RT_ERR_IO; }
 	text[got] = '\0';
-	int rc = rt_parse_scene_string(text, (size_t) size, scene);
+	int rc = rt_parse_scene_string(text, got, scene);     /* what was read, not what ftell promised */
 	free(text);
 	return rc;
 }

@@ -11,8 +11,8 @@ size_t     rt_scene_lds_bytes(int num_objects);
 size_t     rt_wavefront_lds_bytes(int num_objects);
 /* spec_fn: kernel compiled by rt_compile_scene for the current scene, or nullptr */
 hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, hipFunction_t spec_fn,
-                           unsigned int *block_counter, int num_cus, hipStream_t stream);
-int        rt_jit_build(const rt_geom *geom, int n, int light_index, const float light_pos[3], hipModule_t *module, hipFunction_t *function, std::string &message);
+                           unsigned int *block_counter, int num_cus, int workgroups_per_cu, hipStream_t stream);
+int        rt_jit_build(const rt_geom *geom, int n, int light_index, const float light_pos[3], int waves_per_simd, const char *extra_flags, hipModule_t *module, hipFunction_t *function, std::string &message);
 hipError_t rt_launch_deinterleave(const float *strips, float *frame, int width, int height,
                                   int row_block, int world, int rows_per_rank, hipStream_t stream);
 

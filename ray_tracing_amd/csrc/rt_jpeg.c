@@ -5,8 +5,9 @@
  * (gpu_and_windowing.c:5-6,27) and sample_cubemap() reads those bytes (gpu_and_windowing.c:106).
  * JPEG decoders differ in their inverse DCT, chroma upsampling and colour conversion, so "the
  * skybox" is defined by that decoder's integer arithmetic (libjpeg differs in 1-3 % of the bytes).
- * This file restates stb_image's published (public-domain) algorithm for the baseline, Huffman,
- * 8-bit path -- written from the algorithm, not copied:
+ * This file restates stb_image v2.29's published (public-domain) algorithm for the baseline, Huffman,
+ * 8-bit path (the IDCT butterfly, the resamplers and the YCbCr row follow stb's statement order, which
+ * byte-identical texels require):
  *   - entropy decoding per ITU T.81 annex F (any conforming decoder yields the same coefficients),
  *     each coefficient multiplied by its quantiser and kept as int16;
  *   - 2-D IDCT: column pass then row pass of the 12-bit fixed-point LLM butterfly
@@ -15,7 +16,7 @@
  *   - chroma upsampling with the 3:1 / 9:3:3:1 triangle filters ("fancy upsampling");
  *   - YCbCr -> RGB in 20-bit fixed point with constants round(x * 4096) << 8, the Cb->G term masked
  *     with 0xffff0000.
- * Pinned by tests/test_jpeg.py against the SHA-256 of the reference's decoded faces
+ * Pinned by tests/test_host_mirror.py (test_jpeg_decoder_matches_stb_decode_of_reference) against the SHA-256 of the reference's decoded faces
  * (tests/golden/reference_meta.json) and texel probes.
  *
  * Not supported (RT_ERR_FORMAT): progressive / arithmetic / 12-bit / CMYK streams -- the reference's
@@ -189,8 +190,10 @@ static int decode_block(Jpeg *j, Comp *c, short data[64])
 			k += 16;
 		} else {
 			k += r;
-			int zig = ZIGZAG[k];
-			data[zig] = (short) (receive_extend(j, s) * q[k]);
+			/* a run that overshoots the block (corrupt stream): stb_image's dezigzag table is padded with 63s,
+			 * so the coefficient lands on position 63; do the same instead of indexing past the tables */
+			const int kk = k > 63 ? 63 : k;
+			data[ZIGZAG[kk]] = (short) (receive_extend(j, s) * q[kk]);
 			k++;
 		}
 	}

@@ -508,7 +508,7 @@ rt_trace_simple(const rt_launch L)
 
 			const float n_dot_v = clamp01(dot3(hit.n, neg3(rd)));            /* main.c:214-216 */
 			/* main.c:128: (float)pow(1.0 - (double)u, 5.0) == x2*x2*x in fp64 for u in [0,1]
-			 * (re-checked in tests/test_pow5.py) */
+			 * (pinned exhaustively by tests/test_pow5.py) */
 			const double xg = 1.0 - (double) n_dot_v;
 			const double xg2 = xg * xg;
 			const float grazing = (float) (xg2 * xg2 * xg);
@@ -1335,7 +1335,7 @@ size_t rt_scene_lds_bytes(int num_objects) { return (size_t) num_objects * (size
 size_t rt_wavefront_lds_bytes(int num_objects) { return rt_scene_lds_bytes(num_objects) + (RT_BLOCK / 64) * sizeof(WaveLDS); }
 
 hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, hipFunction_t spec_fn,
-                           unsigned int *block_counter, int num_cus, hipStream_t stream)
+                           unsigned int *block_counter, int num_cus, int workgroups_per_cu, hipStream_t stream)
 {
 	if (L.local_rows <= 0 || L.width <= 0) return hipSuccess;
 	const bool simple = variant == 1 /* RT_KERNEL_SIMPLE */ || L.max_bounces < 1;
@@ -1350,7 +1350,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	int per_cu = (int) ((160u * 1024u) / lds);
 	if (per_cu < 1) per_cu = 1;
 	if (per_cu > 4) per_cu = 4;
-	if (const char *e = getenv("RT_WF_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }   /* tuning aid */
+	if (workgroups_per_cu >= 1 && workgroups_per_cu < per_cu) per_cu = workgroups_per_cu;     /* rt_tuning */
 	const long long blocks = (long long) ((L.width + 7) / 8) * ((L.local_rows + 7) / 8) * (L.num_chunks > 1 ? L.num_chunks : 1);
 	long long grid = (long long) num_cus * per_cu;
 	const long long useful = (blocks + (RT_BLOCK / 64) - 1) / (RT_BLOCK / 64);

@@ -6,6 +6,13 @@ which is badly load-imbalanced (sky columns finish long before object columns). 
 rank renders its blocks into a compact strip (kernel side: rt_device.h `rt_launch`), rank 0 receives
 all strips with a single gather and de-interleaves them.  One process per GPU, `torch.distributed`
 supplies the communicator (backend "nccl" = RCCL on ROCm; "gloo" on CPU for the tests).
+
+Stream discipline (GPU): every stage of a frame -- strip render, gather, de-interleave -- is issued from ONE
+dedicated, non-default torch stream (its handle is what the C ABI receives, so the kernels, torch's
+collective hand-off events and the de-interleave are ordered by construction); the copy of the finished
+frame to pinned host memory runs on a second stream behind an event.  Frames are double-buffered, so the
+gather / copy of frame k overlaps the render of frame k+1 -- the way the reference's workers keep
+accumulating while its main thread presents (main.c:354-408 vs 450-482).
 """
 import numpy as np
 import torch
@@ -34,44 +41,47 @@ def frame_index(height, row_block, world):
     return (blk % world) * n + (blk // world) * row_block + j % row_block
 
 
-_use_all_gather = False      # set if the backend in use has no gather (then every rank receives all strips)
+def collective_for(backend=None):
+    """Which primitive moves the strips, decided ONCE from the backend name (never by catching errors in the
+    data path: a rank that fails must fail, not drift into a different collective than its peers).
+    nccl (= RCCL) and gloo both implement gather; anything else gets one all-gather (7x the bytes)."""
+    backend = backend or dist.get_backend()
+    return "gather" if str(backend).lower() in ("nccl", "gloo") else "all_gather"
 
 
-def gather_strips(strip, rank, world, dst=0, out=None):
-    """One gather of equally-sized strips to `dst`.  Returns [world, rows, W, 3] on dst, None elsewhere.
-    Backends without a gather primitive fall back to one all-gather (same traffic pattern per link on a
-    fully connected xGMI node, 7x more bytes overall)."""
-    global _use_all_gather
+def gather_strips(strip, rank, world, dst=0, out=None, primitive=None, async_op=False):
+    """One collective of equally-sized strips to `dst`.  Returns (result, work): result is [world, rows, W, 3] on
+    dst and None elsewhere; work is the torch Work handle when async_op is set (wait() on it before touching
+    the result), else None.  `out` must be passed on dst when the call is asynchronous or repeated."""
     if world == 1:
-        return strip.unsqueeze(0)
-    if not _use_all_gather:
-        try:
-            if rank == dst:
-                if out is None:
-                    out = torch.empty((world,) + tuple(strip.shape), dtype=strip.dtype, device=strip.device)
-                dist.gather(strip, list(out.unbind(0)), dst=dst)
-                return out
-            dist.gather(strip, None, dst=dst)
-            return None
-        except (RuntimeError, NotImplementedError):
-            _use_all_gather = True       # every rank takes this branch on the same call
+        return strip.unsqueeze(0), None
+    primitive = primitive or collective_for()
+    if primitive == "gather":
+        if rank == dst:
+            if out is None:
+                out = torch.empty((world,) + tuple(strip.shape), dtype=strip.dtype, device=strip.device)
+            work = dist.gather(strip, list(out.unbind(0)), dst=dst, async_op=async_op)
+            return out, work
+        work = dist.gather(strip, None, dst=dst, async_op=async_op)
+        return None, work
     if out is None:
         out = torch.empty((world,) + tuple(strip.shape), dtype=strip.dtype, device=strip.device)
-    dist.all_gather_into_tensor(out, strip)
-    return out if rank == dst else None
+    work = dist.all_gather_into_tensor(out, strip, async_op=async_op)
+    return (out if rank == dst else None), work
 
 
-def assemble(strips, height, row_block, world, renderer=None, out=None):
+def assemble(strips, height, row_block, world, renderer=None, out=None, stream=None):
     """De-interleave gathered strips into the frame [height, W, 3].  On a GPU tensor this is the
-    library's rt_deinterleave kernel; on CPU tensors (gloo tests) an index_select."""
+    library's rt_deinterleave kernel, enqueued on `stream` (a torch stream; default: the current one);
+    on CPU tensors (gloo tests) an index_select."""
     W = strips.shape[2]
     if strips.is_cuda:
         if renderer is None:
             raise ValueError("assemble: a Renderer is required for device tensors")
         if out is None:
             out = torch.empty((height, W, 3), dtype=torch.float32, device=strips.device)
-        renderer.deinterleave_device(strips.data_ptr(), out.data_ptr(), W, height, row_block, world,
-                                     torch.cuda.current_stream().cuda_stream)
+        s = stream if stream is not None else torch.cuda.current_stream(strips.device)
+        renderer.deinterleave_device(strips.data_ptr(), out.data_ptr(), W, height, row_block, world, s.cuda_stream)
         return out
     idx = torch.from_numpy(frame_index(height, row_block, world))
     flat = strips.reshape(-1, W, 3)
@@ -79,26 +89,100 @@ def assemble(strips, height, row_block, world, renderer=None, out=None):
 
 
 class TiledFrame:
-    """The N-GPU step of bench.py: render own strip -> gather -> de-interleave on rank 0."""
+    """The N-GPU frame loop of bench.py: render own strip -> gather -> de-interleave on rank 0 -> frame in
+    pinned host memory on rank 0 (what update_frame() hands to the presenter, main.c:467-479).
+
+    step() enqueues one frame and returns at once; up to two frames are in flight.  flush() completes
+    everything and leaves the last frame in `host_frame` (rank 0).  `seed` may be changed between steps
+    (`step(seed=...)`): every frame is rendered from scratch, nothing is reused across frames.
+    """
 
     def __init__(self, renderer, width, height, spp, max_bounces, seed=0, row_block=8, rank=0, world=1,
-                 kernel=0, device=None):
+                 kernel=0, device=None, to_host=True):
         self.r, self.W, self.H = renderer, width, height
         self.row_block, self.rank, self.world = row_block, rank, world
-        self.params = renderer.params(width, height, spp, max_bounces, seed=seed, row_block=row_block,
-                                      rank=rank, world=world, kernel=kernel)
+        self.spp, self.max_bounces, self.kernel, self.seed = spp, max_bounces, kernel, seed
+        self.to_host = to_host and rank == 0
+        self.device = device
         rows = strip_rows(height, row_block, world)
-        self.strip = torch.empty((rows, width, 3), dtype=torch.float32, device=device)
-        self.strips = self.frame = None
-        if world > 1 and rank == 0:
-            self.strips = torch.empty((world, rows, width, 3), dtype=torch.float32, device=device)
-            self.frame = torch.empty((height, width, 3), dtype=torch.float32, device=device)
+        self.stream = torch.cuda.Stream(device)            # render, collective hand-off, de-interleave
+        self.copy_stream = torch.cuda.Stream(device)       # frame -> pinned host memory
+        assert self.stream.cuda_stream != 0
+        self.primitive = collective_for() if world > 1 else None
+        with torch.cuda.stream(self.stream):
+            self.strip = [torch.empty((rows, width, 3), dtype=torch.float32, device=device) for _ in range(2)]
+            self.strips = self.frame = None
+            if world > 1 and (rank == 0 or self.primitive == "all_gather"):
+                self.strips = [torch.empty((world, rows, width, 3), dtype=torch.float32, device=device) for _ in range(2)]
+            if world > 1 and rank == 0:
+                self.frame = [torch.empty((height, width, 3), dtype=torch.float32, device=device) for _ in range(2)]
+        self.host_frame = torch.empty((height, width, 3), dtype=torch.float32, pin_memory=True) if self.to_host else None
+        self.copied = [None, None]        # event: the host copy that read buffer k has finished
+        self.pending = None               # (work, k) of the frame whose gather is in flight
+        self.k = 0
+        self.done_events = []             # one per completed frame when record_events is set
+        self.record_events = False
 
-    def step(self):
-        self.r.render_device(self.params, self.strip.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        if self.world == 1:
-            return self.strip[:self.H]
-        got = gather_strips(self.strip, self.rank, self.world, dst=0, out=self.strips)
+    # -- one frame ---------------------------------------------------------------------------------
+    def step(self, seed=None):
+        k = self.k & 1
+        self.k += 1
+        s = self.stream
+        with torch.cuda.stream(s):
+            if self.copied[k] is not None and self.world == 1:
+                s.wait_event(self.copied[k])           # the copy two frames ago still reads strip[k]
+            p = self.r.params(self.W, self.H, self.spp, self.max_bounces, seed=self.seed if seed is None else seed,
+                              row_block=self.row_block, rank=self.rank, world=self.world, kernel=self.kernel)
+            self.r.render_device(p, self.strip[k].data_ptr(), s.cuda_stream)
+            if self.world == 1:
+                self._deliver(self.strip[k][:self.H], k)
+                return
+            _, work = gather_strips(self.strip[k], self.rank, self.world, dst=0,
+                                    out=self.strips[k] if self.strips is not None else None,
+                                    primitive=self.primitive, async_op=True)
+            prev, self.pending = self.pending, (work, k)
+            if prev is not None:
+                self._finish(prev)
+
+    def _finish(self, pending):
+        work, k = pending
+        work.wait()                                        # self.stream waits for the collective (no host block on nccl)
         if self.rank == 0:
-            return assemble(got, self.H, self.row_block, self.world, renderer=self.r, out=self.frame)
-        return None
+            if self.copied[k] is not None:
+                self.stream.wait_event(self.copied[k])     # frame[k] is still being copied out
+            frame = assemble(self.strips[k], self.H, self.row_block, self.world, renderer=self.r,
+                             out=self.frame[k], stream=self.stream)
+            self._deliver(frame, k)
+
+    def _deliver(self, frame, k):
+        """frame (device, on self.stream) -> pinned host memory, on the copy stream."""
+        if self.to_host:
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+            self.copy_stream.wait_event(ready)
+            with torch.cuda.stream(self.copy_stream):
+                self.host_frame.copy_(frame, non_blocking=True)
+                done = torch.cuda.Event(enable_timing=self.record_events)
+                done.record(self.copy_stream)
+            self.copied[k] = done
+        else:
+            done = torch.cuda.Event(enable_timing=self.record_events)
+            done.record(self.stream)
+        if self.record_events:
+            self.done_events.append(done)
+
+    def flush(self):
+        """Complete every frame in flight; afterwards host_frame (rank 0) holds the last one."""
+        with torch.cuda.stream(self.stream):
+            prev, self.pending = self.pending, None
+            if prev is not None:
+                self._finish(prev)
+        self.stream.synchronize()
+        self.copy_stream.synchronize()
+
+    def render_now(self, seed=None):
+        """One frame, start to finish (no overlap): returns the host frame on rank 0 (a view of host_frame)."""
+        self.flush()
+        self.step(seed=seed)
+        self.flush()
+        return self.host_frame

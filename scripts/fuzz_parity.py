@@ -40,21 +40,22 @@ for case in range(cases):
     if jit:
         try: gpu.compile_scene()
         except rt.RtError: jit = False
-    chunks = rng.choice(["", "1", "2", "5", "64"])
-    if chunks: os.environ["RT_CHUNKS"] = chunks
-    else: os.environ.pop("RT_CHUNKS", None)
+    chunks = int(rng.choice([0, 1, 2, 5, 64]))
+    gpu.set_tuning(sample_chunks=chunks)
     got = gpu.render(W, H, spp, nb, seed=seed)
     ok = bool((bits(got) == bits(want)).all())
     world = int(rng.choice([2, 3, 8]))
     rows = rt.strip_rows(H, 8, world)
     strips = torch.zeros((world, rows, W, 3), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
     for rank in range(world):
         gpu.render_device(gpu.params(W, H, spp, nb, seed=seed, row_block=8, rank=rank, world=world), strips[rank].data_ptr())
     gpu.synchronize()
     frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
     gpu.deinterleave_device(strips.data_ptr(), frame.data_ptr(), W, H, 8, world); gpu.synchronize()
     ok2 = bool((bits(frame.cpu().numpy()) == bits(want)).all())
-    os.environ.pop("RT_CHUNKS", None)
+    gpu.set_tuning()
     if not (ok and ok2):
         bad += 1
         print(f"MISMATCH case {case}: n={n} {W}x{H} spp={spp} nb={nb} jit={jit} chunks={chunks!r} world={world} frame_ok={ok} strips_ok={ok2}", flush=True)

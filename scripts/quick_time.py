@@ -13,7 +13,7 @@ def main():
     g.profile(True)
     for name, scene, W, H, spp, nb in [("C1", 0, 1920, 1080, 64, 4), ("C2", 1, 1920, 1080, 256, 8), ("C3", 2, 3840, 2160, 64, 8), ("C4 on 1 GPU", 0, 3840, 2160, 1024, 8)]:
         g.set_scene(f"{rt.DATA_DIR}/scene_{scene}.txt")
-        if kernel == 0 and not os.environ.get("RT_NO_JIT"):
+        if kernel == 0 and not os.environ.get("NO_JIT"):
             g.compile_scene()
         g.render(W, H, 1, nb, kernel=kernel)
         g.profile_collect()

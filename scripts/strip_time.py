@@ -1,5 +1,5 @@
 """Kernel time of one rank's strip for world = 1, 2, 4, 8 on a single GPU (what each GPU of an N-GPU
-run executes), with the automatic sample chunking and with it disabled (RT_CHUNKS=1)."""
+run executes), with the automatic sample chunking and with it disabled (sample_chunks = 1)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,8 +12,7 @@ for world in (1, 2, 4, 8):
     rows = rt.strip_rows(H, 8, world)
     strip = torch.empty((rows, W, 3), dtype=torch.float32, device="cuda:0")
     for mode in ("auto", "1"):
-        if mode == "1": os.environ["RT_CHUNKS"] = "1"
-        else: os.environ.pop("RT_CHUNKS", None)
+        g.set_tuning(sample_chunks=1 if mode == "1" else 0)
         ts = []
         for rank in (0, world - 1):
             p = g.params(W, H, spp, nb, row_block=8, rank=rank, world=world)

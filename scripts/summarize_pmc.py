@@ -1,26 +1,49 @@
-"""Summarise rocprofv3 CSV output of scripts/profile_round.sh into one small text file."""
-import collections, csv, glob, os, sys
+"""Summarise rocprofv3 CSV output of scripts/profile_round.sh into one small text file (stdout) and, with a
+third argument, merge the traffic figures into profiles/pmc_latest.json (what bench.py reports as
+roofline.traffic).  usage: summarize_pmc.py gpurun_out/<tag> <config> [profiles/pmc_latest.json]"""
+import collections, csv, glob, json, os, sys
 root = sys.argv[1]
+config = sys.argv[2] if len(sys.argv) > 2 else "C1"
 lines = []
-for f in sorted(glob.glob(os.path.join(root, "stats", "*", "*_kernel_stats.csv"))):
+for f in sorted(glob.glob(os.path.join(root, "stats", "**", "*_kernel_stats.csv"), recursive=True)):
     lines.append(f"== kernel stats ({os.path.basename(f)})")
     lines += [l.rstrip() for l in open(f)]
-for d in ("pmc_valu", "pmc_fetch", "pmc_write"):
-    for f in sorted(glob.glob(os.path.join(root, d, "*", "*_counter_collection.csv"))):
-        agg = collections.defaultdict(list)
+totals = {}
+KERNELS = ("rt_trace", "rt_primary_pass", "rt_sum_samples")
+for d in ("pmc_valu", "pmc_busy", "pmc_fetch", "pmc_write"):
+    for f in sorted(glob.glob(os.path.join(root, d, "**", "*_counter_collection.csv"), recursive=True)):
+        per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
-            if "rt_trace" in r["Kernel_Name"]:
-                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        lines.append(f"== {d}: mean per launch of rt_trace_* over {max(map(len, agg.values()), default=0)} launches (C1, 1920x1080x64spp)")
-        for k in sorted(agg):
-            lines.append(f"{k:28s} {sum(agg[k]) / len(agg[k]):.6g}")
-        if "SQ_THREAD_CYCLES_VALU" in agg:
-            u = sum(agg["SQ_THREAD_CYCLES_VALU"]) / sum(agg["SQ_ACTIVE_INST_VALU"]) / 64
-            lines.append(f"{'VALU lane utilisation':28s} {u:.4f}   (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64)")
-        if "FETCH_SIZE" in agg:
-            kb = sum(agg["FETCH_SIZE"]) / len(agg["FETCH_SIZE"])
-            lines.append(f"{'HBM read bytes (FETCH_SIZE KiB x1024 x2, gfx950 correction)':28s} {kb * 1024 * 2:.6g}")
-        if "WRITE_SIZE" in agg:
-            kb = sum(agg["WRITE_SIZE"]) / len(agg["WRITE_SIZE"])
-            lines.append(f"{'HBM write bytes (WRITE_SIZE KiB x1024)':28s} {kb * 1024:.6g}")
+            for k in KERNELS:
+                if r["Kernel_Name"].startswith(k):
+                    per_kernel[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k in KERNELS:
+            agg = per_kernel.get(k)
+            if not agg:
+                continue
+            lines.append(f"== {d}: mean per launch of {k}* over {max(map(len, agg.values()), default=0)} launches ({config})")
+            for c in sorted(agg):
+                mean = sum(agg[c]) / len(agg[c])
+                lines.append(f"{c:28s} {mean:.6g}")
+                totals.setdefault(k, {})[c] = mean
+            if "SQ_THREAD_CYCLES_VALU" in agg:
+                u = sum(agg["SQ_THREAD_CYCLES_VALU"]) / sum(agg["SQ_ACTIVE_INST_VALU"]) / 64
+                lines.append(f"{'VALU lane utilisation':28s} {u:.4f}   (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64)")
+            if "SQ_ACTIVE_INST_VALU" in agg and "SQ_WAVE_CYCLES" in agg:
+                lines.append(f"{'VALU-active share of wave cycles':28s} {sum(agg['SQ_ACTIVE_INST_VALU']) / sum(agg['SQ_WAVE_CYCLES']):.4f}   (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, both in quad-cycles)")
+            if "FETCH_SIZE" in agg:
+                kb = sum(agg["FETCH_SIZE"]) / len(agg["FETCH_SIZE"])
+                lines.append(f"{'L2->fabric read bytes':28s} {kb * 1024:.6g}   (FETCH_SIZE KiB x 1024; x2 for wide streaming reads on gfx950: {kb * 2048:.6g})")
+            if "WRITE_SIZE" in agg:
+                kb = sum(agg["WRITE_SIZE"]) / len(agg["WRITE_SIZE"])
+                lines.append(f"{'L2->fabric write bytes':28s} {kb * 1024:.6g}   (WRITE_SIZE KiB x 1024)")
 print("\n".join(lines))
+if len(sys.argv) > 3:
+    path = sys.argv[3]
+    table = json.load(open(path)) if os.path.exists(path) else {}
+    fetch = sum(v.get("FETCH_SIZE", 0.0) for v in totals.values()) * 1024
+    write = sum(v.get("WRITE_SIZE", 0.0) for v in totals.values()) * 1024
+    table[config] = {"kernel": "rt_primary_pass + rt_trace_* (+ rt_sum_samples)", "fetch_bytes": fetch, "write_bytes": write,
+                     "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB x 1024, per frame = all kernels of one launch), {root}; "
+                               "reads are scattered 4-byte skybox gathers served by the Infinity Cache, so the x2 streaming correction is not applied"}
+    json.dump(table, open(path, "w"), indent=1, sort_keys=True)

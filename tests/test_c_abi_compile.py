@@ -4,6 +4,8 @@ import os
 import subprocess
 import textwrap
 
+import pytest
+
 import ray_tracing_amd as rt
 from rtlibs import ROOT
 
@@ -64,3 +66,42 @@ def test_header_is_valid_c11_and_links(tmp_path, scene_paths):
 
 def test_header_is_valid_cxx_and_links(tmp_path, scene_paths):
     _build_and_run(tmp_path, "g++", "-std=c++17", "host.cpp", scene_paths[0])
+
+
+REF_SRC = "/root/reference/src"
+
+REF_HOST = textwrap.dedent(r'''
+    /* A reference translation unit that binds the library: the reference's OWN headers supply Vector3, Scene,
+     * Cubemap (scene.h:3-47, vector.h:32-61, gpu_and_windowing.h:4-16); rt_hip.h adds only its own types. */
+    #include <stddef.h>
+    #include "vector.h"
+    #include "scene.h"
+    #include "gpu_and_windowing.h"
+    #define RT_HAVE_REFERENCE_TYPES
+    #include "rt_hip.h"
+
+    _Static_assert(sizeof(Scene) == 69636 && sizeof(Object) == 68 && sizeof(Cubemap) == 64, "reference layouts");
+
+    static Scene scene;
+    static Cubemap skybox;
+
+    int bind(rt_context *ctx, Vector3 *frame, int w, int h)
+    {
+        rt_render_params p;
+        rt_default_params(&p, w, h, 1, 10);
+        if (rt_set_scene(ctx, &scene) != RT_OK || rt_set_skybox(ctx, &skybox) != RT_OK) return -1;
+        if (rt_render(ctx, &p, frame) != RT_OK) return -1;
+        move_frame_to_the_gpu(w, h, frame);                 /* the reference's presenter, gpu_and_windowing.h:44 */
+        return sample_cubemap(&skybox, (Vector3) {0, 0, 1}).x >= 0;
+    }
+''')
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="the reference checkout is not on this machine")
+def test_header_compiles_against_the_reference_headers(tmp_path):
+    """The drop-in claim of INTEGRATION.md section 2: with RT_HAVE_REFERENCE_TYPES the boundary header takes
+    Scene / Cubemap / Vector3 from the reference's own scene.h, gpu_and_windowing.h and vector.h."""
+    src = tmp_path / "ref_host.c"
+    src.write_text(REF_HOST)
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-c", "-I", REF_SRC, "-I", os.path.join(ROOT, "include"),
+                    str(src), "-o", str(tmp_path / "ref_host.o")], check=True, capture_output=True, text=True)

@@ -27,18 +27,28 @@ def _worker(rank, world, port, W, H, rb, q):
     from rtlibs import DATA_DIR, Oracle, synthetic_skybox
     from ray_tracing_amd import multi_gpu as mg
     o = Oracle(); o.set_skybox(synthetic_skybox(32, seed=7)); o.load_scene(os.path.join(DATA_DIR, "scene_0.txt"))
+    assert mg.collective_for() == "gather"
     rows = mg.owned_rows(H, rb, rank, world)
-    strip = torch.zeros((len(rows), W, 3), dtype=torch.float32)
-    for lr, j in enumerate(rows):
-        if j >= 0:
-            strip[lr] = torch.from_numpy(o.render_counter(W, H, 2, 4, seed=3, rows=(int(j), int(j) + 1), threads=1)[j])
-    got = mg.gather_strips(strip, rank, world, dst=0)
+    ok = True
+    out = torch.empty((world, len(rows), W, 3), dtype=torch.float32) if rank == 0 else None
+    # two consecutive frames with different seeds through the same buffers (a stale strip would show), the
+    # first with the blocking call, the second with the asynchronous one TiledFrame uses
+    for frame_no, seed in enumerate((3, 4)):
+        strip = torch.zeros((len(rows), W, 3), dtype=torch.float32)
+        for lr, j in enumerate(rows):
+            if j >= 0:
+                strip[lr] = torch.from_numpy(o.render_counter(W, H, 2, 4, seed=seed, rows=(int(j), int(j) + 1), threads=1)[j])
+        got, work = mg.gather_strips(strip, rank, world, dst=0, out=out, async_op=frame_no == 1)
+        if work is not None:
+            work.wait()
+        if rank == 0:
+            frame = mg.assemble(got, H, rb, world)
+            full = o.render_counter(W, H, 2, 4, seed=seed, threads=2)
+            ok = ok and bool((frame.numpy().view(np.uint32) == full.view(np.uint32)).all())
+        else:
+            assert got is None
     if rank == 0:
-        frame = mg.assemble(got, H, rb, world)
-        full = o.render_counter(W, H, 2, 4, seed=3, threads=2)
-        q.put(bool((frame.numpy().view(np.uint32) == full.view(np.uint32)).all()))
-    else:
-        assert got is None
+        q.put(ok)
     dist.barrier()
     dist.destroy_process_group()
 

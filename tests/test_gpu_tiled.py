@@ -1,0 +1,88 @@
+"""The frame loop bench.py runs (ray_tracing_amd/multi_gpu.py TiledFrame): strip render -> gather ->
+de-interleave -> pinned host frame, two frames in flight, everything ordered on its own non-default stream.
+Every step uses a DIFFERENT seed, so a stale strip / frame (a stream-ordering bug) cannot look correct."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import ray_tracing_amd as rt
+from rtlibs import bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    r = rt.Renderer(0)
+    r.set_skybox(rt.load_skybox()); r.set_scene(os.path.join(rt.DATA_DIR, "scene_0.txt")); r.set_camera()
+    yield r
+    r.close()
+
+
+def test_pipelined_frames_world_1(gpu):
+    from ray_tracing_amd.multi_gpu import TiledFrame
+    W, H, spp, nb = 320, 180, 8, 4
+    want = {s: gpu.render(W, H, spp, nb, seed=s) for s in (1, 2, 3, 4, 5)}
+    t = TiledFrame(gpu, W, H, spp, nb, seed=1, rank=0, world=1, device=torch.device("cuda", 0))
+    for s in (1, 2, 3):
+        got = t.render_now(seed=s).numpy()
+        assert (bits(got) == bits(want[s])).all(), s
+    for s in (1, 2, 3, 4, 5):            # five frames back to back, two in flight
+        t.step(seed=s)
+    t.flush()
+    assert (bits(t.host_frame.numpy()) == bits(want[5])).all()
+    # the legacy null stream is a distinct, explicit choice (handle 0 -> RT_STREAM_LEGACY), not the context's stream
+    strip = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")     # filled on the null stream ...
+    gpu.render_device(gpu.params(W, H, spp, nb, seed=2), strip.data_ptr(), 0)   # ... rendered on the null stream: ordered
+    assert (bits(strip.cpu().numpy()) == bits(want[2])).all()                  # .cpu() syncs the null stream
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _nccl_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from ray_tracing_amd.multi_gpu import TiledFrame
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    g = rt.Renderer(rank)
+    g.set_skybox(rt.load_skybox()); g.set_scene(os.path.join(rt.DATA_DIR, "scene_0.txt")); g.set_camera()
+    W, H, spp, nb = 320, 180, 8, 4
+    t = TiledFrame(g, W, H, spp, nb, rank=rank, world=world, device=dev)
+    ok = True
+    for s in (1, 2, 3):
+        got = t.render_now(seed=s)
+        if rank == 0:
+            ok = ok and bool((bits(got.numpy()) == bits(g.render(W, H, spp, nb, seed=s))).all())
+    for s in (4, 5, 6, 7):
+        t.step(seed=s)
+    t.flush()
+    if rank == 0:
+        ok = ok and bool((bits(t.host_frame.numpy()) == bits(g.render(W, H, spp, nb, seed=7))).all())
+        q.put(ok)
+    dist.barrier()
+    g.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL gather between ranks)")
+def test_pipelined_frames_two_ranks_over_rccl():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
