@@ -10,7 +10,7 @@ for f in sorted(glob.glob(os.path.join(root, "stats", "**", "*_kernel_stats.csv"
     lines += [l.rstrip() for l in open(f)]
 totals = {}
 KERNELS = ("rt_trace", "rt_primary_pass", "rt_sum_samples")
-for d in ("pmc_valu", "pmc_busy", "pmc_fetch", "pmc_write"):
+for d in ("pmc_valu", "pmc_busy", "pmc_mix1", "pmc_mix2", "pmc_fetch", "pmc_write"):
     for f in sorted(glob.glob(os.path.join(root, d, "**", "*_counter_collection.csv"), recursive=True)):
         per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):

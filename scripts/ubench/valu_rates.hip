@@ -65,6 +65,28 @@ __global__ void __launch_bounds__(256) k(float *out, Stamp *stamps, int iters, f
 		if (WHICH == 17) { REP8(asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
 		                                     "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc"
 		                                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");) }
+		if (WHICH == 19) { F8("v_max3_f32", a, ) }
+		if (WHICH == 20) { F8("v_med3_f32", a, ) }
+		if (WHICH == 21) { G8("v_min_f32", a, b) }
+		if (WHICH == 22) { REP8(asm volatile("v_cmp_gt_f32 s[20:21], %0, %8\n v_cndmask_b32 %1, %1, %8, s[20:21]\n v_cmp_lt_f32 s[22:23], %2, %8\n v_cndmask_b32 %3, %3, %8, s[22:23]\n"
+		                                     "v_cmp_gt_f32 s[24:25], %4, %8\n v_cndmask_b32 %5, %5, %8, s[24:25]\n v_cmp_lt_f32 s[26:27], %6, %8\n v_cndmask_b32 %7, %7, %8, s[26:27]"
+		                                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");) }
+		if (WHICH == 23) { G8("v_xor_b32", u, u0) }
+		if (WHICH == 24) { G8("v_lshlrev_b32", u, u1) }
+		if (WHICH == 25) { G8("v_sub_f32", a, c) }
+		if (WHICH == 26) { G8("v_mul_hi_u32", u, u1) }
+		if (WHICH == 27) { REP8(asm volatile("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8"
+		                                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));) }
+		if (WHICH == 28) { REP8(asm volatile("v_cvt_f32_u32 %0, %8\n v_cvt_f32_u32 %1, %9\n v_cvt_f32_u32 %2, %8\n v_cvt_f32_u32 %3, %9\n v_cvt_f32_u32 %4, %8\n v_cvt_f32_u32 %5, %9\n v_cvt_f32_u32 %6, %8\n v_cvt_f32_u32 %7, %9"
+		                                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(u0), "v"(u1));) }
+		if (WHICH == 29) { REP8(asm volatile("v_add_co_u32 %0, vcc, %0, %8\n v_addc_co_u32 %1, vcc, %1, %9, vcc\n v_add_co_u32 %2, vcc, %2, %8\n v_addc_co_u32 %3, vcc, %3, %9, vcc\n"
+		                                     "v_add_co_u32 %4, vcc, %4, %8\n v_addc_co_u32 %5, vcc, %5, %9, vcc\n v_add_co_u32 %6, vcc, %6, %8\n v_addc_co_u32 %7, vcc, %7, %9, vcc"
+		                                     : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(0x9E3779B9u), "v"(0x7F4A7C15u) : "vcc");) }
+		if (WHICH == 30) { REP8(asm volatile("v_lshl_add_u64 %0, %0, 0, %8\n v_lshl_add_u64 %1, %1, 0, %8\n v_lshl_add_u64 %2, %2, 0, %8\n v_lshl_add_u64 %3, %3, 0, %8\n"
+		                                     "v_lshl_add_u64 %4, %4, 0, %8\n v_lshl_add_u64 %5, %5, 0, %8\n v_lshl_add_u64 %6, %6, 0, %8\n v_lshl_add_u64 %7, %7, 0, %8"
+		                                     : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3), "+v"(l4), "+v"(l5), "+v"(l6), "+v"(l7) : "v"(l0));) }
+		if (WHICH == 31) { REP8(asm volatile("v_and_b32 %0, %0, %8\n v_or_b32 %1, %1, %8\n v_and_b32 %2, %2, %8\n v_or_b32 %3, %3, %8\n v_bfe_u32 %4, %4, 3, 9\n v_lshrrev_b32 %5, 3, %5\n v_bfe_u32 %6, %6, 3, 9\n v_lshrrev_b32 %7, 3, %7"
+		                                     : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(0x9E3779B9u));) }
 		if (WHICH == 18) { REP8(asm volatile("v_cmp_gt_f32 vcc, %0, %8\n v_cmp_lt_f32 vcc, %1, %8\n v_cmp_gt_f32 vcc, %2, %8\n v_cmp_lt_f32 vcc, %3, %8\n"
 		                                     "v_cmp_gt_f32 vcc, %4, %8\n v_cmp_lt_f32 vcc, %5, %8\n v_cmp_gt_f32 vcc, %6, %8\n v_cmp_lt_f32 vcc, %7, %8"
 		                                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");) }
@@ -94,10 +116,14 @@ template <int W> void run(const char *name, float *d_out, Stamp *d_stamps, int c
 		std::vector<double> ticks, ghz;
 		for (auto &s : st) { ticks.push_back((double) s.ticks); ghz.push_back((double) s.ticks / (double) s.real * 0.1); }
 		std::sort(ticks.begin(), ticks.end()); std::sort(ghz.begin(), ghz.end());
+		/* cycles the SIMD spent per instruction = wall time x the clock the waves measured / instructions per SIMD
+		 * (a wave's own tick count only covers the time it was resident: with more waves than fit at once, or a
+		 * dispatcher that fills CUs unevenly, it under-counts -- the wall time does not) */
 		const double instr_per_simd = (double) wps * iters * 64.0;
-		const double real_cyc = ticks[ticks.size() / 2] / instr_per_simd;
-		const double nominal_cyc = ms * 1e-3 * 2.4e9 / instr_per_simd;
-		printf("  | %d w/SIMD: %5.2f clk @ %.2f GHz (wall@2.4: %5.2f)", wps, real_cyc, ghz[ghz.size() / 2], nominal_cyc);
+		const double clock_ghz = ghz[ghz.size() / 2];
+		const double real_cyc = ms * 1e-3 * clock_ghz * 1e9 / instr_per_simd;
+		const double wave_cyc = ticks[ticks.size() / 2] / ((double) iters * 64.0);
+		printf("  | %dw: %5.2f clk @%.2f GHz (wave: %5.1f)", wps, real_cyc, clock_ghz, wave_cyc);
 		hipEventDestroy(e0); hipEventDestroy(e1);
 	}
 	printf("\n");
@@ -115,6 +141,19 @@ int main()
 	run<2>("v_add_f32", d, s, cus);
 	run<13>("v_max_f32", d, s, cus);
 	run<12>("v_add_u32", d, s, cus);
+	run<25>("v_sub_f32", d, s, cus);
+	run<27>("v_mov_b32", d, s, cus);
+	run<21>("v_min_f32", d, s, cus);
+	run<19>("v_max3_f32", d, s, cus);
+	run<20>("v_med3_f32", d, s, cus);
+	run<23>("v_xor_b32", d, s, cus);
+	run<24>("v_lshlrev_b32", d, s, cus);
+	run<31>("v_and/or/bfe/lshr", d, s, cus);
+	run<29>("v_add_co/addc_co_u32", d, s, cus);
+	run<30>("v_lshl_add_u64", d, s, cus);
+	run<26>("v_mul_hi_u32", d, s, cus);
+	run<28>("v_cvt_f32_u32", d, s, cus);
+	run<22>("v_cmp->sgpr + v_cndmask", d, s, cus);
 	run<18>("v_cmp_f32 (vcc)", d, s, cus);
 	run<17>("v_cndmask_b32 (vcc)", d, s, cus);
 	run<11>("v_cmp + v_cndmask pairs", d, s, cus);
