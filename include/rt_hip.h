@@ -75,13 +75,14 @@ RT_API void rt_default_params(rt_render_params *p, int width, int height, int sp
  * particular code path.  0 / NULL = let the library decide.  Set per context, read at every launch; the
  * library never reads environment variables. */
 typedef struct {
-	int    sample_chunks;       /* work items per pixel: a pixel's spp samples are split into this many chunks
-	                             * that different lanes take (>= 1; clipped to spp) */
-	int    dequeue_shards;      /* work-item queues of the persistent waves: 1 or 64 */
+	int    pixel_streams;       /* pixels a wave adds up at the same time: 1, 2, 4 or 8 (64 / this many lanes share
+	                             * the samples of one pixel) */
+	int    dequeue_shards;      /* lists the object pixels are dealt from: 1 or 64 */
 	int    workgroups_per_cu;   /* resident workgroups per CU, 1..4 */
-	size_t scratch_limit_bytes; /* launches whose per-sample scratch would exceed this run unchunked (default 8 GiB) */
 	int    jit_waves_per_simd;  /* rt_compile_scene: register budget = 512 / this many VGPRs (default 4) */
 	const char *jit_flags;      /* rt_compile_scene: extra hiprtc options, space separated (copied) */
+	int    poison_frame;        /* testing aid: fill the destination with NaNs before every launch, so that a pixel the
+	                             * launch fails to write cannot pass for correct because an earlier frame left it there */
 } rt_tuning;
 RT_API void rt_default_tuning(rt_tuning *t);
 
@@ -112,7 +113,7 @@ RT_API int rt_render(rt_context *ctx, const rt_render_params *params, Vector3 *f
 /* Same, but the destination is DEVICE memory (rt_strip_rows()*width*12 bytes) and the call only
  * enqueues work on `hip_stream` (a hipStream_t; NULL = the context's own non-blocking stream;
  * RT_STREAM_LEGACY = the device's legacy null stream, which a literal 0 cannot name here).  No sync.
- * A context owns ONE set of launch scratch (work queues, primary-hit tables, sample planes): launches of one
+ * A context owns ONE set of launch scratch (work queues, primary-hit tables): launches of one
  * context are ordered one after another even when they are enqueued on different streams (a launch on a new
  * stream waits for the context's previous launch through an event), and rt_set_scene / rt_set_skybox wait
  * for the context's own launches only, not for the whole device. */

@@ -48,8 +48,9 @@ class RenderParams(C.Structure):
 
 
 class Tuning(C.Structure):
-    _fields_ = [("sample_chunks", C.c_int), ("dequeue_shards", C.c_int), ("workgroups_per_cu", C.c_int),
-                ("scratch_limit_bytes", C.c_size_t), ("jit_waves_per_simd", C.c_int), ("jit_flags", C.c_char_p)]
+    _fields_ = [("pixel_streams", C.c_int), ("dequeue_shards", C.c_int),
+                ("workgroups_per_cu", C.c_int), ("jit_waves_per_simd", C.c_int), ("jit_flags", C.c_char_p),
+                ("poison_frame", C.c_int)]
 
 
 STREAM_LEGACY = C.c_void_p(-1).value      # RT_STREAM_LEGACY: the device's legacy null stream
@@ -258,14 +259,17 @@ class Renderer:
             cam.fov = fov
         _check(lib().rt_set_camera(self._ctx, C.byref(cam)), "rt_set_camera")
 
-    def set_tuning(self, sample_chunks=0, dequeue_shards=0, workgroups_per_cu=0, scratch_limit_bytes=0,
-                   jit_waves_per_simd=0, jit_flags=None):
+    def set_tuning(self, pixel_streams=0, dequeue_shards=0, workgroups_per_cu=0,
+                   jit_waves_per_simd=0, jit_flags=None, poison_frame=None):
         """rt_set_tuning(): scheduling knobs (0 / None = automatic).  They never change a frame."""
         t = Tuning()
         lib().rt_default_tuning(C.byref(t))
-        t.sample_chunks, t.dequeue_shards, t.workgroups_per_cu = sample_chunks, dequeue_shards, workgroups_per_cu
-        t.scratch_limit_bytes, t.jit_waves_per_simd = scratch_limit_bytes, jit_waves_per_simd
+        t.pixel_streams, t.dequeue_shards = pixel_streams, dequeue_shards
+        t.workgroups_per_cu, t.jit_waves_per_simd = workgroups_per_cu, jit_waves_per_simd
         t.jit_flags = jit_flags.encode() if jit_flags else None
+        if poison_frame is not None:
+            self._poison = bool(poison_frame)
+        t.poison_frame = 1 if getattr(self, "_poison", False) else 0
         _check(lib().rt_set_tuning(self._ctx, C.byref(t)), "rt_set_tuning")
 
     @staticmethod

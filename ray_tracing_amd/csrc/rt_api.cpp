@@ -69,18 +69,11 @@ struct rt_context {
 	rt_camera    camera;
 	bool         have_camera = false;
 
-	unsigned int *d_counter = nullptr;   /* pixel-block counter of the persistent kernel */
+	unsigned int *d_counter = nullptr;   /* dequeue + fill counters of the pixel lists */
 	int          num_cus = 256;
 
-	float       *d_samples = nullptr;    /* per-sample colours of the chunked mode */
-	size_t       samples_bytes = 0;
-	unsigned char *d_direct = nullptr;   /* per-pixel "written directly" flags of the chunked mode */
-	size_t       direct_bytes = 0;
-	float       *d_blk_hits = nullptr;   /* rt_primary_pass outputs (rt_device.h) */
-	unsigned char *d_blk_list = nullptr;
-	int         *d_blk_count = nullptr;
-	unsigned int *d_obj_blocks = nullptr;
-	size_t       blk_capacity = 0;       /* pixel blocks the four buffers above hold */
+	float       *d_pix = nullptr;        /* rt_primary_pass output: pixel records (rt_device.h) */
+	size_t       pix_capacity = 0;       /* records it holds */
 
 	float       *d_frame = nullptr;      /* scratch for rt_render() */
 	size_t       frame_bytes = 0;
@@ -148,7 +141,8 @@ void rt_default_tuning(rt_tuning *t) { if (t) memset(t, 0, sizeof(*t)); }
 int rt_set_tuning(rt_context *ctx, const rt_tuning *t)
 {
 	if (!ctx || !t) return fail(RT_ERR_ARGUMENT, "rt_set_tuning: NULL argument");
-	if (t->sample_chunks < 0 || (t->dequeue_shards != 0 && t->dequeue_shards != 1 && t->dequeue_shards != 64) ||
+	auto pow2_upto = [](int v, int hi) { return v == 0 || (v >= 1 && v <= hi && (v & (v - 1)) == 0); };
+	if (!pow2_upto(t->pixel_streams, 8) || (t->dequeue_shards != 0 && t->dequeue_shards != 1 && t->dequeue_shards != 64) ||
 	    t->workgroups_per_cu < 0 || t->workgroups_per_cu > 4 || t->jit_waves_per_simd < 0 || t->jit_waves_per_simd > 8)
 		return fail(RT_ERR_ARGUMENT, "rt_set_tuning: value out of range");
 	ctx->tuning = *t;
@@ -205,7 +199,7 @@ void rt_destroy(rt_context *ctx)
 	if (ctx->last_launch) (void) hipEventDestroy(ctx->last_launch);
 	if (ctx->spec_module) (void) hipModuleUnload(ctx->spec_module);
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
-	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame); (void) hipFree(ctx->d_counter); (void) hipFree(ctx->d_samples); (void) hipFree(ctx->d_direct); (void) hipFree(ctx->d_blk_hits); (void) hipFree(ctx->d_blk_list); (void) hipFree(ctx->d_blk_count); (void) hipFree(ctx->d_obj_blocks);
+	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame); (void) hipFree(ctx->d_counter); (void) hipFree(ctx->d_pix);
 	(void) hipFree(ctx->prog.d_accum); (void) hipFree(ctx->prog.d_low); (void) hipFree(ctx->prog.d_out);
 	(void) hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -399,21 +393,33 @@ static hipEvent_t take_event(rt_context *ctx)
 
 static void give_event(rt_context *ctx, hipEvent_t e) { if (e) ctx->event_pool.push_back(e); }
 
-/* buffers rt_primary_pass fills for the trace kernel: sized by the launch's 8x8 pixel blocks, grown on demand */
-static int attach_block_buffers(rt_context *ctx, rt_launch &L)
+/* Scheduling parameters of the wavefront kernels for one launch (rt_device.h) and the pixel lists rt_primary_pass
+ * fills for the trace kernel (grown on demand).  Any schedule renders the same frame. */
+static int prepare_launch(rt_context *ctx, rt_launch &L)
 {
-	const size_t blocks = (size_t) ((L.width + 7) / 8) * (size_t) ((L.local_rows + 7) / 8);
-	if (blocks > ctx->blk_capacity) {
-		(void) hipFree(ctx->d_blk_hits); (void) hipFree(ctx->d_blk_list); (void) hipFree(ctx->d_blk_count); (void) hipFree(ctx->d_obj_blocks);
-		ctx->d_blk_hits = nullptr; ctx->d_blk_list = nullptr; ctx->d_blk_count = nullptr; ctx->d_obj_blocks = nullptr; ctx->blk_capacity = 0;
-		HIP_TRY(hipMalloc((void**) &ctx->d_blk_hits, blocks * 7 * 64 * sizeof(float)));
-		HIP_TRY(hipMalloc((void**) &ctx->d_blk_list, blocks * 64));
-		HIP_TRY(hipMalloc((void**) &ctx->d_blk_count, blocks * sizeof(int)));
-		HIP_TRY(hipMalloc((void**) &ctx->d_obj_blocks, blocks * sizeof(unsigned int)));
-		ctx->blk_capacity = blocks;
+	const long long pixel_blocks = (long long) ((L.width + 7) / 8) * ((L.local_rows + 7) / 8);
+	const long long waves = (long long) ctx->num_cus * 16;                    /* resident waves of the persistent kernel */
+	const long long pixels_per_wave = pixel_blocks * 64 / (waves > 0 ? waves : 1);
+	int streams = 8;
+	while (streams > 1 && pixels_per_wave < 4LL * streams) streams >>= 1;       /* about four pixels per stream, at least */
+	if (ctx->tuning.pixel_streams) streams = ctx->tuning.pixel_streams;
+	L.num_streams = streams;
+	/* 64 lists (a single dequeue counter takes ~88 atomics per microsecond: 4 K waves asking for their first pixels at
+	 * once would already queue up) unless the launch is small */
+	L.num_shards = (pixel_blocks >= 64 * 16 && ctx->num_cus >= 64) ? 64 : 1;
+	if (ctx->tuning.dequeue_shards) L.num_shards = ctx->tuning.dequeue_shards;
+
+	const size_t cap = rt_pixel_list_capacity(L.width, L.local_rows, ctx->num_cus, L.num_shards);
+	const size_t records = cap * (size_t) L.num_shards;
+	if (cap > (size_t) 0x7fffffff) return fail(RT_ERR_ARGUMENT, "render: frame too large");
+	if (records > ctx->pix_capacity) {
+		(void) hipFree(ctx->d_pix); ctx->d_pix = nullptr; ctx->pix_capacity = 0;
+		HIP_TRY(hipMalloc((void**) &ctx->d_pix, records * 12 * sizeof(float)));
+		ctx->pix_capacity = records;
 	}
-	L.blk_hits = ctx->d_blk_hits; L.blk_list = ctx->d_blk_list; L.blk_count = ctx->d_blk_count; L.obj_blocks = ctx->d_obj_blocks;
-	L.obj_block_count = ctx->d_counter + rt_counter_bytes() / sizeof(unsigned int) - 32;     /* last 128-byte line of the counter block */
+	L.pix = ctx->d_pix;
+	L.pix_shard_cap = (int) cap;
+	L.pix_count = ctx->d_counter + rt_counter_bytes() / sizeof(unsigned int) / 2;     /* second half of the counter block */
 	return RT_OK;
 }
 
@@ -448,51 +454,10 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.sky_wm1 = (float) (ctx->sky_w - 1); L.sky_hm1 = (float) (ctx->sky_h - 1);
 	L.frame = (float*) d_strip;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
-	L.num_chunks = 1; L.chunk_spp = p->spp; L.samples = nullptr; L.direct = nullptr;
-	L.num_shards = 1;
-	/* Few pixels per GPU (multi-GPU strips, small frames): one lane per pixel cannot fill the chip, so a
-	 * pixel's samples are split over several lanes and summed afterwards in sample order. */
-	if (p->kernel != RT_KERNEL_SIMPLE && p->max_bounces >= 1 && p->spp > 1) {
-		const long long pixel_blocks = (long long) ((p->width + 7) / 8) * ((L.local_rows + 7) / 8);
-		/* Work items are (8x8 pixel block with object pixels, chunk of samples).  Measured (scripts/chunk_sweep.py,
-		 * scripts/ab.py with AB_CHUNKS_*): items of about 8 samples balance the persistent waves' tails best
-		 * (C1: 8 chunks, C2: 32), and a launch wants about 24 items per resident wave (multi-GPU strips). */
-		const long long want_blocks = (long long) ctx->num_cus * 16 * 24;
-		int chunks = (p->spp + 7) / 8;
-		if (pixel_blocks > 0 && pixel_blocks * chunks < want_blocks) chunks = (int) ((want_blocks + pixel_blocks - 1) / pixel_blocks);
-		if (chunks > 32) chunks = 32;
-		if (ctx->tuning.sample_chunks > 0) chunks = ctx->tuning.sample_chunks;    /* measurement / test override */
-		if (chunks > p->spp) chunks = p->spp;
-		if (chunks > 1) {
-			const int chunk_spp = (p->spp + chunks - 1) / chunks;
-			chunks = (p->spp + chunk_spp - 1) / chunk_spp;
-			const size_t pixels = (size_t) L.local_rows * p->width;
-			const size_t need = (size_t) p->spp * pixels * 3 * sizeof(float);
-			const size_t limit = ctx->tuning.scratch_limit_bytes ? ctx->tuning.scratch_limit_bytes : (size_t) 8 << 30;
-			if (chunks > 1 && need <= limit) {
-				if (need > ctx->samples_bytes) {
-					(void) hipFree(ctx->d_samples); ctx->d_samples = nullptr; ctx->samples_bytes = 0;
-					HIP_TRY(hipMalloc((void**) &ctx->d_samples, need));
-					ctx->samples_bytes = need;
-				}
-				if (pixels > ctx->direct_bytes) {
-					(void) hipFree(ctx->d_direct); ctx->d_direct = nullptr; ctx->direct_bytes = 0;
-					HIP_TRY(hipMalloc((void**) &ctx->d_direct, pixels));
-					ctx->direct_bytes = pixels;
-				}
-				L.num_chunks = chunks; L.chunk_spp = chunk_spp; L.samples = ctx->d_samples; L.direct = ctx->d_direct;
-			}
-		}
-	}
-
-	/* 64 dequeue counters instead of one (a single address takes ~88 atomics per microsecond: 16 K waves asking for
-	 * their first item at once already cost ~0.2 ms) unless the launch is too small to give every queue its
-	 * workgroups and a fair share of items */
-	if ((long long) ((p->width + 7) / 8) * ((L.local_rows + 7) / 8) * L.num_chunks >= 64 * 64 && ctx->num_cus >= 64) L.num_shards = 64;
-	if (ctx->tuning.dequeue_shards) L.num_shards = ctx->tuning.dequeue_shards;
-
-	{ const int rc = attach_block_buffers(ctx, L); if (rc != RT_OK) return rc; }
+	{ const int rc = prepare_launch(ctx, L); if (rc != RT_OK) return rc; }
 	{ const int rc = order_behind_previous(ctx, stream); if (rc != RT_OK) return rc; }
+	if (ctx->tuning.poison_frame)
+		HIP_TRY(hipMemsetAsync(d_strip, 0xff, (size_t) rt_strip_rows(p->height, p->row_block, p->world) * p->width * 3 * sizeof(float), stream));
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (ctx->profiling) {
 		e0 = take_event(ctx); e1 = take_event(ctx);
@@ -507,8 +472,6 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 		else { give_event(ctx, e0); give_event(ctx, e1); }                 /* a failed launch keeps no events */
 	}
 	if (le != hipSuccess) return fail(RT_ERR_DEVICE, "trace launch: %s", hipGetErrorString(le));
-	if (L.num_chunks > 1)
-		HIP_TRY(rt_launch_sum_samples(L.samples, L.direct, L.frame, (size_t) L.local_rows * L.width * 3, L.spp, stream));
 	return mark_launch(ctx, stream);
 }
 
@@ -616,9 +579,9 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.sky_wm1 = (float) (ctx->sky_w - 1); L.sky_hm1 = (float) (ctx->sky_h - 1);
 	L.frame = g.d_low;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
-	L.num_chunks = 1; L.chunk_spp = 1; L.samples = nullptr; L.direct = nullptr; L.num_shards = 1;
-	{ const int rc = attach_block_buffers(ctx, L); if (rc != RT_OK) return rc; }
+	{ const int rc = prepare_launch(ctx, L); if (rc != RT_OK) return rc; }
 	{ const int rc = order_behind_previous(ctx, ctx->stream); if (rc != RT_OK) return rc; }
+	if (ctx->tuning.poison_frame) HIP_TRY(hipMemsetAsync(g.d_low, 0xff, g.low_bytes, ctx->stream));
 	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream));
 	const float weight = 1.0f / (s * s);                                         /* main.c:278 */
 	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), ctx->stream));

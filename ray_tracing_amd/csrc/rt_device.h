@@ -72,20 +72,17 @@ typedef struct {
 	float sky_wm1, sky_hm1;    /* (float)(w - 1), (float)(h - 1): the texel scale of gpu_and_windowing.c:103-104 */
 
 	float *frame;              /* local_rows x width x 3 floats, resolved      */
-	/* sample chunking (few pixels per GPU): a pixel's spp samples are split into num_chunks work
-	 * items of chunk_spp samples so that more lanes than pixels can be busy; each clamped sample is
-	 * stored to samples[s][pixel][3] and rt_sum_samples adds them in sample order (main.c:394).
-	 * num_chunks == 1: the lane sums its pixel itself and writes `frame`. */
-	int    num_shards;         /* work-item queues in use (1 or 64), see wavefront_body */
-	int    num_chunks, chunk_spp;
-	float *samples;
-	unsigned char *direct;     /* per local pixel, set by rt_primary_pass: 1 = finished there (sky-only), 0 = sum its samples */
-	/* written by rt_primary_pass, read by the trace kernels (per 8x8 pixel block of the strip) */
-	float *blk_hits;           /* [block][7][64]: camera-ray hit of each pixel: point xyz, normal xyz, object (-1 sky, -2 outside) */
-	unsigned char *blk_list;   /* [block][64]: the block's object pixels (index in block), compacted */
-	int   *blk_count;          /* [block]: entries in blk_list */
-	unsigned int *obj_blocks;  /* blocks with at least one object pixel, in the order they were found */
-	unsigned int *obj_block_count;
+	/* scheduling of the wavefront kernels (any values give the same frame):
+	 *   num_shards   pixel lists in use (1 or 64), each with its own fill and dequeue counter
+	 *   num_streams  pixels a wave adds up at the same time (power of two, 1..8): 64 / num_streams lanes share the
+	 *                samples of one pixel */
+	int    num_shards, num_streams;
+	/* written by rt_primary_pass, read by the trace kernels: one 12-word record per object pixel (camera-ray hit
+	 * point xyz, normal xyz, object, camera ray xyz, RNG pixel index, offset in the strip), word k of record c at
+	 * pix[k * num_shards * pix_shard_cap + c]; list s holds records s * pix_shard_cap ... + pix_count[32 * s] */
+	float *pix;
+	unsigned int *pix_count;   /* one fill counter per list, 128 bytes apart */
+	int    pix_shard_cap;
 	const rt_geom  *geom;      /* num_objects records (global; staged to LDS)  */
 	const rt_shade *shade;
 } rt_launch;

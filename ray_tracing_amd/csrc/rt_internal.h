@@ -9,6 +9,8 @@
 size_t     rt_counter_bytes();
 size_t     rt_scene_lds_bytes(int num_objects);
 size_t     rt_wavefront_lds_bytes(int num_objects);
+void       rt_primary_geometry(int width, int local_rows, int num_cus, unsigned int *groups_out, int *per_group_out);
+size_t     rt_pixel_list_capacity(int width, int local_rows, int num_cus, int num_shards);
 /* spec_fn: kernel compiled by rt_compile_scene for the current scene, or nullptr */
 hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, hipFunction_t spec_fn,
                            unsigned int *block_counter, int num_cus, int workgroups_per_cu, hipStream_t stream);
@@ -18,7 +20,6 @@ hipError_t rt_launch_deinterleave(const float *strips, float *frame, int width, 
 
 hipError_t rt_launch_accumulate(float *accum, const float *lowres, int width, int height, int scale,
                                 int low_w, int low_h, float k, hipStream_t stream);
-hipError_t rt_launch_sum_samples(const float *samples, const unsigned char *direct, float *frame, size_t plane_floats, int spp, hipStream_t stream);
 hipError_t rt_launch_resolve(const float *accum, float *frame, size_t floats, float inv_count, hipStream_t stream);
 hipError_t rt_launch_selftest(int which, uint64_t seed, int blocks, int iters, unsigned long long *d_out, hipStream_t stream);
 

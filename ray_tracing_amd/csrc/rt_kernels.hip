@@ -10,8 +10,7 @@
  *   rt_primary_pass      camera rays of all pixels, once per launch: sky-only pixels are finished, the rest is handed on
  *   rt_trace_wavefront   the tuned schedule: persistent waves, per-wave LDS ray queue, exact shortcuts
  *   rt_trace_spec        the same, recompiled by hiprtc with the scene as constants (rt_compile_scene)
- *   rt_sum_samples       sums chunked samples in sample order; rt_accumulate / rt_resolve (progressive
- *                        passes); rt_deinterleave (multi-GPU root); rt_selftest_kernel
+ *   rt_accumulate / rt_resolve (progressive passes); rt_deinterleave (multi-GPU root); rt_selftest_kernel
  * One lane owns one path at a time and the samples of a pixel are always added in sample order
  * (main.c:394), whichever kernel runs.  Scene geometry and shading records are staged once per
  * workgroup into LDS and read with wave-uniform (broadcast) ds_read_b128; the skybox stays in HBM /
@@ -420,6 +419,11 @@ RT_DEV V3 sky_lookup(const rt_launch &L, V3 dir) { return sky_colour<FAST>(sky_t
 
 /* ---- pixel mapping --------------------------------------------------------------------------- */
 
+RT_DEV int lanes_below(unsigned long long m)      /* number of set bits of m below this lane */
+{
+	return (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u));
+}
+
 RT_DEV int global_row(int row_block, int rank, int world, int local_row)
 {
 	return ((local_row / row_block) * world + rank) * row_block + local_row % row_block;
@@ -556,9 +560,11 @@ rt_trace_simple(const rt_launch L)
  * rt_primary_pass: the camera ray of every pixel, once per launch.  The reference has no sub-pixel jitter
  * (main.c:293-296), so bounce 0 of every sample of a pixel is the same ray: one wave per 8x8 pixel block traces
  * the block's 64 camera rays, finishes its sky-only pixels on the spot -- every sample is clamp(0 + sky * 1)
- * (main.c:171,267-269), summed in sample order and resolved (main.c:394,476) -- and leaves for the trace kernel
- * the hits of the other pixels, their compacted list, and the list of blocks that have any.
+ * (main.c:171,267-269), summed in sample order and resolved (main.c:394,476) -- and appends a 12-word record
+ * per OBJECT pixel (hit point, normal, object, camera ray, RNG pixel index, frame offset) to one of
+ * L.num_shards pixel lists, from which the trace kernel's waves deal pixels to their lanes.
  * ============================================================================================= */
+#define RT_PIX_WORDS 12
 template <bool FAST>
 __global__ void __launch_bounds__(RT_BLOCK)
 rt_primary_pass(const rt_launch L, int blocks_per_group)
@@ -569,12 +575,11 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int tiles_x = (L.width + 7) >> 3, tiles_y = (L.local_rows + 7) >> 3;
 	const unsigned int total = (unsigned int) (tiles_x * tiles_y);
-	/* the workgroup's share of the blocks: blocks_per_group consecutive ones; the ones that have object pixels
-	 * are collected in LDS and appended to L.obj_blocks with ONE atomic per workgroup (a single address takes
-	 * ~88 atomics per microsecond: one per block would cost more than the camera rays) */
-	unsigned int *found = reinterpret_cast<unsigned int*>(lds + 6 * n);      /* count, blocks_per_group ids, base */
-	if (threadIdx.x == 0) found[0] = 0;
-	__syncthreads();
+	/* the workgroup's share of the blocks: blocks_per_group consecutive ones.  Its object pixels go to list
+	 * blockIdx.x % num_shards: one atomic per block with object pixels, spread over the lists' counters (a single
+	 * address takes ~88 atomics per microsecond: one counter for all blocks would cost more than the camera rays) */
+	const unsigned int shard = blockIdx.x % (unsigned int) L.num_shards;
+	const size_t plane = (size_t) L.pix_shard_cap * (size_t) L.num_shards;
 	const V3 cam = ld3(L.pos);
 	const float inv_spp = 1.0f / (float) L.spp;
 	const unsigned int first = blockIdx.x * (unsigned int) blocks_per_group;
@@ -584,17 +589,16 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 		const int i = (int) (blk % (unsigned int) tiles_x) * 8 + (lane & 7), lr = (int) (blk / (unsigned int) tiles_x) * 8 + (lane >> 3);
 		const int j = global_row(L, lr);
 		int obj = -2;                                   /* outside the frame */
-		V3 a = mk3(0, 0, 0), nn = mk3(0, 0, 0);
+		V3 a = mk3(0, 0, 0), nn = mk3(0, 0, 0), pd = mk3(0, 0, 0);
 		if (i < L.width && lr < L.local_rows && j < L.height) {
 			float u = (float) i / (float) L.u_den;      /* main.c:293-296 */
 			float v = (float) j / (float) L.v_den;
 			u = 1.0f - u;
 			v = 1.0f - v;
-			const V3 pd = primary_dir(L, u, v);
+			pd = primary_dir(L, u, v);
 			const V3 dn = FAST ? unit3_fast(pd) : unit3(pd);                           /* scene.c:158 */
 			const Hit hit = FAST ? nearest_hit_fast(sc, n, cam, dn) : nearest_hit(sc, n, cam, dn);
 			obj = hit.obj;
-			if (L.num_chunks > 1) L.direct[(size_t) lr * L.width + i] = obj < 0;      /* 1: finished here, rt_sum_samples skips it */
 			if (obj >= 0) {
 				a = madd3(cam, dn, hit.t);                                               /* scene.c:186 */
 				nn = hit.n;
@@ -609,30 +613,24 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 			}
 		}
 		else if (i < L.width && lr < L.local_rows) {    /* padding row of a strip (multi_gpu.py): inside the buffer, outside the frame */
-			if (L.num_chunks > 1) L.direct[(size_t) lr * L.width + i] = 1;
 			float *dst = L.frame + ((size_t) lr * L.width + i) * 3;
 			dst[0] = 0.0f; dst[1] = 0.0f; dst[2] = 0.0f;
 		}
 		const unsigned long long om = __ballot(obj >= 0);
 		if (om) {                                       /* sky-only blocks leave nothing behind */
-			float *dst = L.blk_hits + (size_t) blk * (7 * 64) + lane;
-			dst[0] = a.x; dst[64] = a.y; dst[128] = a.z; dst[192] = nn.x; dst[256] = nn.y; dst[320] = nn.z; dst[384] = __int_as_float(obj);
-			if (obj >= 0)
-				L.blk_list[(size_t) blk * 64 + __builtin_amdgcn_mbcnt_hi((unsigned int) (om >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) om, 0u))] = (unsigned char) lane;
-			if (lane == 0) {
-				L.blk_count[blk] = __popcll(om);
-				found[1 + atomicAdd(&found[0], 1u)] = blk;
+			unsigned int base = 0;
+			if (lane == 0) base = atomicAdd(L.pix_count + shard * 32u, (unsigned int) __popcll(om));
+			base = (unsigned int) __builtin_amdgcn_readfirstlane((int) base);
+			if (obj >= 0) {
+				float *dst = L.pix + (size_t) shard * L.pix_shard_cap + base + (unsigned int) lanes_below(om);
+				dst[0] = a.x;  dst[plane] = a.y;  dst[2 * plane] = a.z;
+				dst[3 * plane] = nn.x; dst[4 * plane] = nn.y; dst[5 * plane] = nn.z;
+				dst[6 * plane] = __int_as_float(obj);
+				dst[7 * plane] = pd.x; dst[8 * plane] = pd.y; dst[9 * plane] = pd.z;
+				dst[10 * plane] = __uint_as_float((uint32_t) ((j * L.pix_scale) * L.pix_width + i * L.pix_scale));   /* main.c:286 order */
+				dst[11 * plane] = __int_as_float(lr * L.width + i);
 			}
 		}
-	}
-	__syncthreads();
-	const unsigned int mine = found[0];
-	if (mine) {
-		unsigned int *base_slot = found + 1 + blocks_per_group;
-		if (threadIdx.x == 0) *base_slot = atomicAdd(L.obj_block_count, mine);     /* the group's range in L.obj_blocks */
-		__syncthreads();
-		const unsigned int base = *base_slot;
-		for (unsigned int k = threadIdx.x; k < mine; k += RT_BLOCK) L.obj_blocks[base + k] = found[1 + k];
 	}
 }
 #endif /* RT_SPEC_ONLY */
@@ -645,9 +643,10 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
  * per lane (main.c:194), so most trace_ray() instructions run on half-empty waves.  Here every
  * wave is a small wavefront path tracer of its own:
  *
- *   - persistent waves pull 8x8 pixel blocks from a global counter; inside a wave a lane that
- *     finishes a pixel takes the next one of the wave's current block (ballot + mbcnt prefix),
- *     so a lane never waits for its neighbours' pixels;
+ *   - persistent waves pull object pixels, a few at a time, from the lists rt_primary_pass filled (global
+ *     counters); inside a wave every free lane takes the next SAMPLE of a pixel the wave is working on
+ *     (ballot + mbcnt prefix), so a lane never waits for its neighbours and a pixel's samples run on several
+ *     lanes at once (a 1080p frame has about as many object pixels as the chip has lanes);
  *   - a path lives in its lane's registers, but the RAYS it needs traced (next bounce ray +
  *     up to three shadow taps, all known right after shading because the taps only feed the
  *     light term that is added afterwards, main.c:257-261) are compacted into a per-wave LDS
@@ -660,15 +659,21 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
  *   - the primary hit is traced once per pixel, by rt_primary_pass, and re-used by all samples (the
  *     reference has no sub-pixel jitter, main.c:293-296, so bounce 0 of every sample is the same ray):
  *     bit-exact; sky-only pixels never reach this kernel;
- *   - when a launch has few pixels per wave (multi-GPU strips) a pixel's samples are split into
- *     chunks that different lanes take; samples are then stored and summed by rt_sum_samples.
- * The per-pixel sample sum is still formed in sample order (main.c:394), so results are
- * bit-identical to rt_trace_simple and to the CPU oracle.
+ *   - the samples of a pixel are ADDED IN SAMPLE ORDER (main.c:394) although they finish in any order on
+ *     any lane: a finished sample's clamped colour goes into a slot of a per-wave LDS window (its slot was
+ *     reserved, in sample order, when the sample was handed out), and at the end of every round one lane per
+ *     pixel stream adds the slots that have become contiguous, resolves a pixel whose last sample went in
+ *     (main.c:476) and writes it -- 12 bytes per pixel -- to the frame.  No sample ever leaves the chip.
+ * Results are bit-identical to rt_trace_simple and to the CPU oracle.
  * ============================================================================================= */
 
-#define RT_COUNTER_BYTES (65 * 128)     /* WF_SHARDS counters, one per 128-byte line, + rt_primary_pass's block count */
-#define WF_SHARDS  64                  /* work-item queues (counters 128 B apart), see wavefront_body */
+#define WF_SHARDS  64                  /* pixel lists (at most); each has a fill counter and a dequeue counter, 128 B apart */
+#define RT_COUNTER_BYTES (2 * WF_SHARDS * 128)
 #define WF_QUEUE   128                 /* ring: at most 63 waiting + 64 pushed at a time */
+#define WF_STREAMS 8                   /* pixels a wave adds up concurrently (at most) */
+#define WF_WINDOW  256                 /* sample slots per wave, shared equally by its streams */
+#define WF_EMPTY   0xffffffffu         /* window slot not written yet (a colour channel is in [0,1]: never this pattern) */
+#define WF_LAST    0x8000              /* slot word: this sample is the last one of its pixel */
 #define REC_VALID    1                /* per-bounce record handed from the front to the back (wavefront_body) */
 #define REC_SPECULAR 2
 #define REC_LAST     4                /* the path ends after this bounce ...               */
@@ -680,13 +685,16 @@ struct WaveLDS {
 	unsigned short qmeta[WF_QUEUE];    /* owner lane | kind << 8 | parity << 12                      */
 	float res[7][64];                  /* bounce-ray result per owner lane: xyz, nxyz, obj          */
 	short tap[2][3][64];               /* shadow tap results per owner lane (object index < 1024 or -1), by parity of the round that queued them */
-	float blk[7][64];                  /* primary hits of the current pixel block, by pixel in block */
-	float cache[7][64];                /* per-lane copy of its pixel's primary hit                  */
-	/* per-block tables written when the block is taken, so that handing a pixel to a lane is a few LDS reads */
-	float colv[3][8];                  /* llc + horiz*u for the block's 8 columns (camera.c:121, left to right) */
-	float rowv[3][8];                  /* vert*v for its 8 rows                                      */
-	int   rowpart[8];                  /* (j*pix_scale)*pix_width: row part of the RNG pixel index   */
-	unsigned char list[64];            /* the block's object pixels (index in block), compacted      */
+	/* Sample window.  Stream g (one pixel at a time, pixels one after another) owns slots [g*WF_WINDOW/P, (g+1)*WF_WINDOW/P)
+	 * as a ring indexed by the sequence number of the sample within the stream.  win[0] holds the red channel
+	 * with bit 31 = "last sample of its pixel" (red is >= +0, and adding +0 for a -0 changes no sum), or WF_EMPTY;
+	 * the slot after a pixel's last sample holds the pixel's frame offset instead of a colour. */
+	float win[3][WF_WINDOW];
+	float rec[12][WF_STREAMS];         /* the stream's current pixel: primary hit xyz, normal xyz, object, camera ray xyz, RNG pixel index, frame offset */
+	unsigned int s_nxt[WF_STREAMS];    /* next sample of the current pixel to hand out (== spp: the stream needs a pixel) */
+	unsigned int s_seq[WF_STREAMS];    /* slots reserved so far (sequence number of the next one) */
+	unsigned int s_drained[WF_STREAMS];/* slots added up and released so far */
+	float s_sum[3][WF_STREAMS];        /* running sum of the pixel being added up */
 };
 
 /* The launch record as the code that takes a new pixel block reads it.  Kernel arguments are invariant, so the
@@ -710,6 +718,30 @@ RT_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 
 template <bool FAST> RT_DEV V3 unit3_sel(V3 v) { return FAST ? unit3_fast(v) : unit3(v); }
 
+/* the value the lane below holds (lane 0: zero); every lane must be active */
+RT_DEV float from_lane_below(float v)
+{
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+
+/* What a path needs to know about its pixel; filled by the lane that hands the pixel out. */
+struct PixelRec { V3 a, n; int obj; V3 dir; uint32_t index; int off; };
+
+/* record c of the pixel lists rt_primary_pass filled */
+RT_DEV PixelRec load_pixel(rt_launch_cold C, size_t c)
+{
+	const size_t plane = (size_t) C->pix_shard_cap * (size_t) C->num_shards;
+	const float *src = C->pix + c;
+	PixelRec p;
+	p.a = mk3(src[0], src[plane], src[2 * plane]);
+	p.n = mk3(src[3 * plane], src[4 * plane], src[5 * plane]);
+	p.obj = __float_as_int(src[6 * plane]);
+	p.dir = mk3(src[7 * plane], src[8 * plane], src[9 * plane]);
+	p.index = __float_as_uint(src[10 * plane]);
+	p.off = __float_as_int(src[11 * plane]);
+	return p;
+}
+
 template <bool FAST>
 RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 {
@@ -719,13 +751,17 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + 6 * n)[wave];
 
-	const int tiles_x = (L.width + 7) >> 3;
-	const bool chunked = L.num_chunks > 1;
-	const size_t sample_stride = (size_t) L.local_rows * L.width * 3;      /* floats per sample plane */
 	const float inv_spp = 1.0f / (float) L.spp;
-	/* work items: (block with object pixels, chunk of samples); rt_primary_pass counted and listed the blocks */
-	const unsigned int num_blocks = (unsigned int) __builtin_amdgcn_readfirstlane((int) *L.obj_block_count) * (unsigned int) L.num_chunks;
-	const V3 cam = ld3(L.pos);
+	const unsigned int spp = (unsigned int) L.spp;
+	/* spp == 1 (progressive passes): a pixel is its one sample, nothing has to be ordered -- every lane takes a
+	 * pixel for itself and writes it when the path retires.  Otherwise the wave runs P pixel streams. */
+	const bool direct = L.spp == 1;
+	const int P = L.num_streams;                            /* power of two, 1..WF_STREAMS */
+	const int G = 64 / P;                                   /* lanes whose home stream is the same */
+	const int g = lane / G;                                 /* this lane's home stream */
+	const bool leader = (lane & (G - 1)) == 0;              /* does the bookkeeping of a stream */
+	const unsigned int wn = (unsigned int) (WF_WINDOW / P); /* slots per stream */
+	const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (lane & ~(G - 1));
 #ifdef RT_SPEC_HEADER
 	const bool have_light = SPEC_LIGHT >= 0;               /* the compiled scene's emitter: literals, no scalar registers */
 	const V3 light_pos = mk3(SPEC_LIGHT_POS[0], SPEC_LIGHT_POS[1], SPEC_LIGHT_POS[2]);
@@ -734,28 +770,32 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	const bool have_light = L.light_index >= 0;
 #endif
 
-	/* wave-uniform pixel supply: the wave owns one 8x8 pixel block (and one chunk of its samples) at a time.
-	 * When it takes a new one it loads the block's camera-ray hits and its list of object pixels (rt_primary_pass)
-	 * into W.blk / W.list and fills the block's column/row tables; lanes then take listed pixels as they become
-	 * free. */
-	int  tile_i0 = 0, tile_lr0 = 0;         /* frame column / strip row of the block's first pixel */
-	int  cur_s0 = 0, cur_s1 = L.spp;        /* its sample range (one chunk of the pixels' samples) */
-	int  cur_next = 0, cur_count = 0;       /* next entry of W.list to hand out, entries in it */
-	bool blk_done = true;                   /* nothing left to hand out: take another block */
+	for (int k = lane; k < WF_WINDOW; k += 64) W.win[0][k] = __uint_as_float(WF_EMPTY);
+	if (lane < WF_STREAMS) {
+		W.s_nxt[lane] = spp; W.s_seq[lane] = 0u; W.s_drained[lane] = 0u;
+		W.s_sum[0][lane] = 0.0f; W.s_sum[1][lane] = 0.0f; W.s_sum[2][lane] = 0.0f;
+	}
+	wave_fence();
+
+	/* wave-uniform pixel supply: object pixels are dealt from the lists rt_primary_pass filled, each with its own
+	 * dequeue counter on its own 128-byte line (one counter saturates at ~88 dequeues/us, MI355X_MICROARCH.md).  A
+	 * wave starts at the list of its workgroup and moves on to the next one when a list has run out. */
+	unsigned int shard = blockIdx.x % (unsigned int) L.num_shards;
+	int  shards_left = L.num_shards;        /* lists this wave has not yet found empty */
 	bool exhausted = false;
 
-	/* per-lane path state */
-	int   px_off = -1;                      /* the back's pixel: row * width + column inside the strip; < 0: none */
-	int   f_off = -1, f_end = 0;            /* the front's pixel and the end of its sample range */
-	uint32_t pixel_index = 0;               /* its index for the RNG seed (main.c:286 order) */
-	/* A path is worked on at two places one round apart.  The FRONT (section 2) turns the pending hit into the
-	 * next rays: it owns rng, bounce, fsample and the hit.  The BACK (section 5) does the radiance arithmetic
-	 * of a bounce (main.c:232,248,257-261) one round later, when its shadow taps are certainly traced: it owns
-	 * rad, carry, sum, sample.  `prev` is the record of the bounce the front shaded in the previous round. */
-	int   sample = 0, fsample = 0, sample_end = 0, bounce = 0;
+	/* per-lane path state.  A path is worked on at two places one round apart.  The FRONT (section 2) turns the
+	 * pending hit into the next rays: it owns rng, bounce, the hit and f_slot.  The BACK (section 5) does the
+	 * radiance arithmetic of a bounce (main.c:232,248,257-261) one round later, when its shadow taps are certainly
+	 * traced: it owns rad, carry and b_slot.  `prev` is the record of the bounce the front shaded in the previous
+	 * round.  A slot word is the window slot the sample's colour goes to (| WF_LAST); in direct mode, the pixel's
+	 * frame offset. */
+	bool  f_live = false;                   /* the front is on a sample */
+	int   f_slot = 0, b_slot = 0;
+	int   bounce = 0;
 	bool  has_hit = false;
-	V3    sum = mk3(0, 0, 0), carry = mk3(1, 1, 1), rad = mk3(0, 0, 0);
-	V3    hp = mk3(0, 0, 0), hn = mk3(0, 0, 0), hdir = mk3(0, 0, 0), pdir = mk3(0, 0, 0);
+	V3    carry = mk3(1, 1, 1), rad = mk3(0, 0, 0);
+	V3    hp = mk3(0, 0, 0), hn = mk3(0, 0, 0), hdir = mk3(0, 0, 0);
 	uint32_t end_sky = 0;                   /* sky texel that ends the sample of `prev` (REC_SKY): fetched when the bounce ray
 	                                         * is found to have left the scene, converted a round later when it is used */
 	int   hobj = -1;
@@ -764,89 +804,155 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	/* the ray queue persists across rounds: taps that do not fill a batch wait for the next round's rays */
 	unsigned int q_head = 0, q_tail = 0, parity = 0;
 
+	/* Section 6 of a round: adding the finished samples in sample order (main.c:394).  Lane j of a stream's group
+	 * looks at the j-th slot after the stream's last added one.  The slots that are filled without a gap from the
+	 * first form the run; their colours are added to the stream's running sum one after the other -- lane j's
+	 * partial sum is lane j-1's plus its own colour, passed along with DPP lane shifts, all streams in lockstep --
+	 * and a pixel whose last sample is in the run is resolved (main.c:476) and written by the lane that holds the
+	 * frame-offset slot behind it; the sum restarts at 0 there.  Every lane of the wave must be active. */
+	auto add_finished_samples = [&]() {
+		bool again;
+		do {
+			STAT(23);
+			const unsigned int d = W.s_drained[g], seq = W.s_seq[g];
+			const unsigned int j = (unsigned int) lane & (unsigned int) (G - 1);
+			const unsigned int slot = d + j;
+			const unsigned int e = (unsigned int) g * wn + (slot & (wn - 1u));
+			uint32_t xb = WF_EMPTY;
+			if ((int) (seq - slot) > 0) xb = __float_as_uint(W.win[0][e]);
+			const bool filled = xb != WF_EMPTY;
+			const unsigned long long fm = __ballot(filled);
+			const unsigned long long lm = __ballot(filled && (xb >> 31) != 0u);      /* last samples of their pixels */
+			const int gbase = lane & ~(G - 1);
+			const unsigned long long gap = ~(fm >> gbase);
+			int k = gap != 0ull ? (int) __builtin_ctzll(gap) : 64;                      /* length of the run */
+			if (k > G) k = G;
+			/* a pixel's last sample and the offset slot behind it stay in the same pass */
+			const bool cut = k == G && ((lm >> (gbase + G - 1)) & 1ull) != 0ull;
+			if (cut) k = G - 1;
+			const bool active = (int) j < k;
+			const bool offset_slot = active && j > 0u && ((lm >> ((lane - 1) & 63)) & 1ull) != 0ull;
+			V3 c = mk3(0, 0, 0);
+			if (active && !offset_slot) c = mk3(__uint_as_float(xb & 0x7fffffffu), W.win[1][e], W.win[2][e]);
+			if (j == 0u) c = add3(mk3(W.s_sum[0][g], W.s_sum[1][g], W.s_sum[2][g]), c);   /* the running sum enters at the first lane */
+			const uint32_t keep = (j == 0u || offset_slot) ? 0u : 0xffffffffu;     /* what comes from the lane below counts */
+			V3 sum = c;
+			for (unsigned int t = 1u; __ballot(active && j >= t) != 0ull; t++)      /* after step t lanes j <= t are final */
+				sum = mk3(__uint_as_float(__float_as_uint(from_lane_below(sum.x)) & keep) + c.x,
+				          __uint_as_float(__float_as_uint(from_lane_below(sum.y)) & keep) + c.y,
+				          __uint_as_float(__float_as_uint(from_lane_below(sum.z)) & keep) + c.z);
+			const V3 total = mk3(from_lane_below(sum.x), from_lane_below(sum.y), from_lane_below(sum.z));
+			if (offset_slot) {                  /* the pixel below is complete: resolve and write it (main.c:476) */
+				const V3 res = scale3(total, inv_spp);
+				float *dst = L.frame + (size_t) xb * 3;
+				dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+			}
+			if (active) W.win[0][e] = __uint_as_float(WF_EMPTY);
+			if (active && (int) j == k - 1) {
+				W.s_drained[g] = d + (unsigned int) k;
+				W.s_sum[0][g] = sum.x; W.s_sum[1][g] = sum.y; W.s_sum[2][g] = sum.z;
+			}
+			again = __ballot(k == G || cut) != 0ull;       /* a full run: more may be waiting behind it */
+			wave_fence();
+		} while (again);
+	};
+
 	for (;; parity ^= 1u) {
-		/* ---- 1. pixel supply --------------------------------------------------------------- */
+		/* ---- 1. sample supply ---------------------------------------------------------------
+		 * Lanes whose front is free take new samples.  A lane asks its home stream first and, in the following
+		 * attempts, the streams next to it (stream (g + attempt) mod P is asked by exactly one group of lanes per
+		 * attempt, so the group's leader lane does that stream's bookkeeping).  A stream hands out the samples of
+		 * its pixel in order, each with the next slot of the stream's window; when the pixel has none left the
+		 * stream takes the next object pixel of the wave's work item. */
 #pragma unroll 1
 		for (int attempt = 0; attempt < 4; attempt++) {
-			const bool want = f_off < 0 && (chunked || px_off < 0);
+			const bool want = !f_live;
 			const unsigned long long wmask = __ballot(want);
 			if (wmask == 0ull) break;
-			if (blk_done) {
-				if (exhausted) break;
-				/* Work items are dealt from `num_shards` interleaved queues (item = shard + num_shards * k), each
-				 * with its own counter on its own 128-byte line: one counter saturates at ~88 dequeues/us
-				 * (MI355X_MICROARCH.md), which a 4K frame of cheap items exceeds.  A wave pulls only from the
-				 * queue of its workgroup; the queues hold equal, interleaved shares of the items.  The host uses
-				 * one queue unless the frame has >= 100k pixel blocks. */
+			const int sg = (g + attempt) & (P - 1);
+			const unsigned long long gm = wmask & gmask;              /* wanting lanes of my group */
+			STAT(20);
+			unsigned int nxt = 0;
+			bool need_pixel = want;
+			if (!direct) {
+				nxt = W.s_nxt[sg];
+				need_pixel = leader && gm != 0ull && nxt >= spp;
+			}
+			const unsigned long long nmask = __ballot(need_pixel);
+			if (nmask != 0ull) {
+				STAT(21);
 				const rt_launch_cold C = cold_view();
-				const unsigned int shards = (unsigned int) C->num_shards, chunks = (unsigned int) C->num_chunks;
-				unsigned int b = 0;
-				if (lane == 0) b = atomicAdd(block_counter + (blockIdx.x % shards) * 32u, 1u);
-				b = (unsigned int) __builtin_amdgcn_readfirstlane((int) b);
-				b = blockIdx.x % shards + shards * b;
-				if (b >= num_blocks) { exhausted = true; break; }
-				const unsigned int blk = (unsigned int) __builtin_amdgcn_readfirstlane((int) C->obj_blocks[b / chunks]);
-				/* the block's camera-ray hits and its list of object pixels come from rt_primary_pass */
-				{
-					const float *src = C->blk_hits + (size_t) blk * (7 * 64) + lane;
-#pragma unroll
-					for (int k = 0; k < 7; k++) W.blk[k][lane] = src[k * 64];
-					W.list[lane] = C->blk_list[(size_t) blk * 64 + lane];
+				const int asked = __popcll(nmask);
+				int got = 0;
+				size_t first = 0;
+				if (!exhausted) {
+					unsigned int k = 0;
+					if (lane == 0) k = atomicAdd(block_counter + shard * 32u, (unsigned int) asked);
+					k = (unsigned int) __builtin_amdgcn_readfirstlane((int) k);
+					const unsigned int filled = (unsigned int) __builtin_amdgcn_readfirstlane((int) C->pix_count[shard * 32u]);
+					got = k < filled ? (filled - k < (unsigned int) asked ? (int) (filled - k) : asked) : 0;
+					first = (size_t) shard * (size_t) C->pix_shard_cap + k;
+					if (got < asked) {                  /* this list has run out: the rest is served from the next one */
+						shard = (shard + 1u) % (unsigned int) C->num_shards;
+						if (--shards_left == 0) exhausted = true;
+					}
 				}
-				cur_count = __builtin_amdgcn_readfirstlane(C->blk_count[blk]);
-				cur_next = 0; blk_done = false;
-				const int chunk_spp = C->chunk_spp, spp = C->spp;
-				cur_s0 = (int) (b % chunks) * chunk_spp;
-				cur_s1 = cur_s0 + chunk_spp < spp ? cur_s0 + chunk_spp : spp;
-				tile_i0 = (int) (blk % (unsigned int) tiles_x) * 8;
-				tile_lr0 = (int) (blk / (unsigned int) tiles_x) * 8;
-				const int i = tile_i0 + (lane & 7), lr = tile_lr0 + (lane >> 3);
-				const int j = global_row(C->row_block, C->rank, C->world, lr);
-				float u = (float) i / (float) C->u_den;                     /* main.c:293-296 */
-				float v = (float) j / (float) C->v_den;
-				u = 1.0f - u;
-				v = 1.0f - v;
-				/* camera.c:121: ((llc + horiz*u) + vert*v) - pos, split into its column and row parts */
-				const V3 cv = mk3(C->llc[0] + C->horiz[0] * u, C->llc[1] + C->horiz[1] * u, C->llc[2] + C->horiz[2] * u);
-				const V3 rv = mk3(C->vert[0] * v, C->vert[1] * v, C->vert[2] * v);
-				if (lane < 8) { W.colv[0][lane] = cv.x; W.colv[1][lane] = cv.y; W.colv[2][lane] = cv.z; }
-				if ((lane & 7) == 0) {
-					const int r = lane >> 3;
-					W.rowv[0][r] = rv.x; W.rowv[1][r] = rv.y; W.rowv[2][r] = rv.z;
-					W.rowpart[r] = (j * C->pix_scale) * C->pix_width;
+				const int rr = lanes_below(nmask);
+				if (need_pixel && rr < got) {
+					const PixelRec px = load_pixel(C, first + (size_t) rr);
+					if (direct) {
+						f_slot = px.off; f_live = true;
+						rng = path_seed(L.seed, px.index, (uint32_t) L.sample_base);
+						bounce = 0;
+						hp = px.a; hn = px.n; hobj = px.obj; hdir = px.dir;
+						has_hit = true;
+					} else {
+						W.rec[0][sg] = px.a.x;   W.rec[1][sg] = px.a.y;   W.rec[2][sg] = px.a.z;
+						W.rec[3][sg] = px.n.x;   W.rec[4][sg] = px.n.y;   W.rec[5][sg] = px.n.z;
+						W.rec[6][sg] = __int_as_float(px.obj);
+						W.rec[7][sg] = px.dir.x; W.rec[8][sg] = px.dir.y; W.rec[9][sg] = px.dir.z;
+						W.rec[10][sg] = __uint_as_float(px.index);
+						W.rec[11][sg] = __int_as_float(px.off);
+						W.s_nxt[sg] = 0u;
+					}
 				}
 				wave_fence();
 			}
-			const int rank_in = __builtin_amdgcn_mbcnt_hi((unsigned int) (wmask >> 32),
-			                    __builtin_amdgcn_mbcnt_lo((unsigned int) wmask, 0u));
-			const int avail = cur_count - cur_next;
-			if (want && rank_in < avail) {
-				const int q = W.list[cur_next + rank_in];
-				const int c = q & 7, r = q >> 3;
-				f_off = (tile_lr0 + r) * L.width + tile_i0 + c;
-				pixel_index = (uint32_t) (W.rowpart[r] + (tile_i0 + c) * L.pix_scale);
-				pdir = sub3(add3(mk3(W.colv[0][c], W.colv[1][c], W.colv[2][c]), mk3(W.rowv[0][r], W.rowv[1][r], W.rowv[2][r])), cam);
-				const V3 a = mk3(W.blk[0][q], W.blk[1][q], W.blk[2][q]);
-				const V3 nn = mk3(W.blk[3][q], W.blk[4][q], W.blk[5][q]);
-				const int obj = __float_as_int(W.blk[6][q]);
-				W.cache[0][lane] = a.x;  W.cache[1][lane] = a.y;  W.cache[2][lane] = a.z;
-				W.cache[3][lane] = nn.x; W.cache[4][lane] = nn.y; W.cache[5][lane] = nn.z;
-				W.cache[6][lane] = __int_as_float(obj);
-				fsample = cur_s0; f_end = cur_s1; bounce = 0;
-				rng = path_seed(L.seed, pixel_index, (uint32_t) (L.sample_base + fsample));
-				if (px_off < 0) {                   /* the back is idle: it follows at once */
-					px_off = f_off; sample = fsample; sample_end = f_end; sum = mk3(0, 0, 0);
-					carry = mk3(1, 1, 1); rad = mk3(0, 0, 0); prev = 0;
+			if (!direct) {
+				nxt = W.s_nxt[sg];
+				const unsigned int seq = W.s_seq[sg], drained = W.s_drained[sg];
+				/* samples the pixel still has, and slots free in the stream's window (one is kept back for the
+				 * frame-offset slot that follows a pixel's last sample) */
+				const int left = (int) spp - (int) nxt, room = (int) wn - 1 - (int) (seq - drained);
+				const int avail = left < room ? left : room;
+				const int r = lanes_below(gm);
+				if (want && r < avail) {
+					STAT(22);
+					const unsigned int s = nxt + (unsigned int) r, slot = seq + (unsigned int) r;
+					const bool last = s + 1u == spp;
+					f_slot = (int) ((unsigned int) sg * wn + (slot & (wn - 1u))) | (last ? WF_LAST : 0);
+					if (last) W.win[0][(unsigned int) sg * wn + ((slot + 1u) & (wn - 1u))] = W.rec[11][sg];
+					rng = path_seed(L.seed, __float_as_uint(W.rec[10][sg]), (uint32_t) L.sample_base + s);
+					bounce = 0;
+					hp = mk3(W.rec[0][sg], W.rec[1][sg], W.rec[2][sg]);
+					hn = mk3(W.rec[3][sg], W.rec[4][sg], W.rec[5][sg]);
+					hobj = __float_as_int(W.rec[6][sg]);
+					hdir = mk3(W.rec[7][sg], W.rec[8][sg], W.rec[9][sg]);
+					has_hit = true; f_live = true;
 				}
-				hp = a; hn = nn; hobj = obj; hdir = pdir;
-				has_hit = true;
+				if (leader && gm != 0ull && avail > 0) {
+					const int asked = __popcll(gm);
+					const unsigned int handed = (unsigned int) (asked < avail ? asked : avail);
+					W.s_nxt[sg] = nxt + handed;
+					W.s_seq[sg] = seq + handed + (nxt + handed == spp ? 1u : 0u);
+				}
+				wave_fence();
 			}
-			const int taken = __popcll(wmask);
-			cur_next += taken < avail ? taken : avail;
-			if (cur_next >= cur_count) blk_done = true;
 		}
-		if (__ballot(px_off >= 0 || f_off >= 0) == 0ull) {
-			if (exhausted && blk_done) break;
+		if (__ballot(f_live || (prev & REC_VALID) != 0) == 0ull) {
+			/* nothing in flight: every reserved slot is filled, so whatever is still waiting can be added now */
+			if (!direct && __ballot(W.s_drained[g] != W.s_seq[g]) != 0ull) { add_finished_samples(); continue; }
+			if (exhausted) break;
 			continue;
 		}
 
@@ -869,6 +975,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			const V3 f0 = mk3(m0.x, m0.y, m0.z), omf0 = mk3(m1.x, m1.y, m1.z);
 
 			const float n_dot_v = clamp01(dot3(hn, neg3(hdir)));
+			/* main.c:128: (float) pow(1.0 - (double) u, 5.0) == x2*x2*x in fp64 for every float u in [0,1] (tests/test_pow5.py) */
 			const double xg = 1.0 - (double) n_dot_v;
 			const double xg2 = xg * xg;
 			const float grazing = (float) (xg2 * xg2 * xg);
@@ -905,8 +1012,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		auto push = [&](bool on, V3 qo, V3 qd, int k) {
 			const unsigned long long m = __ballot(on);
 			if (on) {
-				const unsigned int slot = (q_tail + __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32),
-				                           __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u))) & (WF_QUEUE - 1);
+				const unsigned int slot = (q_tail + (unsigned int) lanes_below(m)) & (WF_QUEUE - 1);
 				W.q[0][slot] = qo.x; W.q[1][slot] = qo.y; W.q[2][slot] = qo.z;
 				W.q[3][slot] = qd.x; W.q[4][slot] = qd.y; W.q[5][slot] = qd.z;
 				W.qmeta[slot] = (unsigned short) (lane | (k << 8) | (int) (parity << 12));
@@ -957,88 +1063,70 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		}
 
 		/* ---- 5. back: retire the bounce shaded one round ago (its taps are traced by now), take this round's
-		 * bounce-ray result, and move the front to the next sample when the path has ended ------------------ */
+		 * bounce-ray result, and free the front when the path has ended --------------------------------------- */
 		STAT(16);
-		if (px_off >= 0) {
+		if (prev & REC_VALID) {
 			STAT(17);
-			if (prev & REC_VALID) {
-				const int pobj = prev >> 8, ptaps = (prev >> 4) & 7;
-				const float4 m2 = sc.shade[4 * pobj + 2], m3 = sc.shade[4 * pobj + 3];
-				rad = add3(rad, had3(mk3(m3.x, m3.y, m3.z), carry));                    /* main.c:232 */
-				if (!(prev & REC_SPECULAR)) carry = had3(carry, mk3(m2.x, m2.y, m2.z));  /* main.c:248 */
-				if (ptaps) {
-					V3 lit = mk3(0, 0, 0);
-					int taps = 0;
+			const int pobj = prev >> 8, ptaps = (prev >> 4) & 7;
+			const float4 m2 = sc.shade[4 * pobj + 2], m3 = sc.shade[4 * pobj + 3];
+			rad = add3(rad, had3(mk3(m3.x, m3.y, m3.z), carry));                    /* main.c:232 */
+			if (!(prev & REC_SPECULAR)) carry = had3(carry, mk3(m2.x, m2.y, m2.z));  /* main.c:248 */
+			if (ptaps) {
+				V3 lit = mk3(0, 0, 0);
+				int taps = 0;
 #pragma unroll
-					for (int k = 0; k < 3; k++)
-						if ((ptaps >> k) & 1) {
-							const int obj = W.tap[parity ^ 1u][k][lane];
-							if (obj >= 0) { const float4 e = sc.shade[4 * obj + 3]; lit = add3(lit, mk3(e.x, e.y, e.z)); }
-							taps++;
-						}
-					/* main.c:208-209: 1.0f / num_samples, num_samples in 1..3 (the quotients as literals; RN(1/3) = 0x3eaaaaab) */
-					lit = scale3(lit, FAST ? (taps == 1 ? 1.0f : (taps == 2 ? 0.5f : __uint_as_float(0x3eaaaaabu))) : 1.0f / (float) taps);
-					const bool dark = FAST ? (tiny_f_fast(lit.x) && tiny_f_fast(lit.y) && tiny_f_fast(lit.z))
-					                       : (tiny_f(lit.x) && tiny_f(lit.y) && tiny_f(lit.z));
-					if (!dark) {                                                      /* main.c:257-261 */
-						const float w = 0.05f;
-						rad = madd3(rad, had3(lit, carry), w);
-						carry = scale3(carry, 1.0f - w);
+				for (int k = 0; k < 3; k++)
+					if ((ptaps >> k) & 1) {
+						const int obj = W.tap[parity ^ 1u][k][lane];
+						if (obj >= 0) { const float4 e = sc.shade[4 * obj + 3]; lit = add3(lit, mk3(e.x, e.y, e.z)); }
+						taps++;
 					}
-				}
-				if (prev & REC_LAST) {              /* the path ended with that bounce: sky (main.c:171) or bounce limit (main.c:158) */
-					if (prev & REC_SKY) rad = add3(rad, had3(sky_colour<FAST>(end_sky), carry));
-					const V3 col = mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z));     /* main.c:267-269 */
-					if (chunked) {
-						float *dst = L.samples + (size_t) sample * sample_stride + (size_t) px_off * 3;
-						dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
-					} else
-						sum = add3(sum, col);                                                /* main.c:394 */
-					sample++;
-					carry = mk3(1, 1, 1); rad = mk3(0, 0, 0);
-					if (sample >= sample_end) {
-						if (!chunked) {
-							const V3 res = scale3(sum, inv_spp);                     /* main.c:476 */
-							float *dst = L.frame + (size_t) px_off * 3;
-							dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
-						}
-						px_off = -1;
-						if (f_off >= 0) {           /* the front is already on the next pixel: follow it */
-							px_off = f_off; sample = fsample; sample_end = f_end; sum = mk3(0, 0, 0);
-						}
-					}
+				/* main.c:208-209: 1.0f / num_samples, num_samples in 1..3 (the quotients as literals; RN(1/3) = 0x3eaaaaab) */
+				lit = scale3(lit, FAST ? (taps == 1 ? 1.0f : (taps == 2 ? 0.5f : __uint_as_float(0x3eaaaaabu))) : 1.0f / (float) taps);
+				const bool dark = FAST ? (tiny_f_fast(lit.x) && tiny_f_fast(lit.y) && tiny_f_fast(lit.z))
+				                       : (tiny_f(lit.x) && tiny_f(lit.y) && tiny_f(lit.z));
+				if (!dark) {                                                      /* main.c:257-261 */
+					const float w = 0.05f;
+					rad = madd3(rad, had3(lit, carry), w);
+					carry = scale3(carry, 1.0f - w);
 				}
 			}
-			prev = cur;
-			if (cur & REC_VALID) {
-				bool path_ended = true;                                  /* bounce limit (main.c:158) */
-				if (emit_main) {
-					const int obj = __float_as_int(W.res[6][lane]);
-					const V3 a = mk3(W.res[0][lane], W.res[1][lane], W.res[2][lane]);
-					if (obj < 0) {
-						STAT(14);
-						end_sky = sky_texel<FAST>(L, a); prev |= REC_LAST | REC_SKY;               /* main.c:163-172 */
-					} else {
-						hp = a; hn = mk3(W.res[3][lane], W.res[4][lane], W.res[5][lane]); hobj = obj;
-						has_hit = true; path_ended = false;
-					}
+			if (prev & REC_LAST) {              /* the path ended with that bounce: sky (main.c:171) or bounce limit (main.c:158) */
+				if (prev & REC_SKY) rad = add3(rad, had3(sky_colour<FAST>(end_sky), carry));
+				const V3 col = mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z));     /* main.c:267-269 */
+				if (direct) {                   /* the pixel's only sample: 0 + colour (main.c:394), resolved (main.c:476) */
+					const V3 res = scale3(add3(mk3(0, 0, 0), col), inv_spp);
+					float *dst = L.frame + (size_t) b_slot * 3;
+					dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+				} else {                        /* into its slot of the window; section 6 adds it when its turn comes */
+					const unsigned int e = (unsigned int) b_slot & (WF_WINDOW - 1);
+					W.win[1][e] = col.y; W.win[2][e] = col.z;
+					W.win[0][e] = __uint_as_float((__float_as_uint(col.x) & 0x7fffffffu) | ((b_slot & WF_LAST) ? 0x80000000u : 0u));
 				}
-				if (path_ended) {
-					fsample++;
-					if (fsample >= f_end) f_off = -1;     /* item done: the front may take another pixel */
-					else {                               /* the front starts the next sample from the pixel's primary hit */
-						rng = path_seed(L.seed, pixel_index, (uint32_t) (L.sample_base + fsample));
-						bounce = 0;
-						hp = mk3(W.cache[0][lane], W.cache[1][lane], W.cache[2][lane]);
-						hn = mk3(W.cache[3][lane], W.cache[4][lane], W.cache[5][lane]);
-						hobj = __float_as_int(W.cache[6][lane]);
-						hdir = pdir;
-						has_hit = true;
-					}
-				}
+				carry = mk3(1, 1, 1); rad = mk3(0, 0, 0);
 			}
 		}
+		prev = cur;
+		if (cur & REC_VALID) {
+			b_slot = f_slot;
+			bool path_ended = true;                                  /* bounce limit (main.c:158) */
+			if (emit_main) {
+				const int obj = __float_as_int(W.res[6][lane]);
+				const V3 a = mk3(W.res[0][lane], W.res[1][lane], W.res[2][lane]);
+				if (obj < 0) {
+					STAT(14);
+					end_sky = sky_texel<FAST>(L, a); prev |= REC_LAST | REC_SKY;               /* main.c:163-172 */
+				} else {
+					hp = a; hn = mk3(W.res[3][lane], W.res[4][lane], W.res[5][lane]); hobj = obj;
+					has_hit = true; path_ended = false;
+				}
+			}
+			if (path_ended) f_live = false;      /* the front takes its next sample at the top of the next round */
+		}
 		wave_fence();
+
+		/* ---- 6. add the finished samples in sample order (main.c:394) ---------------------------------------- */
+		if (!direct) add_finished_samples();
 	}
 }
 
@@ -1074,39 +1162,6 @@ rt_accumulate(float *accum, const float *lowres, int width, int height, int scal
 		const float *c = lowres + ((size_t) j * low_w + i) * 3;
 		float *a = accum + p * 3;
 		a[0] = a[0] + c[0] * k; a[1] = a[1] + c[1] * k; a[2] = a[2] + c[2] * k;
-	}
-}
-
-/* chunked mode: add a pixel's stored samples in sample order and resolve (main.c:394,476).  Pixels
- * flagged in `direct` (sky-only pixels) were written by the trace kernel itself and are skipped. */
-extern "C" __global__ void __launch_bounds__(RT_BLOCK)
-rt_sum_samples(const float *samples, const unsigned char *direct, float *frame, size_t plane_floats, int spp, float inv_spp)
-{
-	/* 16 B per lane: four independent sequential sums per thread, coalesced across the wave */
-	const size_t quads = plane_floats / 4;
-	for (size_t q = (size_t) blockIdx.x * RT_BLOCK + threadIdx.x; q < quads; q += (size_t) gridDim.x * RT_BLOCK) {
-		const size_t p0 = (4 * q) / 3, p1 = (4 * q + 3) / 3;          /* the (at most two) pixels these four floats belong to */
-		const bool d0 = direct[p0] != 0, d1 = direct[p1] != 0;
-		if (d0 && d1) continue;
-		float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-		for (int s = 0; s < spp; s++) {
-			const float4 v = *reinterpret_cast<const float4*>(samples + (size_t) s * plane_floats + 4 * q);
-			acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
-		}
-		float *dst = frame + 4 * q;
-		if (!d0 && !d1)
-			*reinterpret_cast<float4*>(dst) = make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp);
-		else {
-			const float r[4] = { acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp };
-			for (int k = 0; k < 4; k++)
-				if (!direct[(4 * q + k) / 3]) dst[k] = r[k];
-		}
-	}
-	for (size_t p = quads * 4 + (size_t) blockIdx.x * RT_BLOCK + threadIdx.x; p < plane_floats; p += (size_t) gridDim.x * RT_BLOCK) {
-		if (direct[p / 3]) continue;
-		float acc = 0.0f;
-		for (int s = 0; s < spp; s++) acc = acc + samples[(size_t) s * plane_floats + p];
-		frame[p] = acc * inv_spp;
 	}
 }
 
@@ -1295,12 +1350,6 @@ hipError_t rt_launch_accumulate(float *accum, const float *lowres, int width, in
 	return hipGetLastError();
 }
 
-hipError_t rt_launch_sum_samples(const float *samples, const unsigned char *direct, float *frame, size_t plane_floats, int spp, hipStream_t stream)
-{
-	hipLaunchKernelGGL(rt_sum_samples, dim3(4096), dim3(RT_BLOCK), 0, stream, samples, direct, frame, plane_floats, spp, 1.0f / (float) spp);
-	return hipGetLastError();
-}
-
 hipError_t rt_launch_resolve(const float *accum, float *frame, size_t floats, float inv_count, hipStream_t stream)
 {
 	hipLaunchKernelGGL(rt_resolve, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, frame, floats, inv_count);
@@ -1334,6 +1383,27 @@ size_t rt_scene_lds_bytes(int num_objects) { return (size_t) num_objects * (size
 
 size_t rt_wavefront_lds_bytes(int num_objects) { return rt_scene_lds_bytes(num_objects) + (RT_BLOCK / 64) * sizeof(WaveLDS); }
 
+/* rt_primary_pass: a few workgroups per CU, each with a run of consecutive 8x8 pixel blocks (at least one per wave) */
+void rt_primary_geometry(int width, int local_rows, int num_cus, unsigned int *groups_out, int *per_group_out)
+{
+	const unsigned int pixel_blocks = (unsigned int) (((width + 7) / 8) * ((local_rows + 7) / 8));
+	unsigned int groups = (unsigned int) num_cus * 8u;
+	if (groups * (RT_BLOCK / 64) > pixel_blocks) groups = (pixel_blocks + RT_BLOCK / 64 - 1) / (RT_BLOCK / 64);
+	if (groups < 1) groups = 1;
+	const int per_group = (int) ((pixel_blocks + groups - 1) / groups) > 0 ? (int) ((pixel_blocks + groups - 1) / groups) : 1;
+	groups = (pixel_blocks + (unsigned int) per_group - 1) / (unsigned int) per_group;
+	*groups_out = groups; *per_group_out = per_group;
+}
+
+/* records one pixel list must be able to hold: workgroup w of rt_primary_pass appends to list w % num_shards */
+size_t rt_pixel_list_capacity(int width, int local_rows, int num_cus, int num_shards)
+{
+	unsigned int groups; int per_group;
+	rt_primary_geometry(width, local_rows, num_cus, &groups, &per_group);
+	const size_t groups_per_list = (groups + (unsigned int) num_shards - 1) / (unsigned int) num_shards;
+	return groups_per_list * (size_t) per_group * 64;
+}
+
 hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, hipFunction_t spec_fn,
                            unsigned int *block_counter, int num_cus, int workgroups_per_cu, hipStream_t stream)
 {
@@ -1351,22 +1421,18 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	if (per_cu < 1) per_cu = 1;
 	if (per_cu > 4) per_cu = 4;
 	if (workgroups_per_cu >= 1 && workgroups_per_cu < per_cu) per_cu = workgroups_per_cu;     /* rt_tuning */
-	const long long blocks = (long long) ((L.width + 7) / 8) * ((L.local_rows + 7) / 8) * (L.num_chunks > 1 ? L.num_chunks : 1);
+	const long long blocks = (long long) ((L.width + 7) / 8) * ((L.local_rows + 7) / 8);
 	long long grid = (long long) num_cus * per_cu;
 	const long long useful = (blocks + (RT_BLOCK / 64) - 1) / (RT_BLOCK / 64);
 	if (grid > useful) grid = useful;
 	if (grid < 1) grid = 1;
-	if (grid < L.num_shards) return hipErrorInvalidValue;      /* every queue needs a workgroup (rt_api.cpp picks num_shards) */
+	const rt_launch &Lq = L;
 	hipError_t e = hipMemsetAsync(block_counter, 0, RT_COUNTER_BYTES, stream);
 	if (e != hipSuccess) return e;
 	{
-		const unsigned int pixel_blocks = (unsigned int) (((L.width + 7) / 8) * ((L.local_rows + 7) / 8));
-		/* a few workgroups per CU, each with a run of consecutive blocks (at least one per wave) */
-		unsigned int groups = (unsigned int) num_cus * 8u;
-		if (groups * (RT_BLOCK / 64) > pixel_blocks) groups = (pixel_blocks + RT_BLOCK / 64 - 1) / (RT_BLOCK / 64);
-		const int per_group = (int) ((pixel_blocks + groups - 1) / groups);
-		groups = (pixel_blocks + (unsigned int) per_group - 1) / (unsigned int) per_group;
-		const size_t plds = rt_scene_lds_bytes(L.num_objects) + (size_t) (per_group + 2) * sizeof(unsigned int);
+		unsigned int groups; int per_group;
+		rt_primary_geometry(L.width, L.local_rows, num_cus, &groups, &per_group);
+		const size_t plds = rt_scene_lds_bytes(L.num_objects);
 		if (variant == 2 || !scene_fast_ok)
 			hipLaunchKernelGGL(rt_primary_pass<false>, dim3(groups), dim3(RT_BLOCK), plds, stream, L, per_group);
 		else
@@ -1376,15 +1442,15 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	}
 	if (variant == 0 /* RT_KERNEL_AUTO */ && scene_fast_ok && spec_fn) {
 		/* same kernel, trace loop specialised for this scene by rt_compile_scene() */
-		rt_launch Lc = L;
+		rt_launch Lc = Lq;
 		unsigned int *counter = block_counter;
 		void *args[] = { &Lc, &counter };
 		return hipModuleLaunchKernel(spec_fn, (unsigned int) grid, 1, 1, RT_BLOCK, 1, 1, (unsigned int) lds, stream, args, nullptr);
 	}
 	if (variant == 2 /* RT_KERNEL_WAVEFRONT: same schedule, plain IEEE operations */ || !scene_fast_ok)
-		hipLaunchKernelGGL(rt_trace_wavefront<false>, dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, L, block_counter);
+		hipLaunchKernelGGL(rt_trace_wavefront<false>, dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, Lq, block_counter);
 	else
-		hipLaunchKernelGGL(rt_trace_wavefront<true>, dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, L, block_counter);
+		hipLaunchKernelGGL(rt_trace_wavefront<true>, dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, Lq, block_counter);
 	return hipGetLastError();
 }
 

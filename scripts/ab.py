@@ -36,8 +36,8 @@ for name, scene, W, H, spp, nb in cfgs:
     for it in range(rounds + 1):
         for k, r in enumerate(rs):
             rt._lib = r._L
-            ck = os.environ.get("AB_CHUNKS_A" if k == 0 else "AB_CHUNKS_B")      # per-build sample_chunks override
-            if ck and hasattr(r._L, "rt_set_tuning"): r.set_tuning(sample_chunks=int(ck))
+            tk = os.environ.get("AB_TUNING_A" if k == 0 else "AB_TUNING_B")      # per-build override, e.g. "pixel_streams=4"
+            if tk and hasattr(r._L, "rt_set_tuning"): r.set_tuning(**{a: int(b) for a, b in (kv.split("=") for kv in tk.split(","))})
             frames[k] = r.render(W, H, spp, nb)
             ms, n = r.profile_collect()
             if it:

@@ -1,5 +1,5 @@
 """Development aid: randomised GPU-vs-oracle parity sweep (bit-exact) over scenes, cameras, frame sizes, sample
-counts, bounce limits, chunkings, compiled/generic kernels and strips.  usage: fuzz_parity.py [cases] [seed]"""
+counts, bounce limits, schedules, compiled/generic kernels and strips.  usage: fuzz_parity.py [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,6 +11,7 @@ from rtlibs import Oracle, bits, make_scene, synthetic_skybox
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 gpu, orc = rt.Renderer(0), Oracle()
+gpu.set_tuning(poison_frame=True)
 bad = 0
 for case in range(cases):
     n = int(rng.integers(1, 14))
@@ -40,8 +41,8 @@ for case in range(cases):
     if jit:
         try: gpu.compile_scene()
         except rt.RtError: jit = False
-    chunks = int(rng.choice([0, 1, 2, 5, 64]))
-    gpu.set_tuning(sample_chunks=chunks)
+    chunks = (int(rng.choice([0, 1, 2, 4, 8])), int(rng.choice([0, 1, 64])))     # pixel streams, pixel lists
+    gpu.set_tuning(pixel_streams=chunks[0], dequeue_shards=chunks[1])
     got = gpu.render(W, H, spp, nb, seed=seed)
     ok = bool((bits(got) == bits(want)).all())
     world = int(rng.choice([2, 3, 8]))

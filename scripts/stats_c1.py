@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ray_tracing_amd as rt
 rt.LIB_PATH = os.path.join(os.path.dirname(rt.LIB_PATH), "librt_hip_stats.so")
 scene = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-W, H, spp, nb = (1920, 1080, 16, 4) if scene == 0 else (1920, 1080, 16, 8)
+W, H, spp, nb = (1920, 1080, 64, 4) if scene == 0 else (1920, 1080, 256, 8)
 g = rt.Renderer(0)
 g.set_skybox(rt.load_skybox()); g.set_scene(f"{rt.DATA_DIR}/scene_{scene}.txt")
 out = (C.c_ulonglong * 64)()
@@ -13,7 +13,7 @@ g.render(W, H, spp, nb)
 rt.lib().rt_stats_read(out, 1)
 names = {1: "box test", 2: "box slow path", 3: "sphere test", 4: "sphere discr>0 (fp64 roots)", 5: "sphere 2nd root", 6: "sphere slow path",
          7: "round (setup site)", 8: "setup body", 9: "tap0 sd", 10: "tap1 sd", 11: "tap2 sd", 12: "trace batch", 13: "trace batch active",
-         14: "sky lookup", 15: "specular branch", 16: "consume site", 17: "consume body", 18: "box: dir outside window", 19: "box: |num| < 2^-100", 20: "box: |num| > 2^30", 21: "box: num == 0"}
+         14: "sky lookup", 15: "specular branch", 16: "consume site", 17: "consume body", 20: "supply attempt", 21: "pixel reload event", 22: "sample hand-out", 23: "drain iteration", 18: "box: dir outside window", 19: "box: |num| < 2^-100", 20: "box: |num| > 2^30", 21: "box: num == 0"}
 samples = W * H * spp
 for k in sorted(names):
     n, lanes = out[2 * k], out[2 * k + 1]

@@ -26,6 +26,7 @@ def test_cli_renders_the_same_frame(tmp_path, scene_paths):
     assert raw.startswith(head)
     img = np.frombuffer(raw[len(head):], np.uint8).reshape(H, W, 3)
     g = rt.Renderer(0)
+    g.set_tuning(poison_frame=True)
     g.set_scene(scene_paths[0]); g.set_skybox(rt.load_skybox()); g.set_camera()
     frame = g.render(W, H, spp, nb, seed=seed)
     g.close()

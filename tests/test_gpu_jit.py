@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def gpu():
     r = rt.Renderer(0)
+    r.set_tuning(poison_frame=True)      # a pixel a launch fails to write must not pass as a leftover of an earlier frame
     yield r
     r.close()
 

@@ -33,6 +33,7 @@ def compare(gpu, cpu, what, exact=True):
 @pytest.fixture(scope="module")
 def gpu():
     r = rt.Renderer(0)
+    r.set_tuning(poison_frame=True)      # a pixel a launch fails to write must not pass as a leftover of an earlier frame
     yield r
     r.close()
 
@@ -238,8 +239,8 @@ def _strips_reassemble(gpu, W, H, spp, nb, seed, world, rb):
     ("C3", 2, 3840, 2160, 64, 8),       # BASELINE configs[3], exactly: 4K, sky-dominated
 ])
 def test_baseline_configs_at_their_stated_workload(gpu, real_sky, scene_paths, name, scene_i, W, H, spp, nb):
-    """BASELINE.json configs C2 and C3 at their full frame size AND full spp (spp selects the schedule: number of
-    sample chunks, work-item count, queue shards): tuned == scene-compiled == reference-order kernel bit for
+    """BASELINE.json configs C2 and C3 at their full frame size AND full spp (the frame size and spp select the
+    schedule: pixel streams per wave, number of pixel lists): tuned == scene-compiled == reference-order kernel bit for
     bit, oracle rows, and the 8-rank strip partition reassembles to the same frame."""
     gpu.set_skybox(real_sky); gpu.set_scene(scene_paths[scene_i]); gpu.set_camera()
     a = gpu.render(W, H, spp, nb, seed=0, kernel=rt.KERNEL_AUTO)
@@ -291,24 +292,6 @@ def test_c4_one_rank_of_eight_at_stated_workload(gpu, real_sky, scene_paths):
         assert (bits(c[j]) == bits(out["tuned"][lr])).all(), (lr, j)
 
 
-def test_scratch_limit_falls_back_to_unchunked(gpu, oracle, scene_paths):
-    """Launches whose per-sample scratch would exceed the limit run unchunked (rt_api.cpp); the limit is a tuning
-    parameter so that the branch is reachable at test size.  Same frame either way."""
-    sky = synthetic_skybox(24, seed=2)
-    gpu.set_skybox(sky); oracle.set_skybox(sky)
-    gpu.set_scene(scene_paths[0]); oracle.load_scene(scene_paths[0])
-    gpu.set_camera(); oracle.set_camera()
-    W, H, spp, nb = 96, 40, 48, 6
-    want = oracle.render_counter(W, H, spp, nb, seed=11)
-    try:
-        for limit in (0, 1, W * H * spp * 12 - 1, W * H * spp * 12):
-            gpu.set_tuning(scratch_limit_bytes=limit)
-            got = gpu.render(W, H, spp, nb, seed=11)
-            assert (bits(got) == bits(want)).all(), limit
-    finally:
-        gpu.set_tuning()
-
-
 def test_c1_exact_benchmark_config(gpu, real_sky, scene_paths):
     """BASELINE config C1 exactly as bench.py runs it (1920x1080, 64 spp, 4 bounces, seed 0): generic tuned
     kernel == scene-compiled kernel == reference-order kernel, and oracle rows."""
@@ -329,7 +312,8 @@ def test_c1_exact_benchmark_config(gpu, real_sky, scene_paths):
 
 
 def test_parameter_sweep_small_frames(gpu, oracle, scene_paths):
-    """Odd sizes, extreme spp / bounce limits, every chunking regime (rt_set_tuning), seeds near 2^64."""
+    """Odd sizes, extreme spp / bounce limits, every scheduling regime (rt_set_tuning: pixel streams per wave, pixel
+    lists), seeds near 2^64."""
     sky = synthetic_skybox(24, seed=2)
     gpu.set_skybox(sky); oracle.set_skybox(sky)
     gpu.set_camera(); oracle.set_camera()
@@ -338,10 +322,10 @@ def test_parameter_sweep_small_frames(gpu, oracle, scene_paths):
     for (si, W, H, spp, nb, seed) in cases:
         gpu.set_scene(scene_paths[si]); oracle.load_scene(scene_paths[si])
         want = oracle.render_counter(W, H, spp, nb, seed=seed)
-        for chunks, shards in ((0, 0), (1, 1), (3, 0), (1000, 1)):
+        for streams, shards in ((0, 0), (1, 1), (2, 64), (4, 1), (8, 0), (8, 64)):
             try:
-                gpu.set_tuning(sample_chunks=chunks, dequeue_shards=shards)
+                gpu.set_tuning(pixel_streams=streams, dequeue_shards=shards)
                 got = gpu.render(W, H, spp, nb, seed=seed)
             finally:
                 gpu.set_tuning()
-            assert (bits(got) == bits(want)).all(), (si, W, H, spp, nb, seed, chunks)
+            assert (bits(got) == bits(want)).all(), (si, W, H, spp, nb, seed, streams, shards)

@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 def test_progressive_matches_oracle(oracle, scene_paths, W, H, init_scale, passes):
     sky = synthetic_skybox(32, seed=7)
     g = rt.Renderer(0)
+    g.set_tuning(poison_frame=True)
     g.set_skybox(sky); oracle.set_skybox(sky)
     for si in (0, 1):
         g.set_scene(scene_paths[si]); oracle.load_scene(scene_paths[si])
@@ -31,6 +32,7 @@ def test_progressive_matches_oracle(oracle, scene_paths, W, H, init_scale, passe
 def test_invalidate_restarts_the_ladder(oracle, scene_paths):
     sky = synthetic_skybox(32, seed=7)
     g = rt.Renderer(0)
+    g.set_tuning(poison_frame=True)
     g.set_skybox(sky); g.set_scene(scene_paths[0]); oracle.set_skybox(sky); oracle.load_scene(scene_paths[0])
     g.progressive_begin(64, 32, init_scale=8, max_bounces=4, seed=1)
     gen0 = g.progressive_state()["generation"]
@@ -54,6 +56,7 @@ def test_full_resolution_passes_equal_rt_render(scene_paths):
     """With init_scale 1 the accumulated passes are the samples of rt_render(): same frame, bit for bit."""
     sky = synthetic_skybox(32, seed=7)
     g = rt.Renderer(0)
+    g.set_tuning(poison_frame=True)
     g.set_skybox(sky); g.set_scene(scene_paths[0])
     g.progressive_begin(160, 90, init_scale=1, max_bounces=4, seed=9)
     for _ in range(6):

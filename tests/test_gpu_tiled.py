@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def gpu():
     r = rt.Renderer(0)
+    r.set_tuning(poison_frame=True)
     r.set_skybox(rt.load_skybox()); r.set_scene(os.path.join(rt.DATA_DIR, "scene_0.txt")); r.set_camera()
     yield r
     r.close()
@@ -54,6 +55,7 @@ def _nccl_worker(rank, world, port, q):
     dev = torch.device("cuda", rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     g = rt.Renderer(rank)
+    g.set_tuning(poison_frame=True)
     g.set_skybox(rt.load_skybox()); g.set_scene(os.path.join(rt.DATA_DIR, "scene_0.txt")); g.set_camera()
     W, H, spp, nb = 320, 180, 8, 4
     t = TiledFrame(g, W, H, spp, nb, rank=rank, world=world, device=dev)
