@@ -75,8 +75,6 @@ RT_API void rt_default_params(rt_render_params *p, int width, int height, int sp
  * particular code path.  0 / NULL = let the library decide.  Set per context, read at every launch; the
  * library never reads environment variables. */
 typedef struct {
-	int    pixel_streams;       /* pixels a wave adds up at the same time: 1, 2, 4 or 8 (64 / this many lanes share
-	                             * the samples of one pixel) */
 	int    dequeue_shards;      /* lists the object pixels are dealt from: 1 or 64 */
 	int    workgroups_per_cu;   /* resident workgroups per CU, 1..4 */
 	int    jit_waves_per_simd;  /* rt_compile_scene: register budget = 512 / this many VGPRs (default 4) */

@@ -141,8 +141,7 @@ void rt_default_tuning(rt_tuning *t) { if (t) memset(t, 0, sizeof(*t)); }
 int rt_set_tuning(rt_context *ctx, const rt_tuning *t)
 {
 	if (!ctx || !t) return fail(RT_ERR_ARGUMENT, "rt_set_tuning: NULL argument");
-	auto pow2_upto = [](int v, int hi) { return v == 0 || (v >= 1 && v <= hi && (v & (v - 1)) == 0); };
-	if (!pow2_upto(t->pixel_streams, 8) || (t->dequeue_shards != 0 && t->dequeue_shards != 1 && t->dequeue_shards != 64) ||
+	if ((t->dequeue_shards != 0 && t->dequeue_shards != 1 && t->dequeue_shards != 64) ||
 	    t->workgroups_per_cu < 0 || t->workgroups_per_cu > 4 || t->jit_waves_per_simd < 0 || t->jit_waves_per_simd > 8)
 		return fail(RT_ERR_ARGUMENT, "rt_set_tuning: value out of range");
 	ctx->tuning = *t;
@@ -398,12 +397,6 @@ static void give_event(rt_context *ctx, hipEvent_t e) { if (e) ctx->event_pool.p
 static int prepare_launch(rt_context *ctx, rt_launch &L)
 {
 	const long long pixel_blocks = (long long) ((L.width + 7) / 8) * ((L.local_rows + 7) / 8);
-	const long long waves = (long long) ctx->num_cus * 16;                    /* resident waves of the persistent kernel */
-	const long long pixels_per_wave = pixel_blocks * 64 / (waves > 0 ? waves : 1);
-	int streams = 8;
-	while (streams > 1 && pixels_per_wave < 4LL * streams) streams >>= 1;       /* about four pixels per stream, at least */
-	if (ctx->tuning.pixel_streams) streams = ctx->tuning.pixel_streams;
-	L.num_streams = streams;
 	/* 64 lists (a single dequeue counter takes ~88 atomics per microsecond: 4 K waves asking for their first pixels at
 	 * once would already queue up) unless the launch is small */
 	L.num_shards = (pixel_blocks >= 64 * 16 && ctx->num_cus >= 64) ? 64 : 1;

@@ -73,10 +73,8 @@ typedef struct {
 
 	float *frame;              /* local_rows x width x 3 floats, resolved      */
 	/* scheduling of the wavefront kernels (any values give the same frame):
-	 *   num_shards   pixel lists in use (1 or 64), each with its own fill and dequeue counter
-	 *   num_streams  pixels a wave adds up at the same time (power of two, 1..8): 64 / num_streams lanes share the
-	 *                samples of one pixel */
-	int    num_shards, num_streams;
+	 *   num_shards   pixel lists in use (1 or 64), each with its own fill and dequeue counter */
+	int    num_shards;
 	/* written by rt_primary_pass, read by the trace kernels: one 12-word record per object pixel (camera-ray hit
 	 * point xyz, normal xyz, object, camera ray xyz, RNG pixel index, offset in the strip), word k of record c at
 	 * pix[k * num_shards * pix_shard_cap + c]; list s holds records s * pix_shard_cap ... + pix_count[32 * s] */

@@ -718,10 +718,10 @@ RT_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 
 template <bool FAST> RT_DEV V3 unit3_sel(V3 v) { return FAST ? unit3_fast(v) : unit3(v); }
 
-/* the value the lane below holds (lane 0: zero); every lane must be active */
-RT_DEV float from_lane_below(float v)
+/* the value lane - 2 of the same 16-lane row holds (the row's first two lanes: zero); every lane must be active */
+RT_DEV float from_lane_two_below(float v)
 {
-	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112 /* row_shr:2 */, 0xf, 0xf, true));
 }
 
 /* What a path needs to know about its pixel; filled by the lane that hands the pixel out. */
@@ -756,12 +756,17 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	/* spp == 1 (progressive passes): a pixel is its one sample, nothing has to be ordered -- every lane takes a
 	 * pixel for itself and writes it when the path retires.  Otherwise the wave runs P pixel streams. */
 	const bool direct = L.spp == 1;
-	const int P = L.num_streams;                            /* power of two, 1..WF_STREAMS */
-	const int G = 64 / P;                                   /* lanes whose home stream is the same */
-	const int g = lane / G;                                 /* this lane's home stream */
-	const bool leader = (lane & (G - 1)) == 0;              /* does the bookkeeping of a stream */
-	const unsigned int wn = (unsigned int) (WF_WINDOW / P); /* slots per stream */
-	const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (lane & ~(G - 1));
+	/* Eight streams of eight lanes.  The lanes of a stream are every second lane of one 16-lane DPP row (streams 2r
+	 * and 2r+1 share row r), so that "the value of the stream's previous lane" is one DPP row_shr:2 -- which hands
+	 * the stream's first lane a zero -- in the in-order sum of section 6. */
+	constexpr int P = WF_STREAMS, G = 64 / P;
+	constexpr unsigned int wn = WF_WINDOW / P;              /* slots per stream */
+	static_assert(P == 8 && G == 8, "the lane layout below is written for 8 streams of 8 lanes");
+	const int g = 2 * (lane >> 4) + (lane & 1);             /* this lane's home stream */
+	const unsigned int j = (unsigned int) (lane & 15) >> 1; /* its place among the stream's lanes */
+	const bool leader = j == 0u;                            /* does the bookkeeping of a stream */
+	const int gshift = (lane & 48) + (lane & 1);            /* position of the stream's first lane */
+	const unsigned long long gmask = 0x5555ull << gshift;
 #ifdef RT_SPEC_HEADER
 	const bool have_light = SPEC_LIGHT >= 0;               /* the compiled scene's emitter: literals, no scalar registers */
 	const V3 light_pos = mk3(SPEC_LIGHT_POS[0], SPEC_LIGHT_POS[1], SPEC_LIGHT_POS[2]);
@@ -781,7 +786,6 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	 * dequeue counter on its own 128-byte line (one counter saturates at ~88 dequeues/us, MI355X_MICROARCH.md).  A
 	 * wave starts at the list of its workgroup and moves on to the next one when a list has run out. */
 	unsigned int shard = blockIdx.x % (unsigned int) L.num_shards;
-	int  shards_left = L.num_shards;        /* lists this wave has not yet found empty */
 	bool exhausted = false;
 
 	/* per-lane path state.  A path is worked on at two places one round apart.  The FRONT (section 2) turns the
@@ -804,18 +808,17 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	/* the ray queue persists across rounds: taps that do not fill a batch wait for the next round's rays */
 	unsigned int q_head = 0, q_tail = 0, parity = 0;
 
-	/* Section 6 of a round: adding the finished samples in sample order (main.c:394).  Lane j of a stream's group
-	 * looks at the j-th slot after the stream's last added one.  The slots that are filled without a gap from the
-	 * first form the run; their colours are added to the stream's running sum one after the other -- lane j's
-	 * partial sum is lane j-1's plus its own colour, passed along with DPP lane shifts, all streams in lockstep --
-	 * and a pixel whose last sample is in the run is resolved (main.c:476) and written by the lane that holds the
-	 * frame-offset slot behind it; the sum restarts at 0 there.  Every lane of the wave must be active. */
+	/* Section 6 of a round: adding the finished samples in sample order (main.c:394).  Lane j of a stream looks at
+	 * the j-th slot after the stream's last added one.  The slots that are filled without a gap from the first form
+	 * the run (it ends behind the first pixel that is completed in it); their colours are added to the stream's
+	 * running sum one after the other -- lane j's partial sum is lane j-1's plus its own colour, handed on with DPP
+	 * row shifts, all eight streams in lockstep -- and a pixel whose last sample is in the run is resolved
+	 * (main.c:476) and written to the frame.  Every lane of the wave must be active. */
 	auto add_finished_samples = [&]() {
 		bool again;
 		do {
 			STAT(23);
 			const unsigned int d = W.s_drained[g], seq = W.s_seq[g];
-			const unsigned int j = (unsigned int) lane & (unsigned int) (G - 1);
 			const unsigned int slot = d + j;
 			const unsigned int e = (unsigned int) g * wn + (slot & (wn - 1u));
 			uint32_t xb = WF_EMPTY;
@@ -823,36 +826,34 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			const bool filled = xb != WF_EMPTY;
 			const unsigned long long fm = __ballot(filled);
 			const unsigned long long lm = __ballot(filled && (xb >> 31) != 0u);      /* last samples of their pixels */
-			const int gbase = lane & ~(G - 1);
-			const unsigned long long gap = ~(fm >> gbase);
-			int k = gap != 0ull ? (int) __builtin_ctzll(gap) : 64;                      /* length of the run */
-			if (k > G) k = G;
-			/* a pixel's last sample and the offset slot behind it stay in the same pass */
-			const bool cut = k == G && ((lm >> (gbase + G - 1)) & 1ull) != 0ull;
-			if (cut) k = G - 1;
+			const uint32_t fbits = (uint32_t) (fm >> gshift) & 0x5555u, lbits = (uint32_t) (lm >> gshift) & 0x5555u;
+			int k = (int) __builtin_ctz((~fbits & 0x5555u) | 0x10000u) >> 1;        /* length of the run, 0..8 */
+			/* the run ends with the first pixel that is completed in it: its last sample and the frame-offset slot
+			 * behind it (filled since the sample was handed out); a last sample in the stream's last lane waits */
+			const int lastpos = (int) __builtin_ctz(lbits | 0x10000u) >> 1;          /* 8: none */
+			const bool boundary = lastpos < k;
+			if (boundary) k = lastpos + 2 <= G ? lastpos + 2 : lastpos;
 			const bool active = (int) j < k;
-			const bool offset_slot = active && j > 0u && ((lm >> ((lane - 1) & 63)) & 1ull) != 0ull;
+			const bool offset_slot = boundary && (int) j == lastpos + 1 && active;
 			V3 c = mk3(0, 0, 0);
 			if (active && !offset_slot) c = mk3(__uint_as_float(xb & 0x7fffffffu), W.win[1][e], W.win[2][e]);
-			if (j == 0u) c = add3(mk3(W.s_sum[0][g], W.s_sum[1][g], W.s_sum[2][g]), c);   /* the running sum enters at the first lane */
-			const uint32_t keep = (j == 0u || offset_slot) ? 0u : 0xffffffffu;     /* what comes from the lane below counts */
+			if (leader) c = add3(mk3(W.s_sum[0][g], W.s_sum[1][g], W.s_sum[2][g]), c);   /* the running sum enters at the first lane */
 			V3 sum = c;
-			for (unsigned int t = 1u; __ballot(active && j >= t) != 0ull; t++)      /* after step t lanes j <= t are final */
-				sum = mk3(__uint_as_float(__float_as_uint(from_lane_below(sum.x)) & keep) + c.x,
-				          __uint_as_float(__float_as_uint(from_lane_below(sum.y)) & keep) + c.y,
-				          __uint_as_float(__float_as_uint(from_lane_below(sum.z)) & keep) + c.z);
-			const V3 total = mk3(from_lane_below(sum.x), from_lane_below(sum.y), from_lane_below(sum.z));
-			if (offset_slot) {                  /* the pixel below is complete: resolve and write it (main.c:476) */
-				const V3 res = scale3(total, inv_spp);
+#pragma unroll
+			for (int t = 1; t < G; t++)             /* after step t lanes j <= t hold their final partial sums */
+				sum = mk3(from_lane_two_below(sum.x) + c.x, from_lane_two_below(sum.y) + c.y, from_lane_two_below(sum.z) + c.z);
+			if (offset_slot) {                  /* the pixel is complete: resolve and write it (main.c:476); this lane's own colour was zero */
+				const V3 res = scale3(sum, inv_spp);
 				float *dst = L.frame + (size_t) xb * 3;
 				dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
 			}
 			if (active) W.win[0][e] = __uint_as_float(WF_EMPTY);
 			if (active && (int) j == k - 1) {
 				W.s_drained[g] = d + (unsigned int) k;
-				W.s_sum[0][g] = sum.x; W.s_sum[1][g] = sum.y; W.s_sum[2][g] = sum.z;
+				W.s_sum[0][g] = offset_slot ? 0.0f : sum.x; W.s_sum[1][g] = offset_slot ? 0.0f : sum.y; W.s_sum[2][g] = offset_slot ? 0.0f : sum.z;
 			}
-			again = __ballot(k == G || cut) != 0ull;       /* a full run: more may be waiting behind it */
+			/* more may be waiting behind the run; it can wait for the next round unless the window is filling up */
+			again = __ballot(k > 0 && (k == G || boundary) && seq - (d + (unsigned int) k) > wn / 2u) != 0ull;
 			wave_fence();
 		} while (again);
 	};
@@ -865,10 +866,13 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		 * its pixel in order, each with the next slot of the stream's window; when the pixel has none left the
 		 * stream takes the next object pixel of the wave's work item. */
 #pragma unroll 1
-		for (int attempt = 0; attempt < 4; attempt++) {
+		for (int attempt = 0; attempt < P; attempt++) {
 			const bool want = !f_live;
 			const unsigned long long wmask = __ballot(want);
 			if (wmask == 0ull) break;
+			/* the lists have run out: go on only while some stream still has samples (and slots) to give */
+			if (exhausted && (direct || (attempt > 0 &&
+			    __ballot(leader && W.s_nxt[g] < spp && W.s_seq[g] - W.s_drained[g] < wn - 1u) == 0ull))) break;
 			const int sg = (g + attempt) & (P - 1);
 			const unsigned long long gm = wmask & gmask;              /* wanting lanes of my group */
 			STAT(20);
@@ -892,9 +896,22 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					const unsigned int filled = (unsigned int) __builtin_amdgcn_readfirstlane((int) C->pix_count[shard * 32u]);
 					got = k < filled ? (filled - k < (unsigned int) asked ? (int) (filled - k) : asked) : 0;
 					first = (size_t) shard * (size_t) C->pix_shard_cap + k;
-					if (got < asked) {                  /* this list has run out: the rest is served from the next one */
-						shard = (shard + 1u) % (unsigned int) C->num_shards;
-						if (--shards_left == 0) exhausted = true;
+					if (got < asked) {
+						/* This list has run out: look at all of them at once (lane s reads list s's two counters; a stale
+						 * dequeue count can only show more pixels left than there are, never fewer) and move to the next
+						 * one that still has pixels.  None: the launch has no pixels left to hand out. */
+						unsigned int left = 0;
+						if (lane < C->num_shards) {
+							const unsigned int taken = __hip_atomic_load(block_counter + (unsigned int) lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							const unsigned int have = C->pix_count[(unsigned int) lane * 32u];
+							left = have > taken ? have - taken : 0u;
+						}
+						const unsigned long long some = __ballot(left != 0u);
+						if (some == 0ull) exhausted = true;
+						else {      /* the waves spread over the lists that are left (one address takes ~88 atomics per microsecond) */
+							const int pick = (int) ((blockIdx.x * (RT_BLOCK / 64) + (unsigned int) wave) % (unsigned int) __popcll(some));
+							shard = (unsigned int) __builtin_ctzll(__ballot(left != 0u && lanes_below(some) == pick));
+						}
 					}
 				}
 				const int rr = lanes_below(nmask);

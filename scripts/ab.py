@@ -14,7 +14,9 @@ def load(path):
     r._L = L
     return r
 
-cfgs = [("C1", 0, 1920, 1080, 64, 4), ("C2", 1, 1920, 1080, 256, 8)]
+cfgs = [("C1", 0, 1920, 1080, 64, 4, 1), ("C2", 1, 1920, 1080, 256, 8, 1), ("C1 strip 3/8", 0, 1920, 1080, 64, 4, 8), ("C3", 2, 3840, 2160, 64, 8, 1),
+        ("C4 strip 3/8", 0, 3840, 2160, 1024, 8, 8)]
+if os.environ.get("AB_CFGS"): cfgs = [c for c in cfgs if c[0].split()[0] in os.environ["AB_CFGS"].split(",")]
 libs = sys.argv[1:3]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 sky = None
@@ -26,7 +28,7 @@ for p in libs:
     r.set_skybox(sky); r.profile(True)
     r._jit = bool(os.environ.get("AB_JIT"))
     rs.append(r)
-for name, scene, W, H, spp, nb in cfgs:
+for name, scene, W, H, spp, nb, world in cfgs:
     times = [[], []]
     for k, r in enumerate(rs):
         rt._lib = r._L
@@ -38,7 +40,13 @@ for name, scene, W, H, spp, nb in cfgs:
             rt._lib = r._L
             tk = os.environ.get("AB_TUNING_A" if k == 0 else "AB_TUNING_B")      # per-build override, e.g. "pixel_streams=4"
             if tk and hasattr(r._L, "rt_set_tuning"): r.set_tuning(**{a: int(b) for a, b in (kv.split("=") for kv in tk.split(","))})
-            frames[k] = r.render(W, H, spp, nb)
+            if world == 1:
+                frames[k] = r.render(W, H, spp, nb)
+            else:
+                strip = torch.zeros((rt.strip_rows(H, 8, world), W, 3), dtype=torch.float32, device="cuda:0")
+                torch.cuda.synchronize()
+                r.render_device(r.params(W, H, spp, nb, row_block=8, rank=3, world=world), strip.data_ptr()); r.synchronize()
+                frames[k] = strip.cpu().numpy()
             ms, n = r.profile_collect()
             if it:
                 times[k].append(ms)

@@ -41,8 +41,8 @@ for case in range(cases):
     if jit:
         try: gpu.compile_scene()
         except rt.RtError: jit = False
-    chunks = (int(rng.choice([0, 1, 2, 4, 8])), int(rng.choice([0, 1, 64])))     # pixel streams, pixel lists
-    gpu.set_tuning(pixel_streams=chunks[0], dequeue_shards=chunks[1])
+    chunks = (int(rng.choice([0, 1, 64])), int(rng.choice([0, 1, 2, 3])))     # pixel lists, resident workgroups per CU
+    gpu.set_tuning(dequeue_shards=chunks[0], workgroups_per_cu=chunks[1])
     got = gpu.render(W, H, spp, nb, seed=seed)
     ok = bool((bits(got) == bits(want)).all())
     world = int(rng.choice([2, 3, 8]))

@@ -240,7 +240,7 @@ def _strips_reassemble(gpu, W, H, spp, nb, seed, world, rb):
 ])
 def test_baseline_configs_at_their_stated_workload(gpu, real_sky, scene_paths, name, scene_i, W, H, spp, nb):
     """BASELINE.json configs C2 and C3 at their full frame size AND full spp (the frame size and spp select the
-    schedule: pixel streams per wave, number of pixel lists): tuned == scene-compiled == reference-order kernel bit for
+    schedule: number of pixel lists, workgroups): tuned == scene-compiled == reference-order kernel bit for
     bit, oracle rows, and the 8-rank strip partition reassembles to the same frame."""
     gpu.set_skybox(real_sky); gpu.set_scene(scene_paths[scene_i]); gpu.set_camera()
     a = gpu.render(W, H, spp, nb, seed=0, kernel=rt.KERNEL_AUTO)
@@ -312,8 +312,7 @@ def test_c1_exact_benchmark_config(gpu, real_sky, scene_paths):
 
 
 def test_parameter_sweep_small_frames(gpu, oracle, scene_paths):
-    """Odd sizes, extreme spp / bounce limits, every scheduling regime (rt_set_tuning: pixel streams per wave, pixel
-    lists), seeds near 2^64."""
+    """Odd sizes, extreme spp / bounce limits, every scheduling regime (rt_set_tuning: pixel lists, resident workgroups), seeds near 2^64."""
     sky = synthetic_skybox(24, seed=2)
     gpu.set_skybox(sky); oracle.set_skybox(sky)
     gpu.set_camera(); oracle.set_camera()
@@ -322,10 +321,10 @@ def test_parameter_sweep_small_frames(gpu, oracle, scene_paths):
     for (si, W, H, spp, nb, seed) in cases:
         gpu.set_scene(scene_paths[si]); oracle.load_scene(scene_paths[si])
         want = oracle.render_counter(W, H, spp, nb, seed=seed)
-        for streams, shards in ((0, 0), (1, 1), (2, 64), (4, 1), (8, 0), (8, 64)):
+        for shards, per_cu in ((0, 0), (1, 0), (64, 0), (1, 1), (64, 2)):
             try:
-                gpu.set_tuning(pixel_streams=streams, dequeue_shards=shards)
+                gpu.set_tuning(dequeue_shards=shards, workgroups_per_cu=per_cu)
                 got = gpu.render(W, H, spp, nb, seed=seed)
             finally:
                 gpu.set_tuning()
-            assert (bits(got) == bits(want)).all(), (si, W, H, spp, nb, seed, streams, shards)
+            assert (bits(got) == bits(want)).all(), (si, W, H, spp, nb, seed, shards, per_cu)
