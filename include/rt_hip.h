@@ -79,6 +79,8 @@ typedef struct {
 	int    workgroups_per_cu;   /* resident workgroups per CU, 1..4 */
 	int    jit_waves_per_simd;  /* rt_compile_scene: register budget = 512 / this many VGPRs (default 4) */
 	const char *jit_flags;      /* rt_compile_scene: extra hiprtc options, space separated (copied) */
+	int    force_collective;    /* testing aid: rt_multi_render() runs its ncclGather + de-interleave path even for a
+	                             * single device (a one-rank communicator), so that path can be checked on a 1-GPU box */
 	int    poison_frame;        /* testing aid: fill the destination with NaNs before every launch, so that a pixel the
 	                             * launch fails to write cannot pass for correct because an earlier frame left it there */
 } rt_tuning;
@@ -127,6 +129,26 @@ RT_API int rt_deinterleave_device(rt_context *ctx, const void *d_strips, void *d
                                   int width, int height, int row_block, int world, void *hip_stream);
 
 RT_API int rt_synchronize(rt_context *ctx);
+
+/* ---- several GPUs of one node, one host process: replaces start_workers()'s fan-out (main.c:695-718) ----
+ * rt_multi_create() makes one context per listed device and, for n > 1, the RCCL communicators of the group
+ * (librccl.so is loaded on first use; a single-device handle never touches it).  The setters broadcast to
+ * every device.  rt_multi_render() renders the frame with the interleaved row-block partition of
+ * rt_render_device() -- device i takes the row blocks b with b % n == i, all devices at once -- gathers the
+ * strips on the first device with ONE ncclGather over xGMI, de-interleaves them there and returns the frame
+ * in host memory exactly as rt_render() does; params->rank / world are ignored.  Frames are bit-identical
+ * to rt_render()'s for every n. */
+typedef struct rt_multi rt_multi;
+RT_API int  rt_multi_create(rt_multi **out, const int *device_ids, int n);
+RT_API void rt_multi_destroy(rt_multi *m);
+RT_API int  rt_multi_size(const rt_multi *m);
+RT_API rt_context *rt_multi_context(rt_multi *m, int i);       /* device i's context (owned by the handle) */
+RT_API int  rt_multi_set_scene(rt_multi *m, const Scene *scene);
+RT_API int  rt_multi_set_skybox(rt_multi *m, const Cubemap *skybox);
+RT_API int  rt_multi_set_camera(rt_multi *m, const rt_camera *camera);
+RT_API int  rt_multi_set_tuning(rt_multi *m, const rt_tuning *tuning);
+RT_API int  rt_multi_compile_scene(rt_multi *m);
+RT_API int  rt_multi_render(rt_multi *m, const rt_render_params *params, Vector3 *frame_out);
 
 /* ---- progressive accumulation: the reference's interactive protocol ----------------------------
  * worker() renders passes of 1 sample per (low-resolution) pixel, starting at 1/init_scale resolution

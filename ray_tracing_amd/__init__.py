@@ -50,7 +50,7 @@ class RenderParams(C.Structure):
 class Tuning(C.Structure):
     _fields_ = [("dequeue_shards", C.c_int),
                 ("workgroups_per_cu", C.c_int), ("jit_waves_per_simd", C.c_int), ("jit_flags", C.c_char_p),
-                ("poison_frame", C.c_int)]
+                ("force_collective", C.c_int), ("poison_frame", C.c_int)]
 
 
 STREAM_LEGACY = C.c_void_p(-1).value      # RT_STREAM_LEGACY: the device's legacy null stream
@@ -69,6 +69,8 @@ EXPORTS = [
     "rt_progressive_invalidate", "rt_progressive_state", "rt_selftest", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
     "rt_parse_scene_string", "rt_load_cubemap", "rt_free_cubemap", "rt_decode_jpeg_file",
     "rt_camera_default", "rt_camera_basis_for", "rt_mouse_state_default", "rt_move_camera",
+    "rt_multi_create", "rt_multi_destroy", "rt_multi_size", "rt_multi_context", "rt_multi_set_scene", "rt_multi_set_skybox",
+    "rt_multi_set_camera", "rt_multi_set_tuning", "rt_multi_compile_scene", "rt_multi_render",
     "rt_rotate_camera", "rt_path_seed", "rt_set_frame_sink", "rt_move_frame_to_the_gpu", "rt_write_ppm", "rt_write_png", "rt_screenshot",
 ]
 
@@ -108,6 +110,17 @@ def lib():
     L.rt_strip_rows.argtypes = [C.c_int, C.c_int, C.c_int]
     L.rt_deinterleave_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
     L.rt_synchronize.argtypes = [C.c_void_p]
+    L.rt_multi_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
+    L.rt_multi_destroy.argtypes = [C.c_void_p]
+    L.rt_multi_size.argtypes = [C.c_void_p]
+    L.rt_multi_context.argtypes = [C.c_void_p, C.c_int]
+    L.rt_multi_context.restype = C.c_void_p
+    L.rt_multi_set_scene.argtypes = [C.c_void_p, C.c_void_p]
+    L.rt_multi_set_skybox.argtypes = [C.c_void_p, C.POINTER(Cubemap)]
+    L.rt_multi_set_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
+    L.rt_multi_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
+    L.rt_multi_compile_scene.argtypes = [C.c_void_p]
+    L.rt_multi_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p]
     L.rt_progressive_begin.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
     L.rt_progressive_pass.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.rt_progressive_resolve.argtypes = [C.c_void_p, C.c_void_p]
@@ -343,3 +356,63 @@ class Renderer:
         ms, n = C.c_double(), C.c_int()
         _check(lib().rt_profile_collect(self._ctx, C.byref(ms), C.byref(n)), "rt_profile_collect")
         return ms.value, n.value
+
+
+class MultiRenderer:
+    """rt_multi_*: one frame on several GPUs of this node from one process (native RCCL gather, no torch)."""
+
+    def __init__(self, devices):
+        devices = list(devices)
+        self._m = C.c_void_p()
+        ids = (C.c_int * len(devices))(*devices)
+        _check(lib().rt_multi_create(C.byref(self._m), ids, len(devices)), "rt_multi_create")
+
+    def close(self):
+        if self._m:
+            lib().rt_multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return lib().rt_multi_size(self._m)
+
+    def set_scene(self, scene):
+        if isinstance(scene, (str, bytes, os.PathLike)):
+            rc, buf = parse_scene_file(scene)
+            _check(rc, f"rt_parse_scene_file({scene})")
+        else:
+            buf = np.ascontiguousarray(scene, dtype=np.uint8)
+        _check(lib().rt_multi_set_scene(self._m, buf.ctypes.data_as(C.c_void_p)), "rt_multi_set_scene")
+
+    def set_skybox(self, faces):
+        faces = np.ascontiguousarray(faces, dtype=np.uint8)
+        cm = Cubemap()
+        for i in range(6):
+            cm.data[i] = faces[i].ctypes.data
+        cm.h, cm.w, cm.chan = faces.shape[1], faces.shape[2], faces.shape[3]
+        _check(lib().rt_multi_set_skybox(self._m, C.byref(cm)), "rt_multi_set_skybox")
+
+    def set_camera(self):
+        cam = default_camera()
+        _check(lib().rt_multi_set_camera(self._m, C.byref(cam)), "rt_multi_set_camera")
+
+    def set_tuning(self, **kw):
+        t = Tuning()
+        lib().rt_default_tuning(C.byref(t))
+        for k, v in kw.items():
+            setattr(t, k, v)
+        _check(lib().rt_multi_set_tuning(self._m, C.byref(t)), "rt_multi_set_tuning")
+
+    def compile_scene(self):
+        _check(lib().rt_multi_compile_scene(self._m), "rt_multi_compile_scene")
+
+    def render(self, width, height, spp, max_bounces, seed=0, row_block=8):
+        p = Renderer.params(width, height, spp, max_bounces, seed=seed, row_block=row_block)
+        out = np.empty((height, width, 3), dtype=np.float32)
+        _check(lib().rt_multi_render(self._m, C.byref(p), out.ctypes.data_as(C.c_void_p)), "rt_multi_render")
+        return out

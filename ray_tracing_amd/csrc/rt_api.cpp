@@ -38,6 +38,15 @@ static int fail(int code, const char *fmt, ...)
 	return code;
 }
 
+int rt_fail(int code, const char *fmt, ...)      /* for the library's other translation units (rt_internal.h) */
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_error, sizeof(g_error), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
 #define HIP_TRY(expr)                                                                       \
 	do {                                                                                    \
 		hipError_t e_ = (expr);                                                             \
@@ -131,6 +140,8 @@ static hipStream_t pick_stream(rt_context *ctx, void *hip_stream)
 	if (hip_stream == RT_STREAM_LEGACY) return nullptr;             /* the device's legacy null stream */
 	return hip_stream ? (hipStream_t) hip_stream : ctx->stream;
 }
+
+void *rt_context_stream(rt_context *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
 
 extern "C" {
 

@@ -6,6 +6,11 @@
 #include <string>
 #include "rt_device.h"
 
+struct rt_context;
+/* rt_api.cpp: sets the thread's error text (rt_last_error()) and returns `code`; the context's own stream */
+int        rt_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void      *rt_context_stream(rt_context *ctx);
+
 size_t     rt_counter_bytes();
 size_t     rt_scene_lds_bytes(int num_objects);
 size_t     rt_wavefront_lds_bytes(int num_objects);

@@ -13,6 +13,8 @@
  *   --seed <n>           counter-mode seed
  *   --skybox <dir>       directory with {right,left,top,bottom,front,back}.jpg (default assets/skybox)
  *   --device <n>         GPU index
+ *   --gpus <n>           render on GPUs 0..n-1 of this node at once (row blocks interleaved over them, one RCCL
+ *                        gather of the strips): the counterpart of the reference's --threads
  *   --out <file>         where the presenter hook writes the frame: .png or .ppm (default frame.ppm)
  */
 #include <stdio.h>
@@ -44,7 +46,7 @@ static double now_s(void)
 int main(int argc, char **argv)
 {
 	const char *scene_file = NULL, *sky_dir = "assets/skybox";
-	int width = 1280, height = 960, spp = 16, bounces = 10, device = 0;
+	int width = 1280, height = 960, spp = 16, bounces = 10, device = 0, gpus = 0;
 	unsigned long long seed = 0;
 
 	for (int i = 1; i < argc; i++) {
@@ -61,6 +63,7 @@ int main(int argc, char **argv)
 		else if (!strcmp(a, "--seed"))       { NEED_VALUE(); seed = strtoull(v, NULL, 0); }
 		else if (!strcmp(a, "--skybox"))     { NEED_VALUE(); sky_dir = v; }
 		else if (!strcmp(a, "--device"))     { NEED_VALUE(); device = atoi(v); }
+		else if (!strcmp(a, "--gpus"))       { NEED_VALUE(); gpus = atoi(v); }
 		else if (!strcmp(a, "--out"))        { NEED_VALUE(); out_file = v; }
 		else fprintf(stderr, "Warning: Ignoring option %s\n", a);
 #undef NEED_VALUE
@@ -89,14 +92,19 @@ int main(int argc, char **argv)
 		return -1;
 	fprintf(stderr, "Cubemap loaded (%dx%dx%d)\n", skybox.w, skybox.h, skybox.chan);
 
-	rt_context *ctx = NULL;
-	if (rt_create(&ctx, device) != RT_OK || rt_set_scene(ctx, &scene) != RT_OK || rt_set_skybox(ctx, &skybox) != RT_OK) {
+	/* one device: a context; several: a group of contexts with their RCCL communicators (rt_multi_*) */
+	int ids[64];
+	if (gpus > 64) gpus = 64;
+	for (int i = 0; i < gpus; i++) ids[i] = i;
+	if (gpus < 1) { gpus = 1; ids[0] = device; }
+	rt_multi *group = NULL;
+	if (rt_multi_create(&group, ids, gpus) != RT_OK || rt_multi_set_scene(group, &scene) != RT_OK || rt_multi_set_skybox(group, &skybox) != RT_OK) {
 		fprintf(stderr, "Error: %s\n", rt_last_error());
 		return -1;
 	}
 	rt_camera cam;
 	rt_camera_default(&cam);
-	rt_set_camera(ctx, &cam);
+	rt_multi_set_camera(group, &cam);
 
 	Vector3 *frame = malloc(sizeof(Vector3) * (size_t) width * height);
 	if (!frame) { printf("OUT OF MEMORY\n"); return -1; }
@@ -105,19 +113,19 @@ int main(int argc, char **argv)
 	rt_default_params(&p, width, height, spp, bounces);
 	p.seed = seed;
 	double t0 = now_s();
-	if (rt_render(ctx, &p, frame) != RT_OK) {
+	if (rt_multi_render(group, &p, frame) != RT_OK) {
 		fprintf(stderr, "Error: %s\n", rt_last_error());
 		return -1;
 	}
 	double dt = now_s() - t0;
-	fprintf(stderr, "Rendered %dx%d, %d spp, %d bounces in %.3f s (%.1f Msamples/s incl. copy-back)\n",
-	        width, height, spp, bounces, dt, (double) width * height * spp / dt / 1e6);
+	fprintf(stderr, "Rendered %dx%d, %d spp, %d bounces on %d GPU(s) in %.3f s (%.1f Msamples/s incl. copy-back)\n",
+	        width, height, spp, bounces, rt_multi_size(group), dt, (double) width * height * spp / dt / 1e6);
 
 	rt_set_frame_sink(write_frame, NULL);
 	rt_move_frame_to_the_gpu(width, height, frame);   /* where update_frame() hands off, main.c:479 */
 
 	free(frame);
 	rt_free_cubemap(&skybox);
-	rt_destroy(ctx);
+	rt_multi_destroy(group);
 	return 0;
 }

@@ -40,7 +40,9 @@ SRC = textwrap.dedent(r'''
                         (void*) rt_compile_scene, (void*) rt_render, (void*) rt_render_device, (void*) rt_deinterleave_device,
                         (void*) rt_progressive_begin, (void*) rt_progressive_pass, (void*) rt_progressive_resolve,
                         (void*) rt_progressive_invalidate, (void*) rt_load_cubemap, (void*) rt_free_cubemap,
-                        (void*) rt_move_frame_to_the_gpu, (void*) rt_write_png, (void*) rt_last_error };
+                        (void*) rt_move_frame_to_the_gpu, (void*) rt_write_png, (void*) rt_last_error,
+                        (void*) rt_set_tuning, (void*) rt_multi_create, (void*) rt_multi_destroy, (void*) rt_multi_set_scene,
+                        (void*) rt_multi_set_skybox, (void*) rt_multi_set_camera, (void*) rt_multi_compile_scene, (void*) rt_multi_render };
         return fns[argc & 1] == NULL;
     }
 ''')

@@ -13,11 +13,12 @@ pytestmark = pytest.mark.gpu
 CLI = os.path.join(os.path.dirname(rt.LIB_PATH), "rt_cli")
 
 
-def test_cli_renders_the_same_frame(tmp_path, scene_paths):
+@pytest.mark.parametrize("extra", [[], ["--gpus", "1"]])
+def test_cli_renders_the_same_frame(tmp_path, scene_paths, extra):
     out = tmp_path / "frame.ppm"
     W, H, spp, nb, seed = 96, 54, 4, 4, 7
     cmd = [CLI, "--scene", scene_paths[0], "--threads", "8", "--init-scale", "8", "--skybox", os.path.join(rt.DATA_DIR, "skybox"),
-           "--width", str(W), "--height", str(H), "--spp", str(spp), "--bounces", str(nb), "--seed", str(seed), "--out", str(out)]
+           "--width", str(W), "--height", str(H), "--spp", str(spp), "--bounces", str(nb), "--seed", str(seed), "--out", str(out)] + extra
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr
     assert "Scene parsed (9 objects)" in p.stderr and "Cubemap loaded (2048x2048x3)" in p.stderr

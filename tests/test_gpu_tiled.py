@@ -88,3 +88,41 @@ def test_pipelined_frames_two_ranks_over_rccl():
         p.join(300)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_native_multi_gpu_entry_world_1(gpu):
+    """rt_multi_*: the single-process, native-RCCL entry of the C ABI.  With one device it must equal rt_render()
+    bit for bit and never load RCCL; duplicate / out-of-range device lists are argument errors, not crashes."""
+    import ctypes as C
+    W, H, spp, nb = 200, 77, 5, 6
+    want = gpu.render(W, H, spp, nb, seed=4)
+    m = rt.MultiRenderer([0])
+    assert m.size() == 1
+    m.set_tuning(poison_frame=1)
+    m.set_skybox(rt.load_skybox()); m.set_scene(os.path.join(rt.DATA_DIR, "scene_0.txt")); m.set_camera()
+    assert (bits(m.render(W, H, spp, nb, seed=4)) == bits(want)).all()
+    m.compile_scene()
+    assert (bits(m.render(W, H, spp, nb, seed=4)) == bits(want)).all()
+    # the multi-device path itself -- RCCL loaded with dlopen, ncclCommInitAll, one grouped ncclGather, de-interleave,
+    # copy to the host -- on a one-rank communicator (all a 1-GPU box can run); row_block 4: 77 rows = 19 blocks + 1 row
+    m.set_tuning(poison_frame=1, force_collective=1)
+    for rb in (8, 4):
+        assert (bits(m.render(W, H, spp, nb, seed=4, row_block=rb)) == bits(want)).all()
+    m.close()
+    L = rt.lib()
+    h = C.c_void_p()
+    assert L.rt_multi_create(C.byref(h), (C.c_int * 2)(0, 0), 2) == -1 and b"twice" in L.rt_last_error()
+    assert L.rt_multi_create(C.byref(h), (C.c_int * 1)(99), 1) == -1
+    assert L.rt_multi_create(C.byref(h), None, 0) == -1
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (ncclGather between them)")
+def test_native_multi_gpu_entry_two_devices(gpu):
+    W, H, spp, nb = 320, 181, 8, 4
+    want = gpu.render(W, H, spp, nb, seed=9)
+    m = rt.MultiRenderer([0, 1])
+    m.set_tuning(poison_frame=1)
+    m.set_skybox(rt.load_skybox()); m.set_scene(os.path.join(rt.DATA_DIR, "scene_0.txt")); m.set_camera()
+    for _ in range(2):
+        assert (bits(m.render(W, H, spp, nb, seed=9)) == bits(want)).all()
+    m.close()
