@@ -110,17 +110,18 @@ def lib():
     L.rt_strip_rows.argtypes = [C.c_int, C.c_int, C.c_int]
     L.rt_deinterleave_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
     L.rt_synchronize.argtypes = [C.c_void_p]
-    L.rt_multi_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
-    L.rt_multi_destroy.argtypes = [C.c_void_p]
-    L.rt_multi_size.argtypes = [C.c_void_p]
-    L.rt_multi_context.argtypes = [C.c_void_p, C.c_int]
-    L.rt_multi_context.restype = C.c_void_p
-    L.rt_multi_set_scene.argtypes = [C.c_void_p, C.c_void_p]
-    L.rt_multi_set_skybox.argtypes = [C.c_void_p, C.POINTER(Cubemap)]
-    L.rt_multi_set_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
-    L.rt_multi_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
-    L.rt_multi_compile_scene.argtypes = [C.c_void_p]
-    L.rt_multi_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p]
+    if hasattr(L, "rt_multi_create"):       # (scripts/ab.py also loads older builds of the library)
+        L.rt_multi_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
+        L.rt_multi_destroy.argtypes = [C.c_void_p]
+        L.rt_multi_size.argtypes = [C.c_void_p]
+        L.rt_multi_context.argtypes = [C.c_void_p, C.c_int]
+        L.rt_multi_context.restype = C.c_void_p
+        L.rt_multi_set_scene.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_multi_set_skybox.argtypes = [C.c_void_p, C.POINTER(Cubemap)]
+        L.rt_multi_set_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
+        L.rt_multi_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
+        L.rt_multi_compile_scene.argtypes = [C.c_void_p]
+        L.rt_multi_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p]
     L.rt_progressive_begin.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
     L.rt_progressive_pass.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.rt_progressive_resolve.argtypes = [C.c_void_p, C.c_void_p]

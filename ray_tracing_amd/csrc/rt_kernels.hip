@@ -966,6 +966,9 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				wave_fence();
 			}
 		}
+#ifdef RT_STATS
+		if (!f_live) STAT(24);                  /* lanes that start the round without a sample */
+#endif
 		if (__ballot(f_live || (prev & REC_VALID) != 0) == 0ull) {
 			/* nothing in flight: every reserved slot is filled, so whatever is still waiting can be added now */
 			if (!direct && __ballot(W.s_drained[g] != W.s_seq[g]) != 0ull) { add_finished_samples(); continue; }

@@ -1,6 +1,6 @@
 """Interleaved A/B timing of two builds of librt_hip.so in ONE process on ONE device (device-to-device
 clock differences on this pool are larger than most kernel deltas).  usage: ab.py libA.so libB.so [rounds]"""
-import ctypes as C, os, sys, statistics
+import ctypes as C, os, sys, statistics, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # one HIP runtime for both libraries
 import numpy as np
@@ -29,7 +29,7 @@ for p in libs:
     r._jit = bool(os.environ.get("AB_JIT"))
     rs.append(r)
 for name, scene, W, H, spp, nb, world in cfgs:
-    times = [[], []]
+    times = [[], []]; walls = [[], []]
     for k, r in enumerate(rs):
         rt._lib = r._L
         r.set_scene(f"{rt.DATA_DIR}/scene_{scene}.txt")
@@ -41,15 +41,24 @@ for name, scene, W, H, spp, nb, world in cfgs:
             tk = os.environ.get("AB_TUNING_A" if k == 0 else "AB_TUNING_B")      # per-build override, e.g. "pixel_streams=4"
             if tk and hasattr(r._L, "rt_set_tuning"): r.set_tuning(**{a: int(b) for a, b in (kv.split("=") for kv in tk.split(","))})
             if world == 1:
-                frames[k] = r.render(W, H, spp, nb)
+                strip = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r.render_device(r.params(W, H, spp, nb), strip.data_ptr()); r.synchronize()
+                wall = (time.perf_counter() - t0) * 1e3
+                frames[k] = strip.cpu().numpy()
             else:
                 strip = torch.zeros((rt.strip_rows(H, 8, world), W, 3), dtype=torch.float32, device="cuda:0")
                 torch.cuda.synchronize()
+                t0 = time.perf_counter()
                 r.render_device(r.params(W, H, spp, nb, row_block=8, rank=3, world=world), strip.data_ptr()); r.synchronize()
+                wall = (time.perf_counter() - t0) * 1e3
                 frames[k] = strip.cpu().numpy()
             ms, n = r.profile_collect()
             if it:
-                times[k].append(ms)
+                times[k].append(ms); walls[k].append(wall)
     same = bool((frames[0].view(np.uint32) == frames[1].view(np.uint32)).all())
     a, b = statistics.median(times[0]), statistics.median(times[1])
-    print(f"{name}: A {a:.3f} ms (min {min(times[0]):.3f})   B {b:.3f} ms (min {min(times[1]):.3f})   B/A {b / a:.4f}   identical={same}", flush=True)
+    wa, wb = statistics.median(walls[0]), statistics.median(walls[1])
+    print(f"{name}: events (primary pass + trace kernel) A {a:.3f} ms (min {min(times[0]):.3f})   B {b:.3f} ms (min {min(times[1]):.3f})   B/A {b / a:.4f} | "
+          f"whole launch, enqueue -> synchronised: A {wa:.3f}   B {wb:.3f}   B/A {wb / wa:.4f}   identical={same}", flush=True)

@@ -13,7 +13,7 @@ g.render(W, H, spp, nb)
 rt.lib().rt_stats_read(out, 1)
 names = {1: "box test", 2: "box slow path", 3: "sphere test", 4: "sphere discr>0 (fp64 roots)", 5: "sphere 2nd root", 6: "sphere slow path",
          7: "round (setup site)", 8: "setup body", 9: "tap0 sd", 10: "tap1 sd", 11: "tap2 sd", 12: "trace batch", 13: "trace batch active",
-         14: "sky lookup", 15: "specular branch", 16: "consume site", 17: "consume body", 20: "supply attempt", 21: "pixel reload event", 22: "sample hand-out", 23: "drain iteration", 18: "box: dir outside window", 19: "box: |num| < 2^-100", 20: "box: |num| > 2^30", 21: "box: num == 0"}
+         14: "sky lookup", 15: "specular branch", 16: "consume site", 17: "consume body", 22: "sample hand-out", 23: "in-order sum pass", 24: "lanes left without a sample", 20: "supply attempt", 21: "pixel fetch event"}
 samples = W * H * spp
 for k in sorted(names):
     n, lanes = out[2 * k], out[2 * k + 1]

@@ -1,5 +1,5 @@
 """Kernel time of one rank's strip for world = 1, 2, 4, 8 on a single GPU (what each GPU of an N-GPU
-run executes), with the automatic schedule and with explicit pixel_streams settings."""
+run executes), with the automatic schedule."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,8 +11,7 @@ g.profile(True)
 for world in (1, 2, 4, 8):
     rows = rt.strip_rows(H, 8, world)
     strip = torch.empty((rows, W, 3), dtype=torch.float32, device="cuda:0")
-    for mode in ("auto", "8", "4", "2", "1"):
-        g.set_tuning(**({} if mode == "auto" else dict(pixel_streams=int(mode))))
+    for mode in ("auto",):
         ts = []
         for rank in (0, world - 1):
             p = g.params(W, H, spp, nb, row_block=8, rank=rank, world=world)
@@ -23,4 +22,4 @@ for world in (1, 2, 4, 8):
                 dt = (time.perf_counter() - t) * 1e3
                 ms, n = g.profile_collect()
                 if it: ts.append((ms, dt))
-        print(f"world {world} streams={mode:4s}: primary pass + trace kernel {min(t[0] for t in ts):.3f} ms, wall {min(t[1] for t in ts):.3f} ms", flush=True)
+        print(f"world {world} schedule={mode:4s}: primary pass + trace kernel {min(t[0] for t in ts):.3f} ms, wall {min(t[1] for t in ts):.3f} ms", flush=True)

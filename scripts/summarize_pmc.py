@@ -9,13 +9,13 @@ for f in sorted(glob.glob(os.path.join(root, "stats", "**", "*_kernel_stats.csv"
     lines.append(f"== kernel stats ({os.path.basename(f)})")
     lines += [l.rstrip() for l in open(f)]
 totals = {}
-KERNELS = ("rt_trace", "rt_primary_pass", "rt_sum_samples")
+KERNELS = ("rt_trace", "rt_primary_pass")
 for d in ("pmc_valu", "pmc_busy", "pmc_mix1", "pmc_mix2", "pmc_fetch", "pmc_write"):
     for f in sorted(glob.glob(os.path.join(root, d, "**", "*_counter_collection.csv"), recursive=True)):
         per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             for k in KERNELS:
-                if r["Kernel_Name"].startswith(k):
+                if k in r["Kernel_Name"]:
                     per_kernel[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k in KERNELS:
             agg = per_kernel.get(k)
@@ -43,7 +43,7 @@ if len(sys.argv) > 3:
     table = json.load(open(path)) if os.path.exists(path) else {}
     fetch = sum(v.get("FETCH_SIZE", 0.0) for v in totals.values()) * 1024
     write = sum(v.get("WRITE_SIZE", 0.0) for v in totals.values()) * 1024
-    table[config] = {"kernel": "rt_primary_pass + rt_trace_* (+ rt_sum_samples)", "fetch_bytes": fetch, "write_bytes": write,
+    table[config] = {"kernel": "rt_primary_pass + rt_trace_*", "fetch_bytes": fetch, "write_bytes": write,
                      "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB x 1024, per frame = all kernels of one launch), {root}; "
                                "reads are scattered 4-byte skybox gathers served by the Infinity Cache, so the x2 streaming correction is not applied"}
     json.dump(table, open(path, "w"), indent=1, sort_keys=True)
