@@ -34,6 +34,7 @@ extern "C" {
 #define RT_API __attribute__((visibility("default")))
 
 typedef enum {
+	RT_CANCELLED     =  1,   /* not an error: the launch was cut short by rt_cancel(); the frame is incomplete */
 	RT_OK            =  0,
 	RT_ERR_ARGUMENT  = -1,   /* NULL / out-of-range argument                     */
 	RT_ERR_DEVICE    = -2,   /* HIP runtime error (text in rt_last_error())      */
@@ -129,6 +130,16 @@ RT_API int rt_deinterleave_device(rt_context *ctx, const void *d_strips, void *d
                                   int width, int height, int row_block, int world, void *hip_stream);
 
 RT_API int rt_synchronize(rt_context *ctx);
+
+/* Giving up a frame, as the reference's workers do when the camera moves mid-pass (main.c:316-317): rt_cancel()
+ * asks the launch that is running (or already enqueued) on this context to stop -- its waves hand out no more
+ * samples, finish the paths in flight and leave, within a few hundred microseconds.  It may be called from ANY
+ * host thread while another one is inside rt_render*() for the same context; it returns at once.  rt_render()
+ * then returns RT_CANCELLED and its frame is incomplete; after rt_render_device(), rt_was_cancelled() (which
+ * waits for the launch) tells.  The request is forgotten when the next launch starts.
+ * rt_progressive_invalidate() does this by itself for a pass in flight, and that pass is not accumulated. */
+RT_API int rt_cancel(rt_context *ctx);
+RT_API int rt_was_cancelled(rt_context *ctx);
 
 /* ---- several GPUs of one node, one host process: replaces start_workers()'s fan-out (main.c:695-718) ----
  * rt_multi_create() makes one context per listed device and, for n > 1, the RCCL communicators of the group

@@ -65,7 +65,7 @@ class MouseState(C.Structure):
 EXPORTS = [
     "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
     "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_render", "rt_render_device", "rt_strip_rows", "rt_deinterleave_device",
-    "rt_synchronize", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
+    "rt_synchronize", "rt_cancel", "rt_was_cancelled", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
     "rt_progressive_invalidate", "rt_progressive_state", "rt_selftest", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
     "rt_parse_scene_string", "rt_load_cubemap", "rt_free_cubemap", "rt_decode_jpeg_file",
     "rt_camera_default", "rt_camera_basis_for", "rt_mouse_state_default", "rt_move_camera",
@@ -110,6 +110,9 @@ def lib():
     L.rt_strip_rows.argtypes = [C.c_int, C.c_int, C.c_int]
     L.rt_deinterleave_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
     L.rt_synchronize.argtypes = [C.c_void_p]
+    if hasattr(L, "rt_cancel"):
+        L.rt_cancel.argtypes = [C.c_void_p]
+        L.rt_was_cancelled.argtypes = [C.c_void_p]
     if hasattr(L, "rt_multi_create"):       # (scripts/ab.py also loads older builds of the library)
         L.rt_multi_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
         L.rt_multi_destroy.argtypes = [C.c_void_p]
@@ -297,7 +300,10 @@ class Renderer:
         """Whole frame -> host float32 array (height, width, 3), row 0 = bottom (as the reference's `frame`)."""
         p = self.params(width, height, spp, max_bounces, seed=seed, kernel=kernel)
         out = np.empty((height, width, 3), dtype=np.float32)
-        _check(lib().rt_render(self._ctx, C.byref(p), out.ctypes.data_as(C.c_void_p)), "rt_render")
+        rc = lib().rt_render(self._ctx, C.byref(p), out.ctypes.data_as(C.c_void_p))
+        if rc == 1:
+            raise RtError("rt_render: cancelled (rt_cancel): the frame is incomplete")
+        _check(rc, "rt_render")
         return out
 
     @staticmethod
@@ -349,6 +355,16 @@ class Renderer:
 
     def synchronize(self):
         _check(lib().rt_synchronize(self._ctx), "rt_synchronize")
+
+    def cancel(self):
+        """rt_cancel(): ask the launch in flight to stop (callable from any thread)."""
+        _check(lib().rt_cancel(self._ctx), "rt_cancel")
+
+    def was_cancelled(self):
+        rc = lib().rt_was_cancelled(self._ctx)
+        if rc < 0:
+            _check(rc, "rt_was_cancelled")
+        return rc == 1
 
     def profile(self, on=True):
         _check(lib().rt_profile_enable(self._ctx, 1 if on else 0), "rt_profile_enable")

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -78,7 +79,11 @@ struct rt_context {
 	rt_camera    camera;
 	bool         have_camera = false;
 
-	unsigned int *d_counter = nullptr;   /* dequeue + fill counters of the pixel lists */
+	unsigned int *d_counter = nullptr;   /* dequeue + fill counters of the pixel lists, launch control words */
+	hipStream_t  cancel_stream = nullptr; /* rt_cancel(): a copy that overtakes the running kernel */
+	hipEvent_t   cancel_event = nullptr;  /* recorded behind that copy: the next launch's clearing of the control words waits for it */
+	std::atomic<bool> cancel_pending{false};
+	unsigned int *h_words = nullptr;     /* pinned: [0] = read-back of control[1]; [32 ...] = 64 x 128 bytes of 0x80000000 (source of the stop request) */
 	int          num_cus = 256;
 
 	float       *d_pix = nullptr;        /* rt_primary_pass output: pixel records (rt_device.h) */
@@ -125,6 +130,8 @@ static int wait_for_launches(rt_context *ctx)
 static int order_behind_previous(rt_context *ctx, hipStream_t stream)
 {
 	if (ctx->launched && ctx->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->last_launch, 0));
+	/* a stop request meant for an earlier launch must have landed before this launch clears the control words */
+	if (ctx->cancel_pending.exchange(false)) HIP_TRY(hipStreamWaitEvent(stream, ctx->cancel_event, 0));
 	return RT_OK;
 }
 
@@ -189,6 +196,10 @@ int rt_create(rt_context **out, int device_id)
 			ctx->num_cus = prop.multiProcessorCount;
 		e = hipMalloc((void**) &ctx->d_counter, rt_counter_bytes());
 		if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->last_launch, hipEventDisableTiming);
+		if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->cancel_stream, hipStreamNonBlocking);
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->cancel_event, hipEventDisableTiming);
+		if (e == hipSuccess) e = hipHostMalloc((void**) &ctx->h_words, (size_t) (32 + 64 * 32) * sizeof(unsigned int), hipHostMallocDefault);
+		if (e == hipSuccess) { ctx->h_words[0] = 0u; for (int k = 0; k < 64 * 32; k++) ctx->h_words[32 + k] = 0x80000000u; }
 		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 		if (e != hipSuccess) { (void) hipStreamDestroy(ctx->stream); delete ctx; return fail(RT_ERR_DEVICE, "rt_create: %s", hipGetErrorString(e)); }
 	}
@@ -207,6 +218,9 @@ void rt_destroy(rt_context *ctx)
 	for (auto &e : ctx->event_pool) (void) hipEventDestroy(e);
 	if (ctx->launched) (void) hipEventSynchronize(ctx->last_launch);
 	if (ctx->last_launch) (void) hipEventDestroy(ctx->last_launch);
+	if (ctx->cancel_stream) { (void) hipStreamSynchronize(ctx->cancel_stream); (void) hipStreamDestroy(ctx->cancel_stream); }
+	if (ctx->cancel_event) (void) hipEventDestroy(ctx->cancel_event);
+	if (ctx->h_words) (void) hipHostFree(ctx->h_words);
 	if (ctx->spec_module) (void) hipModuleUnload(ctx->spec_module);
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
 	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame); (void) hipFree(ctx->d_counter); (void) hipFree(ctx->d_pix);
@@ -423,7 +437,8 @@ static int prepare_launch(rt_context *ctx, rt_launch &L)
 	}
 	L.pix = ctx->d_pix;
 	L.pix_shard_cap = (int) cap;
-	L.pix_count = ctx->d_counter + rt_counter_bytes() / sizeof(unsigned int) / 2;     /* second half of the counter block */
+	L.pix_count = ctx->d_counter + 64 * 32;      /* counter block: 64 dequeue counters, 64 fill counters, one control line */
+	L.control = ctx->d_counter + 128 * 32;
 	return RT_OK;
 }
 
@@ -497,8 +512,33 @@ int rt_render(rt_context *ctx, const rt_render_params *p, Vector3 *frame_out)
 	if (rc != RT_OK) return rc;
 	HIP_TRY(hipMemcpyAsync(frame_out, ctx->d_frame, (size_t) p->height * p->width * 3 * sizeof(float),
 	                       hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(&ctx->h_words[0], ctx->d_counter + 128 * 32 + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return ctx->h_words[0] ? RT_CANCELLED : RT_OK;
+}
+
+/* The stop request travels on its own stream, so it overtakes the kernel it is meant for; the counter block is
+ * cleared at the start of every launch.  Uses nothing of the context that a render call on
+ * another thread changes. */
+int rt_cancel(rt_context *ctx)
+{
+	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_cancel: NULL context");
+	HIP_TRY(hipSetDevice(ctx->device));
+	/* every dequeue counter jumps beyond any fill count: from now on no fetch returns a pixel (rt_kernels.hip) */
+	HIP_TRY(hipMemcpyAsync(ctx->d_counter, &ctx->h_words[32], (size_t) 64 * 32 * sizeof(unsigned int), hipMemcpyHostToDevice, ctx->cancel_stream));
+	HIP_TRY(hipEventRecord(ctx->cancel_event, ctx->cancel_stream));
+	ctx->cancel_pending.store(true);
 	return RT_OK;
+}
+
+int rt_was_cancelled(rt_context *ctx)
+{
+	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_was_cancelled: NULL context");
+	HIP_TRY(hipSetDevice(ctx->device));
+	{ const int rc = wait_for_launches(ctx); if (rc != RT_OK) return rc; }
+	unsigned int w = 0;
+	HIP_TRY(hipMemcpy(&w, ctx->d_counter + 128 * 32 + 1, sizeof(w), hipMemcpyDeviceToHost));
+	return w ? RT_CANCELLED : RT_OK;
 }
 
 int rt_deinterleave_device(rt_context *ctx, const void *d_strips, void *d_frame,
@@ -551,6 +591,9 @@ int rt_progressive_invalidate(rt_context *ctx)
 	if (!ctx || !ctx->prog.active) return fail(RT_ERR_STATE, "rt_progressive_invalidate: call rt_progressive_begin first");
 	HIP_TRY(hipSetDevice(ctx->device));
 	auto &g = ctx->prog;
+	/* a pass still in flight is given up as soon as its waves notice (main.c:316-317) and is not published
+	 * (main.c:382: rt_accumulate looks at control[1]); the clear below is ordered behind it */
+	if (ctx->launched) { const int rc = rt_cancel(ctx); if (rc != RT_OK) return rc; }
 	HIP_TRY(hipMemsetAsync(g.d_accum, 0, g.accum_bytes, ctx->stream));
 	g.count = 0; g.passes = 0; g.scale = g.init_scale; g.generation++;
 	return RT_OK;
@@ -588,7 +631,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	if (ctx->tuning.poison_frame) HIP_TRY(hipMemsetAsync(g.d_low, 0xff, g.low_bytes, ctx->stream));
 	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream));
 	const float weight = 1.0f / (s * s);                                         /* main.c:278 */
-	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), ctx->stream));
+	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), L.control + 1, ctx->stream));
 	{ const int rc = mark_launch(ctx, ctx->stream); if (rc != RT_OK) return rc; }
 	g.count += weight;                                                           /* main.c:396 */
 	g.passes++;

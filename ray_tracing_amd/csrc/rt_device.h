@@ -81,6 +81,9 @@ typedef struct {
 	float *pix;
 	unsigned int *pix_count;   /* one fill counter per list, 128 bytes apart */
 	int    pix_shard_cap;
+	/* control[1]: set by a wave that gave up because of rt_cancel() (which pushes the lists' dequeue counters beyond
+	 * any fill count, so that no fetch returns a pixel) -- the frame is incomplete */
+	unsigned int *control;
 	const rt_geom  *geom;      /* num_objects records (global; staged to LDS)  */
 	const rt_shade *shade;
 } rt_launch;

@@ -668,7 +668,7 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
  * ============================================================================================= */
 
 #define WF_SHARDS  64                  /* pixel lists (at most); each has a fill counter and a dequeue counter, 128 B apart */
-#define RT_COUNTER_BYTES (2 * WF_SHARDS * 128)
+#define RT_COUNTER_BYTES ((2 * WF_SHARDS + 1) * 128)   /* + one line of launch control words (rt_launch.control) */
 #define WF_QUEUE   128                 /* ring: at most 63 waiting + 64 pushed at a time */
 #define WF_STREAMS 8                   /* pixels a wave adds up concurrently (at most) */
 #define WF_WINDOW  256                 /* sample slots per wave, shared equally by its streams */
@@ -786,7 +786,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	 * dequeue counter on its own 128-byte line (one counter saturates at ~88 dequeues/us, MI355X_MICROARCH.md).  A
 	 * wave starts at the list of its workgroup and moves on to the next one when a list has run out. */
 	unsigned int shard = blockIdx.x % (unsigned int) L.num_shards;
-	bool exhausted = false;
+	bool exhausted = false;                 /* no pixels left to fetch */
+	bool cancelled = false;                 /* rt_cancel(): nothing more is handed out, the paths in flight finish, the wave leaves */
 
 	/* per-lane path state.  A path is worked on at two places one round apart.  The FRONT (section 2) turns the
 	 * pending hit into the next rays: it owns rng, bounce, the hit and f_slot.  The BACK (section 5) does the
@@ -869,7 +870,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		for (int attempt = 0; attempt < P; attempt++) {
 			const bool want = !f_live;
 			const unsigned long long wmask = __ballot(want);
-			if (wmask == 0ull) break;
+			if (wmask == 0ull || cancelled) break;
 			/* the lists have run out: go on only while some stream still has samples (and slots) to give */
 			if (exhausted && (direct || (attempt > 0 &&
 			    __ballot(leader && W.s_nxt[g] < spp && W.s_seq[g] - W.s_drained[g] < wn - 1u) == 0ull))) break;
@@ -900,14 +901,21 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 						/* This list has run out: look at all of them at once (lane s reads list s's two counters; a stale
 						 * dequeue count can only show more pixels left than there are, never fewer) and move to the next
 						 * one that still has pixels.  None: the launch has no pixels left to hand out. */
-						unsigned int left = 0;
+						unsigned int left = 0, taken = 0;
 						if (lane < C->num_shards) {
-							const unsigned int taken = __hip_atomic_load(block_counter + (unsigned int) lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							taken = __hip_atomic_load(block_counter + (unsigned int) lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 							const unsigned int have = C->pix_count[(unsigned int) lane * 32u];
 							left = have > taken ? have - taken : 0u;
 						}
+						/* rt_cancel() makes every list look empty by pushing its dequeue counter beyond any fill count; seeing
+						 * that here (main.c:316-317: the frame has been invalidated) the wave gives up: nothing more is handed
+						 * out, the paths in flight finish, and the launch is marked incomplete */
+						if (__ballot(taken >= 0x80000000u) != 0ull) {
+							cancelled = true;
+							if (lane == 0) C->control[1] = 1u;
+						}
 						const unsigned long long some = __ballot(left != 0u);
-						if (some == 0ull) exhausted = true;
+						if (some == 0ull || cancelled) exhausted = true;
 						else {      /* the waves spread over the lists that are left (one address takes ~88 atomics per microsecond) */
 							const int pick = (int) ((blockIdx.x * (RT_BLOCK / 64) + (unsigned int) wave) % (unsigned int) __popcll(some));
 							shard = (unsigned int) __builtin_ctzll(__ballot(left != 0u && lanes_below(some) == pick));
@@ -1172,8 +1180,9 @@ rt_trace_spec(const rt_launch L, unsigned int *block_counter)
 /* ---- progressive accumulation: worker()'s publish step (main.c:387-396) and update_frame()'s
  * resolve (main.c:467-477) ------------------------------------------------------------------ */
 extern "C" __global__ void __launch_bounds__(RT_BLOCK)
-rt_accumulate(float *accum, const float *lowres, int width, int height, int scale, int low_w, int low_h, float k)
+rt_accumulate(float *accum, const float *lowres, int width, int height, int scale, int low_w, int low_h, float k, const unsigned int *cancelled)
 {
+	if (*cancelled) return;               /* the pass was given up: it is not published (main.c:382) */
 	const size_t total = (size_t) width * height;
 	for (size_t p = (size_t) blockIdx.x * RT_BLOCK + threadIdx.x; p < total; p += (size_t) gridDim.x * RT_BLOCK) {
 		const int y = (int) (p / (size_t) width), x = (int) (p % (size_t) width);
@@ -1364,9 +1373,9 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 }
 
 hipError_t rt_launch_accumulate(float *accum, const float *lowres, int width, int height, int scale,
-                                int low_w, int low_h, float k, hipStream_t stream)
+                                int low_w, int low_h, float k, const unsigned int *cancelled, hipStream_t stream)
 {
-	hipLaunchKernelGGL(rt_accumulate, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, lowres, width, height, scale, low_w, low_h, k);
+	hipLaunchKernelGGL(rt_accumulate, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, lowres, width, height, scale, low_w, low_h, k, cancelled);
 	return hipGetLastError();
 }
 

@@ -63,3 +63,39 @@ def test_full_resolution_passes_equal_rt_render(scene_paths):
         g.progressive_pass()
     assert (bits(g.progressive_resolve()) == bits(g.render(160, 90, 6, 4, seed=9))).all()
     g.close()
+
+
+def test_cancel_gives_up_a_frame_in_flight(scene_paths):
+    """rt_cancel() (main.c:316-317: a worker abandons its pass when the frame is invalidated): a long launch is cut
+    short from another thread, reports RT_CANCELLED, and the next launch renders the complete, correct frame."""
+    import threading
+    import time
+    import torch
+    g = rt.Renderer(0)
+    g.set_tuning(poison_frame=True)
+    g.set_skybox(rt.load_skybox()); g.set_scene(scene_paths[0]); g.set_camera()
+    W, H, spp, nb = 1920, 1080, 1024, 8                     # ~120 ms of GPU work
+    strip = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    p = g.params(W, H, spp, nb)
+    t0 = time.perf_counter()
+    g.render_device(p, strip.data_ptr())
+    g.synchronize()
+    full = time.perf_counter() - t0
+    assert not g.was_cancelled()
+    t0 = time.perf_counter()
+    g.render_device(p, strip.data_ptr())
+    threading.Timer(0.005, g.cancel).start()                # from another thread, 5 ms into the launch
+    g.synchronize()
+    cut = time.perf_counter() - t0
+    assert g.was_cancelled()
+    assert cut < 0.5 * full, (cut, full)
+    print(f"full launch {full * 1e3:.1f} ms, cancelled after 5 ms: returned after {cut * 1e3:.1f} ms")
+    # the request is forgotten by the next launch; rt_render() reports a cancelled frame as such
+    a = g.render(320, 180, 8, 4, seed=3)
+    s = g.render(320, 180, 8, 4, seed=3, kernel=rt.KERNEL_SIMPLE)
+    assert (a.view(np.uint32) == s.view(np.uint32)).all()
+    g.cancel()                                              # nothing in flight: must not leak into the next launch
+    a2 = g.render(320, 180, 8, 4, seed=3)
+    assert (a2.view(np.uint32) == s.view(np.uint32)).all()
+    g.close()
