@@ -440,41 +440,132 @@ static int chunk(FILE *fp, const char *tag, const unsigned char *data, size_t n)
 	return fwrite(head, 1, 8, fp) == 8 && fwrite(data, 1, n, fp) == n && fwrite(tail, 1, 4, fp) == 4;
 }
 
+/* ---- deflate (RFC 1951) with the fixed Huffman code and a hash-chain LZ77 matcher: what a screenshot needs
+ * (stb_image_write, which the reference uses, compresses the same way; file BYTES differ, decoded pixels do not) */
+
+typedef struct { unsigned char *p; size_t n, cap; uint32_t bits; int nbits; int failed; } BitSink;
+
+static void sink_byte(BitSink *s, unsigned v)
+{
+	if (s->n == s->cap) {
+		size_t cap = s->cap ? s->cap * 2 : 1 << 16;
+		unsigned char *q = realloc(s->p, cap);
+		if (!q) { s->failed = 1; return; }
+		s->p = q; s->cap = cap;
+	}
+	s->p[s->n++] = (unsigned char) v;
+}
+
+static void sink_bits(BitSink *s, uint32_t v, int n)        /* LSB first */
+{
+	s->bits |= v << s->nbits; s->nbits += n;
+	while (s->nbits >= 8) { sink_byte(s, s->bits & 0xff); s->bits >>= 8; s->nbits -= 8; }
+}
+
+static uint32_t reverse_bits(uint32_t v, int n) { uint32_t r = 0; while (n--) { r = (r << 1) | (v & 1); v >>= 1; } return r; }
+
+static void sink_huff(BitSink *s, uint32_t code, int n) { sink_bits(s, reverse_bits(code, n), n); }   /* Huffman codes go MSB first */
+
+static void sink_litlen(BitSink *s, int sym)               /* fixed code, RFC 1951 3.2.6 */
+{
+	if      (sym < 144) sink_huff(s, 0x30 + sym, 8);
+	else if (sym < 256) sink_huff(s, 0x190 + (sym - 144), 9);
+	else if (sym < 280) sink_huff(s, sym - 256, 7);
+	else                sink_huff(s, 0xc0 + (sym - 280), 8);
+}
+
+static unsigned char *deflate_fixed(const unsigned char *in, size_t n, size_t *out_n)
+{
+	static const unsigned short len_base[] = { 3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258, 259 };
+	static const unsigned char  len_extra[] = { 0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0 };
+	static const unsigned short dist_base[] = { 1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,257,385,513,769,1025,1537,2049,3073,4097,6145,8193,12289,16385,24577, 32769 };
+	static const unsigned char  dist_extra[] = { 0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13 };
+	enum { HASH_BITS = 15, HASH_SIZE = 1 << HASH_BITS, WINDOW = 32768, CHAIN = 24 };
+	BitSink s = { 0 };
+	int32_t *head = malloc(sizeof(int32_t) * HASH_SIZE), *prev = malloc(sizeof(int32_t) * WINDOW);
+	if (!head || !prev) { free(head); free(prev); return NULL; }
+	for (int i = 0; i < HASH_SIZE; i++) head[i] = -1;
+	sink_byte(&s, 0x78); sink_byte(&s, 0x5e);              /* zlib header: deflate, 32 KiB window */
+	sink_bits(&s, 1, 1); sink_bits(&s, 1, 2);               /* one final block, fixed Huffman */
+	uint32_t a = 1, b = 0;
+	size_t i = 0;
+	while (i < n) {
+		int best_len = 0, best_dist = 0;
+		if (i + 3 <= n) {
+			const uint32_t h = ((uint32_t) in[i] << 10 ^ (uint32_t) in[i + 1] << 5 ^ in[i + 2]) & (HASH_SIZE - 1);
+			int32_t cand = head[h];
+			const size_t max_len = n - i < 258 ? n - i : 258;
+			for (int tries = 0; cand >= 0 && (size_t) cand + WINDOW > i && tries < CHAIN; tries++) {
+				size_t l = 0;
+				while (l < max_len && in[(size_t) cand + l] == in[i + l]) l++;
+				if ((int) l > best_len) { best_len = (int) l; best_dist = (int) (i - (size_t) cand); if (l == max_len) break; }
+				cand = prev[(size_t) cand & (WINDOW - 1)];
+			}
+			prev[i & (WINDOW - 1)] = head[h]; head[h] = (int32_t) i;
+		}
+		if (best_len >= 3) {
+			int lc = 0; while (best_len >= len_base[lc + 1]) lc++;
+			sink_litlen(&s, 257 + lc);
+			if (len_extra[lc]) sink_bits(&s, (uint32_t) (best_len - len_base[lc]), len_extra[lc]);
+			int dc = 0; while (best_dist >= dist_base[dc + 1]) dc++;
+			sink_huff(&s, (uint32_t) dc, 5);
+			if (dist_extra[dc]) sink_bits(&s, (uint32_t) (best_dist - dist_base[dc]), dist_extra[dc]);
+			for (int k = 1; k < best_len; k++) {               /* the skipped positions still enter the dictionary */
+				const size_t q = i + (size_t) k;
+				if (q + 3 <= n) {
+					const uint32_t h = ((uint32_t) in[q] << 10 ^ (uint32_t) in[q + 1] << 5 ^ in[q + 2]) & (HASH_SIZE - 1);
+					prev[q & (WINDOW - 1)] = head[h]; head[h] = (int32_t) q;
+				}
+			}
+			i += (size_t) best_len;
+		} else
+			sink_litlen(&s, in[i++]);
+	}
+	sink_litlen(&s, 256);                                   /* end of block */
+	if (s.nbits) sink_bits(&s, 0, 8 - s.nbits);
+	for (size_t k = 0; k < n; k++) { a += in[k]; b += a; if ((k & 4095) == 4095) { a %= 65521u; b %= 65521u; } }
+	a %= 65521u; b %= 65521u;                               /* adler-32 of the uncompressed bytes */
+	sink_byte(&s, b >> 8); sink_byte(&s, b & 0xff); sink_byte(&s, a >> 8); sink_byte(&s, a & 0xff);
+	free(head); free(prev);
+	if (s.failed) { free(s.p); return NULL; }
+	*out_n = s.n;
+	return s.p;
+}
+
+static int paeth(int a, int b, int c)
+{
+	const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+	return pa <= pb && pa <= pc ? a : (pb <= pc ? b : c);
+}
+
 int rt_write_png(const char *file, int w, int h, const Vector3 *data)
 {
 	if (!file || !data || w < 1 || h < 1) return RT_ERR_ARGUMENT;
 	if (!crc_table[1]) crc_init();
-	const size_t stride = (size_t) w * 3 + 1, raw_n = stride * (size_t) h;
-	unsigned char *raw = malloc(raw_n);
-	if (!raw) return RT_ERR_MEMORY;
+	const size_t row_bytes = (size_t) w * 3, stride = row_bytes + 1, raw_n = stride * (size_t) h;
+	unsigned char *raw = malloc(raw_n), *pix = malloc(row_bytes * 2);
+	if (!raw || !pix) { free(raw); free(pix); return RT_ERR_MEMORY; }
+	unsigned char *cur = pix, *up = pix + row_bytes;
+	memset(up, 0, row_bytes);
 	for (int row = 0; row < h; row++) {
-		unsigned char *dst = raw + stride * (size_t) row;
 		const Vector3 *src = data + (size_t) (h - 1 - row) * w;        /* stbi_flip_vertically_on_write(1) */
-		*dst++ = 0;                                                    /* filter: none */
 		for (int i = 0; i < w; i++) {
-			*dst++ = (unsigned char) (src[i].x * 255);                 /* main.c:662-664: truncation */
-			*dst++ = (unsigned char) (src[i].y * 255);
-			*dst++ = (unsigned char) (src[i].z * 255);
+			cur[3 * i + 0] = (unsigned char) (src[i].x * 255);             /* main.c:662-664: truncation */
+			cur[3 * i + 1] = (unsigned char) (src[i].y * 255);
+			cur[3 * i + 2] = (unsigned char) (src[i].z * 255);
 		}
+		unsigned char *dst = raw + stride * (size_t) row;
+		*dst++ = 4;                                                    /* filter: Paeth */
+		for (size_t k = 0; k < row_bytes; k++) {
+			const int left = k >= 3 ? cur[k - 3] : 0, upleft = k >= 3 ? up[k - 3] : 0;
+			dst[k] = (unsigned char) (cur[k] - paeth(left, up[k], upleft));
+		}
+		unsigned char *t = cur; cur = up; up = t;
 	}
-	/* zlib stream of stored blocks */
-	const size_t blocks = (raw_n + 65534) / 65535;
-	const size_t z_n = 2 + raw_n + 5 * blocks + 4;
-	unsigned char *z = malloc(z_n);
-	if (!z) { free(raw); return RT_ERR_MEMORY; }
 	size_t o = 0;
-	z[o++] = 0x78; z[o++] = 0x01;
-	uint32_t a = 1, b = 0;
-	for (size_t off = 0; off < raw_n; off += 65535) {
-		const size_t n = raw_n - off < 65535 ? raw_n - off : 65535;
-		z[o++] = off + n == raw_n;                                     /* BFINAL, BTYPE = 00 */
-		z[o++] = n & 0xff; z[o++] = n >> 8; z[o++] = ~n & 0xff; z[o++] = (~n >> 8) & 0xff;
-		memcpy(z + o, raw + off, n);
-		o += n;
-		for (size_t i = 0; i < n; i++) { a = (a + raw[off + i]) % 65521u; b = (b + a) % 65521u; }
-	}
-	put32(z + o, (b << 16) | a);
-	o += 4;
+	unsigned char *z = deflate_fixed(raw, raw_n, &o);
+	free(raw); free(pix);
+	if (!z) return RT_ERR_MEMORY;
 
 	FILE *fp = fopen(file, "wb");
 	int ok = fp != NULL;
@@ -486,7 +577,7 @@ int rt_write_png(const char *file, int w, int h, const Vector3 *data)
 		ok = fwrite(sig, 1, 8, fp) == 8 && chunk(fp, "IHDR", ihdr, 13) && chunk(fp, "IDAT", z, o) && chunk(fp, "IEND", NULL, 0);
 		ok = (fclose(fp) == 0) && ok;
 	}
-	free(raw); free(z);
+	free(z);
 	return ok ? RT_OK : RT_ERR_IO;
 }
 

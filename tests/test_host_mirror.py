@@ -242,6 +242,15 @@ def test_png_sink_and_screenshot_naming(tmp_path, monkeypatch):
         got = np.asarray(Image.open(out).convert("RGB"))
         want = (frame * np.float32(255)).astype(np.uint8)[::-1]      # main.c:662-672
         assert got.shape == want.shape and (got == want).all()
+    # a smooth image (what a render looks like) must actually be compressed: Paeth filter + LZ77 + fixed Huffman
+    yy, xx = np.mgrid[0:240, 0:320].astype(np.float32)
+    smooth = np.stack([xx / 320, yy / 240, (xx + yy) / 560], axis=-1).astype(np.float32)
+    smooth[60:120, 80:200] = (0.25, 0.5, 0.75)                      # a flat patch: long matches
+    out = tmp_path / "smooth.png"
+    assert L.rt_write_png(str(out).encode(), 320, 240, smooth.ctypes.data_as(C.c_void_p)) == 0
+    got = np.asarray(Image.open(out).convert("RGB"))
+    assert (got == (smooth * np.float32(255)).astype(np.uint8)[::-1]).all()
+    assert out.stat().st_size < 320 * 240 * 3 // 4, out.stat().st_size
     monkeypatch.chdir(tmp_path)
     (tmp_path / "screenshot_0.png").write_bytes(b"taken")
     name = C.create_string_buffer(64)
