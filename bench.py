@@ -63,6 +63,9 @@ def parse_args(argv=None):
     ap.add_argument("--launch-check", action="store_true",
                     help="only prove the N-rank launch + rendezvous (no GPU work); used by the CPU tests")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="testing aid for 1-GPU boxes: all ranks use GPU 0 and the strips travel over gloo "
+                         "(RCCL refuses two ranks on one device); not a performance configuration")
     return ap.parse_args(argv)
 
 
@@ -206,11 +209,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
+    if args.share_gpu:
+        local_rank = 0
+        args.backend = args.backend or "gloo"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend or "nccl", device_id=dev)
+        if (args.backend or "nccl") == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     w = WORKLOADS[args.config]
     W, H, spp, nb, seed = w["width"], w["height"], w["spp"], w["max_bounces"], w["seed"]
@@ -297,7 +306,7 @@ def main():
                        "timed_region": "K frames, each: strip render -> "
                                        + ("one RCCL gather to rank 0 -> de-interleave -> " if world > 1 else "")
                                        + "resolved frame copied to pinned host memory; two frames in flight",
-                       "partition": f"interleaved blocks of {ROW_BLOCK} rows over {world} GPU(s)"
+                       "partition": f"interleaved blocks of {ROW_BLOCK} rows over {world} " + ("rank(s) SHARING ONE GPU (testing aid)" if args.share_gpu else "GPU(s)")
                                     + (f"; collective: {tiled.primitive}" if world > 1 else ""),
                        "kernel": {0: "wavefront" + ("+scene-specialised (hiprtc)" if compiled else ""), 1: "simple",
                                   2: "wavefront, plain IEEE ops"}.get(args.kernel, str(args.kernel))},

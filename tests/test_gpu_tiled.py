@@ -46,15 +46,19 @@ def _free_port():
     return p
 
 
-def _nccl_worker(rank, world, port, q):
+def _nccl_worker(rank, world, port, q, backend="nccl", share_gpu=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
     from ray_tracing_amd.multi_gpu import TiledFrame
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    g = rt.Renderer(rank)
+    device = 0 if share_gpu else rank
+    torch.cuda.set_device(device)
+    dev = torch.device("cuda", device)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    g = rt.Renderer(device)
     g.set_tuning(poison_frame=True)
     g.set_skybox(rt.load_skybox()); g.set_scene(os.path.join(rt.DATA_DIR, "scene_0.txt")); g.set_camera()
     W, H, spp, nb = 320, 180, 8, 4
@@ -73,6 +77,26 @@ def _nccl_worker(rank, world, port, q):
     dist.barrier()
     g.close()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_frames_ranks_sharing_one_gpu_over_gloo(world):
+    """The N-rank frame loop of bench.py on the ONE GPU this pool's boxes have: every rank is its own process with
+    its own context, streams and strips on GPU 0, the strips travel through gloo (which moves device tensors) instead
+    of RCCL (which refuses two ranks on one device).  Everything but the transport is what an N-GPU run executes:
+    per-rank interleaved strips, asynchronous gather, double buffering, de-interleave, host copy -- with a different
+    seed per step, so a stale strip or a mis-ordered stream cannot look correct."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q, "gloo", True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL gather between ranks)")
