@@ -229,6 +229,7 @@ def main():
     gpu.set_scene(scene_path)
     gpu.set_skybox(sky)
     gpu.set_camera()
+    gpu.reserve(W, H)
     # scene "compilation" (hiprtc, ~1 s, outside the timed region): same frames, fewer instructions
     compiled, jit_s = False, None
     if args.kernel == rt.KERNEL_AUTO and not args.no_jit:

@@ -121,6 +121,11 @@ RT_API int rt_render(rt_context *ctx, const rt_render_params *params, Vector3 *f
 #define RT_STREAM_LEGACY ((void *) (intptr_t) -1)
 RT_API int rt_render_device(rt_context *ctx, const rt_render_params *params, void *d_strip, void *hip_stream);
 
+/* Optional: allocate the launch scratch (48 bytes per pixel of pixel records) and rt_render()'s device frame for
+ * frames of up to width x height now.  Without it they are allocated -- a blocking hipMalloc -- inside the first
+ * render call of a size and kept; nothing is ever allocated per launch. */
+RT_API int rt_reserve(rt_context *ctx, int width, int height);
+
 /* Rows held by one rank's strip, padded so every rank has the same count (gather-friendly). */
 RT_API int rt_strip_rows(int height, int row_block, int world);
 

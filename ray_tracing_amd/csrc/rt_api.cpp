@@ -442,6 +442,28 @@ static int prepare_launch(rt_context *ctx, rt_launch &L)
 	return RT_OK;
 }
 
+/* The launch scratch (pixel lists) and rt_render()'s device frame for frames up to width x height, allocated now
+ * instead of inside the first render call of that size. */
+int rt_reserve(rt_context *ctx, int width, int height)
+{
+	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_reserve: NULL context");
+	if (width < 2 || height < 2 || (int64_t) width * height > (int64_t) 1 << 30)
+		return fail(RT_ERR_ARGUMENT, "rt_reserve: frame %dx%d unsupported (need >= 2x2, <= 2^30 pixels)", width, height);
+	HIP_TRY(hipSetDevice(ctx->device));
+	{ const int rc = wait_for_launches(ctx); if (rc != RT_OK) return rc; }
+	rt_launch L;
+	memset(&L, 0, sizeof(L));
+	L.width = width; L.local_rows = rt_strip_rows(height, 8, 1);
+	{ const int rc = prepare_launch(ctx, L); if (rc != RT_OK) return rc; }
+	const size_t need = (size_t) L.local_rows * width * 3 * sizeof(float);
+	if (need > ctx->frame_bytes) {
+		(void) hipFree(ctx->d_frame); ctx->d_frame = nullptr; ctx->frame_bytes = 0;
+		HIP_TRY(hipMalloc((void**) &ctx->d_frame, need));
+		ctx->frame_bytes = need;
+	}
+	return RT_OK;
+}
+
 int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, void *hip_stream)
 {
 	int rc = check_params(ctx, p);

@@ -195,6 +195,21 @@ def test_full_size_properties(gpu, real_sky, scene_paths):
         assert (bits(c[r0]) == bits(a[r0])).all(), r0
 
 
+def test_reserve_then_render(real_sky, scene_paths):
+    """rt_reserve(): the launch scratch is allocated up front; renders of that size and smaller allocate nothing."""
+    r = rt.Renderer(0)
+    r.set_tuning(poison_frame=True)
+    r.reserve(640, 360)
+    r.set_skybox(real_sky); r.set_scene(scene_paths[0]); r.set_camera()
+    a = r.render(640, 360, 4, 4, seed=1)
+    s = r.render(640, 360, 4, 4, seed=1, kernel=rt.KERNEL_SIMPLE)
+    assert (bits(a) == bits(s)).all()
+    b = r.render(320, 200, 4, 4, seed=1)
+    assert (bits(b) == bits(r.render(320, 200, 4, 4, seed=1, kernel=rt.KERNEL_SIMPLE))).all()
+    assert rt.lib().rt_reserve(r._ctx, 1, 1) == -1
+    r.close()
+
+
 def test_errors_are_reported_not_fatal(gpu):
     """The library returns error codes + text where the reference would abort()/exit()."""
     import ctypes as C
