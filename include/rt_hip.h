@@ -186,9 +186,9 @@ RT_API int rt_progressive_invalidate(rt_context *ctx);
 RT_API int rt_progressive_state(rt_context *ctx, int *next_scale, float *count, uint32_t *generation, int *passes);
 
 /* ---- measurement --------------------------------------------------------------------------- */
-/* When enabled, every rt_render_device()/rt_render() brackets its trace kernel with hipEvents on
- * the launch stream; rt_profile_collect() synchronises and returns the summed kernel time and the
- * number of launches since the last collect. */
+/* When enabled, every rt_render_device()/rt_render() brackets its kernels (the clearing of the launch counters,
+ * rt_primary_pass and the trace kernel) with hipEvents on the launch stream; rt_profile_collect() synchronises and
+ * returns the summed time and the number of launches since the last collect. */
 RT_API int rt_profile_enable(rt_context *ctx, int on);
 RT_API int rt_profile_collect(rt_context *ctx, double *kernel_ms_total, int *launches);
 

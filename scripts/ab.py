@@ -38,7 +38,7 @@ for name, scene, W, H, spp, nb, world in cfgs:
     for it in range(rounds + 1):
         for k, r in enumerate(rs):
             rt._lib = r._L
-            tk = os.environ.get("AB_TUNING_A" if k == 0 else "AB_TUNING_B")      # per-build override, e.g. "pixel_streams=4"
+            tk = os.environ.get("AB_TUNING_A" if k == 0 else "AB_TUNING_B")      # per-build override, e.g. "dequeue_shards=1,workgroups_per_cu=3"
             if tk and hasattr(r._L, "rt_set_tuning"): r.set_tuning(**{a: int(b) for a, b in (kv.split("=") for kv in tk.split(","))})
             if world == 1:
                 strip = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
