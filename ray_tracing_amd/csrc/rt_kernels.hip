@@ -39,11 +39,17 @@ struct Hit { float t; V3 n; int obj; };
  * accumulated in a device array.  Compiled out of the product build. */
 #ifdef RT_STATS
 __device__ unsigned long long rt_stats[64];
+#define STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); rt_tsec[k] += now_ - rt_tlast; rt_tlast = now_; } while (0)
+#define STAMP_DECL unsigned long long rt_tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rt_tlast = __builtin_amdgcn_s_memtime()
+#define STAMP_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&rt_stats[50 + k_], rt_tsec[k_]); } while (0)
 #define STAT(site) do { const unsigned long long m_ = __ballot(true); \
 	if (__builtin_amdgcn_mbcnt_hi((unsigned int) (m_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_, 0u)) == 0) { \
 		atomicAdd(&rt_stats[2 * (site)], 1ull); atomicAdd(&rt_stats[2 * (site) + 1], (unsigned long long) __popcll(m_)); } } while (0)
 #else
 #define STAT(site) do {} while (0)
+#define STAMP(k) do {} while (0)
+#define STAMP_DECL do {} while (0)
+#define STAMP_FLUSH do {} while (0)
 #endif
 
 /* ---- LDS-resident scene ------------------------------------------------------------------- */
@@ -859,7 +865,9 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		} while (again);
 	};
 
+	STAMP_DECL;
 	for (;; parity ^= 1u) {
+		STAMP(7);
 		/* ---- 1. sample supply ---------------------------------------------------------------
 		 * Lanes whose front is free take new samples.  A lane asks its home stream first and, in the following
 		 * attempts, the streams next to it (stream (g + attempt) mod P is asked by exactly one group of lanes per
@@ -984,6 +992,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			continue;
 		}
 
+		STAMP(0);
 		/* ---- 2. shade the pending hit of every live path (main.c:180-261) ------------------- */
 		int  tapmask = 0, cur = 0;
 		bool emit_main = false;
@@ -1032,6 +1041,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			cur = REC_VALID | (specular ? REC_SPECULAR : 0) | (emit_main ? 0 : REC_LAST) | (tapmask << 4) | (hobj << 8);
 		}
 
+		STAMP(1);
 		/* ---- 3+4. compact this round's rays into the wave's ring queue (ballot + mbcnt prefix), one
 		 * kind at a time, and trace full batches of 64 as soon as they exist (scene.c:156-190 on full
 		 * waves); the remainder is flushed after the last kind -------------------------------------- */
@@ -1090,6 +1100,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			}
 		}
 
+		STAMP(2);
 		/* ---- 5. back: retire the bounce shaded one round ago (its taps are traced by now), take this round's
 		 * bounce-ray result, and free the front when the path has ended --------------------------------------- */
 		STAT(16);
@@ -1153,9 +1164,12 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		}
 		wave_fence();
 
+		STAMP(3);
 		/* ---- 6. add the finished samples in sample order (main.c:394) ---------------------------------------- */
 		if (!direct) add_finished_samples();
+		STAMP(4);
 	}
+	STAMP_FLUSH;
 }
 
 #ifndef RT_SPEC_ONLY

@@ -25,3 +25,10 @@ def f(u): return struct.unpack('<f', struct.pack('<I', u & 0xffffffff))[0]
 for k in range(4):
     a, b, c = out[51 + 3 * k], out[52 + 3 * k], out[53 + 3 * k]
     print("zero-num sample: o=(%r, %r, %r) lo.x=%r lo.y=%r hi.y=%r" % (f(a >> 32), f(a), f(b >> 32), f(b), f(c >> 32), f(c)))
+
+sec = ["1 supply", "2 shade", "3+4 push + trace", "5 back", "6 in-order sum", "-", "-", "loop top / idle"]
+tot = sum(out[50 + k] for k in range(8))
+if tot:
+    print("share of wave time (s_memtime stamps at the section boundaries):")
+    for k in range(8):
+        if out[50 + k]: print(f"  {sec[k]:22s} {out[50 + k] / tot * 100:5.1f} %")
