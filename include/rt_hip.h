@@ -100,6 +100,8 @@ RT_API int rt_set_scene(rt_context *ctx, const Scene *scene);
  * 1..64 objects; returns an error -- and leaves the generic kernels in use -- if hiprtc is unavailable. */
 RT_API int rt_compile_scene(rt_context *ctx);
 RT_API int rt_scene_is_compiled(rt_context *ctx);
+/* development aid: instrumentation counters of a compiled kernel built with jit_flags "-DRT_STATS" (scripts/stats_c1.py) */
+RT_API int rt_spec_stats_read(rt_context *ctx, unsigned long long out[64], int reset);
 /* chan must be 3 or 4 (what stb_image returns for the shipped JPEGs is 3); all faces w x h */
 RT_API int rt_set_skybox(rt_context *ctx, const Cubemap *skybox);
 RT_API int rt_set_camera(rt_context *ctx, const rt_camera *camera);

@@ -335,6 +335,22 @@ int rt_compile_scene(rt_context *ctx)
 
 int rt_scene_is_compiled(rt_context *ctx) { return ctx && ctx->spec_fn ? 1 : 0; }
 
+/* Development aid (scripts/stats_c1.py): the instrumentation counters of a scene-specialised kernel that was
+ * compiled with rt_tuning.jit_flags = "-DRT_STATS" (the kernel then carries its own `rt_stats` array). */
+int rt_spec_stats_read(rt_context *ctx, unsigned long long out[64], int reset)
+{
+	if (!ctx || !out) return fail(RT_ERR_ARGUMENT, "rt_spec_stats_read: NULL argument");
+	if (!ctx->spec_module) return fail(RT_ERR_STATE, "rt_spec_stats_read: no compiled scene");
+	HIP_TRY(hipSetDevice(ctx->device));
+	{ const int rc = wait_for_launches(ctx); if (rc != RT_OK) return rc; }
+	hipDeviceptr_t p = nullptr; size_t bytes = 0;
+	HIP_TRY(hipModuleGetGlobal(&p, &bytes, ctx->spec_module, "rt_stats"));
+	if (bytes < 64 * sizeof(unsigned long long)) return fail(RT_ERR_STATE, "rt_spec_stats_read: unexpected symbol size");
+	HIP_TRY(hipMemcpy(out, (void *) p, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	if (reset) HIP_TRY(hipMemset((void *) p, 0, 64 * sizeof(unsigned long long)));
+	return RT_OK;
+}
+
 int rt_set_skybox(rt_context *ctx, const Cubemap *sky)
 {
 	if (!ctx || !sky) return fail(RT_ERR_ARGUMENT, "rt_set_skybox: NULL argument");

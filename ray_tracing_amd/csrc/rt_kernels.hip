@@ -38,7 +38,7 @@ struct Hit { float t; V3 n; int obj; };
 /* Development instrumentation (make stats): per-site counts of executions and of active lanes,
  * accumulated in a device array.  Compiled out of the product build. */
 #ifdef RT_STATS
-__device__ unsigned long long rt_stats[64];
+extern "C" __device__ unsigned long long rt_stats[64];
 #define STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); rt_tsec[k] += now_ - rt_tlast; rt_tlast = now_; } while (0)
 #define STAMP_DECL unsigned long long rt_tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rt_tlast = __builtin_amdgcn_s_memtime()
 #define STAMP_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&rt_stats[50 + k_], rt_tsec[k_]); } while (0)
@@ -892,6 +892,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				need_pixel = leader && gm != 0ull && nxt >= spp;
 			}
 			const unsigned long long nmask = __ballot(need_pixel);
+			STAMP(0);
 			if (nmask != 0ull) {
 				STAT(21);
 				const rt_launch_cold C = cold_view();
@@ -950,6 +951,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					}
 				}
 				wave_fence();
+				STAMP(5);
 			}
 			if (!direct) {
 				nxt = W.s_nxt[sg];
@@ -980,6 +982,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					W.s_seq[sg] = seq + handed + (nxt + handed == spp ? 1u : 0u);
 				}
 				wave_fence();
+				STAMP(6);
 			}
 		}
 #ifdef RT_STATS

@@ -2,15 +2,22 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ray_tracing_amd as rt
-rt.LIB_PATH = os.path.join(os.path.dirname(rt.LIB_PATH), "librt_hip_stats.so")
 scene = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+jit = len(sys.argv) > 2 and sys.argv[2] == "jit"      # the scene-specialised kernel, instrumented through jit_flags
+if not jit: rt.LIB_PATH = os.path.join(os.path.dirname(rt.LIB_PATH), "librt_hip_stats.so")
 W, H, spp, nb = (1920, 1080, 64, 4) if scene == 0 else (1920, 1080, 256, 8)
 g = rt.Renderer(0)
 g.set_skybox(rt.load_skybox()); g.set_scene(f"{rt.DATA_DIR}/scene_{scene}.txt")
 out = (C.c_ulonglong * 64)()
-rt.lib().rt_stats_read(out, 1)
+if jit:
+    g.set_tuning(jit_flags="-DRT_STATS"); g.compile_scene()
+    rt.lib().rt_spec_stats_read.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+    read = lambda: rt.lib().rt_spec_stats_read(g._ctx, out, 1)
+else:
+    read = lambda: rt.lib().rt_stats_read(out, 1)
+read()
 g.render(W, H, spp, nb)
-rt.lib().rt_stats_read(out, 1)
+read()
 names = {1: "box test", 2: "box slow path", 3: "sphere test", 4: "sphere discr>0 (fp64 roots)", 5: "sphere 2nd root", 6: "sphere slow path",
          7: "round (setup site)", 8: "setup body", 9: "tap0 sd", 10: "tap1 sd", 11: "tap2 sd", 12: "trace batch", 13: "trace batch active",
          14: "sky lookup", 15: "specular branch", 16: "consume site", 17: "consume body", 22: "sample hand-out", 23: "in-order sum pass", 24: "lanes left without a sample", 20: "supply attempt", 21: "pixel fetch event"}
@@ -26,9 +33,9 @@ for k in range(4):
     a, b, c = out[51 + 3 * k], out[52 + 3 * k], out[53 + 3 * k]
     print("zero-num sample: o=(%r, %r, %r) lo.x=%r lo.y=%r hi.y=%r" % (f(a >> 32), f(a), f(b >> 32), f(b), f(c >> 32), f(c)))
 
-sec = ["1 supply", "2 shade", "3+4 push + trace", "5 back", "6 in-order sum", "-", "-", "loop top / idle"]
+sec = ["1 supply: ballots, stream state, exit", "2 shade", "3+4 push + trace", "5 back", "6 in-order sum", "1 supply: pixel fetch", "1 supply: hand-out", "loop top / idle"]
 tot = sum(out[50 + k] for k in range(8))
 if tot:
     print("share of wave time (s_memtime stamps at the section boundaries):")
     for k in range(8):
-        if out[50 + k]: print(f"  {sec[k]:22s} {out[50 + k] / tot * 100:5.1f} %")
+        if out[50 + k]: print(f"  {sec[k]:40s} {out[50 + k] / tot * 100:5.1f} %")
