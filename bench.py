@@ -63,6 +63,7 @@ def parse_args(argv=None):
     ap.add_argument("--launch-check", action="store_true",
                     help="only prove the N-rank launch + rendezvous (no GPU work); used by the CPU tests")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--spare-workgroups", type=int, default=0, help="rt_tuning.spare_workgroups (measurement aid)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing aid for 1-GPU boxes: all ranks use GPU 0 and the strips travel over gloo "
                          "(RCCL refuses two ranks on one device); not a performance configuration")
@@ -86,6 +87,7 @@ def self_launch(args, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
+    env.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
     return subprocess.call(cmd, env=env)
 
 
@@ -216,6 +218,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the collective's internal stream on its own (high-priority) hardware queue: streams of equal priority share a
+        # handful of queues, and the gather of frame k must run beside render k+1, not between render k and render k+1
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         if (args.backend or "nccl") == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -230,6 +235,8 @@ def main():
     gpu.set_skybox(sky)
     gpu.set_camera()
     gpu.reserve(W, H)
+    if args.spare_workgroups:
+        gpu.set_tuning(spare_workgroups=args.spare_workgroups)
     # scene "compilation" (hiprtc, ~1 s, outside the timed region): same frames, fewer instructions
     compiled, jit_s = False, None
     if args.kernel == rt.KERNEL_AUTO and not args.no_jit:

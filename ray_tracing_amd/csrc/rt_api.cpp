@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -83,6 +84,10 @@ struct rt_context {
 	hipStream_t  cancel_stream = nullptr; /* rt_cancel(): a copy that overtakes the running kernel */
 	hipEvent_t   cancel_event = nullptr;  /* recorded behind that copy: the next launch's clearing of the control words waits for it */
 	std::atomic<bool> cancel_pending{false};
+	std::once_flag cancel_once;          /* the stream and event are made by the first rt_cancel(): HIP maps streams onto a
+	                                      * handful of hardware queues, and a stream nobody uses would only make two busy ones
+	                                      * share a queue (measured: the host copy of a frame then no longer overlaps the next render) */
+	hipError_t   cancel_setup = hipSuccess;
 	unsigned int *h_words = nullptr;     /* pinned: [0] = read-back of control[1]; [32 ...] = 64 x 128 bytes of 0x80000000 (source of the stop request) */
 	int          num_cus = 256;
 
@@ -160,7 +165,7 @@ int rt_set_tuning(rt_context *ctx, const rt_tuning *t)
 {
 	if (!ctx || !t) return fail(RT_ERR_ARGUMENT, "rt_set_tuning: NULL argument");
 	if ((t->dequeue_shards != 0 && t->dequeue_shards != 1 && t->dequeue_shards != 64) ||
-	    t->workgroups_per_cu < 0 || t->workgroups_per_cu > 4 || t->jit_waves_per_simd < 0 || t->jit_waves_per_simd > 8)
+	    t->workgroups_per_cu < 0 || t->workgroups_per_cu > 4 || t->spare_workgroups < 0 || t->spare_workgroups > 256 || t->jit_waves_per_simd < 0 || t->jit_waves_per_simd > 8)
 		return fail(RT_ERR_ARGUMENT, "rt_set_tuning: value out of range");
 	ctx->tuning = *t;
 	ctx->jit_flags = t->jit_flags ? t->jit_flags : "";
@@ -196,8 +201,6 @@ int rt_create(rt_context **out, int device_id)
 			ctx->num_cus = prop.multiProcessorCount;
 		e = hipMalloc((void**) &ctx->d_counter, rt_counter_bytes());
 		if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->last_launch, hipEventDisableTiming);
-		if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->cancel_stream, hipStreamNonBlocking);
-		if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->cancel_event, hipEventDisableTiming);
 		if (e == hipSuccess) e = hipHostMalloc((void**) &ctx->h_words, (size_t) (32 + 64 * 32) * sizeof(unsigned int), hipHostMallocDefault);
 		if (e == hipSuccess) { ctx->h_words[0] = 0u; for (int k = 0; k < 64 * 32; k++) ctx->h_words[32 + k] = 0x80000000u; }
 		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -522,7 +525,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 		hipError_t e = hipEventRecord(e0, stream);
 		if (e != hipSuccess) { give_event(ctx, e0); give_event(ctx, e1); return fail(RT_ERR_DEVICE, "hipEventRecord: %s", hipGetErrorString(e)); }
 	}
-	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->tuning.workgroups_per_cu, stream);
+	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->tuning.spare_workgroups, stream);
 	if (le == hipSuccess && ctx->profiling) le = hipEventRecord(e1, stream);
 	if (ctx->profiling) {
 		if (le == hipSuccess) ctx->events.emplace_back(e0, e1);
@@ -562,6 +565,13 @@ int rt_cancel(rt_context *ctx)
 {
 	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_cancel: NULL context");
 	HIP_TRY(hipSetDevice(ctx->device));
+	std::call_once(ctx->cancel_once, [ctx]() {
+		hipError_t e = hipStreamCreateWithPriority(&ctx->cancel_stream, hipStreamNonBlocking, -1);     /* high priority: it must overtake */
+		if (e != hipSuccess) e = hipStreamCreateWithFlags(&ctx->cancel_stream, hipStreamNonBlocking);
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->cancel_event, hipEventDisableTiming);
+		ctx->cancel_setup = e;
+	});
+	if (ctx->cancel_setup != hipSuccess) return fail(RT_ERR_DEVICE, "rt_cancel: %s", hipGetErrorString(ctx->cancel_setup));
 	/* every dequeue counter jumps beyond any fill count: from now on no fetch returns a pixel (rt_kernels.hip) */
 	HIP_TRY(hipMemcpyAsync(ctx->d_counter, &ctx->h_words[32], (size_t) 64 * 32 * sizeof(unsigned int), hipMemcpyHostToDevice, ctx->cancel_stream));
 	HIP_TRY(hipEventRecord(ctx->cancel_event, ctx->cancel_stream));
@@ -667,7 +677,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	{ const int rc = prepare_launch(ctx, L); if (rc != RT_OK) return rc; }
 	{ const int rc = order_behind_previous(ctx, ctx->stream); if (rc != RT_OK) return rc; }
 	if (ctx->tuning.poison_frame) HIP_TRY(hipMemsetAsync(g.d_low, 0xff, g.low_bytes, ctx->stream));
-	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream));
+	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->tuning.spare_workgroups, ctx->stream));
 	const float weight = 1.0f / (s * s);                                         /* main.c:278 */
 	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), L.control + 1, ctx->stream));
 	{ const int rc = mark_launch(ctx, ctx->stream); if (rc != RT_OK) return rc; }

@@ -106,7 +106,10 @@ class TiledFrame:
         self.device = device
         rows = strip_rows(height, row_block, world)
         self.stream = torch.cuda.Stream(device)            # render, collective hand-off, de-interleave
-        self.copy_stream = torch.cuda.Stream(device)       # frame -> pinned host memory
+        # frame -> pinned host memory.  High priority: its own hardware queue (streams of equal priority share a handful of
+        # queues, and two streams on one queue run in enqueue order: the copy of frame k would then sit between render k and
+        # render k+1 instead of beside the latter), and its copy kernel is dispatched ahead of the next frame's kernels.
+        self.copy_stream = torch.cuda.Stream(device, priority=-1)
         assert self.stream.cuda_stream != 0
         self.primitive = collective_for() if world > 1 else None
         with torch.cuda.stream(self.stream):
