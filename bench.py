@@ -63,7 +63,6 @@ def parse_args(argv=None):
     ap.add_argument("--launch-check", action="store_true",
                     help="only prove the N-rank launch + rendezvous (no GPU work); used by the CPU tests")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
-    ap.add_argument("--spare-workgroups", type=int, default=0, help="rt_tuning.spare_workgroups (measurement aid)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing aid for 1-GPU boxes: all ranks use GPU 0 and the strips travel over gloo "
                          "(RCCL refuses two ranks on one device); not a performance configuration")
@@ -235,8 +234,6 @@ def main():
     gpu.set_skybox(sky)
     gpu.set_camera()
     gpu.reserve(W, H)
-    if args.spare_workgroups:
-        gpu.set_tuning(spare_workgroups=args.spare_workgroups)
     # scene "compilation" (hiprtc, ~1 s, outside the timed region): same frames, fewer instructions
     compiled, jit_s = False, None
     if args.kernel == rt.KERNEL_AUTO and not args.no_jit:

@@ -78,8 +78,6 @@ RT_API void rt_default_params(rt_render_params *p, int width, int height, int sp
 typedef struct {
 	int    dequeue_shards;      /* lists the object pixels are dealt from: 1 or 64 */
 	int    workgroups_per_cu;   /* resident workgroups per CU, 1..4 */
-	int    spare_workgroups;    /* the persistent trace kernel starts this many workgroups fewer than the chip holds, so that
-	                             * another stream's copy kernels (a frame on its way to the host) find registers to run in */
 	int    jit_waves_per_simd;  /* rt_compile_scene: register budget = 512 / this many VGPRs (default 4) */
 	const char *jit_flags;      /* rt_compile_scene: extra hiprtc options, space separated (copied) */
 	int    force_collective;    /* testing aid: rt_multi_render() runs its ncclGather + de-interleave path even for a

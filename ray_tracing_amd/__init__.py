@@ -49,7 +49,7 @@ class RenderParams(C.Structure):
 
 class Tuning(C.Structure):
     _fields_ = [("dequeue_shards", C.c_int),
-                ("workgroups_per_cu", C.c_int), ("spare_workgroups", C.c_int), ("jit_waves_per_simd", C.c_int), ("jit_flags", C.c_char_p),
+                ("workgroups_per_cu", C.c_int), ("jit_waves_per_simd", C.c_int), ("jit_flags", C.c_char_p),
                 ("force_collective", C.c_int), ("poison_frame", C.c_int)]
 
 
@@ -278,13 +278,13 @@ class Renderer:
             cam.fov = fov
         _check(lib().rt_set_camera(self._ctx, C.byref(cam)), "rt_set_camera")
 
-    def set_tuning(self, dequeue_shards=0, workgroups_per_cu=0, spare_workgroups=0,
+    def set_tuning(self, dequeue_shards=0, workgroups_per_cu=0,
                    jit_waves_per_simd=0, jit_flags=None, poison_frame=None):
         """rt_set_tuning(): scheduling knobs (0 / None = automatic).  They never change a frame."""
         t = Tuning()
         lib().rt_default_tuning(C.byref(t))
         t.dequeue_shards = dequeue_shards
-        t.workgroups_per_cu, t.spare_workgroups, t.jit_waves_per_simd = workgroups_per_cu, spare_workgroups, jit_waves_per_simd
+        t.workgroups_per_cu, t.jit_waves_per_simd = workgroups_per_cu, jit_waves_per_simd
         t.jit_flags = jit_flags.encode() if jit_flags else None
         if poison_frame is not None:
             self._poison = bool(poison_frame)

@@ -165,7 +165,7 @@ int rt_set_tuning(rt_context *ctx, const rt_tuning *t)
 {
 	if (!ctx || !t) return fail(RT_ERR_ARGUMENT, "rt_set_tuning: NULL argument");
 	if ((t->dequeue_shards != 0 && t->dequeue_shards != 1 && t->dequeue_shards != 64) ||
-	    t->workgroups_per_cu < 0 || t->workgroups_per_cu > 4 || t->spare_workgroups < 0 || t->spare_workgroups > 256 || t->jit_waves_per_simd < 0 || t->jit_waves_per_simd > 8)
+	    t->workgroups_per_cu < 0 || t->workgroups_per_cu > 4 || t->jit_waves_per_simd < 0 || t->jit_waves_per_simd > 8)
 		return fail(RT_ERR_ARGUMENT, "rt_set_tuning: value out of range");
 	ctx->tuning = *t;
 	ctx->jit_flags = t->jit_flags ? t->jit_flags : "";
@@ -525,7 +525,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 		hipError_t e = hipEventRecord(e0, stream);
 		if (e != hipSuccess) { give_event(ctx, e0); give_event(ctx, e1); return fail(RT_ERR_DEVICE, "hipEventRecord: %s", hipGetErrorString(e)); }
 	}
-	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->tuning.spare_workgroups, stream);
+	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->tuning.workgroups_per_cu, stream);
 	if (le == hipSuccess && ctx->profiling) le = hipEventRecord(e1, stream);
 	if (ctx->profiling) {
 		if (le == hipSuccess) ctx->events.emplace_back(e0, e1);
@@ -677,7 +677,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	{ const int rc = prepare_launch(ctx, L); if (rc != RT_OK) return rc; }
 	{ const int rc = order_behind_previous(ctx, ctx->stream); if (rc != RT_OK) return rc; }
 	if (ctx->tuning.poison_frame) HIP_TRY(hipMemsetAsync(g.d_low, 0xff, g.low_bytes, ctx->stream));
-	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->tuning.spare_workgroups, ctx->stream));
+	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream));
 	const float weight = 1.0f / (s * s);                                         /* main.c:278 */
 	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), L.control + 1, ctx->stream));
 	{ const int rc = mark_launch(ctx, ctx->stream); if (rc != RT_OK) return rc; }

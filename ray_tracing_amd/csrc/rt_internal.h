@@ -18,7 +18,7 @@ void       rt_primary_geometry(int width, int local_rows, int num_cus, unsigned 
 size_t     rt_pixel_list_capacity(int width, int local_rows, int num_cus, int num_shards);
 /* spec_fn: kernel compiled by rt_compile_scene for the current scene, or nullptr */
 hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, hipFunction_t spec_fn,
-                           unsigned int *block_counter, int num_cus, int workgroups_per_cu, int spare_workgroups, hipStream_t stream);
+                           unsigned int *block_counter, int num_cus, int workgroups_per_cu, hipStream_t stream);
 int        rt_jit_build(const rt_geom *geom, int n, int light_index, const float light_pos[3], int waves_per_simd, const char *extra_flags, hipModule_t *module, hipFunction_t *function, std::string &message);
 hipError_t rt_launch_deinterleave(const float *strips, float *frame, int width, int height,
                                   int row_block, int world, int rows_per_rank, hipStream_t stream);

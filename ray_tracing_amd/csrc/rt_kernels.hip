@@ -1451,7 +1451,7 @@ size_t rt_pixel_list_capacity(int width, int local_rows, int num_cus, int num_sh
 }
 
 hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, hipFunction_t spec_fn,
-                           unsigned int *block_counter, int num_cus, int workgroups_per_cu, int spare_workgroups, hipStream_t stream)
+                           unsigned int *block_counter, int num_cus, int workgroups_per_cu, hipStream_t stream)
 {
 	if (L.local_rows <= 0 || L.width <= 0) return hipSuccess;
 	const bool simple = variant == 1 /* RT_KERNEL_SIMPLE */ || L.max_bounces < 1;
@@ -1468,7 +1468,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	if (per_cu > 4) per_cu = 4;
 	if (workgroups_per_cu >= 1 && workgroups_per_cu < per_cu) per_cu = workgroups_per_cu;     /* rt_tuning */
 	const long long blocks = (long long) ((L.width + 7) / 8) * ((L.local_rows + 7) / 8);
-	long long grid = (long long) num_cus * per_cu - spare_workgroups;      /* rt_tuning.spare_workgroups: room left for copy kernels */
+	long long grid = (long long) num_cus * per_cu;
 	const long long useful = (blocks + (RT_BLOCK / 64) - 1) / (RT_BLOCK / 64);
 	if (grid > useful) grid = useful;
 	if (grid < 1) grid = 1;
