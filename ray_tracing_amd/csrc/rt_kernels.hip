@@ -8,7 +8,8 @@
  * Kernels:
  *   rt_trace_simple      the path loop in the reference's own order, one lane per pixel (cross-check)
  *   rt_primary_pass      camera rays of all pixels, once per launch: sky-only pixels are finished, the rest is handed on
- *   rt_trace_wavefront   the tuned schedule: persistent waves, per-wave LDS ray queue, exact shortcuts
+ *   rt_trace_wavefront   the tuned schedule: persistent waves that deal samples to lanes, per-wave LDS ray queue,
+ *                        in-order sample sum through a per-wave LDS window, exact shortcuts
  *   rt_trace_spec        the same, recompiled by hiprtc with the scene as constants (rt_compile_scene)
  *   rt_accumulate / rt_resolve (progressive passes); rt_deinterleave (multi-GPU root); rt_selftest_kernel
  * One lane owns one path at a time and the samples of a pixel are always added in sample order
