@@ -200,6 +200,7 @@ int rt_create(rt_context **out, int device_id)
 		if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
 			ctx->num_cus = prop.multiProcessorCount;
 		e = hipMalloc((void**) &ctx->d_counter, rt_counter_bytes());
+		if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counter, 0, rt_counter_bytes(), ctx->stream);
 		if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->last_launch, hipEventDisableTiming);
 		if (e == hipSuccess) e = hipHostMalloc((void**) &ctx->h_words, (size_t) (32 + 64 * 32) * sizeof(unsigned int), hipHostMallocDefault);
 		if (e == hipSuccess) { ctx->h_words[0] = 0u; for (int k = 0; k < 64 * 32; k++) ctx->h_words[32 + k] = 0x80000000u; }
