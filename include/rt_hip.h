@@ -196,7 +196,7 @@ RT_API int rt_profile_collect(rt_context *ctx, double *kernel_ms_total, int *lau
 
 /* On-GPU self-test of the exact-arithmetic shortcuts the tuned kernel uses (shared-reciprocal
  * division, vector normalisation): compares them bit-for-bit with the plain IEEE forms on
- * blocks*256*iters random operand sets.  which = 0 (f32 divide), 1 (f64 divide), 2 (normalize), 3 (f64 sqrt of a float), 4 (|x| < 0.0001 threshold).
+ * blocks*256*iters random operand sets.  which = 0 (f32 divide), 1 (f64 divide), 2 (normalize), 3 (f64 sqrt of a float), 4 (|x| < 0.0001 threshold), 7 (normalize of a `draw * 2 - 1` vector).
  * Three sweeps are exhaustive instead of random: which = 3 checks the fp64 square root of every normal
  * float up to 2^120 (`iters` ignored); which = 5 checks the refined reciprocal for all 2^23
  * significands and the 3-instruction quotient for every denominator significand x `iters` numerator

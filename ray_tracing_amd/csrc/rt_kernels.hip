@@ -1244,6 +1244,7 @@ rt_deinterleave(const float *strips, float *frame, int width, int height, int ro
  *         5: EXHAUSTIVE: rcp_refined vs 1/d for all 2^23 significands; div_by_refined vs `/` for every d significand x
  *            `iters` n significands (iters = 2^23 = all 2^46 pairs, 52 s; `seed` picks the first numerator)
  *         6: EXHAUSTIVE: sqrt_in_window vs sqrtf (+ the refined reciprocal of the root) for every float in [2^-30, 2^60]
+ *         7: unit3_of_draws   vs unit3 on vectors with `draw * 2 - 1` components (rng_direction)
  * out[0] = number of mismatching results, out[1..] = operands of one mismatch. */
 RT_DEV uint64_t st_next(uint64_t &s)
 {
@@ -1355,6 +1356,28 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 				bad++;
 				out[1] = (unsigned long long) __double_as_longlong(num); out[2] = (unsigned long long) __double_as_longlong(den);
 				out[3] = (unsigned long long) __double_as_longlong(want); out[4] = (unsigned long long) __double_as_longlong(got);
+			}
+		} else if (which == 7) {
+			/* unit3_of_draws on vectors of `draw * 2 - 1` components: draws anywhere in [0, 1], with extra weight on
+			 * 0, 1, the neighbourhood of 0.5 (components of 0 and +-2^-24) and all three components tiny at once */
+			const uint64_t r0 = st_next(s), r1 = st_next(s), r2 = st_next(s), r3 = st_next(s);
+			float dr[3] = { (float) r0 * 0x1p-64f, (float) r1 * 0x1p-64f, (float) r2 * 0x1p-64f };
+			const bool all_near_half = (it & 7) == 7 && ((r3 >> 40) & 3) == 0;
+			for (int c = 0; c < 3; c++) {
+				const uint32_t pick = (uint32_t) (r3 >> (8 * c)) & 255u;
+				if (pick == 0) dr[c] = 0.0f;
+				if (pick == 1) dr[c] = 1.0f;
+				if (pick == 2) dr[c] = 0.5f;
+				if ((pick < 16 && pick > 2) || all_near_half)
+					dr[c] = __uint_as_float(0x3f000000u + (int) ((r3 >> (32 + 2 * c)) % (pick < 8 || all_near_half ? 9u : 4097u)) - (int) (pick < 8 || all_near_half ? 4 : 2048));
+			}
+			const V3 v = mk3(dr[0] * 2.0f - 1.0f, dr[1] * 2.0f - 1.0f, dr[2] * 2.0f - 1.0f);
+			const V3 want = unit3(v), got = unit3_of_draws(v);
+			if (__float_as_uint(want.x) != __float_as_uint(got.x) || __float_as_uint(want.y) != __float_as_uint(got.y) ||
+			    __float_as_uint(want.z) != __float_as_uint(got.z)) {
+				bad++;
+				out[1] = __float_as_uint(v.x); out[2] = __float_as_uint(v.y); out[3] = __float_as_uint(v.z);
+				out[4] = __float_as_uint(want.x); out[5] = __float_as_uint(got.x);
 			}
 		} else if (which == 4) {
 			const uint64_t r0 = st_next(s);

@@ -194,6 +194,21 @@ RT_DEV uint64_t path_seed(uint64_t seed, uint32_t pixel_index, uint32_t sample_i
 	return z ^ (z >> 31);
 }
 
+/* unit3_fast for a vector of `draw * 2 - 1` components (draw in [0, 1]): each is +0 -- never -0: RN(1 - 1) -- or at
+ * least 2^-24 in magnitude, and the squared length is at most 3, so of unit3_fast's window only the lower bound of
+ * the squared length is left to test.  A +0 numerator is exact in div_by_refined: q = +0, fma(-len, +0, +0) = +0,
+ * fma(+0, r, +0) = +0 = 0 / len.  (rt_selftest(7) compares with unit3 on such vectors.) */
+RT_DEV V3 unit3_of_draws(V3 v)
+{
+	const float s2 = v.x * v.x + v.y * v.y + v.z * v.z;
+	if (__ballot(!(s2 >= 0x1p-30f)) == 0ull) {
+		const float len = sqrt_in_window(s2);
+		const float r = rcp_refined(len);
+		return mk3(div_by_refined(v.x, len, r), div_by_refined(v.y, len, r), div_by_refined(v.z, len, r));
+	}
+	return unit3(v);
+}
+
 /* vector.c:99-111: x, y, z drawn in that order */
 template <bool FAST = false>
 RT_DEV V3 rng_direction(uint64_t &state)
@@ -201,7 +216,7 @@ RT_DEV V3 rng_direction(uint64_t &state)
 	float x = rng_draw(state) * 2.0f - 1.0f;
 	float y = rng_draw(state) * 2.0f - 1.0f;
 	float z = rng_draw(state) * 2.0f - 1.0f;
-	return FAST ? unit3_fast(mk3(x, y, z)) : unit3(mk3(x, y, z));
+	return FAST ? unit3_of_draws(mk3(x, y, z)) : unit3(mk3(x, y, z));
 }
 
 #endif
