@@ -64,7 +64,7 @@ class MouseState(C.Structure):
 # every symbol include/rt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
-    "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_spec_stats_read", "rt_render", "rt_render_device", "rt_reserve", "rt_strip_rows", "rt_deinterleave_device",
+    "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_spec_stats_read", "rt_spec_symbol_read", "rt_render", "rt_render_device", "rt_reserve", "rt_strip_rows", "rt_deinterleave_device",
     "rt_synchronize", "rt_cancel", "rt_was_cancelled", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
     "rt_progressive_invalidate", "rt_progressive_state", "rt_selftest", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
     "rt_parse_scene_string", "rt_load_cubemap", "rt_free_cubemap", "rt_decode_jpeg_file",

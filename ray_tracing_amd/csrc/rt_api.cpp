@@ -355,6 +355,22 @@ int rt_spec_stats_read(rt_context *ctx, unsigned long long out[64], int reset)
 	return RT_OK;
 }
 
+/* Development aid: copy a named device variable of the compiled scene's module (instrumented builds carry more than
+ * rt_stats, e.g. rt_wave_log) to the host; at most `bytes` bytes, returns the number copied through *copied. */
+int rt_spec_symbol_read(rt_context *ctx, const char *name, void *dst, size_t bytes, size_t *copied)
+{
+	if (!ctx || !name || !dst) return fail(RT_ERR_ARGUMENT, "rt_spec_symbol_read: NULL argument");
+	if (!ctx->spec_module) return fail(RT_ERR_STATE, "rt_spec_symbol_read: no compiled scene");
+	HIP_TRY(hipSetDevice(ctx->device));
+	{ const int rc = wait_for_launches(ctx); if (rc != RT_OK) return rc; }
+	hipDeviceptr_t p = nullptr; size_t have = 0;
+	HIP_TRY(hipModuleGetGlobal(&p, &have, ctx->spec_module, name));
+	const size_t n = have < bytes ? have : bytes;
+	HIP_TRY(hipMemcpy(dst, (void *) p, n, hipMemcpyDeviceToHost));
+	if (copied) *copied = n;
+	return RT_OK;
+}
+
 int rt_set_skybox(rt_context *ctx, const Cubemap *sky)
 {
 	if (!ctx || !sky) return fail(RT_ERR_ARGUMENT, "rt_set_skybox: NULL argument");

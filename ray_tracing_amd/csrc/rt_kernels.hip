@@ -39,18 +39,36 @@ struct Hit { float t; V3 n; int obj; };
 /* Development instrumentation (make stats): per-site counts of executions and of active lanes,
  * accumulated in a device array.  Compiled out of the product build. */
 #ifdef RT_STATS
-extern "C" __device__ unsigned long long rt_stats[64];
+extern "C" { __device__ unsigned long long rt_stats[64]; }
+#ifdef RT_STATS_LIFETIMES_ONLY
+/* The per-site atomics slow a launch down a hundredfold and the section stamps by a third; what a look at the end of a
+ * launch needs is the real pace: every wave writes four words of its own -- start, the time it found the pixel lists
+ * empty, the rounds it ran after that, its end (s_memrealtime, 10 ns) -- and nothing else (scripts/tail_probe.py). */
+extern "C" { __device__ unsigned long long rt_wave_log[4 * 8192]; }
+#define STAT(site) do {} while (0)
+#define STAMP(k) do {} while (0)
+#define STAMP_DECL unsigned long long rt_t0 = __builtin_amdgcn_s_memrealtime(), rt_tdry = 0, rt_dry_rounds = 0
+#define STAMP_DRY do { if (!rt_tdry) rt_tdry = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAMP_ROUND do { if (rt_tdry) rt_dry_rounds++; } while (0)
+#define STAMP_FLUSH do { const unsigned int w_ = blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6); if ((threadIdx.x & 63) == 0 && w_ < 8192u) { \
+	rt_wave_log[4 * w_] = rt_t0; rt_wave_log[4 * w_ + 1] = rt_tdry; rt_wave_log[4 * w_ + 2] = rt_dry_rounds; rt_wave_log[4 * w_ + 3] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
 #define STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); rt_tsec[k] += now_ - rt_tlast; rt_tlast = now_; } while (0)
 #define STAMP_DECL unsigned long long rt_tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rt_tlast = __builtin_amdgcn_s_memtime()
 #define STAMP_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&rt_stats[50 + k_], rt_tsec[k_]); } while (0)
+#define STAMP_DRY do {} while (0)
+#define STAMP_ROUND do {} while (0)
 #define STAT(site) do { const unsigned long long m_ = __ballot(true); \
 	if (__builtin_amdgcn_mbcnt_hi((unsigned int) (m_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_, 0u)) == 0) { \
 		atomicAdd(&rt_stats[2 * (site)], 1ull); atomicAdd(&rt_stats[2 * (site) + 1], (unsigned long long) __popcll(m_)); } } while (0)
+#endif
 #else
 #define STAT(site) do {} while (0)
 #define STAMP(k) do {} while (0)
 #define STAMP_DECL do {} while (0)
 #define STAMP_FLUSH do {} while (0)
+#define STAMP_DRY do {} while (0)
+#define STAMP_ROUND do {} while (0)
 #endif
 
 /* ---- LDS-resident scene ------------------------------------------------------------------- */
@@ -869,6 +887,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	STAMP_DECL;
 	for (;; parity ^= 1u) {
 		STAMP(7);
+		STAMP_ROUND;
 		/* ---- 1. sample supply ---------------------------------------------------------------
 		 * Lanes whose front is free take new samples.  A lane asks its home stream first and, in the following
 		 * attempts, the streams next to it (stream (g + attempt) mod P is asked by exactly one group of lanes per
@@ -925,7 +944,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 							if (lane == 0) C->control[1] = 1u;
 						}
 						const unsigned long long some = __ballot(left != 0u);
-						if (some == 0ull || cancelled) exhausted = true;
+						if (some == 0ull || cancelled) { exhausted = true; STAMP_DRY; }
 						else {      /* the waves spread over the lists that are left (one address takes ~88 atomics per microsecond) */
 							const int pick = (int) ((blockIdx.x * (RT_BLOCK / 64) + (unsigned int) wave) % (unsigned int) __popcll(some));
 							shard = (unsigned int) __builtin_ctzll(__ballot(left != 0u && lanes_below(some) == pick));

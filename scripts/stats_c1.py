@@ -27,12 +27,6 @@ for k in sorted(names):
     if n:
         print(f"{names[k]:32s} execs/sample*64 {n * 64 / samples:8.3f}   avg active lanes {lanes / n:5.1f} ({lanes / n / 64 * 100:4.1f}%)")
 
-import struct
-def f(u): return struct.unpack('<f', struct.pack('<I', u & 0xffffffff))[0]
-for k in range(4):
-    a, b, c = out[51 + 3 * k], out[52 + 3 * k], out[53 + 3 * k]
-    print("zero-num sample: o=(%r, %r, %r) lo.x=%r lo.y=%r hi.y=%r" % (f(a >> 32), f(a), f(b >> 32), f(b), f(c >> 32), f(c)))
-
 sec = ["1 supply: ballots, stream state, exit", "2 shade", "3+4 push + trace", "5 back", "6 in-order sum", "1 supply: pixel fetch", "1 supply: hand-out", "loop top / idle"]
 tot = sum(out[50 + k] for k in range(8))
 if tot:
