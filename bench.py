@@ -262,18 +262,30 @@ def main():
     gpu.profile(True)
     tiled.record_events = True
     start = torch.cuda.Event(enable_timing=True)
-    start.record(tiled.stream)
+    start.record(tiled.streams[tiled.k & 1])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tiled.step()
     tiled.flush()                       # every frame gathered, de-interleaved and resident in host memory
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = gpu.profile_collect()
-    gpu.profile(False)
     tiled.record_events = False
+    # Kernel time of a launch, two ways (HIP events, all launches of the timed region).  (a) per launch: from its first
+    # compute unit (behind the clearing of its counters) to the end of its trace kernel, summed -- consecutive launches
+    # are enqueued on two streams and overlap on the GPU (the next frame's waves fill the compute units while this
+    # frame's run out of pixels), and the ~0.1 ms two launches share is in both of them, as it is in rocprofv3's
+    # per-kernel durations.  (b) the span from before the first launch to behind the last trace kernel, over the
+    # launches in it: no double counting, but it contains idle time when the launches wait for something else (C3:
+    # for the host copy of the frame before last).  Both are upper bounds of the time the GPU needs per launch.
+    per_launch_ms, launches = gpu.profile_collect()
+    gpu.profile(False)
+    span_ms = start.elapsed_time(tiled.render_events[-1]) if tiled.render_events else 0.0
+    span_launches = len(tiled.render_events)
+    tiled.render_events = []
+    kernel_ms = min(per_launch_ms, span_ms * launches / span_launches) if span_launches and launches else per_launch_ms
     marks = [start] + tiled.done_events
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)) if len(marks) > 1 else []
+    tiled.done_events = []
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -358,14 +370,18 @@ def main():
                 "bound": "hbm" if gather_bound else "valu", "traffic": None,
                 "kernel": ("rt_primary_pass + " if gather_bound else "") + ("rt_trace_spec" if compiled else "rt_trace_wavefront"),
                 "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
+                "avg_kernel_ms_per_launch_events": round(per_launch_ms / launches, 4),
+                "avg_kernel_ms_span": round(span_ms / span_launches, 4) if span_launches else None,
                 "flops_per_sample": round(work["flops"], 1), "rays_per_sample": round(work["rays"], 3),
                 "object_tests_per_sample": round(work["object_tests"], 2),
                 "rng_draws_per_sample": round(work["rng_draws"], 2),
                 "valu" if gather_bound else "hbm": valu if gather_bound else hbm,
                 "note": "peak (valu) = fp32 VALU issue rate without FMA (parity forbids contraction) = 157.3/2 TFLOP/s, flops counted as "
                         "written in the reference (SURVEY.md 8d); peak (hbm) = 8 TB/s, bytes = 3 B per sky texel fetch + 12 B per pixel; "
-                        "avg_kernel_ms = HIP events around rt_primary_pass (camera rays) + the trace kernel (which now contains the "
-                        "in-order sample sum that was the separate rt_sum_samples kernel in round 1)",
+                        "avg_kernel_ms = rt_primary_pass + the trace kernel (which contains the in-order sample sum), HIP events over "
+                        "the timed region: the smaller of (per launch: first compute unit -> end of the trace kernel; consecutive "
+                        "launches overlap on two streams and the shared time is in both) and (span from the first launch to the end "
+                        "of the last trace kernel / launches; contains idle time when launches wait for host copies)",
             })
             tr = traffic_from_profiles(args.config, compiled) if world == 1 else None
             if tr:
@@ -376,13 +392,18 @@ def main():
             gpu.set_scene(scene_path)                 # drops the compiled kernel
             tiled.render_now()
             gpu.profile(True)
+            tiled.record_events = True
+            g_start = torch.cuda.Event(enable_timing=True)
+            g_start.record(tiled.streams[tiled.k & 1])
             for _ in range(5):
                 tiled.step()
             tiled.flush()
+            tiled.record_events = False
             g_ms, g_n = gpu.profile_collect()
             gpu.profile(False)
-            if g_n:
-                out.setdefault("roofline", {})["generic_kernel_ms"] = round(g_ms / g_n, 4)
+            if tiled.render_events and g_n:
+                g_span = g_start.elapsed_time(tiled.render_events[-1]) / len(tiled.render_events)
+                out.setdefault("roofline", {})["generic_kernel_ms"] = round(min(g_ms / g_n, g_span), 4)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(rt, w, sky)

@@ -119,14 +119,21 @@ RT_API int rt_render(rt_context *ctx, const rt_render_params *params, Vector3 *f
 /* Same, but the destination is DEVICE memory (rt_strip_rows()*width*12 bytes) and the call only
  * enqueues work on `hip_stream` (a hipStream_t; NULL = the context's own non-blocking stream;
  * RT_STREAM_LEGACY = the device's legacy null stream, which a literal 0 cannot name here).  No sync.
- * A context owns ONE set of launch scratch (work queues, primary-hit tables): launches of one
- * context are ordered one after another even when they are enqueued on different streams (a launch on a new
- * stream waits for the context's previous launch through an event), and rt_set_scene / rt_set_skybox wait
- * for the context's own launches only, not for the whole device. */
+ * A context owns TWO sets of launch scratch (pixel lists, counters) and uses them alternately: a launch is
+ * ordered (through an event, when the streams differ) behind the launch before the previous one, never behind the
+ * previous one -- two consecutive launches enqueued on different streams may be on the GPU together, the second
+ * filling the compute units as the first runs out of pixels (about 10 % more frames per second for strips of a
+ * millisecond; they must of course write different destinations).  Launches on one stream run in stream order as
+ * always.  rt_set_scene / rt_set_skybox wait for the context's own launches only, not for the whole device. */
 #define RT_STREAM_LEGACY ((void *) (intptr_t) -1)
 RT_API int rt_render_device(rt_context *ctx, const rt_render_params *params, void *d_strip, void *hip_stream);
 
-/* Optional: allocate the launch scratch (48 bytes per pixel of pixel records) and rt_render()'s device frame for
+/* The context's streams as hipStream_t: which = 0 the stream NULL stands for above; which = 1 a second one (created on
+ * first request, with the device's lowest stream priority so that it gets a hardware queue of its own) for hosts that
+ * alternate consecutive frames between two streams to let them overlap.  NULL on error. */
+RT_API void *rt_stream(rt_context *ctx, int which);
+
+/* Optional: allocate the launch scratch (2 x 48 bytes per pixel of pixel records) and rt_render()'s device frame for
  * frames of up to width x height now.  Without it they are allocated -- a blocking hipMalloc -- inside the first
  * render call of a size and kept; nothing is ever allocated per launch. */
 RT_API int rt_reserve(rt_context *ctx, int width, int height);
@@ -191,9 +198,11 @@ RT_API int rt_progressive_invalidate(rt_context *ctx);
 RT_API int rt_progressive_state(rt_context *ctx, int *next_scale, float *count, uint32_t *generation, int *passes);
 
 /* ---- measurement --------------------------------------------------------------------------- */
-/* When enabled, every rt_render_device()/rt_render() brackets its kernels (the clearing of the launch counters,
- * rt_primary_pass and the trace kernel) with hipEvents on the launch stream; rt_profile_collect() synchronises and
- * returns the summed time and the number of launches since the last collect. */
+/* When enabled, every rt_render_device()/rt_render() brackets its kernels (rt_primary_pass and the trace kernel) with
+ * hipEvents on the launch stream, the first one behind the clearing of the launch counters -- that is when a launch
+ * that overlaps its predecessor (rt_stream) has got its first compute unit; rt_profile_collect() synchronises and
+ * returns the summed time and the number of launches since the last collect.  (The time two overlapping launches are
+ * on the GPU together is counted in both.) */
 RT_API int rt_profile_enable(rt_context *ctx, int on);
 RT_API int rt_profile_collect(rt_context *ctx, double *kernel_ms_total, int *launches);
 

@@ -64,7 +64,7 @@ class MouseState(C.Structure):
 # every symbol include/rt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
-    "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_spec_stats_read", "rt_spec_symbol_read", "rt_render", "rt_render_device", "rt_reserve", "rt_strip_rows", "rt_deinterleave_device",
+    "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_spec_stats_read", "rt_spec_symbol_read", "rt_render", "rt_render_device", "rt_stream", "rt_reserve", "rt_strip_rows", "rt_deinterleave_device",
     "rt_synchronize", "rt_cancel", "rt_was_cancelled", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
     "rt_progressive_invalidate", "rt_progressive_state", "rt_selftest", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
     "rt_parse_scene_string", "rt_load_cubemap", "rt_free_cubemap", "rt_decode_jpeg_file",
@@ -110,6 +110,9 @@ def lib():
     L.rt_strip_rows.argtypes = [C.c_int, C.c_int, C.c_int]
     if hasattr(L, "rt_reserve"):
         L.rt_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    if hasattr(L, "rt_stream"):
+        L.rt_stream.argtypes = [C.c_void_p, C.c_int]
+        L.rt_stream.restype = C.c_void_p
     L.rt_deinterleave_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
     L.rt_synchronize.argtypes = [C.c_void_p]
     if hasattr(L, "rt_cancel"):
@@ -316,6 +319,13 @@ class Renderer:
         if stream is None:
             return None
         return C.c_void_p(STREAM_LEGACY if stream == 0 else stream)
+
+    def stream(self, which=0):
+        """rt_stream(): the context's stream (0) or its second, low-priority one (1) as a hipStream_t handle (int)."""
+        h = lib().rt_stream(self._ctx, which)
+        if not h:
+            raise RtError(f"rt_stream({which}) failed: {lib().rt_last_error().decode(errors='replace')}")
+        return int(h)
 
     def reserve(self, width, height):
         _check(lib().rt_reserve(self._ctx, width, height), "rt_reserve")

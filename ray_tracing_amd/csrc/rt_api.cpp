@@ -80,19 +80,31 @@ struct rt_context {
 	rt_camera    camera;
 	bool         have_camera = false;
 
-	unsigned int *d_counter = nullptr;   /* dequeue + fill counters of the pixel lists, launch control words */
+	/* Scratch of a launch.  There are two sets, used alternately, so that two consecutive launches enqueued on
+	 * different streams can be on the GPU together: the waves of the second fill the compute units as the waves of the
+	 * first run out of pixels (the last wave of a launch leaves 100 us after the average one). */
+	struct launch_slot {
+		unsigned int *d_counter = nullptr;   /* dequeue + fill counters of the pixel lists, launch control words */
+		float       *d_pix = nullptr;        /* rt_primary_pass output: pixel records (rt_device.h) */
+		size_t       pix_capacity = 0;       /* records it holds */
+		hipEvent_t   done = nullptr;         /* recorded behind the last launch that used the set, on that launch's stream */
+		hipEvent_t   started = nullptr;      /* recorded behind that launch's primary pass, i.e. in front of its trace kernel */
+		hipStream_t  stream = nullptr;
+		bool         used = false;
+		std::atomic<bool> cancel_pending{false};  /* a stop request was sent since the set's last launch: see begin_launch() */
+	} slot[2];
+	unsigned     launches = 0;           /* launch n uses slot[n & 1] */
+	int          cur = 0;                /* set of the most recent launch */
+	hipStream_t  stream2 = nullptr;      /* rt_stream(ctx, 1): made on first request */
+	std::once_flag stream2_once;
 	hipStream_t  cancel_stream = nullptr; /* rt_cancel(): a copy that overtakes the running kernel */
-	hipEvent_t   cancel_event = nullptr;  /* recorded behind that copy: the next launch's clearing of the control words waits for it */
-	std::atomic<bool> cancel_pending{false};
+	hipEvent_t   cancel_event = nullptr;  /* recorded behind that copy: the next launches' clearing of the control words waits for it */
 	std::once_flag cancel_once;          /* the stream and event are made by the first rt_cancel(): HIP maps streams onto a
 	                                      * handful of hardware queues, and a stream nobody uses would only make two busy ones
 	                                      * share a queue (measured: the host copy of a frame then no longer overlaps the next render) */
 	hipError_t   cancel_setup = hipSuccess;
 	unsigned int *h_words = nullptr;     /* pinned: [0] = read-back of control[1]; [32 ...] = 64 x 128 bytes of 0x80000000 (source of the stop request) */
 	int          num_cus = 256;
-
-	float       *d_pix = nullptr;        /* rt_primary_pass output: pixel records (rt_device.h) */
-	size_t       pix_capacity = 0;       /* records it holds */
 
 	float       *d_frame = nullptr;      /* scratch for rt_render() */
 	size_t       frame_bytes = 0;
@@ -111,39 +123,45 @@ struct rt_context {
 	rt_tuning    tuning = {};
 	std::string  jit_flags;              /* owns tuning.jit_flags */
 
-	/* launches of one context share its scratch: `last_launch` is recorded after every launch, on the launch's
-	 * stream; a launch on another stream waits for it, and the setters wait for it instead of the whole device */
-	hipEvent_t   last_launch = nullptr;
-	hipStream_t  last_stream = nullptr;
-	bool         launched = false;
-
 	bool         profiling = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 	std::vector<hipEvent_t> event_pool;
 };
 
-/* Everything this context has enqueued -- on its own stream or on a caller's -- has finished. */
+/* Everything this context has enqueued -- on its own streams or on a caller's -- has finished. */
 static int wait_for_launches(rt_context *ctx)
 {
-	if (ctx->launched) HIP_TRY(hipEventSynchronize(ctx->last_launch));
+	for (auto &sl : ctx->slot)
+		if (sl.used) HIP_TRY(hipEventSynchronize(sl.done));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	return RT_OK;
 }
 
-/* Called before a launch is enqueued on `stream`: the context's scratch is shared, so the launch is ordered
- * behind the context's previous one when that ran on a different stream. */
+/* Called before launch number ctx->launches is enqueued on `stream`: the launch before the previous one used the
+ * same scratch set, so this one is ordered behind it when that ran on a different stream.  (The previous launch has
+ * the other set: the two may overlap.) */
 static int order_behind_previous(rt_context *ctx, hipStream_t stream)
 {
-	if (ctx->launched && ctx->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->last_launch, 0));
-	/* a stop request meant for an earlier launch must have landed before this launch clears the control words */
-	if (ctx->cancel_pending.exchange(false)) HIP_TRY(hipStreamWaitEvent(stream, ctx->cancel_event, 0));
+	rt_context::launch_slot &sl = ctx->slot[ctx->launches & 1u];
+	if (sl.used && sl.stream != stream) HIP_TRY(hipStreamWaitEvent(stream, sl.done, 0));
+	/* ... and it starts when the previous launch's trace kernel is next in line on its stream: that kernel's workgroups
+	 * take the whole chip first, and this launch gets the compute units as they leave.  (Two launches that become ready
+	 * together would share the chip half and half from start to end, and finish together: nothing gained, and the late
+	 * half of either grid finds no pixels left.) */
+	rt_context::launch_slot &prev = ctx->slot[(ctx->launches + 1u) & 1u];
+	if (prev.used && prev.stream != stream) HIP_TRY(hipStreamWaitEvent(stream, prev.started, 0));
+	/* a stop request meant for earlier launches must have landed before this launch clears the set's control words */
+	if (sl.cancel_pending.exchange(false)) HIP_TRY(hipStreamWaitEvent(stream, ctx->cancel_event, 0));
 	return RT_OK;
 }
 
 static int mark_launch(rt_context *ctx, hipStream_t stream)
 {
-	HIP_TRY(hipEventRecord(ctx->last_launch, stream));
-	ctx->last_stream = stream; ctx->launched = true;
+	rt_context::launch_slot &sl = ctx->slot[ctx->launches & 1u];
+	HIP_TRY(hipEventRecord(sl.done, stream));
+	sl.stream = stream; sl.used = true;
+	ctx->cur = (int) (ctx->launches & 1u);
+	ctx->launches++;
 	return RT_OK;
 }
 
@@ -154,6 +172,23 @@ static hipStream_t pick_stream(rt_context *ctx, void *hip_stream)
 }
 
 void *rt_context_stream(rt_context *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
+
+extern "C" void *rt_stream(rt_context *ctx, int which)
+{
+	if (!ctx || which < 0 || which > 1) return nullptr;
+	if (which == 0) return (void *) ctx->stream;
+	/* Made on first request (a stream nobody uses only makes busy ones share a hardware queue), with the lowest priority
+	 * the device offers: streams of different priority never share a queue, so the launches of the two streams overlap. */
+	std::call_once(ctx->stream2_once, [ctx]() {
+		if (hipSetDevice(ctx->device) != hipSuccess) return;
+		int least = 0, greatest = 0;
+		if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+		if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, least) != hipSuccess &&
+		    hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) ctx->stream2 = nullptr;
+	});
+	if (!ctx->stream2) { fail(RT_ERR_DEVICE, "rt_stream: could not create the second stream"); return nullptr; }
+	return (void *) ctx->stream2;
+}
 
 extern "C" {
 
@@ -199,13 +234,21 @@ int rt_create(rt_context **out, int device_id)
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
 			ctx->num_cus = prop.multiProcessorCount;
-		e = hipMalloc((void**) &ctx->d_counter, rt_counter_bytes());
-		if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counter, 0, rt_counter_bytes(), ctx->stream);
-		if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->last_launch, hipEventDisableTiming);
+		for (auto &sl : ctx->slot) {
+			if (e == hipSuccess) e = hipMalloc((void**) &sl.d_counter, rt_counter_bytes());
+			if (e == hipSuccess) e = hipMemsetAsync(sl.d_counter, 0, rt_counter_bytes(), ctx->stream);
+			if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+			if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.started, hipEventDisableTiming);
+		}
 		if (e == hipSuccess) e = hipHostMalloc((void**) &ctx->h_words, (size_t) (32 + 64 * 32) * sizeof(unsigned int), hipHostMallocDefault);
 		if (e == hipSuccess) { ctx->h_words[0] = 0u; for (int k = 0; k < 64 * 32; k++) ctx->h_words[32 + k] = 0x80000000u; }
 		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-		if (e != hipSuccess) { (void) hipStreamDestroy(ctx->stream); delete ctx; return fail(RT_ERR_DEVICE, "rt_create: %s", hipGetErrorString(e)); }
+		if (e != hipSuccess) {
+			for (auto &sl : ctx->slot) { (void) hipFree(sl.d_counter); if (sl.done) (void) hipEventDestroy(sl.done); if (sl.started) (void) hipEventDestroy(sl.started); }
+			if (ctx->h_words) (void) hipHostFree(ctx->h_words);
+			(void) hipStreamDestroy(ctx->stream); delete ctx;
+			return fail(RT_ERR_DEVICE, "rt_create: %s", hipGetErrorString(e));
+		}
 	}
 	rt_camera_default(&ctx->camera);
 	ctx->have_camera = true;     /* the reference starts from its default pose too (camera.c:33-35) */
@@ -220,14 +263,19 @@ void rt_destroy(rt_context *ctx)
 	(void) hipStreamSynchronize(ctx->stream);
 	for (auto &p : ctx->events) { (void) hipEventDestroy(p.first); (void) hipEventDestroy(p.second); }
 	for (auto &e : ctx->event_pool) (void) hipEventDestroy(e);
-	if (ctx->launched) (void) hipEventSynchronize(ctx->last_launch);
-	if (ctx->last_launch) (void) hipEventDestroy(ctx->last_launch);
+	for (auto &sl : ctx->slot) {
+		if (sl.used) (void) hipEventSynchronize(sl.done);
+		if (sl.done) (void) hipEventDestroy(sl.done);
+		if (sl.started) (void) hipEventDestroy(sl.started);
+		(void) hipFree(sl.d_counter); (void) hipFree(sl.d_pix);
+	}
+	if (ctx->stream2) { (void) hipStreamSynchronize(ctx->stream2); (void) hipStreamDestroy(ctx->stream2); }
 	if (ctx->cancel_stream) { (void) hipStreamSynchronize(ctx->cancel_stream); (void) hipStreamDestroy(ctx->cancel_stream); }
 	if (ctx->cancel_event) (void) hipEventDestroy(ctx->cancel_event);
 	if (ctx->h_words) (void) hipHostFree(ctx->h_words);
 	if (ctx->spec_module) (void) hipModuleUnload(ctx->spec_module);
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
-	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame); (void) hipFree(ctx->d_counter); (void) hipFree(ctx->d_pix);
+	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame);
 	(void) hipFree(ctx->prog.d_accum); (void) hipFree(ctx->prog.d_low); (void) hipFree(ctx->prog.d_out);
 	(void) hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -455,8 +503,9 @@ static void give_event(rt_context *ctx, hipEvent_t e) { if (e) ctx->event_pool.p
 
 /* Scheduling parameters of the wavefront kernels for one launch (rt_device.h) and the pixel lists rt_primary_pass
  * fills for the trace kernel (grown on demand).  Any schedule renders the same frame. */
-static int prepare_launch(rt_context *ctx, rt_launch &L)
+static int prepare_launch(rt_context *ctx, rt_launch &L, unsigned which)
 {
+	rt_context::launch_slot &sl = ctx->slot[which & 1u];
 	const long long pixel_blocks = (long long) ((L.width + 7) / 8) * ((L.local_rows + 7) / 8);
 	/* 64 lists (a single dequeue counter takes ~88 atomics per microsecond: 4 K waves asking for their first pixels at
 	 * once would already queue up) unless the launch is small */
@@ -466,15 +515,15 @@ static int prepare_launch(rt_context *ctx, rt_launch &L)
 	const size_t cap = rt_pixel_list_capacity(L.width, L.local_rows, ctx->num_cus, L.num_shards);
 	const size_t records = cap * (size_t) L.num_shards;
 	if (cap > (size_t) 0x7fffffff) return fail(RT_ERR_ARGUMENT, "render: frame too large");
-	if (records > ctx->pix_capacity) {
-		(void) hipFree(ctx->d_pix); ctx->d_pix = nullptr; ctx->pix_capacity = 0;
-		HIP_TRY(hipMalloc((void**) &ctx->d_pix, records * 12 * sizeof(float)));
-		ctx->pix_capacity = records;
+	if (records > sl.pix_capacity) {
+		(void) hipFree(sl.d_pix); sl.d_pix = nullptr; sl.pix_capacity = 0;    /* (hipFree waits for the device: nothing still reads it) */
+		HIP_TRY(hipMalloc((void**) &sl.d_pix, records * 12 * sizeof(float)));
+		sl.pix_capacity = records;
 	}
-	L.pix = ctx->d_pix;
+	L.pix = sl.d_pix;
 	L.pix_shard_cap = (int) cap;
-	L.pix_count = ctx->d_counter + 64 * 32;      /* counter block: 64 dequeue counters, 64 fill counters, one control line */
-	L.control = ctx->d_counter + 128 * 32;
+	L.pix_count = sl.d_counter + 64 * 32;      /* counter block: 64 dequeue counters, 64 fill counters, one control line */
+	L.control = sl.d_counter + 128 * 32;
 	return RT_OK;
 }
 
@@ -490,7 +539,7 @@ int rt_reserve(rt_context *ctx, int width, int height)
 	rt_launch L;
 	memset(&L, 0, sizeof(L));
 	L.width = width; L.local_rows = rt_strip_rows(height, 8, 1);
-	{ const int rc = prepare_launch(ctx, L); if (rc != RT_OK) return rc; }
+	for (unsigned which = 0; which < 2; which++) { const int rc = prepare_launch(ctx, L, which); if (rc != RT_OK) return rc; }
 	const size_t need = (size_t) L.local_rows * width * 3 * sizeof(float);
 	if (need > ctx->frame_bytes) {
 		(void) hipFree(ctx->d_frame); ctx->d_frame = nullptr; ctx->frame_bytes = 0;
@@ -531,7 +580,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.sky_wm1 = (float) (ctx->sky_w - 1); L.sky_hm1 = (float) (ctx->sky_h - 1);
 	L.frame = (float*) d_strip;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
-	{ const int rc = prepare_launch(ctx, L); if (rc != RT_OK) return rc; }
+	{ const int rc = prepare_launch(ctx, L, ctx->launches); if (rc != RT_OK) return rc; }
 	{ const int rc = order_behind_previous(ctx, stream); if (rc != RT_OK) return rc; }
 	if (ctx->tuning.poison_frame)
 		HIP_TRY(hipMemsetAsync(d_strip, 0xff, (size_t) rt_strip_rows(p->height, p->row_block, p->world) * p->width * 3 * sizeof(float), stream));
@@ -539,10 +588,8 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	if (ctx->profiling) {
 		e0 = take_event(ctx); e1 = take_event(ctx);
 		if (!e0 || !e1) { give_event(ctx, e0); give_event(ctx, e1); return fail(RT_ERR_DEVICE, "rt_render_device: hipEventCreate failed"); }
-		hipError_t e = hipEventRecord(e0, stream);
-		if (e != hipSuccess) { give_event(ctx, e0); give_event(ctx, e1); return fail(RT_ERR_DEVICE, "hipEventRecord: %s", hipGetErrorString(e)); }
 	}
-	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->tuning.workgroups_per_cu, stream);
+	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->slot[ctx->launches & 1u].d_counter, e0, ctx->slot[ctx->launches & 1u].started, ctx->num_cus, ctx->tuning.workgroups_per_cu, stream);
 	if (le == hipSuccess && ctx->profiling) le = hipEventRecord(e1, stream);
 	if (ctx->profiling) {
 		if (le == hipSuccess) ctx->events.emplace_back(e0, e1);
@@ -570,7 +617,7 @@ int rt_render(rt_context *ctx, const rt_render_params *p, Vector3 *frame_out)
 	if (rc != RT_OK) return rc;
 	HIP_TRY(hipMemcpyAsync(frame_out, ctx->d_frame, (size_t) p->height * p->width * 3 * sizeof(float),
 	                       hipMemcpyDeviceToHost, ctx->stream));
-	HIP_TRY(hipMemcpyAsync(&ctx->h_words[0], ctx->d_counter + 128 * 32 + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(&ctx->h_words[0], ctx->slot[ctx->cur].d_counter + 128 * 32 + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	return ctx->h_words[0] ? RT_CANCELLED : RT_OK;
 }
@@ -590,9 +637,10 @@ int rt_cancel(rt_context *ctx)
 	});
 	if (ctx->cancel_setup != hipSuccess) return fail(RT_ERR_DEVICE, "rt_cancel: %s", hipGetErrorString(ctx->cancel_setup));
 	/* every dequeue counter jumps beyond any fill count: from now on no fetch returns a pixel (rt_kernels.hip) */
-	HIP_TRY(hipMemcpyAsync(ctx->d_counter, &ctx->h_words[32], (size_t) 64 * 32 * sizeof(unsigned int), hipMemcpyHostToDevice, ctx->cancel_stream));
+	for (auto &sl : ctx->slot)
+		HIP_TRY(hipMemcpyAsync(sl.d_counter, &ctx->h_words[32], (size_t) 64 * 32 * sizeof(unsigned int), hipMemcpyHostToDevice, ctx->cancel_stream));
 	HIP_TRY(hipEventRecord(ctx->cancel_event, ctx->cancel_stream));
-	ctx->cancel_pending.store(true);
+	for (auto &sl : ctx->slot) sl.cancel_pending.store(true);
 	return RT_OK;
 }
 
@@ -602,7 +650,7 @@ int rt_was_cancelled(rt_context *ctx)
 	HIP_TRY(hipSetDevice(ctx->device));
 	{ const int rc = wait_for_launches(ctx); if (rc != RT_OK) return rc; }
 	unsigned int w = 0;
-	HIP_TRY(hipMemcpy(&w, ctx->d_counter + 128 * 32 + 1, sizeof(w), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(&w, ctx->slot[ctx->cur].d_counter + 128 * 32 + 1, sizeof(w), hipMemcpyDeviceToHost));
 	return w ? RT_CANCELLED : RT_OK;
 }
 
@@ -658,7 +706,7 @@ int rt_progressive_invalidate(rt_context *ctx)
 	auto &g = ctx->prog;
 	/* a pass still in flight is given up as soon as its waves notice (main.c:316-317) and is not published
 	 * (main.c:382: rt_accumulate looks at control[1]); the clear below is ordered behind it */
-	if (ctx->launched) { const int rc = rt_cancel(ctx); if (rc != RT_OK) return rc; }
+	if (ctx->launches) { const int rc = rt_cancel(ctx); if (rc != RT_OK) return rc; }
 	HIP_TRY(hipMemsetAsync(g.d_accum, 0, g.accum_bytes, ctx->stream));
 	g.count = 0; g.passes = 0; g.scale = g.init_scale; g.generation++;
 	return RT_OK;
@@ -691,10 +739,10 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.sky_wm1 = (float) (ctx->sky_w - 1); L.sky_hm1 = (float) (ctx->sky_h - 1);
 	L.frame = g.d_low;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
-	{ const int rc = prepare_launch(ctx, L); if (rc != RT_OK) return rc; }
+	{ const int rc = prepare_launch(ctx, L, ctx->launches); if (rc != RT_OK) return rc; }
 	{ const int rc = order_behind_previous(ctx, ctx->stream); if (rc != RT_OK) return rc; }
 	if (ctx->tuning.poison_frame) HIP_TRY(hipMemsetAsync(g.d_low, 0xff, g.low_bytes, ctx->stream));
-	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, ctx->d_counter, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream));
+	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, ctx->slot[ctx->launches & 1u].d_counter, nullptr, ctx->slot[ctx->launches & 1u].started, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream));
 	const float weight = 1.0f / (s * s);                                         /* main.c:278 */
 	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), L.control + 1, ctx->stream));
 	{ const int rc = mark_launch(ctx, ctx->stream); if (rc != RT_OK) return rc; }

@@ -16,9 +16,11 @@ size_t     rt_scene_lds_bytes(int num_objects);
 size_t     rt_wavefront_lds_bytes(int num_objects);
 void       rt_primary_geometry(int width, int local_rows, int num_cus, unsigned int *groups_out, int *per_group_out);
 size_t     rt_pixel_list_capacity(int width, int local_rows, int num_cus, int num_shards);
-/* spec_fn: kernel compiled by rt_compile_scene for the current scene, or nullptr */
+/* spec_fn: kernel compiled by rt_compile_scene for the current scene, or nullptr.  Events recorded on `stream`: `cleared`
+ * (may be nullptr) behind the clearing of the counters, i.e. when the launch has got its first compute unit;
+ * `primary_done` in front of the trace kernel (behind the whole launch when there is no separate primary pass) */
 hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, hipFunction_t spec_fn,
-                           unsigned int *block_counter, int num_cus, int workgroups_per_cu, hipStream_t stream);
+                           unsigned int *block_counter, hipEvent_t cleared, hipEvent_t primary_done, int num_cus, int workgroups_per_cu, hipStream_t stream);
 int        rt_jit_build(const rt_geom *geom, int n, int light_index, const float light_pos[3], int waves_per_simd, const char *extra_flags, hipModule_t *module, hipFunction_t *function, std::string &message);
 hipError_t rt_launch_deinterleave(const float *strips, float *frame, int width, int height,
                                   int row_block, int world, int rows_per_rank, hipStream_t stream);

@@ -1494,15 +1494,23 @@ size_t rt_pixel_list_capacity(int width, int local_rows, int num_cus, int num_sh
 }
 
 hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, hipFunction_t spec_fn,
-                           unsigned int *block_counter, int num_cus, int workgroups_per_cu, hipStream_t stream)
+                           unsigned int *block_counter, hipEvent_t cleared, hipEvent_t primary_done, int num_cus, int workgroups_per_cu, hipStream_t stream)
 {
-	if (L.local_rows <= 0 || L.width <= 0) return hipSuccess;
+	if (L.local_rows <= 0 || L.width <= 0) {
+		hipError_t e = cleared ? hipEventRecord(cleared, stream) : hipSuccess;
+		return e != hipSuccess ? e : hipEventRecord(primary_done, stream);
+	}
 	const bool simple = variant == 1 /* RT_KERNEL_SIMPLE */ || L.max_bounces < 1;
 	if (simple) {
+		/* it has no use for the counters, but every launch leaves its scratch set's control words describing itself */
+		hipError_t e = hipMemsetAsync(block_counter, 0, RT_COUNTER_BYTES, stream);
+		if (e == hipSuccess && cleared) e = hipEventRecord(cleared, stream);
+		if (e != hipSuccess) return e;
 		const int tiles_x = (L.width + RT_TILE_W - 1) / RT_TILE_W;
 		const int tiles_y = (L.local_rows + RT_TILE_H - 1) / RT_TILE_H;
 		hipLaunchKernelGGL(rt_trace_simple, dim3(tiles_x * tiles_y), dim3(RT_BLOCK), rt_scene_lds_bytes(L.num_objects), stream, L);
-		return hipGetLastError();
+		e = hipGetLastError();
+		return e != hipSuccess ? e : hipEventRecord(primary_done, stream);
 	}
 	/* persistent waves: as many workgroups as fit on the chip at once, capped by the work */
 	const size_t lds = rt_wavefront_lds_bytes(L.num_objects);
@@ -1517,6 +1525,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	if (grid < 1) grid = 1;
 	const rt_launch &Lq = L;
 	hipError_t e = hipMemsetAsync(block_counter, 0, RT_COUNTER_BYTES, stream);
+	if (e == hipSuccess && cleared) e = hipEventRecord(cleared, stream);
 	if (e != hipSuccess) return e;
 	{
 		unsigned int groups; int per_group;
@@ -1527,6 +1536,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 		else
 			hipLaunchKernelGGL(rt_primary_pass<true>, dim3(groups), dim3(RT_BLOCK), plds, stream, L, per_group);
 		e = hipGetLastError();
+		if (e == hipSuccess) e = hipEventRecord(primary_done, stream);       /* the next launch of the context may start (rt_api.cpp) */
 		if (e != hipSuccess) return e;
 	}
 	if (variant == 0 /* RT_KERNEL_AUTO */ && scene_fast_ok && spec_fn) {

@@ -8,11 +8,12 @@ all strips with a single gather and de-interleaves them.  One process per GPU, `
 supplies the communicator (backend "nccl" = RCCL on ROCm; "gloo" on CPU for the tests).
 
 Stream discipline (GPU): every stage of a frame -- strip render, gather, de-interleave -- is issued from ONE
-dedicated, non-default torch stream (its handle is what the C ABI receives, so the kernels, torch's
-collective hand-off events and the de-interleave are ordered by construction); the copy of the finished
-frame to pinned host memory runs on a second stream behind an event.  Frames are double-buffered, so the
-gather / copy of frame k overlaps the render of frame k+1 -- the way the reference's workers keep
-accumulating while its main thread presents (main.c:354-408 vs 450-482).
+stream (its handle is what the C ABI receives, so the kernels, torch's collective hand-off events and the
+de-interleave are ordered by construction); the copy of the finished frame to pinned host memory runs on a
+copy stream behind an event.  Consecutive frames alternate between the renderer's two streams (rt_stream: different
+priorities, hence different hardware queues) and are double-buffered, so the waves of frame k+1 fill the compute units
+as the waves of frame k run out of pixels, and the gather / copy of frame k overlaps the render of frame k+1 -- the
+way the reference's workers keep accumulating while its main thread presents (main.c:354-408 vs 450-482).
 """
 import numpy as np
 import torch
@@ -98,19 +99,26 @@ class TiledFrame:
     """
 
     def __init__(self, renderer, width, height, spp, max_bounces, seed=0, row_block=8, rank=0, world=1,
-                 kernel=0, device=None, to_host=True):
+                 kernel=0, device=None, to_host=True, overlap_frames=True):
         self.r, self.W, self.H = renderer, width, height
         self.row_block, self.rank, self.world = row_block, rank, world
         self.spp, self.max_bounces, self.kernel, self.seed = spp, max_bounces, kernel, seed
         self.to_host = to_host and rank == 0
         self.device = device
         rows = strip_rows(height, row_block, world)
-        self.stream = torch.cuda.Stream(device)            # render, collective hand-off, de-interleave
+        # render, collective hand-off, de-interleave: frame k on streams[k & 1].  The library's own two streams, wrapped: they
+        # have different priorities, so they never share a hardware queue and consecutive frames overlap on the GPU
+        # (two torch streams of equal priority were seen to share one: then nothing overlaps)
+        if overlap_frames:
+            self.streams = [torch.cuda.ExternalStream(renderer.stream(w), device=device) for w in (0, 1)]
+        else:
+            self.streams = [torch.cuda.Stream(device)] * 2
+        self.stream = self.streams[0]
         # frame -> pinned host memory.  High priority: its own hardware queue (streams of equal priority share a handful of
         # queues, and two streams on one queue run in enqueue order: the copy of frame k would then sit between render k and
         # render k+1 instead of beside the latter), and its copy kernel is dispatched ahead of the next frame's kernels.
         self.copy_stream = torch.cuda.Stream(device, priority=-1)
-        assert self.stream.cuda_stream != 0
+        assert all(s.cuda_stream != 0 for s in self.streams)
         self.primitive = collective_for() if world > 1 else None
         with torch.cuda.stream(self.stream):
             self.strip = [torch.empty((rows, width, 3), dtype=torch.float32, device=device) for _ in range(2)]
@@ -124,44 +132,51 @@ class TiledFrame:
         self.pending = None               # (work, k) of the frame whose gather is in flight
         self.k = 0
         self.done_events = []             # one per completed frame when record_events is set
+        self.render_events = []           # one behind every strip render when record_events is set
         self.record_events = False
 
     # -- one frame ---------------------------------------------------------------------------------
     def step(self, seed=None):
         k = self.k & 1
         self.k += 1
-        s = self.stream
+        s = self.streams[k]
         with torch.cuda.stream(s):
             if self.copied[k] is not None and self.world == 1:
                 s.wait_event(self.copied[k])           # the copy two frames ago still reads strip[k]
             p = self.r.params(self.W, self.H, self.spp, self.max_bounces, seed=self.seed if seed is None else seed,
                               row_block=self.row_block, rank=self.rank, world=self.world, kernel=self.kernel)
             self.r.render_device(p, self.strip[k].data_ptr(), s.cuda_stream)
+            if self.record_events:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(s)
+                self.render_events.append(ev)
             if self.world == 1:
                 self._deliver(self.strip[k][:self.H], k)
                 return
             _, work = gather_strips(self.strip[k], self.rank, self.world, dst=0,
                                     out=self.strips[k] if self.strips is not None else None,
                                     primitive=self.primitive, async_op=True)
-            prev, self.pending = self.pending, (work, k)
-            if prev is not None:
-                self._finish(prev)
+        prev, self.pending = self.pending, (work, k)
+        if prev is not None:
+            self._finish(prev)
 
     def _finish(self, pending):
         work, k = pending
-        work.wait()                                        # self.stream waits for the collective (no host block on nccl)
-        if self.rank == 0:
-            if self.copied[k] is not None:
-                self.stream.wait_event(self.copied[k])     # frame[k] is still being copied out
-            frame = assemble(self.strips[k], self.H, self.row_block, self.world, renderer=self.r,
-                             out=self.frame[k], stream=self.stream)
-            self._deliver(frame, k)
+        s = self.streams[k]                                    # the frame's own stream
+        with torch.cuda.stream(s):
+            work.wait()                                        # s waits for the collective (no host block on nccl)
+            if self.rank == 0:
+                if self.copied[k] is not None:
+                    s.wait_event(self.copied[k])               # frame[k] is still being copied out
+                frame = assemble(self.strips[k], self.H, self.row_block, self.world, renderer=self.r,
+                                 out=self.frame[k], stream=s)
+                self._deliver(frame, k)
 
     def _deliver(self, frame, k):
-        """frame (device, on self.stream) -> pinned host memory, on the copy stream."""
+        """frame (device, on the frame's stream) -> pinned host memory, on the copy stream."""
         if self.to_host:
             ready = torch.cuda.Event()
-            ready.record(self.stream)
+            ready.record(self.streams[k])
             self.copy_stream.wait_event(ready)
             with torch.cuda.stream(self.copy_stream):
                 self.host_frame.copy_(frame, non_blocking=True)
@@ -170,17 +185,17 @@ class TiledFrame:
             self.copied[k] = done
         else:
             done = torch.cuda.Event(enable_timing=self.record_events)
-            done.record(self.stream)
+            done.record(self.streams[k])
         if self.record_events:
             self.done_events.append(done)
 
     def flush(self):
         """Complete every frame in flight; afterwards host_frame (rank 0) holds the last one."""
-        with torch.cuda.stream(self.stream):
-            prev, self.pending = self.pending, None
-            if prev is not None:
-                self._finish(prev)
-        self.stream.synchronize()
+        prev, self.pending = self.pending, None
+        if prev is not None:
+            self._finish(prev)
+        for s in self.streams:
+            s.synchronize()
         self.copy_stream.synchronize()
 
     def render_now(self, seed=None):

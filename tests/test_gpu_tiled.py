@@ -79,6 +79,43 @@ def _nccl_worker(rank, world, port, q, backend="nccl", share_gpu=False):
     dist.destroy_process_group()
 
 
+def test_consecutive_launches_overlap_on_the_two_streams(gpu):
+    """rt_stream(ctx, 0 / 1): launches alternate between the context's two streams and use its two scratch sets, so
+    consecutive ones are on the GPU together.  Every launch has its own seed and destination; each frame must equal the
+    one rendered alone.  Large enough (a few hundred microseconds a launch) for the launches to really overlap."""
+    W, H, spp, nb = 1920, 1080, 16, 4
+    seeds = [11, 12, 13, 14, 15, 16, 17]
+    streams = [gpu.stream(0), gpu.stream(1)]
+    assert streams[0] and streams[1] and streams[0] != streams[1]
+    want = {}
+    for s in seeds[:3] + seeds[-1:]:
+        alone = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        gpu.render_device(gpu.params(W, H, spp, nb, seed=s), alone.data_ptr()); gpu.synchronize()
+        want[s] = alone.cpu().numpy()
+    out = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0") for _ in seeds]
+    torch.cuda.synchronize()
+    for k, s in enumerate(seeds):                       # nothing waits in between: up to two launches run together
+        gpu.render_device(gpu.params(W, H, spp, nb, seed=s), out[k].data_ptr(), streams[k & 1])
+    gpu.synchronize(); torch.cuda.synchronize()
+    for k, s in enumerate(seeds):
+        if s in want:
+            assert (bits(out[k].cpu().numpy()) == bits(want[s])).all(), s
+    # strips of different ranks on the two streams, as a host that renders for two ranks would issue them
+    rows = rt.strip_rows(H, 8, 8)
+    strips = [torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda:0") for _ in range(8)]
+    torch.cuda.synchronize()
+    for r in range(8):
+        gpu.render_device(gpu.params(W, H, spp, nb, seed=11, row_block=8, rank=r, world=8), strips[r].data_ptr(), streams[r & 1])
+    gpu.synchronize(); torch.cuda.synchronize()
+    frame = np.empty((H, W, 3), dtype=np.float32)
+    from ray_tracing_amd.multi_gpu import owned_rows
+    for r in range(8):
+        g = owned_rows(H, 8, r, 8)
+        frame[g[g >= 0]] = strips[r].cpu().numpy()[g >= 0]
+    assert (bits(frame) == bits(want[11])).all()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_pipelined_frames_ranks_sharing_one_gpu_over_gloo(world):
     """The N-rank frame loop of bench.py on the ONE GPU this pool's boxes have: every rank is its own process with
