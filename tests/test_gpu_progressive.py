@@ -99,3 +99,39 @@ def test_cancel_gives_up_a_frame_in_flight(scene_paths):
     a2 = g.render(320, 180, 8, 4, seed=3)
     assert (a2.view(np.uint32) == s.view(np.uint32)).all()
     g.close()
+
+
+def test_cancel_reaches_both_launches_in_flight(scene_paths):
+    """Two launches on the context's two streams are on the GPU together (rt_stream); rt_cancel() stops both, and
+    the next launches on either stream -- each reuses one of the two scratch sets -- are complete and correct."""
+    import threading
+    import time
+    import torch
+    g = rt.Renderer(0)
+    g.set_tuning(poison_frame=True)
+    g.set_skybox(rt.load_skybox()); g.set_scene(scene_paths[0]); g.set_camera()
+    W, H, spp, nb = 1920, 1080, 512, 8                      # ~60 ms of GPU work each
+    bufs = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0") for _ in range(2)]
+    streams = [g.stream(0), g.stream(1)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.render_device(g.params(W, H, spp, nb, seed=1), bufs[0].data_ptr(), streams[0]); g.synchronize()
+    one = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for k in range(2):
+        g.render_device(g.params(W, H, spp, nb, seed=k), bufs[k].data_ptr(), streams[k])
+    threading.Timer(0.005, g.cancel).start()
+    g.synchronize()
+    cut = time.perf_counter() - t0
+    assert g.was_cancelled()
+    assert cut < one, (cut, one)                            # two launches, stopped: less than ONE takes
+    want = g.render(320, 180, 8, 4, seed=3, kernel=rt.KERNEL_SIMPLE)
+    small = [torch.zeros((180, 320, 3), dtype=torch.float32, device="cuda:0") for _ in range(4)]
+    torch.cuda.synchronize()
+    for k in range(4):
+        g.render_device(g.params(320, 180, 8, 4, seed=3), small[k].data_ptr(), streams[k & 1])
+    g.synchronize()
+    assert not g.was_cancelled()
+    for k in range(4):
+        assert (small[k].cpu().numpy().view(np.uint32) == want.view(np.uint32)).all(), k
+    g.close()
