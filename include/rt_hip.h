@@ -84,6 +84,8 @@ typedef struct {
 	                             * single device (a one-rank communicator), so that path can be checked on a 1-GPU box */
 	int    poison_frame;        /* testing aid: fill the destination with NaNs before every launch, so that a pixel the
 	                             * launch fails to write cannot pass for correct because an earlier frame left it there */
+	int    trace_known_taps;    /* testing aid: trace every soft-shadow tap, also those of camera-ray hit points from which
+	                             * every tap provably reaches the emitter first (csrc/rt_lit.h; normally answered untraced) */
 } rt_tuning;
 RT_API void rt_default_tuning(rt_tuning *t);
 

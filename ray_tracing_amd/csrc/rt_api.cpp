@@ -579,6 +579,8 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	}
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.sky_wm1 = (float) (ctx->sky_w - 1); L.sky_hm1 = (float) (ctx->sky_h - 1);
 	L.frame = (float*) d_strip;
+	/* classifying a pixel costs about what tracing its taps once costs: it pays from the second sample on */
+	L.skip_known_taps = (ctx->tuning.trace_known_taps || p->spp < 2) ? 0 : 1;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
 	{ const int rc = prepare_launch(ctx, L, ctx->launches); if (rc != RT_OK) return rc; }
 	{ const int rc = order_behind_previous(ctx, stream); if (rc != RT_OK) return rc; }
@@ -738,6 +740,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	L.row_block = 8; L.rank = 0; L.world = 1;
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.sky_wm1 = (float) (ctx->sky_w - 1); L.sky_hm1 = (float) (ctx->sky_h - 1);
 	L.frame = g.d_low;
+	L.skip_known_taps = 0;      /* one sample per pixel and pass: see rt_render_device */
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
 	{ const int rc = prepare_launch(ctx, L, ctx->launches); if (rc != RT_OK) return rc; }
 	{ const int rc = order_behind_previous(ctx, ctx->stream); if (rc != RT_OK) return rc; }

@@ -72,6 +72,7 @@ typedef struct {
 	float sky_wm1, sky_hm1;    /* (float)(w - 1), (float)(h - 1): the texel scale of gpu_and_windowing.c:103-104 */
 
 	float *frame;              /* local_rows x width x 3 floats, resolved      */
+	int    skip_known_taps;    /* rt_primary_pass flags the pixels whose bounce-0 taps need no tracing (rt_lit.h); 0: every tap is traced */
 	/* scheduling of the wavefront kernels (any values give the same frame):
 	 *   num_shards   pixel lists in use (1 or 64), each with its own fill and dequeue counter */
 	int    num_shards;

@@ -35,6 +35,7 @@
 #define RT_TILE_H   8
 
 struct Hit { float t; V3 n; int obj; };
+#define RT_PIX_TAPS_LIT 0x10000      /* flag beside the object index of a pixel record (objects: < 1024) */
 
 /* Development instrumentation (make stats): per-site counts of executions and of active lanes,
  * accumulated in a device array.  Compiled out of the product build. */
@@ -590,6 +591,8 @@ rt_trace_simple(const rt_launch L)
  * L.num_shards pixel lists, from which the trace kernel's waves deal pixels to their lanes.
  * ============================================================================================= */
 #define RT_PIX_WORDS 12
+#define RT_LIT_FN __device__ static inline
+#include "rt_lit.h"
 template <bool FAST>
 __global__ void __launch_bounds__(RT_BLOCK)
 rt_primary_pass(const rt_launch L, int blocks_per_group)
@@ -613,7 +616,7 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 		if (blk >= total) break;
 		const int i = (int) (blk % (unsigned int) tiles_x) * 8 + (lane & 7), lr = (int) (blk / (unsigned int) tiles_x) * 8 + (lane >> 3);
 		const int j = global_row(L, lr);
-		int obj = -2;                                   /* outside the frame */
+		int obj = -2, known = 0;                        /* outside the frame */
 		V3 a = mk3(0, 0, 0), nn = mk3(0, 0, 0), pd = mk3(0, 0, 0);
 		if (i < L.width && lr < L.local_rows && j < L.height) {
 			float u = (float) i / (float) L.u_den;      /* main.c:293-296 */
@@ -627,6 +630,11 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 			if (obj >= 0) {
 				a = madd3(cam, dn, hit.t);                                               /* scene.c:186 */
 				nn = hit.n;
+				/* every soft-shadow tap from this point certainly hits the emitter first (rt_lit.h): bounce 0 of all the
+				 * pixel's samples needs no tap traced */
+				if (FAST && L.skip_known_taps && rt_taps_certainly_lit(reinterpret_cast<const float*>(sc.geom), n, L.light_index,
+				        L.light_pos[0], L.light_pos[1], L.light_pos[2], obj, a.x, a.y, a.z, nn.x, nn.y, nn.z))
+					known = RT_PIX_TAPS_LIT;
 			} else {
 				const V3 sky = sky_lookup<FAST>(L, dn);                                  /* main.c:170 */
 				const V3 c = mk3(clamp01(sky.x), clamp01(sky.y), clamp01(sky.z));
@@ -650,7 +658,7 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 				float *dst = L.pix + (size_t) shard * L.pix_shard_cap + base + (unsigned int) lanes_below(om);
 				dst[0] = a.x;  dst[plane] = a.y;  dst[2 * plane] = a.z;
 				dst[3 * plane] = nn.x; dst[4 * plane] = nn.y; dst[5 * plane] = nn.z;
-				dst[6 * plane] = __int_as_float(obj);
+				dst[6 * plane] = __int_as_float(obj | known);
 				dst[7 * plane] = pd.x; dst[8 * plane] = pd.y; dst[9 * plane] = pd.z;
 				dst[10 * plane] = __uint_as_float((uint32_t) ((j * L.pix_scale) * L.pix_width + i * L.pix_scale));   /* main.c:286 order */
 				dst[11 * plane] = __int_as_float(lr * L.width + i);
@@ -703,6 +711,7 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 #define REC_SPECULAR 2
 #define REC_LAST     4                /* the path ends after this bounce ...               */
 #define REC_SKY      8                /* ... because its bounce ray left the scene (end_sky) */
+#define REC_TAPS_LIT 128              /* the bounce's accepted taps are known to hit the emitter (rt_lit.h): none was queued */
 #define WF_KIND_MAIN    1              /* next bounce ray of lane `owner`; kinds 2..4 = its shadow tap 0..2 */
 
 struct WaveLDS {
@@ -795,9 +804,11 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 #ifdef RT_SPEC_HEADER
 	const bool have_light = SPEC_LIGHT >= 0;               /* the compiled scene's emitter: literals, no scalar registers */
 	const V3 light_pos = mk3(SPEC_LIGHT_POS[0], SPEC_LIGHT_POS[1], SPEC_LIGHT_POS[2]);
+	const int light_obj = SPEC_LIGHT;
 #else
 	const V3 light_pos = ld3(L.light_pos);
 	const bool have_light = L.light_index >= 0;
+	const int light_obj = L.light_index;
 #endif
 
 	for (int k = lane; k < WF_WINDOW; k += 64) W.win[0][k] = __uint_as_float(WF_EMPTY);
@@ -1024,6 +1035,10 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		STAT(7);
 		if (has_hit) {
 			STAT(8);
+			/* a camera-ray hit point from which every tap certainly reaches the emitter (flagged by rt_primary_pass): the taps
+			 * are drawn and accepted as always (main.c:193-195), but not traced */
+			const bool taps_lit = (hobj & RT_PIX_TAPS_LIT) != 0;
+			hobj &= RT_PIX_TAPS_LIT - 1;
 			if (have_light) {
 				/* main.c:191-195: three rand_dir draws, a tap is skipped when it points into the surface.  The
 				 * tap's direction and origin (main.c:197-198) are formed where it is traced, on a full batch. */
@@ -1062,6 +1077,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			hdir = out_dir;
 			has_hit = false;
 			cur = REC_VALID | (specular ? REC_SPECULAR : 0) | (emit_main ? 0 : REC_LAST) | (tapmask << 4) | (hobj << 8);
+			if (taps_lit) { cur |= REC_TAPS_LIT; tapmask = 0; }      /* the record keeps the accepted taps, the queue gets none */
 		}
 
 		STAMP(1);
@@ -1139,7 +1155,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 #pragma unroll
 				for (int k = 0; k < 3; k++)
 					if ((ptaps >> k) & 1) {
-						const int obj = W.tap[parity ^ 1u][k][lane];
+						const int obj = (prev & REC_TAPS_LIT) ? light_obj : W.tap[parity ^ 1u][k][lane];
 						if (obj >= 0) { const float4 e = sc.shade[4 * obj + 3]; lit = add3(lit, mk3(e.x, e.y, e.z)); }
 						taps++;
 					}

@@ -1,0 +1,46 @@
+"""Development aid (CPU only): random scenes with a sphere emitter through scripts/lit_probe.c -- the shipped rt_lit.h against
+the oracle's trace at every shading point of every bounce.  usage: lit_fuzz.py [cases] [seed]   (exit status 1 on a violation)"""
+import os, subprocess, sys, tempfile
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+exe = os.path.join(tempfile.gettempdir(), "lit_probe")
+subprocess.check_call(["gcc", "-O2", "-std=c11", "-o", exe, os.path.join(ROOT, "scripts", "lit_probe.c"), "-lm", "-lpthread"])
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+def num(x): return "%.9f" % float(x)
+def vec(v): return "{%s}" % " ".join(num(x) for x in v)
+bad = taps = known = 0
+for case in range(cases):
+    n = int(rng.integers(2, 14))
+    light = int(rng.integers(0, n))
+    txt = []
+    for k in range(n):
+        P = lambda name, value: name.ljust(15) + value       # the reference's parser skips fixed widths after some names (scene.c:280,320)
+        mat = [P("emission_color", "{1.0 1.0 1.0}"), P("emission_power", num(4.0 if k == light else 0.0)), P("metallic", num(rng.choice([0, 0, 1]))),
+               P("reflectance", num(rng.uniform(0, 1))), P("roughness", num(rng.choice([0, 0.3, 1.0]))), P("albedo", vec(rng.uniform(0, 1, 3)))]
+        tight = rng.random() < 0.5          # objects that touch: shared planes, spheres resting on slabs
+        if k == light or rng.random() < 0.4:
+            c = rng.integers(-3, 7, 3).astype(float) if tight else rng.uniform(-3, 7, 3)
+            r = float(rng.choice([0.25, 0.5, 1.0, 2.0])) if tight else float(rng.uniform(0.06, 2.0))
+            txt += ["sphere"] + ["\t" + m for m in mat] + ["\t" + P("center", vec(c)), "\t" + P("radius", num(r)), ""]
+        else:
+            o = rng.integers(-3, 7, 3).astype(float) if tight else rng.uniform(-3, 7, 3)
+            sz = rng.choice([0.1, 0.5, 1.0, 3.0, 9.0], 3) if tight else rng.uniform(0.05, 5, 3)
+            txt += ["cube"] + ["\t" + m for m in mat] + ["\t" + P("origin", vec(o)), "\t" + P("size", vec(sz)), ""]
+    path = os.path.join(tempfile.gettempdir(), "lit_fuzz_scene.txt")
+    open(path, "w").write("\n".join(txt))
+    pos = rng.integers(-2, 9, 3).astype(float) if rng.random() < 0.3 else rng.uniform(-2, 9, 3)
+    front = rng.uniform(-1, 1, 3)
+    r = subprocess.run([exe, path, "160", "120", "4", "6"] + [repr(float(x)) for x in list(pos) + list(front)], capture_output=True, text=True)
+    last = [l for l in r.stdout.splitlines() if l.startswith("all:")]
+    if last:
+        w = last[0].split()
+        taps += int(w[2]); known += int(round(float(w[7]) / 100 * int(w[2])))
+    if r.returncode == 2:
+        raise SystemExit(f"case {case}: scene file rejected\n{r.stderr}")
+    if r.returncode != 0:
+        bad += 1
+        print(f"case {case}: rc={r.returncode}\n{r.stdout}{r.stderr}", flush=True)
+        os.replace(path, os.path.join(tempfile.gettempdir(), f"lit_fuzz_bad_{case}.txt"))
+print(f"{cases} scenes, {taps} taps checked, {known} answered without tracing ({100.0 * known / max(taps, 1):.1f} %), {bad} scenes with violations")
+sys.exit(1 if bad else 0)

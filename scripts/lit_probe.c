@@ -1,0 +1,77 @@
+/* Development probe (CPU, test infrastructure): checks ray_tracing_amd/csrc/rt_lit.h against the oracle.
+ *
+ * rt_taps_certainly_lit() claims, for a hit point, that every soft-shadow tap from it (main.c:191-206) has the emitter
+ * as its nearest hit, so that trace_ray() need not run for those taps.  The probe renders a frame with the CPU oracle,
+ * calls the SHIPPED function at every shading point (all bounces, although rt_primary_pass only uses it for the camera
+ * ray's hit), counts the taps it would answer and compares each answer with the real trace: violations must be 0.
+ *
+ * build: gcc -O2 -std=c11 -o /tmp/lit_probe scripts/lit_probe.c -lm -lpthread
+ * usage: /tmp/lit_probe scene.txt W H spp bounces [pos.x pos.y pos.z yaw pitch fov]      exit status 1 on a violation */
+#include <stdio.h>
+#include <stdint.h>
+static void lit_probe_tap(const void *hit, int light, int blocker, int bounce);
+#define ORC_TAP_HOOK(hit, light, blocker, bounce) lit_probe_tap(hit, light, blocker, bounce)
+#include "../oracle/rt_oracle.c"
+#include "../ray_tracing_amd/csrc/rt_lit.h"
+
+static _Atomic uint64_t n_taps[16], n_known[16], n_lit[16], n_viol;
+static float packed[8 * 1024];
+
+static void pack_scene(void)          /* as rt_set_scene packs rt_geom (rt_api.cpp) */
+{
+	const Scene *sc = &G.scene;
+	for (int i = 0; i < sc->num_objects; i++) {
+		const Object *o = &sc->objects[i];
+		float *g = packed + 8 * i;
+		if (o->type == OBJECT_CUBE) {
+			g[0] = o->cube.origin.x; g[1] = o->cube.origin.y; g[2] = o->cube.origin.z;
+			g[3] = o->cube.origin.x * 1.0f + o->cube.size.x * 1.0f;
+			g[4] = o->cube.origin.y * 1.0f + o->cube.size.y * 1.0f;
+			g[5] = o->cube.origin.z * 1.0f + o->cube.size.z * 1.0f;
+			((int *) g)[6] = 0;
+		} else {
+			g[0] = o->sphere.center.x; g[1] = o->sphere.center.y; g[2] = o->sphere.center.z;
+			g[3] = o->sphere.radius * o->sphere.radius; g[4] = g[5] = 0;
+			((int *) g)[6] = 1;
+		}
+	}
+}
+
+static void lit_probe_tap(const void *hit, int light, int blocker, int bounce)
+{
+	const Hit *h = (const Hit *) hit;
+	const V3 c = centre_of(&G.scene.objects[light]);
+	n_taps[bounce]++;
+	if (blocker == light) n_lit[bounce]++;
+	if (rt_taps_certainly_lit(packed, G.scene.num_objects, light, c.x, c.y, c.z, h->object,
+	                          h->point.x, h->point.y, h->point.z, h->normal.x, h->normal.y, h->normal.z)) {
+		n_known[bounce]++;
+		if (blocker != light && n_viol++ < 10)
+			fprintf(stderr, "VIOLATION: point %.9g %.9g %.9g object %d: tap hit %d, not the emitter\n", h->point.x, h->point.y, h->point.z, h->object, blocker);
+	}
+}
+
+int main(int argc, char **argv)
+{
+	static Scene sc;
+	if (argc < 6 || orc_parse_scene_file(argv[1], &sc)) { fprintf(stderr, "usage: lit_probe scene W H spp bounces [camera: 6 floats]\n"); return 2; }
+	orc_set_scene(&sc);
+	pack_scene();
+	static uint8_t texel[4] = { 128, 128, 128, 255 };
+	uint8_t *faces[6] = { texel, texel, texel, texel, texel, texel };
+	orc_set_skybox(faces, 1, 1, 3);
+	rt_camera cam; orc_default_camera(&cam);
+	if (argc >= 12) for (int k = 0; k < 6; k++) ((float *) &cam)[k] = (float) atof(argv[6 + k]);
+	orc_set_camera(&cam);
+	const int W = atoi(argv[2]), H = atoi(argv[3]), spp = atoi(argv[4]), nb = atoi(argv[5]);
+	float *frame = malloc(sizeof(float) * 3 * W * H);
+	orc_render_counter(W, H, spp, nb, 0, 0, H, 8, frame);
+	uint64_t t = 0, k = 0, l = 0;
+	for (int b = 0; b < 16; b++) if (n_taps[b]) {
+		printf("bounce %d: taps %10llu  lit %5.1f %%  answered without tracing %5.1f %%\n", b, (unsigned long long) n_taps[b],
+		       100.0 * n_lit[b] / n_taps[b], 100.0 * n_known[b] / n_taps[b]);
+		t += n_taps[b]; k += n_known[b]; l += n_lit[b];
+	}
+	if (t) printf("all: taps %llu  lit %.1f %%  answered %.1f %%  violations %llu\n", (unsigned long long) t, 100.0 * l / t, 100.0 * k / t, (unsigned long long) n_viol);
+	return n_viol != 0;
+}

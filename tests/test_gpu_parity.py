@@ -343,3 +343,43 @@ def test_parameter_sweep_small_frames(gpu, oracle, scene_paths):
             finally:
                 gpu.set_tuning()
             assert (bits(got) == bits(want)).all(), (si, W, H, spp, nb, seed, shards, per_cu)
+
+
+@pytest.mark.parametrize("compiled", [False, True])
+def test_untraced_taps_change_no_bit(gpu, oracle, real_sky, scene_paths, compiled):
+    """rt_primary_pass flags the camera-ray hit points from which every soft-shadow tap provably reaches the emitter
+    first (csrc/rt_lit.h); the tuned kernels then do not trace the bounce-0 taps of those pixels (main.c:191-206 only asks
+    which object a tap hits).  Frames with the flags honoured, with every tap traced (rt_tuning.trace_known_taps) and the
+    oracle's are bit-identical -- shipped scene from four cameras, and random scenes whose first emitter is a sphere."""
+    rng = np.random.default_rng(5)
+    cases = [(scene_paths[0], cam) for cam in (None, dict(pos=(1, 1, 8), front=(0.3, -0.1, -1)), dict(pos=(0.5, 4, 4), front=(1, -0.6, -0.2)),
+                                               dict(pos=(3, 9, 3), front=(0.01, -1, 0.01)))]
+    for k in range(10):
+        objs = [dict(type="sphere", center=rng.uniform(0, 6, 3), radius=float(rng.uniform(0.3, 1.2)), emission_power=4.0)]
+        objs.append(dict(type="cube", origin=(-3, -0.1, -3), size=(12, 0.1, 12), albedo=rng.uniform(0, 1, 3), roughness=1.0))
+        for _ in range(int(rng.integers(1, 8))):
+            if rng.random() < 0.5:
+                objs.append(dict(type="sphere", center=rng.uniform(-1, 6, 3), radius=float(rng.uniform(0.2, 1.0)), albedo=rng.uniform(0, 1, 3), roughness=1.0))
+            else:
+                objs.append(dict(type="cube", origin=rng.integers(-1, 6, 3).astype(float), size=rng.choice([0.1, 0.5, 1.0, 3.0], 3), albedo=rng.uniform(0, 1, 3),
+                                 metallic=float(rng.choice([0, 1]))))
+        rng.shuffle(objs)
+        cases.append((make_scene(objs), dict(pos=tuple(rng.uniform(-1, 7, 3)), front=tuple(rng.uniform(-1, 1, 3)))))
+    gpu.set_skybox(real_sky); oracle.set_skybox(real_sky)
+    for i, (scene, cam) in enumerate(cases):
+        gpu.set_scene(scene)
+        if isinstance(scene, str): oracle.load_scene(scene)
+        else: oracle.set_scene(scene)
+        gpu.set_camera(**(cam or {})); oracle.set_camera(**(cam or {}))
+        if compiled:
+            gpu.compile_scene()
+        W, H, spp, nb = 128, 72, 6, 5
+        gpu.set_tuning(trace_known_taps=0)
+        a = gpu.render(W, H, spp, nb, seed=40 + i)
+        gpu.set_tuning(trace_known_taps=1)
+        b = gpu.render(W, H, spp, nb, seed=40 + i)
+        gpu.set_tuning(trace_known_taps=0)
+        c = oracle.render_counter(W, H, spp, nb, seed=40 + i)
+        compare(a, c, f"case {i}: known taps not traced vs oracle")
+        compare(b, c, f"case {i}: every tap traced vs oracle")
+    gpu.set_camera(); oracle.set_camera()          # the oracle is shared by the whole session

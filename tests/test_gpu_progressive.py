@@ -16,6 +16,7 @@ def test_progressive_matches_oracle(oracle, scene_paths, W, H, init_scale, passe
     g = rt.Renderer(0)
     g.set_tuning(poison_frame=True)
     g.set_skybox(sky); oracle.set_skybox(sky)
+    oracle.set_camera()
     for si in (0, 1):
         g.set_scene(scene_paths[si]); oracle.load_scene(scene_paths[si])
         g.progressive_begin(W, H, init_scale=init_scale, max_bounces=10, seed=5)

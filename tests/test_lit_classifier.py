@@ -1,0 +1,38 @@
+"""rt_lit.h (which soft-shadow taps need no trace) against the oracle, on the CPU: scripts/lit_probe.c calls the shipped
+function at every shading point of a frame -- every bounce, although the kernels only use it for camera-ray hits -- and
+compares each "certainly lit" with the oracle's trace_ray() result for that tap (main.c:191-206)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def probe(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("lit") / "lit_probe")
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-o", exe, os.path.join(ROOT, "scripts", "lit_probe.c"), "-lm", "-lpthread"])
+    return exe
+
+
+@pytest.mark.parametrize("camera", [(), ("1", "1", "8", "0.3", "-0.1", "-1"), ("0.5", "4", "4", "1", "-0.6", "-0.2"), ("3", "9", "3", "0.01", "-1", "0.01")])
+def test_shipped_scene_every_answer_matches_the_trace(probe, camera):
+    r = subprocess.run([probe, os.path.join(ROOT, "data", "scene_0.txt"), "160", "90", "4", "8", *camera], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    last = r.stdout.strip().splitlines()[-1].split()          # all: taps N lit x % answered y % violations 0
+    assert int(last[2]) > 20000 and float(last[7]) > 40.0 and int(last[-1]) == 0, r.stdout
+
+
+def test_scenes_without_a_sphere_emitter_are_never_answered(probe):
+    for scene in ("scene_1.txt", "scene_2.txt"):              # a cube emitter; no emitter at all
+        r = subprocess.run([probe, os.path.join(ROOT, "data", scene), "64", "48", "2", "4"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "answered" not in r.stdout or " answered 0.0 %" in r.stdout.strip().splitlines()[-1], r.stdout
+
+
+def test_random_scenes(probe):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "lit_fuzz.py"), "150", "11"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " 0 scenes with violations" in r.stdout
