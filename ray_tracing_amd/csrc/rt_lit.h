@@ -32,6 +32,9 @@
 #define RT_LIT_SQRT(x) __builtin_sqrtf(x)
 #endif
 
+#ifndef RT_LIT_REFUSE
+#define RT_LIT_REFUSE(why) ((void) 0)      /* scripts/lit_probe.c counts the reasons */
+#endif
 #define RT_LIT_MARGIN 0.01f          /* clearance demanded of every other object, scene units */
 
 /* geom: the packed geometry records of rt_device.h read as floats, 8 words per object
@@ -44,19 +47,19 @@ RT_LIT_FN int rt_taps_certainly_lit(const float *geom, int num_objects, int ligh
 	if (((const int *) ge)[6] != 1 /* RT_GEOM_SPHERE */) return 0;
 	const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(px), __builtin_fabsf(py)), __builtin_fabsf(pz)),
 	                                  __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(cx), __builtin_fabsf(cy)), __builtin_fabsf(cz)));
-	if (!(big <= 32.0f)) return 0;
+	if (!(big <= 32.0f)) { RT_LIT_REFUSE(-1); return 0; }
 	const float R = RT_LIT_SQRT(ge[3]);
 	const float lx = cx - px, ly = cy - py, lz = cz - pz;
 	const float D = RT_LIT_SQRT(lx * lx + ly * ly + lz * lz);
-	if (!(D >= R + 0.75f) || !(R >= 0.05f)) return 0;
+	if (!(D >= R + 0.75f) || !(R >= 0.05f)) { RT_LIT_REFUSE(-2); return 0; }
 	const float inv = 1.0f / D;
 	const float ax = lx * inv, ay = ly * inv, az = lz * inv;
 	const float s = 0.505f / (D - 0.5f);                 /* sin of the cone's half-angle, 1 % over */
-	if (!(D * s <= 0.95f * R) || !(s <= 0.7f)) return 0;
+	if (!(D * s <= 0.95f * R) || !(s <= 0.7f)) { RT_LIT_REFUSE(-3); return 0; }
 	const float cs = RT_LIT_SQRT(1.0f - s * s);
 	const float tau = 1.01f * s / cs, icos = 1.01f / cs; /* tan, 1 / cos: 1 % over */
 	const float lean = 1.1f * s + 0.1f;                  /* a component of the axis above this: every cone direction has it >= 0.1 */
-	if (!(ax * nx + ay * ny + az * nz >= lean)) return 0;
+	if (!(ax * nx + ay * ny + az * nz >= lean)) { RT_LIT_REFUSE(-4); return 0; }
 	const float T = 1.01f * (D + R);                     /* axial length of the cone that matters: the emitter ends before it */
 	const float m = RT_LIT_MARGIN;
 	const float p[3] = { px, py, pz }, a[3] = { ax, ay, az };
@@ -94,6 +97,7 @@ RT_LIT_FN int rt_taps_certainly_lit(const float *geom, int num_objects, int ligh
 		if (along < -rr || along - rr > T) continue;     /* behind P (the cone opens by less than 45 degrees) or behind the emitter */
 		const float lim = __builtin_fmaxf(along, 0.0f) * tau + rr * icos;
 		if (vv - along * along > lim * lim + 1e-4f * vv + 1e-4f) continue;   /* bounding sphere clear of the cone */
+		RT_LIT_REFUSE(i);
 		return 0;
 	}
 	return 1;

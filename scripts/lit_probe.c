@@ -12,6 +12,9 @@
 static void lit_probe_tap(const void *hit, int light, int blocker, int bounce);
 #define ORC_TAP_HOOK(hit, light, blocker, bounce) lit_probe_tap(hit, light, blocker, bounce)
 #include "../oracle/rt_oracle.c"
+static _Atomic uint64_t n_why[1024 + 8];
+static int why_bounce;
+#define RT_LIT_REFUSE(why) do { if (why_bounce == 0) n_why[(why) + 8]++; } while (0)
 #include "../ray_tracing_amd/csrc/rt_lit.h"
 
 static _Atomic uint64_t n_taps[16], n_known[16], n_lit[16], n_viol;
@@ -42,6 +45,7 @@ static void lit_probe_tap(const void *hit, int light, int blocker, int bounce)
 	const Hit *h = (const Hit *) hit;
 	const V3 c = centre_of(&G.scene.objects[light]);
 	n_taps[bounce]++;
+	why_bounce = bounce;
 	if (blocker == light) n_lit[bounce]++;
 	if (rt_taps_certainly_lit(packed, G.scene.num_objects, light, c.x, c.y, c.z, h->object,
 	                          h->point.x, h->point.y, h->point.z, h->normal.x, h->normal.y, h->normal.z)) {
@@ -73,5 +77,8 @@ int main(int argc, char **argv)
 		t += n_taps[b]; k += n_known[b]; l += n_lit[b];
 	}
 	if (t) printf("all: taps %llu  lit %.1f %%  answered %.1f %%  violations %llu\n", (unsigned long long) t, 100.0 * l / t, 100.0 * k / t, (unsigned long long) n_viol);
+	printf("bounce-0 taps refused: coordinates %llu, emitter too near %llu, cone wider than the emitter %llu, own surface %llu", (unsigned long long) n_why[7], (unsigned long long) n_why[6], (unsigned long long) n_why[5], (unsigned long long) n_why[4]);
+	for (int i = 0; i < sc.num_objects; i++) if (n_why[8 + i]) printf(", object %d: %llu", i, (unsigned long long) n_why[8 + i]);
+	printf("\n");
 	return n_viol != 0;
 }
