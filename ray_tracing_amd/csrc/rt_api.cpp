@@ -26,6 +26,8 @@
 
 #include "../../include/rt_hip.h"
 #include "rt_internal.h"
+#define RT_LIT_FN static inline
+#include "rt_lit.h"
 
 #pragma clang fp contract(off)
 
@@ -71,6 +73,13 @@ struct rt_context {
 	bool         scene_fast_ok = false;  /* every cube has 0 <= size, plane coordinates +0 or 2^-76 <= |x| <= 2^29, sphere data |x| <= 2^29 */
 	int          light_index = -1;
 	float        light_pos[3] = {0, 0, 0};
+	/* rt_lit.h: which hit points need no soft-shadow tap traced -- one bit per cell of a grid over every object, built
+	 * by rt_set_scene on the host (a few milliseconds) */
+	uint32_t    *d_lit_words = nullptr;
+	void        *d_lit_grids = nullptr;
+	size_t       lit_words_capacity = 0;
+	int          lit_grids_capacity = 0;
+	bool         have_lit = false;
 
 	uint32_t    *d_sky = nullptr;
 	size_t       sky_bytes = 0;
@@ -275,6 +284,7 @@ void rt_destroy(rt_context *ctx)
 	if (ctx->h_words) (void) hipHostFree(ctx->h_words);
 	if (ctx->spec_module) (void) hipModuleUnload(ctx->spec_module);
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
+	(void) hipFree(ctx->d_lit_words); (void) hipFree(ctx->d_lit_grids);
 	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame);
 	(void) hipFree(ctx->prog.d_accum); (void) hipFree(ctx->prog.d_low); (void) hipFree(ctx->prog.d_out);
 	(void) hipStreamDestroy(ctx->stream);
@@ -362,6 +372,37 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 	if (n > 0) {
 		HIP_TRY(hipMemcpy(ctx->d_geom, geom.data(), (size_t) n * sizeof(rt_geom), hipMemcpyHostToDevice));
 		HIP_TRY(hipMemcpy(ctx->d_shade, shade.data(), (size_t) n * sizeof(rt_shade), hipMemcpyHostToDevice));
+	}
+	/* the table of hit points whose soft-shadow taps certainly reach the emitter (rt_lit.h): cells of 1/16 scene unit,
+	 * coarser if that takes more than 2^20 cells; scenes of up to 64 objects with a sphere as the first emitter */
+	ctx->have_lit = false;
+	if (light >= 0 && n <= 64 && fast_ok) {
+		static_assert(sizeof(rt_geom) == 8 * sizeof(float) && sizeof(rt_lit_grid) == 48, "rt_lit.h reads rt_geom as 8 floats");
+		std::vector<rt_lit_grid> grids((size_t) n);
+		const float *words8 = reinterpret_cast<const float*>(geom.data());
+		long long bits = 0;
+		for (float cell = 0.0625f; cell <= 64.0f; cell *= 2.0f) {
+			bits = rt_lit_layout(words8, n, light, cell, grids.data());
+			if (bits <= (1ll << 20)) break;
+			bits = 0;
+		}
+		if (bits > 0) {
+			std::vector<uint32_t> words((size_t) ((bits + 31) / 32));
+			rt_lit_build(words8, n, light, ctx->light_pos[0], ctx->light_pos[1], ctx->light_pos[2], grids.data(), words.data(), bits);
+			if (words.size() > ctx->lit_words_capacity) {
+				(void) hipFree(ctx->d_lit_words); ctx->d_lit_words = nullptr; ctx->lit_words_capacity = 0;
+				HIP_TRY(hipMalloc((void**) &ctx->d_lit_words, words.size() * sizeof(uint32_t)));
+				ctx->lit_words_capacity = words.size();
+			}
+			if (n > ctx->lit_grids_capacity) {
+				(void) hipFree(ctx->d_lit_grids); ctx->d_lit_grids = nullptr; ctx->lit_grids_capacity = 0;
+				HIP_TRY(hipMalloc(&ctx->d_lit_grids, (size_t) n * sizeof(rt_lit_grid)));
+				ctx->lit_grids_capacity = n;
+			}
+			HIP_TRY(hipMemcpy(ctx->d_lit_words, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+			HIP_TRY(hipMemcpy(ctx->d_lit_grids, grids.data(), (size_t) n * sizeof(rt_lit_grid), hipMemcpyHostToDevice));
+			ctx->have_lit = true;
+		}
 	}
 	ctx->num_objects = n;
 	ctx->have_scene = true;
@@ -581,6 +622,8 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	L.frame = (float*) d_strip;
 	/* classifying a pixel costs about what tracing its taps once costs: it pays from the second sample on */
 	L.skip_known_taps = (ctx->tuning.trace_known_taps || p->spp < 2) ? 0 : 1;
+	L.lit_words = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_words : nullptr;
+	L.lit_grids = ctx->d_lit_grids;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
 	{ const int rc = prepare_launch(ctx, L, ctx->launches); if (rc != RT_OK) return rc; }
 	{ const int rc = order_behind_previous(ctx, stream); if (rc != RT_OK) return rc; }
@@ -741,6 +784,8 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.sky_wm1 = (float) (ctx->sky_w - 1); L.sky_hm1 = (float) (ctx->sky_h - 1);
 	L.frame = g.d_low;
 	L.skip_known_taps = 0;      /* one sample per pixel and pass: see rt_render_device */
+	L.lit_words = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_words : nullptr;
+	L.lit_grids = ctx->d_lit_grids;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
 	{ const int rc = prepare_launch(ctx, L, ctx->launches); if (rc != RT_OK) return rc; }
 	{ const int rc = order_behind_previous(ctx, ctx->stream); if (rc != RT_OK) return rc; }

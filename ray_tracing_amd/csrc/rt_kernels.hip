@@ -24,6 +24,8 @@
 #endif
 #include "rt_device.h"
 #include "rt_math.hip.h"
+#define RT_LIT_FN __host__ __device__ static inline
+#include "rt_lit.h"
 
 #pragma clang fp contract(off)
 
@@ -591,8 +593,6 @@ rt_trace_simple(const rt_launch L)
  * L.num_shards pixel lists, from which the trace kernel's waves deal pixels to their lanes.
  * ============================================================================================= */
 #define RT_PIX_WORDS 12
-#define RT_LIT_FN __device__ static inline
-#include "rt_lit.h"
 template <bool FAST>
 __global__ void __launch_bounds__(RT_BLOCK)
 rt_primary_pass(const rt_launch L, int blocks_per_group)
@@ -1037,8 +1037,13 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			STAT(8);
 			/* a camera-ray hit point from which every tap certainly reaches the emitter (flagged by rt_primary_pass): the taps
 			 * are drawn and accepted as always (main.c:193-195), but not traced */
-			const bool taps_lit = (hobj & RT_PIX_TAPS_LIT) != 0;
+			bool taps_lit = (hobj & RT_PIX_TAPS_LIT) != 0;
 			hobj &= RT_PIX_TAPS_LIT - 1;
+			/* ... or a hit point of any bounce in a cell of the scene's table all of whose surface points are such points */
+			if (FAST && L.lit_words != nullptr && hobj != light_obj) {
+				const int bit = rt_lit_bit_of(reinterpret_cast<const rt_lit_grid*>(L.lit_grids) + hobj, hp.x, hp.y, hp.z);
+				taps_lit = taps_lit || ((L.lit_words[bit >> 5] >> (bit & 31)) & 1u) != 0u;
+			}
 			if (have_light) {
 				/* main.c:191-195: three rand_dir draws, a tap is skipped when it points into the surface.  The
 				 * tap's direction and origin (main.c:197-198) are formed where it is traced, on a full batch. */

@@ -38,40 +38,49 @@
 #define RT_LIT_MARGIN 0.01f          /* clearance demanded of every other object, scene units */
 
 /* geom: the packed geometry records of rt_device.h read as floats, 8 words per object
- * (cube: lo.xyz, hi.x | hi.y, hi.z, type, -;  sphere: centre.xyz, r*r | -, -, type, -). */
-RT_LIT_FN int rt_taps_certainly_lit(const float *geom, int num_objects, int light, float cx, float cy, float cz,
-                                    int hobj, float px, float py, float pz, float nx, float ny, float nz)
+ * (cube: lo.xyz, hi.x | hi.y, hi.z, type, -;  sphere: centre.xyz, r*r | -, -, type, -).
+ *
+ * rt_region_certainly_lit: the statement for EVERY point P of the box centre +- half (on object `hobj`, with an outward
+ * normal within `nslack` of n there), so that one answer can serve a whole cell of a table.  A tap from P' = P + d
+ * is the tap from P shifted by d: the region's extent is added to every clearance, the direction to the emitter
+ * wobbles by at most |d| / distance, which widens the cone. */
+RT_LIT_FN int rt_region_certainly_lit(const float *geom, int num_objects, int light, float cx, float cy, float cz, int hobj,
+                                      float px, float py, float pz, float hx, float hy, float hz, float nx, float ny, float nz, float nslack)
 {
 	if (light < 0 || hobj == light) return 0;
 	const float *ge = geom + 8 * light;
 	if (((const int *) ge)[6] != 1 /* RT_GEOM_SPHERE */) return 0;
-	const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(px), __builtin_fabsf(py)), __builtin_fabsf(pz)),
+	const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(px) + hx, __builtin_fabsf(py) + hy), __builtin_fabsf(pz) + hz),
 	                                  __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(cx), __builtin_fabsf(cy)), __builtin_fabsf(cz)));
 	if (!(big <= 32.0f)) { RT_LIT_REFUSE(-1); return 0; }
+	const float sl = 1.001f * RT_LIT_SQRT(hx * hx + hy * hy + hz * hz);     /* no point of the region is farther from its centre */
 	const float R = RT_LIT_SQRT(ge[3]);
 	const float lx = cx - px, ly = cy - py, lz = cz - pz;
 	const float D = RT_LIT_SQRT(lx * lx + ly * ly + lz * lz);
-	if (!(D >= R + 0.75f) || !(R >= 0.05f)) { RT_LIT_REFUSE(-2); return 0; }
+	const float Dmin = D - sl, Dmax = D + sl;
+	if (!(Dmin >= R + 0.75f) || !(R >= 0.05f)) { RT_LIT_REFUSE(-2); return 0; }
 	const float inv = 1.0f / D;
 	const float ax = lx * inv, ay = ly * inv, az = lz * inv;
-	const float s = 0.505f / (D - 0.5f);                 /* sin of the cone's half-angle, 1 % over */
-	if (!(D * s <= 0.95f * R) || !(s <= 0.7f)) { RT_LIT_REFUSE(-3); return 0; }
+	const float s1 = 0.505f / (Dmin - 0.5f);             /* sin of the half-angle of one point's cone, 1 % over */
+	if (!(Dmax * s1 <= 0.95f * R)) { RT_LIT_REFUSE(-3); return 0; }
+	const float s = s1 + 1.05f * sl / Dmin;              /* ... of the cone around the centre's axis that holds every point's cone */
+	if (!(s <= 0.7f)) { RT_LIT_REFUSE(-3); return 0; }
 	const float cs = RT_LIT_SQRT(1.0f - s * s);
 	const float tau = 1.01f * s / cs, icos = 1.01f / cs; /* tan, 1 / cos: 1 % over */
 	const float lean = 1.1f * s + 0.1f;                  /* a component of the axis above this: every cone direction has it >= 0.1 */
-	if (!(ax * nx + ay * ny + az * nz >= lean)) { RT_LIT_REFUSE(-4); return 0; }
-	const float T = 1.01f * (D + R);                     /* axial length of the cone that matters: the emitter ends before it */
+	if (!(ax * nx + ay * ny + az * nz - nslack >= lean)) { RT_LIT_REFUSE(-4); return 0; }
+	const float T = 1.01f * (Dmax + R);                  /* axial length of the cone that matters: the emitter ends before it */
 	const float m = RT_LIT_MARGIN;
-	const float p[3] = { px, py, pz }, a[3] = { ax, ay, az };
+	const float p[3] = { px, py, pz }, a[3] = { ax, ay, az }, h[3] = { hx, hy, hz };
 	float lo[3], hi[3];
 	for (int k = 0; k < 3; k++) {
 		const float w = RT_LIT_SQRT(__builtin_fmaxf(0.0f, 1.0f - a[k] * a[k]));
-		const float r = T * tau * w + m;
+		const float r = T * tau * w + m + h[k];
 		const float q = p[k] + T * a[k];
 		/* the rays start 0.001 * direction away from P: where every direction moves away along this axis by >= 0.1,
 		 * they stay >= 1e-4 (minus rounding, < 1e-5 at these coordinate sizes) beyond P */
-		lo[k] = __builtin_fminf(a[k] >= lean ? p[k] + 2e-5f : p[k] - m, q - r);
-		hi[k] = __builtin_fmaxf(-a[k] >= lean ? p[k] - 2e-5f : p[k] + m, q + r);
+		lo[k] = __builtin_fminf(a[k] >= lean ? p[k] - h[k] + 2e-5f : p[k] - h[k] - m, q - r);
+		hi[k] = __builtin_fmaxf(-a[k] >= lean ? p[k] + h[k] - 2e-5f : p[k] + h[k] + m, q + r);
 	}
 	for (int i = 0; i < num_objects; i++) {
 		if (i == light || i == hobj) continue;
@@ -93,7 +102,7 @@ RT_LIT_FN int rt_taps_certainly_lit(const float *geom, int num_objects, int ligh
 		const float vx = q[0] - px, vy = q[1] - py, vz = q[2] - pz;
 		const float along = vx * ax + vy * ay + vz * az;
 		const float vv = vx * vx + vy * vy + vz * vz;
-		const float rr = 1.001f * rho + m;
+		const float rr = 1.001f * rho + m + sl;
 		if (along < -rr || along - rr > T) continue;     /* behind P (the cone opens by less than 45 degrees) or behind the emitter */
 		const float lim = __builtin_fmaxf(along, 0.0f) * tau + rr * icos;
 		if (vv - along * along > lim * lim + 1e-4f * vv + 1e-4f) continue;   /* bounding sphere clear of the cone */
@@ -101,6 +110,122 @@ RT_LIT_FN int rt_taps_certainly_lit(const float *geom, int num_objects, int ligh
 		return 0;
 	}
 	return 1;
+}
+
+/* one point: the hit point of a ray, with the normal trace_ray() reports there */
+RT_LIT_FN int rt_taps_certainly_lit(const float *geom, int num_objects, int light, float cx, float cy, float cz,
+                                    int hobj, float px, float py, float pz, float nx, float ny, float nz)
+{
+	return rt_region_certainly_lit(geom, num_objects, light, cx, cy, cz, hobj, px, py, pz, 0.0f, 0.0f, 0.0f, nx, ny, nz, 0.0f);
+}
+
+/* ---- a table of answers for hit points of any bounce --------------------------------------------------------
+ * Every object gets a grid over its bounding box (cells of about `cell` scene units, at least two per axis so that
+ * opposite faces of a thin slab never share a cell); bit base + (iz * res[1] + iy) * res[0] + ix of the table says:
+ * every point of the object's SURFACE inside that cell, with the normal the surface has there, is a point whose taps
+ * certainly reach the emitter (rt_region_certainly_lit over the cell, per cube face that touches it).  Built once per
+ * scene on the host (rt_set_scene); the trace kernel turns a hit point into its cell with three multiplies and reads
+ * one bit.  Cells are inflated by a thousandth of their size before they are classified, so that a hit point whose
+ * index rounds into the neighbouring cell is still covered. */
+typedef struct { float lo[3]; float scale[3]; int res[3]; int base; int pad[2]; } rt_lit_grid;   /* 48 bytes */
+
+#define RT_LIT_MAX_RES 256
+
+RT_LIT_FN void rt_lit_object_box(const float *g, float blo[3], float bhi[3])
+{
+	if (((const int *) g)[6] == 0) { blo[0] = g[0]; blo[1] = g[1]; blo[2] = g[2]; bhi[0] = g[3]; bhi[1] = g[4]; bhi[2] = g[5]; }
+	else { const float rho = 1.001f * RT_LIT_SQRT(g[3]); for (int k = 0; k < 3; k++) { blo[k] = g[k] - rho; bhi[k] = g[k] + rho; } }
+}
+
+/* grids for all objects; returns the number of table bits (0: nothing to look up -- no sphere emitter) */
+RT_LIT_FN long long rt_lit_layout(const float *geom, int num_objects, int light, float cell, rt_lit_grid *grids)
+{
+	if (light < 0 || ((const int *) (geom + 8 * light))[6] != 1) return 0;
+	long long bits = 0;
+	for (int i = 0; i < num_objects; i++) {
+		float blo[3], bhi[3];
+		rt_lit_object_box(geom + 8 * i, blo, bhi);
+		rt_lit_grid *G = &grids[i];
+		long long cells = 1;
+		for (int k = 0; k < 3; k++) {
+			const float size = bhi[k] - blo[k];
+			int r = size > 0.0f && size < 1e6f ? (int) (size / cell) + 1 : 2;
+			r = r < 2 ? 2 : (r > RT_LIT_MAX_RES ? RT_LIT_MAX_RES : r);
+			G->lo[k] = blo[k]; G->res[k] = r;
+			G->scale[k] = size > 0.0f ? (float) r / size : 0.0f;
+			cells *= r;
+		}
+		G->base = (int) bits; G->pad[0] = G->pad[1] = 0;
+		bits += i == light ? 0 : cells;
+		if (bits > 0x7fffff00ll) return 0;
+	}
+	return bits;
+}
+
+RT_LIT_FN int rt_lit_clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+/* the table bit of a hit point on object G (float -> index exactly as the kernel computes it) */
+RT_LIT_FN int rt_lit_bit_of(const rt_lit_grid *G, float px, float py, float pz)
+{
+	const int ix = rt_lit_clampi((int) __builtin_floorf((px - G->lo[0]) * G->scale[0]), G->res[0] - 1);
+	const int iy = rt_lit_clampi((int) __builtin_floorf((py - G->lo[1]) * G->scale[1]), G->res[1] - 1);
+	const int iz = rt_lit_clampi((int) __builtin_floorf((pz - G->lo[2]) * G->scale[2]), G->res[2] - 1);
+	return G->base + (iz * G->res[1] + iy) * G->res[0] + ix;
+}
+
+RT_LIT_FN int rt_lit_cell_certainly_lit(const float *geom, int num_objects, int light, float cx, float cy, float cz,
+                                        int i, const rt_lit_grid *G, int ix, int iy, int iz)
+{
+	const float *g = geom + 8 * i;
+	const int idx[3] = { ix, iy, iz };
+	float c[3], h[3];
+	for (int k = 0; k < 3; k++) {
+		if (!(G->scale[k] > 0.0f)) return 0;
+		const float w = 1.0f / G->scale[k];
+		c[k] = G->lo[k] + ((float) idx[k] + 0.5f) * w;
+		h[k] = 0.501f * w + 1e-5f;                   /* the cell, a little larger (index rounding at its borders) */
+	}
+	if (((const int *) g)[6] == 0) {                     /* cube: the faces that touch the cell, each with its own normal */
+		int faces = 0;
+		for (int k = 0; k < 3; k++)
+			for (int side = 0; side < 2; side++) {
+				if (idx[k] != (side ? G->res[k] - 1 : 0)) continue;
+				float p[3] = { c[0], c[1], c[2] }, e[3] = { h[0], h[1], h[2] }, n[3] = { 0.0f, 0.0f, 0.0f };
+				p[k] = side ? g[3 + k] : g[k];           /* the face's plane; hit points lie within rounding of it */
+				e[k] = 1e-5f;
+				n[k] = side ? 1.0f : -1.0f;
+				if (!rt_region_certainly_lit(geom, num_objects, light, cx, cy, cz, i, p[0], p[1], p[2], e[0], e[1], e[2], n[0], n[1], n[2], 0.0f)) return 0;
+				faces++;
+			}
+		return faces > 0;
+	}
+	/* sphere: cells the surface passes through; the normal at the cell's centre, off by at most 2 |cell| / radius elsewhere */
+	const float rho = RT_LIT_SQRT(g[3]);
+	const float vx = c[0] - g[0], vy = c[1] - g[1], vz = c[2] - g[2];
+	const float d = RT_LIT_SQRT(vx * vx + vy * vy + vz * vz);
+	const float sl = 1.001f * RT_LIT_SQRT(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+	if (!(d > 1e-3f * rho) || d - sl > rho || d + sl < rho) return 0;
+	const float inv = 1.0f / d;
+	return rt_region_certainly_lit(geom, num_objects, light, cx, cy, cz, i, c[0], c[1], c[2], h[0], h[1], h[2],
+	                               vx * inv, vy * inv, vz * inv, 2.1f * sl / rho);
+}
+
+/* the whole table (host side, once per scene); `words` must hold (bits + 31) / 32 words */
+RT_LIT_FN void rt_lit_build(const float *geom, int num_objects, int light, float cx, float cy, float cz,
+                            const rt_lit_grid *grids, unsigned int *words, long long bits)
+{
+	for (long long w = 0; w < (bits + 31) / 32; w++) words[w] = 0u;
+	for (int i = 0; i < num_objects; i++) {
+		if (i == light) continue;
+		const rt_lit_grid *G = &grids[i];
+		for (int iz = 0; iz < G->res[2]; iz++)
+			for (int iy = 0; iy < G->res[1]; iy++)
+				for (int ix = 0; ix < G->res[0]; ix++)
+					if (rt_lit_cell_certainly_lit(geom, num_objects, light, cx, cy, cz, i, G, ix, iy, iz)) {
+						const long long b = G->base + ((long long) iz * G->res[1] + iy) * G->res[0] + ix;
+						words[b >> 5] |= 1u << (b & 31);
+					}
+	}
 }
 
 #endif

@@ -17,7 +17,11 @@ static int why_bounce;
 #define RT_LIT_REFUSE(why) do { if (why_bounce == 0) n_why[(why) + 8]++; } while (0)
 #include "../ray_tracing_amd/csrc/rt_lit.h"
 
-static _Atomic uint64_t n_taps[16], n_known[16], n_lit[16], n_viol;
+static _Atomic uint64_t n_taps[16], n_known[16], n_lit[16], n_viol, n_table[16], n_table_viol;
+static rt_lit_grid grids[1024];
+static unsigned int *table;
+static long long table_bits;
+static float probe_cell = 0.125f;
 static float packed[8 * 1024];
 
 static void pack_scene(void)          /* as rt_set_scene packs rt_geom (rt_api.cpp) */
@@ -53,6 +57,14 @@ static void lit_probe_tap(const void *hit, int light, int blocker, int bounce)
 		if (blocker != light && n_viol++ < 10)
 			fprintf(stderr, "VIOLATION: point %.9g %.9g %.9g object %d: tap hit %d, not the emitter\n", h->point.x, h->point.y, h->point.z, h->object, blocker);
 	}
+	if (table_bits && h->object != light) {              /* the table of rt_lit_build, read as the trace kernel reads it */
+		const int b = rt_lit_bit_of(&grids[h->object], h->point.x, h->point.y, h->point.z);
+		if ((table[b >> 5] >> (b & 31)) & 1u) {
+			n_table[bounce]++;
+			if (blocker != light && n_table_viol++ < 10)
+				fprintf(stderr, "TABLE VIOLATION: point %.9g %.9g %.9g object %d: tap hit %d, not the emitter\n", h->point.x, h->point.y, h->point.z, h->object, blocker);
+		}
+	}
 }
 
 int main(int argc, char **argv)
@@ -67,18 +79,34 @@ int main(int argc, char **argv)
 	rt_camera cam; orc_default_camera(&cam);
 	if (argc >= 12) for (int k = 0; k < 6; k++) ((float *) &cam)[k] = (float) atof(argv[6 + k]);
 	orc_set_camera(&cam);
+	if (getenv("LIT_CELL")) probe_cell = (float) atof(getenv("LIT_CELL"));
+	{
+		int light = -1;
+		for (int i = 0; i < sc.num_objects; i++) if (sc.objects[i].material.emission_power > 0) { light = i; break; }
+		table_bits = rt_lit_layout(packed, sc.num_objects, light, probe_cell, grids);
+		if (table_bits) {
+			const V3 c = centre_of(&G.scene.objects[light]);
+			table = malloc(sizeof(unsigned int) * (size_t) ((table_bits + 31) / 32));
+			rt_lit_build(packed, sc.num_objects, light, c.x, c.y, c.z, grids, table, table_bits);
+			long long set = 0;
+			for (long long w = 0; w < (table_bits + 31) / 32; w++) set += __builtin_popcount(table[w]);
+			printf("table: %lld cells of %g, %lld set\n", table_bits, probe_cell, set);
+		}
+	}
 	const int W = atoi(argv[2]), H = atoi(argv[3]), spp = atoi(argv[4]), nb = atoi(argv[5]);
 	float *frame = malloc(sizeof(float) * 3 * W * H);
 	orc_render_counter(W, H, spp, nb, 0, 0, H, 8, frame);
-	uint64_t t = 0, k = 0, l = 0;
+	uint64_t t = 0, k = 0, l = 0, kt = 0;
 	for (int b = 0; b < 16; b++) if (n_taps[b]) {
-		printf("bounce %d: taps %10llu  lit %5.1f %%  answered without tracing %5.1f %%\n", b, (unsigned long long) n_taps[b],
-		       100.0 * n_lit[b] / n_taps[b], 100.0 * n_known[b] / n_taps[b]);
+		printf("bounce %d: taps %10llu  lit %5.1f %%  answered without tracing %5.1f %%  by the table %5.1f %%\n", b, (unsigned long long) n_taps[b],
+		       100.0 * n_lit[b] / n_taps[b], 100.0 * n_known[b] / n_taps[b], 100.0 * n_table[b] / n_taps[b]);
+		kt += n_table[b];
 		t += n_taps[b]; k += n_known[b]; l += n_lit[b];
 	}
-	if (t) printf("all: taps %llu  lit %.1f %%  answered %.1f %%  violations %llu\n", (unsigned long long) t, 100.0 * l / t, 100.0 * k / t, (unsigned long long) n_viol);
+	if (t) printf("all: taps %llu  lit %.1f %%  answered %.1f %%  violations %llu  table %.1f %%  table violations %llu\n", (unsigned long long) t, 100.0 * l / t, 100.0 * k / t,
+	              (unsigned long long) (n_viol + n_table_viol), 100.0 * kt / t, (unsigned long long) n_table_viol);
 	printf("bounce-0 taps refused: coordinates %llu, emitter too near %llu, cone wider than the emitter %llu, own surface %llu", (unsigned long long) n_why[7], (unsigned long long) n_why[6], (unsigned long long) n_why[5], (unsigned long long) n_why[4]);
 	for (int i = 0; i < sc.num_objects; i++) if (n_why[8 + i]) printf(", object %d: %llu", i, (unsigned long long) n_why[8 + i]);
 	printf("\n");
-	return n_viol != 0;
+	return n_viol != 0 || n_table_viol != 0;
 }
