@@ -9,7 +9,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 def num(x): return "%.9f" % float(x)
 def vec(v): return "{%s}" % " ".join(num(x) for x in v)
-bad = taps = known = 0
+bad = taps = known = tabled = 0
 for case in range(cases):
     n = int(rng.integers(2, 14))
     light = int(rng.integers(0, n))
@@ -35,12 +35,12 @@ for case in range(cases):
     last = [l for l in r.stdout.splitlines() if l.startswith("all:")]
     if last:
         w = last[0].split()
-        taps += int(w[2]); known += int(round(float(w[7]) / 100 * int(w[2])))
+        taps += int(w[2]); known += int(round(float(w[7]) / 100 * int(w[2]))); tabled += int(round(float(w[12]) / 100 * int(w[2])))
     if r.returncode == 2:
         raise SystemExit(f"case {case}: scene file rejected\n{r.stderr}")
     if r.returncode != 0:
         bad += 1
         print(f"case {case}: rc={r.returncode}\n{r.stdout}{r.stderr}", flush=True)
         os.replace(path, os.path.join(tempfile.gettempdir(), f"lit_fuzz_bad_{case}.txt"))
-print(f"{cases} scenes, {taps} taps checked, {known} answered without tracing ({100.0 * known / max(taps, 1):.1f} %), {bad} scenes with violations")
+print(f"{cases} scenes, {taps} taps checked, {known} answered without tracing ({100.0 * known / max(taps, 1):.1f} %), {tabled} by the per-scene table ({100.0 * tabled / max(taps, 1):.1f} %), {bad} scenes with violations")
 sys.exit(1 if bad else 0)
