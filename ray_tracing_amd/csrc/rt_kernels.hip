@@ -716,9 +716,8 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 
 struct WaveLDS {
 	float q[6][WF_QUEUE];              /* ray queue SoA: o.xyz, d.xyz (un-normalised)                */
-	unsigned short qmeta[WF_QUEUE];    /* owner lane | kind << 8 | parity << 12                      */
-	float res[7][64];                  /* bounce-ray result per owner lane: xyz, nxyz, obj          */
-	short tap[2][3][64];               /* shadow tap results per owner lane (object index < 1024 or -1), by parity of the round that queued them */
+	unsigned short qmeta[WF_QUEUE];    /* owner lane | kind << 8 | round mod 3 << 12                 */
+	short tap[3][3][64];               /* shadow tap results per owner lane (object index < 1024 or -1), by the round (mod 3) that queued them */
 	/* Sample window.  Stream g (one pixel at a time, pixels one after another) owns slots [g*WF_WINDOW/P, (g+1)*WF_WINDOW/P)
 	 * as a ring indexed by the sequence number of the sample within the stream.  win[0] holds the red channel
 	 * with bit 31 = "last sample of its pixel" (red is >= +0, and adding +0 for a -0 changes no sum), or WF_EMPTY;
@@ -832,18 +831,18 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	 * round.  A slot word is the window slot the sample's colour goes to (| WF_LAST); in direct mode, the pixel's
 	 * frame offset. */
 	bool  f_live = false;                   /* the front is on a sample */
-	int   f_slot = 0, b_slot = 0;
+	int   f_slot = 0, slot1 = 0, slot2 = 0;
 	int   bounce = 0;
 	bool  has_hit = false;
 	V3    carry = mk3(1, 1, 1), rad = mk3(0, 0, 0);
 	V3    hp = mk3(0, 0, 0), hn = mk3(0, 0, 0), hdir = mk3(0, 0, 0);
-	uint32_t end_sky = 0;                   /* sky texel that ends the sample of `prev` (REC_SKY): fetched when the bounce ray
-	                                         * is found to have left the scene, converted a round later when it is used */
+	uint32_t sky1 = 0, sky2 = 0;            /* sky texel that ends the sample of rec1 / rec2 (REC_SKY): fetched when the bounce ray
+	                                         * is found to have left the scene, converted two rounds later when it is used */
 	int   hobj = -1;
-	int   prev = 0;                         /* REC_* | tapmask << 4 | object << 8 */
+	int   rec1 = 0, rec2 = 0;               /* REC_* | tapmask << 4 | object << 8 of the bounces shaded one and two rounds ago */
 	uint64_t rng = 0;
-	/* the ray queue persists across rounds: taps that do not fill a batch wait for the next round's rays */
-	unsigned int q_head = 0, q_tail = 0, parity = 0;
+	/* the tap queue persists across rounds: taps that do not fill a batch wait, at most two rounds */
+	unsigned int q_head = 0, q_tail = 0, phase = 0;     /* phase = round number mod 3 */
 
 	/* Section 6 of a round: adding the finished samples in sample order (main.c:394).  Lane j of a stream looks at
 	 * the j-th slot after the stream's last added one.  The slots that are filled without a gap from the first form
@@ -896,7 +895,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	};
 
 	STAMP_DECL;
-	for (;; parity ^= 1u) {
+	for (;; phase = phase == 2u ? 0u : phase + 1u) {
 		STAMP(7);
 		STAMP_ROUND;
 		/* ---- 1. sample supply ---------------------------------------------------------------
@@ -1019,7 +1018,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 #ifdef RT_STATS
 		if (!f_live) STAT(24);                  /* lanes that start the round without a sample */
 #endif
-		if (__ballot(f_live || (prev & REC_VALID) != 0) == 0ull) {
+		if (__ballot(f_live || ((rec1 | rec2) & REC_VALID) != 0) == 0ull) {
 			/* nothing in flight: every reserved slot is filled, so whatever is still waiting can be added now */
 			if (!direct && __ballot(W.s_drained[g] != W.s_seq[g]) != 0ull) { add_finished_samples(); continue; }
 			if (exhausted) break;
@@ -1086,81 +1085,102 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		}
 
 		STAMP(1);
-		/* ---- 3+4. compact this round's rays into the wave's ring queue (ballot + mbcnt prefix), one
-		 * kind at a time, and trace full batches of 64 as soon as they exist (scene.c:156-190 on full
-		 * waves); the remainder is flushed after the last kind -------------------------------------- */
-		unsigned int must = q_tail;            /* rays up to here are needed by the end of this round */
-		/* one ray of kind `k` per lane with `on` set, appended to the ring in lane order */
+		/* ---- 3. the shadow taps go into the wave's ring (ballot + mbcnt prefix), one kind at a time; whenever 64 are
+		 * queued, any lane traces any tap (scene.c:156-190 on full waves).  A tap is queued as (hit point, rand_dir); its
+		 * direction and origin (main.c:197-198) are formed where it is traced.  Taps that do not fill a batch wait: the
+		 * bounce they belong to is retired two rounds from now ------------------------------------------------------- */
 		auto push = [&](bool on, V3 qo, V3 qd, int k) {
 			const unsigned long long m = __ballot(on);
 			if (on) {
 				const unsigned int slot = (q_tail + (unsigned int) lanes_below(m)) & (WF_QUEUE - 1);
 				W.q[0][slot] = qo.x; W.q[1][slot] = qo.y; W.q[2][slot] = qo.z;
 				W.q[3][slot] = qd.x; W.q[4][slot] = qd.y; W.q[5][slot] = qd.z;
-				W.qmeta[slot] = (unsigned short) (lane | (k << 8) | (int) (parity << 12));
+				W.qmeta[slot] = (unsigned short) (lane | (k << 8) | (int) (phase << 12));
 			}
 			q_tail += (unsigned int) __popcll(m);
-			if (k == WF_KIND_MAIN) must = q_tail;        /* bounce rays: their lanes wait for the hit */
+			wave_fence();
+		};
+		/* the ray of the queued tap in ring slot `slot`, and where its answer goes */
+		auto tap_ray = [&](unsigned int slot, V3 &o, V3 &d, int &meta) {
+			o = mk3(W.q[0][slot], W.q[1][slot], W.q[2][slot]);
+			d = mk3(W.q[3][slot], W.q[4][slot], W.q[5][slot]);
+			meta = W.qmeta[slot];
+			d = unit3_sel<FAST>(lin2(d, sub3(light_pos, o), 0.5f, 1.0f));               /* main.c:186,197 */
+			o = madd3(o, d, 0.001f);                                                     /* main.c:198 */
+		};
+		auto tap_answer = [&](int meta, int obj) { W.tap[(meta >> 12) & 3][((meta >> 8) & 15) - 2][meta & 255] = (short) obj; };
+		auto trace_taps = [&](int count) {         /* the `count` <= 64 oldest taps */
+			STAT(12);
+			if (lane < count) {
+				STAT(13);
+				V3 o, d; int meta;
+				tap_ray((q_head + (unsigned int) lane) & (WF_QUEUE - 1), o, d, meta);
+				const V3 dn = unit3_sel<FAST>(d);                                         /* scene.c:158 */
+				const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, n, o, dn, false) : nearest_hit(sc, n, o, dn);
+				tap_answer(meta, hit.obj);
+			}
+			q_head += (unsigned int) count;
 			wave_fence();
 		};
 #pragma unroll 1
-		for (int kind = 0; kind < 6; kind++) {
-			switch (kind) {                 /* a tap is queued as (hit point, rand_dir) */
-			case WF_KIND_MAIN:    push(emit_main, ray_o, ray_d, WF_KIND_MAIN); break;
-			case 2:               push((tapmask & 1) != 0, hp, tap_j0, 2); break;
-			case 3:               push((tapmask & 2) != 0, hp, tap_j1, 3); break;
-			case 4:               push((tapmask & 4) != 0, hp, tap_j2, 4); break;
-			default: break;
+		for (int kind = 2; kind < 5; kind++) {
+			switch (kind) {
+			case 2:  push((tapmask & 1) != 0, hp, tap_j0, 2); break;
+			case 3:  push((tapmask & 2) != 0, hp, tap_j1, 3); break;
+			default: push((tapmask & 4) != 0, hp, tap_j2, 4); break;
 			}
-			while (q_tail - q_head >= 64u || (kind == 5 && (int) (must - q_head) > 0)) {
-				const int count = q_tail - q_head < 64u ? (int) (q_tail - q_head) : 64;
+			while (q_tail - q_head >= 64u) trace_taps(64);
+		}
+
+		/* ---- 4. the bounce rays: every lane traces its own, straight from its registers, and the lanes that have none
+		 * take the oldest waiting taps along, so that this batch is full as well ------------------------------------- */
+		{
+			const unsigned long long mains = __ballot(emit_main);
+			if (mains != 0ull) {
+				const int waiting = (int) (q_tail - q_head);
+				const int r = lanes_below(~mains);
+				const bool take = !emit_main && r < waiting;
 				STAT(12);
-				if (lane < count) {
+				if (emit_main || take) {
 					STAT(13);
-					const unsigned int slot = (q_head + (unsigned int) lane) & (WF_QUEUE - 1);
-					V3 o = mk3(W.q[0][slot], W.q[1][slot], W.q[2][slot]);
-					V3 d = mk3(W.q[3][slot], W.q[4][slot], W.q[5][slot]);
-					const int meta = W.qmeta[slot];
-					const int owner = meta & 255, rkind = (meta >> 8) & 15;
-					if (rkind > WF_KIND_MAIN) {                                                   /* main.c:186,197-198 */
-						d = unit3_sel<FAST>(lin2(d, sub3(light_pos, o), 0.5f, 1.0f));
-						o = madd3(o, d, 0.001f);
-					}
-					const V3 dn = unit3_sel<FAST>(d);                                             /* scene.c:158 */
-					const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, n, o, dn, rkind == WF_KIND_MAIN) : nearest_hit(sc, n, o, dn);
-					if (rkind > WF_KIND_MAIN) {
-						W.tap[meta >> 12][rkind - 2][owner] = (short) hit.obj;
-					} else {
-						V3 a, b = hit.n;
-						if (hit.obj >= 0) a = madd3(o, dn, hit.t);                   /* scene.c:186 */
-						else              a = dn;       /* left the scene: the owner looks the sky up (main.c:170), once per round */
-						W.res[0][owner] = a.x; W.res[1][owner] = a.y; W.res[2][owner] = a.z;
-						W.res[3][owner] = b.x; W.res[4][owner] = b.y; W.res[5][owner] = b.z;
-						W.res[6][owner] = __int_as_float(hit.obj);
+					V3 o = ray_o, d = ray_d; int meta = 0;
+					if (take) tap_ray((q_head + (unsigned int) r) & (WF_QUEUE - 1), o, d, meta);
+					const V3 dn = unit3_sel<FAST>(d);                                     /* scene.c:158 */
+					const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, n, o, dn, emit_main) : nearest_hit(sc, n, o, dn);
+					if (take) tap_answer(meta, hit.obj);
+					else {
+						hobj = hit.obj; hn = hit.n;
+						hp = hit.obj >= 0 ? madd3(o, dn, hit.t)                               /* scene.c:186 */
+						                  : dn;             /* left the scene: the sky is looked up in that direction (main.c:170) */
 					}
 				}
-				q_head += (unsigned int) count;
+				const int idle = 64 - __popcll(mains);
+				q_head += (unsigned int) (idle < waiting ? idle : waiting);
 				wave_fence();
 			}
 		}
+		/* the taps of the bounce that is retired below were queued two rounds ago; whatever is left of them is traced now */
+		while (q_tail != q_head &&
+		       ((unsigned int) __builtin_amdgcn_readfirstlane((int) W.qmeta[q_head & (WF_QUEUE - 1)]) >> 12 & 3u) == (phase == 2u ? 0u : phase + 1u))
+			trace_taps(q_tail - q_head < 64u ? (int) (q_tail - q_head) : 64);
 
 		STAMP(2);
-		/* ---- 5. back: retire the bounce shaded one round ago (its taps are traced by now), take this round's
+		/* ---- 5. back: retire the bounce shaded two rounds ago (its taps are traced by now), take this round's
 		 * bounce-ray result, and free the front when the path has ended --------------------------------------- */
 		STAT(16);
-		if (prev & REC_VALID) {
+		if (rec2 & REC_VALID) {
 			STAT(17);
-			const int pobj = prev >> 8, ptaps = (prev >> 4) & 7;
+			const int pobj = rec2 >> 8, ptaps = (rec2 >> 4) & 7;
 			const float4 m2 = sc.shade[4 * pobj + 2], m3 = sc.shade[4 * pobj + 3];
 			rad = add3(rad, had3(mk3(m3.x, m3.y, m3.z), carry));                    /* main.c:232 */
-			if (!(prev & REC_SPECULAR)) carry = had3(carry, mk3(m2.x, m2.y, m2.z));  /* main.c:248 */
+			if (!(rec2 & REC_SPECULAR)) carry = had3(carry, mk3(m2.x, m2.y, m2.z));  /* main.c:248 */
 			if (ptaps) {
 				V3 lit = mk3(0, 0, 0);
 				int taps = 0;
 #pragma unroll
 				for (int k = 0; k < 3; k++)
 					if ((ptaps >> k) & 1) {
-						const int obj = (prev & REC_TAPS_LIT) ? light_obj : W.tap[parity ^ 1u][k][lane];
+						const int obj = (rec2 & REC_TAPS_LIT) ? light_obj : W.tap[phase == 2u ? 0u : phase + 1u][k][lane];
 						if (obj >= 0) { const float4 e = sc.shade[4 * obj + 3]; lit = add3(lit, mk3(e.x, e.y, e.z)); }
 						taps++;
 					}
@@ -1174,33 +1194,31 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					carry = scale3(carry, 1.0f - w);
 				}
 			}
-			if (prev & REC_LAST) {              /* the path ended with that bounce: sky (main.c:171) or bounce limit (main.c:158) */
-				if (prev & REC_SKY) rad = add3(rad, had3(sky_colour<FAST>(end_sky), carry));
+			if (rec2 & REC_LAST) {              /* the path ended with that bounce: sky (main.c:171) or bounce limit (main.c:158) */
+				if (rec2 & REC_SKY) rad = add3(rad, had3(sky_colour<FAST>(sky2), carry));
 				const V3 col = mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z));     /* main.c:267-269 */
 				if (direct) {                   /* the pixel's only sample: 0 + colour (main.c:394), resolved (main.c:476) */
 					const V3 res = scale3(add3(mk3(0, 0, 0), col), inv_spp);
-					float *dst = L.frame + (size_t) b_slot * 3;
+					float *dst = L.frame + (size_t) slot2 * 3;
 					dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
 				} else {                        /* into its slot of the window; section 6 adds it when its turn comes */
-					const unsigned int e = (unsigned int) b_slot & (WF_WINDOW - 1);
+					const unsigned int e = (unsigned int) slot2 & (WF_WINDOW - 1);
 					W.win[1][e] = col.y; W.win[2][e] = col.z;
-					W.win[0][e] = __uint_as_float((__float_as_uint(col.x) & 0x7fffffffu) | ((b_slot & WF_LAST) ? 0x80000000u : 0u));
+					W.win[0][e] = __uint_as_float((__float_as_uint(col.x) & 0x7fffffffu) | ((slot2 & WF_LAST) ? 0x80000000u : 0u));
 				}
 				carry = mk3(1, 1, 1); rad = mk3(0, 0, 0);
 			}
 		}
-		prev = cur;
+		rec2 = rec1; sky2 = sky1; slot2 = slot1;
+		rec1 = cur;
 		if (cur & REC_VALID) {
-			b_slot = f_slot;
+			slot1 = f_slot;
 			bool path_ended = true;                                  /* bounce limit (main.c:158) */
 			if (emit_main) {
-				const int obj = __float_as_int(W.res[6][lane]);
-				const V3 a = mk3(W.res[0][lane], W.res[1][lane], W.res[2][lane]);
-				if (obj < 0) {
+				if (hobj < 0) {
 					STAT(14);
-					end_sky = sky_texel<FAST>(L, a); prev |= REC_LAST | REC_SKY;               /* main.c:163-172 */
+					sky1 = sky_texel<FAST>(L, hp); rec1 |= REC_LAST | REC_SKY;                  /* main.c:163-172 */
 				} else {
-					hp = a; hn = mk3(W.res[3][lane], W.res[4][lane], W.res[5][lane]); hobj = obj;
 					has_hit = true; path_ended = false;
 				}
 			}
