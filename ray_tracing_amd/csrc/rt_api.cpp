@@ -827,7 +827,7 @@ int rt_progressive_state(rt_context *ctx, int *next_scale, float *count, uint32_
 
 int rt_selftest(rt_context *ctx, int which, uint64_t seed, int blocks, int iters, unsigned long long out[8])
 {
-	if (!ctx || !out || which < 0 || which > 7 || blocks < 1 || iters < 1)
+	if (!ctx || !out || which < 0 || which > 8 || blocks < 1 || iters < 1)
 		return fail(RT_ERR_ARGUMENT, "rt_selftest: bad argument");
 	HIP_TRY(hipSetDevice(ctx->device));
 	unsigned long long *d = nullptr;

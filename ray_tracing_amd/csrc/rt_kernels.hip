@@ -1044,11 +1044,17 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				taps_lit = taps_lit || ((L.lit_words[bit >> 5] >> (bit & 31)) & 1u) != 0u;
 			}
 			if (have_light) {
-				/* main.c:191-195: three rand_dir draws, a tap is skipped when it points into the surface.  The
-				 * tap's direction and origin (main.c:197-198) are formed where it is traced, on a full batch. */
-				tap_j0 = rng_direction<FAST>(rng); if (dot3(tap_j0, hn) > 0) tapmask |= 1;
-				tap_j1 = rng_direction<FAST>(rng); if (dot3(tap_j1, hn) > 0) tapmask |= 2;
-				tap_j2 = rng_direction<FAST>(rng); if (dot3(tap_j2, hn) > 0) tapmask |= 4;
+				/* main.c:191-195: three rand_dir draws, a tap is skipped when it points into the surface.  Only the sign of
+				 * dot(rand_dir, normal) is needed here, and random_vector() has it before normalize() does (rt_math.hip.h:
+				 * side_is_certain): the tap is queued as drawn, and normalised -- with its direction and origin, main.c:197-198 --
+				 * where it is traced, on a full batch, if it is traced at all. */
+				tap_j0 = rng_vector(rng); tap_j1 = rng_vector(rng); tap_j2 = rng_vector(rng);
+				const float side0 = dot3(tap_j0, hn), side1 = dot3(tap_j1, hn), side2 = dot3(tap_j2, hn);
+				if (FAST && wave_all(side_is_certain(tap_j0, side0) && side_is_certain(tap_j1, side1) && side_is_certain(tap_j2, side2)))
+					tapmask = (side0 > 0 ? 1 : 0) | (side1 > 0 ? 2 : 0) | (side2 > 0 ? 4 : 0);
+				else
+					tapmask = (dot3(unit3_of_vector<FAST>(tap_j0), hn) > 0 ? 1 : 0) | (dot3(unit3_of_vector<FAST>(tap_j1), hn) > 0 ? 2 : 0) |
+					          (dot3(unit3_of_vector<FAST>(tap_j2), hn) > 0 ? 4 : 0);
 			}
 			const float4 m0 = sc.shade[4 * hobj], m1 = sc.shade[4 * hobj + 1];
 			const V3 f0 = mk3(m0.x, m0.y, m0.z), omf0 = mk3(m1.x, m1.y, m1.z);
@@ -1105,6 +1111,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			o = mk3(W.q[0][slot], W.q[1][slot], W.q[2][slot]);
 			d = mk3(W.q[3][slot], W.q[4][slot], W.q[5][slot]);
 			meta = W.qmeta[slot];
+			d = unit3_of_vector<FAST>(d);                                                /* main.c:193: normalize(random_vector()) */
 			d = unit3_sel<FAST>(lin2(d, sub3(light_pos, o), 0.5f, 1.0f));               /* main.c:186,197 */
 			o = madd3(o, d, 0.001f);                                                     /* main.c:198 */
 		};
@@ -1303,6 +1310,7 @@ rt_deinterleave(const float *strips, float *frame, int width, int height, int ro
  *            `iters` n significands (iters = 2^23 = all 2^46 pairs, 52 s; `seed` picks the first numerator)
  *         6: EXHAUSTIVE: sqrt_in_window vs sqrtf (+ the refined reciprocal of the root) for every float in [2^-30, 2^60]
  *         7: unit3_of_draws   vs unit3 on vectors with `draw * 2 - 1` components (rng_direction)
+ *         8: side_is_certain: the sign of dot(v, n) vs the sign of dot(normalize(v), n) wherever it answers yes
  * out[0] = number of mismatching results, out[1..] = operands of one mismatch. */
 RT_DEV uint64_t st_next(uint64_t &s)
 {
@@ -1436,6 +1444,35 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 				bad++;
 				out[1] = __float_as_uint(v.x); out[2] = __float_as_uint(v.y); out[3] = __float_as_uint(v.z);
 				out[4] = __float_as_uint(want.x); out[5] = __float_as_uint(got.x);
+			}
+		} else if (which == 8) {
+			/* side_is_certain: where it says yes, dot(v, n) > 0 must equal dot(normalize(v), n) > 0 (main.c:194).  v as in
+			 * case 7; n an axis (cube faces), a random unit vector, or a unit vector all but perpendicular to v */
+			const uint64_t r0 = st_next(s), r1 = st_next(s), r2 = st_next(s), r3 = st_next(s), r4 = st_next(s), r5 = st_next(s);
+			float dr[3] = { (float) r0 * 0x1p-64f, (float) r1 * 0x1p-64f, (float) r2 * 0x1p-64f };
+			for (int c = 0; c < 3; c++) {
+				const uint32_t pick = (uint32_t) (r3 >> (8 * c)) & 255u;
+				if (pick == 0) dr[c] = 0.0f;
+				if (pick == 1) dr[c] = 1.0f;
+				if (pick == 2) dr[c] = 0.5f;
+				if (pick < 16 && pick > 2) dr[c] = __uint_as_float(0x3f000000u + (int) ((r3 >> (32 + 2 * c)) % (pick < 8 ? 9u : 4097u)) - (int) (pick < 8 ? 4 : 2048));
+			}
+			const V3 v = mk3(dr[0] * 2.0f - 1.0f, dr[1] * 2.0f - 1.0f, dr[2] * 2.0f - 1.0f);
+			V3 nn;
+			const uint32_t kind = (uint32_t) (r3 >> 56) & 3u;
+			const V3 w = mk3((float) r4 * 0x1p-63f - 1.0f, (float) (r4 >> 20) * 0x1p-43f - 1.0f, (float) r5 * 0x1p-63f - 1.0f);
+			if (kind == 0) { const int ax = (int) ((r5 >> 3) % 3u); const float sg = (r5 & 1) ? 1.0f : -1.0f; nn = mk3(ax == 0 ? sg : 0.0f, ax == 1 ? sg : 0.0f, ax == 2 ? sg : 0.0f); }
+			else if (kind == 1) nn = unit3(w);
+			else {          /* cross(v, w) is perpendicular to v; a pinch of v decides the side */
+				const V3 c = mk3(v.y * w.z - v.z * w.y, v.z * w.x - v.x * w.z, v.x * w.y - v.y * w.x);
+				const float eps = ((r5 >> 8) & 1 ? 1.0f : -1.0f) * __uint_as_float(0x2f800000u + ((uint32_t) (r5 >> 12) & 0x0fffffffu));   /* 2^-32 .. 2^0 */
+				nn = unit3(madd3(unit3(c), v, eps));
+			}
+			const float side = dot3(v, nn);
+			if (side_is_certain(v, side) && (side > 0) != (dot3(unit3(v), nn) > 0)) {
+				bad++;
+				out[1] = __float_as_uint(v.x); out[2] = __float_as_uint(v.y); out[3] = __float_as_uint(v.z);
+				out[4] = __float_as_uint(nn.x); out[5] = __float_as_uint(nn.y);
 			}
 		} else if (which == 4) {
 			const uint64_t r0 = st_next(s);

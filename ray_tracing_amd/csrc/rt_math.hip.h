@@ -209,14 +209,24 @@ RT_DEV V3 unit3_of_draws(V3 v)
 	return unit3(v);
 }
 
-/* vector.c:99-111: x, y, z drawn in that order */
-template <bool FAST = false>
-RT_DEV V3 rng_direction(uint64_t &state)
+/* vector.c:99-111: x, y, z drawn in that order; rng_vector is random_vector(), before normalize() */
+RT_DEV V3 rng_vector(uint64_t &state)
 {
 	float x = rng_draw(state) * 2.0f - 1.0f;
 	float y = rng_draw(state) * 2.0f - 1.0f;
 	float z = rng_draw(state) * 2.0f - 1.0f;
-	return FAST ? unit3_of_draws(mk3(x, y, z)) : unit3(mk3(x, y, z));
+	return mk3(x, y, z);
 }
+template <bool FAST = false>
+RT_DEV V3 unit3_of_vector(V3 v) { return FAST ? unit3_of_draws(v) : unit3(v); }
+template <bool FAST = false>
+RT_DEV V3 rng_direction(uint64_t &state) { return unit3_of_vector<FAST>(rng_vector(state)); }
+
+/* The sign of dot(normalize(v), n) without normalising: `dot(rand_dir, hit.normal) <= 0` (main.c:194) only needs it.
+ * With u = normalize(v) as the reference computes it (vector.c:129-138: three correctly rounded quotients by the rounded
+ * length, or v itself below the epsilon), float dot(u, n) is within 1e-6 of (v.n)/|v| for a unit normal, and float
+ * dot(v, n) within 4e-7 |v| of v.n: where dot(v, n)^2 > 1e-10 |v|^2 both have the sign of v.n.  Answers whether that
+ * holds; the caller falls back to the real thing for the whole wave otherwise (one tap in 10^5). */
+RT_DEV bool side_is_certain(V3 v, float dot_vn) { return dot_vn * dot_vn > 1e-10f * (v.x * v.x + v.y * v.y + v.z * v.z); }
 
 #endif

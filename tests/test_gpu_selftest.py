@@ -9,7 +9,8 @@ import ray_tracing_amd as rt
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("which,name", [(0, "f32 divide"), (1, "f64 divide"), (2, "normalize"), (3, "f64 sqrt of float"), (4, "iszerof threshold"), (7, "normalize a random direction")])
+@pytest.mark.parametrize("which,name", [(0, "f32 divide"), (1, "f64 divide"), (2, "normalize"), (3, "f64 sqrt of float"), (4, "iszerof threshold"), (7, "normalize a random direction"),
+                                        (8, "side of a surface a random vector points to, before it is normalised")])
 def test_shortcuts_are_bit_exact(which, name):
     g = rt.Renderer(0)
     total = 0
