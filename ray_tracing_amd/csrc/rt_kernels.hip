@@ -1139,36 +1139,22 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			while (q_tail - q_head >= 64u) trace_taps(64);
 		}
 
-		/* ---- 4. the bounce rays: every lane traces its own, straight from its registers, and the lanes that have none
-		 * take the oldest waiting taps along, so that this batch is full as well ------------------------------------- */
-		{
-			const unsigned long long mains = __ballot(emit_main);
-			if (mains != 0ull) {
-				const int waiting = (int) (q_tail - q_head);
-				const int r = lanes_below(~mains);
-				const bool take = !emit_main && r < waiting;
-				STAT(12);
-				if (emit_main || take) {
-					STAT(13);
-					V3 o = ray_o, d = ray_d; int meta = 0;
-					if (take) tap_ray((q_head + (unsigned int) r) & (WF_QUEUE - 1), o, d, meta);
-					const V3 dn = unit3_sel<FAST>(d);                                     /* scene.c:158 */
-					const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, n, o, dn, emit_main) : nearest_hit(sc, n, o, dn);
-					if (take) tap_answer(meta, hit.obj);
-					else {
-						hobj = hit.obj; hn = hit.n;
-						hp = hit.obj >= 0 ? madd3(o, dn, hit.t)                               /* scene.c:186 */
-						                  : dn;             /* left the scene: the sky is looked up in that direction (main.c:170) */
-					}
-				}
-				const int idle = 64 - __popcll(mains);
-				q_head += (unsigned int) (idle < waiting ? idle : waiting);
-				wave_fence();
+		/* ---- 4. the bounce rays: every lane traces its own, straight from its registers -- no queue, no LDS ---------- */
+		if (__ballot(emit_main) != 0ull) {
+			STAT(12);
+			if (emit_main) {
+				STAT(13);
+				const V3 dn = unit3_sel<FAST>(ray_d);                                     /* scene.c:158 */
+				const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, n, ray_o, dn, true) : nearest_hit(sc, n, ray_o, dn);
+				hobj = hit.obj; hn = hit.n;
+				hp = hit.obj >= 0 ? madd3(ray_o, dn, hit.t)                               /* scene.c:186 */
+				                  : dn;                 /* left the scene: the sky is looked up in that direction (main.c:170) */
 			}
 		}
-		/* the taps of the bounce that is retired below were queued two rounds ago; whatever is left of them is traced now */
-		while (q_tail != q_head &&
-		       ((unsigned int) __builtin_amdgcn_readfirstlane((int) W.qmeta[q_head & (WF_QUEUE - 1)]) >> 12 & 3u) == (phase == 2u ? 0u : phase + 1u))
+		/* the bounces retired below were shaded two rounds ago: whatever is left of their taps (the oldest in the queue) is
+		 * traced now, in a batch that need not be full */
+		const unsigned int due = phase == 2u ? 0u : phase + 1u;
+		while (q_tail != q_head && ((unsigned int) __builtin_amdgcn_readfirstlane((int) W.qmeta[q_head & (WF_QUEUE - 1)]) >> 12 & 3u) == due)
 			trace_taps(q_tail - q_head < 64u ? (int) (q_tail - q_head) : 64);
 
 		STAMP(2);
@@ -1187,7 +1173,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 #pragma unroll
 				for (int k = 0; k < 3; k++)
 					if ((ptaps >> k) & 1) {
-						const int obj = (rec2 & REC_TAPS_LIT) ? light_obj : W.tap[phase == 2u ? 0u : phase + 1u][k][lane];
+						const int obj = (rec2 & REC_TAPS_LIT) ? light_obj : W.tap[due][k][lane];
 						if (obj >= 0) { const float4 e = sc.shade[4 * obj + 3]; lit = add3(lit, mk3(e.x, e.y, e.z)); }
 						taps++;
 					}
