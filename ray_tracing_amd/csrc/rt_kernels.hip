@@ -889,7 +889,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				W.s_sum[0][g] = offset_slot ? 0.0f : sum.x; W.s_sum[1][g] = offset_slot ? 0.0f : sum.y; W.s_sum[2][g] = offset_slot ? 0.0f : sum.z;
 			}
 			/* more may be waiting behind the run; it can wait for the next round unless the window is filling up */
-			again = __ballot(k > 0 && (k == G || boundary) && seq - (d + (unsigned int) k) > wn / 2u) != 0ull;
+			again = __ballot(k > 0 && (k == G || boundary) && seq - (d + (unsigned int) k) > 3u * wn / 4u) != 0ull;
 			wave_fence();
 		} while (again);
 	};

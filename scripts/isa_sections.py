@@ -8,7 +8,7 @@ def line_of(pat):
         if pat in l: return i + 1
     raise KeyError(pat)
 marks = [("in-order sum", line_of("auto add_finished_samples = [&]()")), ("supply", line_of("---- 1. sample supply")), ("shade", line_of("---- 2. shade the pending")),
-         ("push", line_of("---- 3+4. compact")), ("trace", line_of("while (q_tail - q_head >= 64")), ("back", line_of("---- 5. back: retire")),
+         ("push", line_of("---- 3. the shadow taps go")), ("mains", line_of("---- 4. the bounce rays")), ("back", line_of("---- 5. back: retire")),
          ("sum call", line_of("---- 6. add the finished samples"))]
 body = line_of("RT_DEV void wavefront_body"); body_end = marks[-1][1] + 80
 fn = {"prepare_ray": line_of("RT_DEV RayPrep prepare_ray"), "box_entry_fast": line_of("RT_DEV bool box_entry_fast"), "sqrt64": line_of("RT_DEV double sqrt_of_float64"),
