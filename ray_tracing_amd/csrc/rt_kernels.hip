@@ -704,7 +704,7 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 #define RT_COUNTER_BYTES ((2 * WF_SHARDS + 1) * 128)   /* + one line of launch control words (rt_launch.control) */
 #define WF_QUEUE   128                 /* ring: at most 63 waiting + 64 pushed at a time */
 #define WF_STREAMS 8                   /* pixels a wave adds up concurrently (at most) */
-#define WF_WINDOW  256                 /* sample slots per wave, shared equally by its streams */
+#define WF_WINDOW  384                 /* sample slots per wave, shared equally by its streams */
 #define WF_EMPTY   0xffffffffu         /* window slot not written yet (a colour channel is in [0,1]: never this pattern) */
 #define WF_LAST    0x8000              /* slot word: this sample is the last one of its pixel */
 #define REC_VALID    1                /* per-bounce record handed from the front to the back (wavefront_body) */
@@ -719,7 +719,7 @@ struct WaveLDS {
 	unsigned short qmeta[WF_QUEUE];    /* owner lane | kind << 8 | round mod 3 << 12                 */
 	short tap[3][3][64];               /* shadow tap results per owner lane (object index < 1024 or -1), by the round (mod 3) that queued them */
 	/* Sample window.  Stream g (one pixel at a time, pixels one after another) owns slots [g*WF_WINDOW/P, (g+1)*WF_WINDOW/P)
-	 * as a ring indexed by the sequence number of the sample within the stream.  win[0] holds the red channel
+	 * as a ring indexed by the sequence number of the sample within the stream (modulo its 48 slots).  win[0] holds the red channel
 	 * with bit 31 = "last sample of its pixel" (red is >= +0, and adding +0 for a -0 changes no sum), or WF_EMPTY;
 	 * the slot after a pixel's last sample holds the pixel's frame offset instead of a colour. */
 	float win[3][WF_WINDOW];
@@ -743,9 +743,10 @@ RT_DEV rt_launch_cold cold_view()
 	return (rt_launch_cold) a;
 }
 
-/* four workgroups (16 waves) per CU need 4 x (96 B x objects + 4 x sizeof(WaveLDS)) <= 160 KiB: keep room for 20
- * objects -- one workgroup less per CU costs 15 % */
-static_assert(4 * sizeof(WaveLDS) + 96 * 20 <= 160 * 1024 / 4, "WaveLDS grew: scenes of up to 20 objects no longer fit four workgroups per CU");
+/* four workgroups (16 waves) per CU need 4 x (96 B x objects + 4 x sizeof(WaveLDS)) <= 160 KiB: keep room for 17
+ * objects -- one workgroup less per CU costs 15 %.  (The sample window is what a wave's LDS is spent on: half the
+ * slots cost 58 % on C1, 48 instead of 32 per stream buy 2 % there and 9 % at 1024 samples per pixel.) */
+static_assert(4 * sizeof(WaveLDS) + 96 * 17 <= 160 * 1024 / 4, "WaveLDS grew: scenes of up to 17 objects no longer fit four workgroups per CU");
 
 RT_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
@@ -856,7 +857,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			STAT(23);
 			const unsigned int d = W.s_drained[g], seq = W.s_seq[g];
 			const unsigned int slot = d + j;
-			const unsigned int e = (unsigned int) g * wn + (slot & (wn - 1u));
+			const unsigned int e = (unsigned int) g * wn + (slot % wn);
 			uint32_t xb = WF_EMPTY;
 			if ((int) (seq - slot) > 0) xb = __float_as_uint(W.win[0][e]);
 			const bool filled = xb != WF_EMPTY;
@@ -995,8 +996,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					STAT(22);
 					const unsigned int s = nxt + (unsigned int) r, slot = seq + (unsigned int) r;
 					const bool last = s + 1u == spp;
-					f_slot = (int) ((unsigned int) sg * wn + (slot & (wn - 1u))) | (last ? WF_LAST : 0);
-					if (last) W.win[0][(unsigned int) sg * wn + ((slot + 1u) & (wn - 1u))] = W.rec[11][sg];
+					f_slot = (int) ((unsigned int) sg * wn + (slot % wn)) | (last ? WF_LAST : 0);
+					if (last) W.win[0][(unsigned int) sg * wn + ((slot + 1u) % wn)] = W.rec[11][sg];
 					rng = path_seed(L.seed, __float_as_uint(W.rec[10][sg]), (uint32_t) L.sample_base + s);
 					bounce = 0;
 					hp = mk3(W.rec[0][sg], W.rec[1][sg], W.rec[2][sg]);
@@ -1195,7 +1196,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					float *dst = L.frame + (size_t) slot2 * 3;
 					dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
 				} else {                        /* into its slot of the window; section 6 adds it when its turn comes */
-					const unsigned int e = (unsigned int) slot2 & (WF_WINDOW - 1);
+					const unsigned int e = (unsigned int) slot2 & (WF_LAST - 1);
 					W.win[1][e] = col.y; W.win[2][e] = col.z;
 					W.win[0][e] = __uint_as_float((__float_as_uint(col.x) & 0x7fffffffu) | ((slot2 & WF_LAST) ? 0x80000000u : 0u));
 				}
