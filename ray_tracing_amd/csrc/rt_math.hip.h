@@ -171,11 +171,15 @@ RT_DEV uint64_t fold_mul(uint64_t a, uint64_t b)
 {
 	const uint32_t a0 = (uint32_t) a, a1 = (uint32_t) (a >> 32), b0 = (uint32_t) b, b1 = (uint32_t) (b >> 32);
 	const uint64_t p0 = (uint64_t) a0 * b0;
-	const uint64_t p1 = (uint64_t) a0 * b1 + (p0 >> 32);
-	const uint64_t p2 = (uint64_t) a1 * b0 + (uint32_t) p1;
-	const uint64_t hi = (uint64_t) a1 * b1 + (p1 >> 32) + (p2 >> 32);
-	const uint64_t lo = (uint64_t) (uint32_t) p0 | (p2 << 32);
-	return hi ^ lo;
+	const uint64_t x  = (uint64_t) a0 * b1 + (p0 >> 32);          /* fits 64 bits */
+	/* a1*b0 + x can carry out of 64 bits: v_mad_u64_u32 reports it (the compiler has no pattern for that carry, so it
+	 * would split x into halves and add them separately: two moves and a 64-bit add more per product) */
+	uint64_t y, carry, unused;
+	asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(y), "=&s"(carry) : "v"(a1), "s"(b0), "v"(x));
+	const uint64_t h = (uint64_t) a1 * b1 + (y >> 32);            /* high 64 bits of a*b, but for that carry (weight 2^96) */
+	uint32_t h1;
+	asm("v_addc_co_u32 %0, %1, 0, %2, %3" : "=v"(h1), "=&s"(unused) : "v"((uint32_t) (h >> 32)), "s"(carry));
+	return ((uint64_t) (h1 ^ (uint32_t) y) << 32) | (uint64_t) ((uint32_t) h ^ (uint32_t) p0);
 }
 
 RT_DEV float rng_draw(uint64_t &state)
