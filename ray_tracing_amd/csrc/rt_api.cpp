@@ -75,9 +75,9 @@ struct rt_context {
 	float        light_pos[3] = {0, 0, 0};
 	/* rt_lit.h: which hit points need no soft-shadow tap traced -- one bit per cell of a grid over every object, built
 	 * by rt_set_scene on the host (a few milliseconds) */
-	uint32_t    *d_lit_words = nullptr;
+	unsigned char *d_lit_cells = nullptr;
 	void        *d_lit_grids = nullptr;
-	size_t       lit_words_capacity = 0;
+	size_t       lit_cells_capacity = 0;
 	int          lit_grids_capacity = 0;
 	bool         have_lit = false;
 
@@ -284,7 +284,7 @@ void rt_destroy(rt_context *ctx)
 	if (ctx->h_words) (void) hipHostFree(ctx->h_words);
 	if (ctx->spec_module) (void) hipModuleUnload(ctx->spec_module);
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
-	(void) hipFree(ctx->d_lit_words); (void) hipFree(ctx->d_lit_grids);
+	(void) hipFree(ctx->d_lit_cells); (void) hipFree(ctx->d_lit_grids);
 	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame);
 	(void) hipFree(ctx->prog.d_accum); (void) hipFree(ctx->prog.d_low); (void) hipFree(ctx->prog.d_out);
 	(void) hipStreamDestroy(ctx->stream);
@@ -389,17 +389,19 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 		if (bits > 0) {
 			std::vector<uint32_t> words((size_t) ((bits + 31) / 32));
 			rt_lit_build(words8, n, light, ctx->light_pos[0], ctx->light_pos[1], ctx->light_pos[2], grids.data(), words.data(), bits);
-			if (words.size() > ctx->lit_words_capacity) {
-				(void) hipFree(ctx->d_lit_words); ctx->d_lit_words = nullptr; ctx->lit_words_capacity = 0;
-				HIP_TRY(hipMalloc((void**) &ctx->d_lit_words, words.size() * sizeof(uint32_t)));
-				ctx->lit_words_capacity = words.size();
+			std::vector<unsigned char> cells((size_t) bits);          /* a byte per cell on the device: one load, no shift */
+			for (long long b = 0; b < bits; b++) cells[(size_t) b] = (unsigned char) ((words[(size_t) (b >> 5)] >> (b & 31)) & 1u);
+			if (cells.size() > ctx->lit_cells_capacity) {
+				(void) hipFree(ctx->d_lit_cells); ctx->d_lit_cells = nullptr; ctx->lit_cells_capacity = 0;
+				HIP_TRY(hipMalloc((void**) &ctx->d_lit_cells, cells.size()));
+				ctx->lit_cells_capacity = cells.size();
 			}
 			if (n > ctx->lit_grids_capacity) {
 				(void) hipFree(ctx->d_lit_grids); ctx->d_lit_grids = nullptr; ctx->lit_grids_capacity = 0;
 				HIP_TRY(hipMalloc(&ctx->d_lit_grids, (size_t) n * sizeof(rt_lit_grid)));
 				ctx->lit_grids_capacity = n;
 			}
-			HIP_TRY(hipMemcpy(ctx->d_lit_words, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+			HIP_TRY(hipMemcpy(ctx->d_lit_cells, cells.data(), cells.size(), hipMemcpyHostToDevice));
 			HIP_TRY(hipMemcpy(ctx->d_lit_grids, grids.data(), (size_t) n * sizeof(rt_lit_grid), hipMemcpyHostToDevice));
 			ctx->have_lit = true;
 		}
@@ -622,7 +624,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	L.frame = (float*) d_strip;
 	/* classifying a pixel costs about what tracing its taps once costs: it pays from the second sample on */
 	L.skip_known_taps = (ctx->tuning.trace_known_taps || p->spp < 2) ? 0 : 1;
-	L.lit_words = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_words : nullptr;
+	L.lit_cells = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_cells : nullptr;
 	L.lit_grids = ctx->d_lit_grids;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
 	{ const int rc = prepare_launch(ctx, L, ctx->launches); if (rc != RT_OK) return rc; }
@@ -784,7 +786,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.sky_wm1 = (float) (ctx->sky_w - 1); L.sky_hm1 = (float) (ctx->sky_h - 1);
 	L.frame = g.d_low;
 	L.skip_known_taps = 0;      /* one sample per pixel and pass: see rt_render_device */
-	L.lit_words = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_words : nullptr;
+	L.lit_cells = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_cells : nullptr;
 	L.lit_grids = ctx->d_lit_grids;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
 	{ const int rc = prepare_launch(ctx, L, ctx->launches); if (rc != RT_OK) return rc; }

@@ -73,10 +73,11 @@ typedef struct {
 
 	float *frame;              /* local_rows x width x 3 floats, resolved      */
 	int    skip_known_taps;    /* rt_primary_pass flags the pixels whose bounce-0 taps need no tracing (rt_lit.h); 0: every tap is traced */
-	/* the same answer for hit points of any bounce, from a table built once per scene (rt_lit.h: one bit per cell of a grid
+	/* the same answer for hit points of any bounce, from a table built once per scene (rt_lit.h: one entry per cell of a grid
 	 * over every object's bounding box, rt_lit_grid per object); NULL: no table (no sphere emitter, or every tap is traced) */
-	const uint32_t *lit_words;
+	const unsigned char *lit_cells;     /* one byte per cell: 1 = every surface point in it is such a point */
 	const void     *lit_grids;
+	int             lit_grids_in_lds;   /* the trace kernel's workgroups keep a copy of the grids behind the scene records */
 	/* scheduling of the wavefront kernels (any values give the same frame):
 	 *   num_shards   pixel lists in use (1 or 64), each with its own fill and dequeue counter */
 	int    num_shards;

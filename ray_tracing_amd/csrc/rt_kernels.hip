@@ -61,9 +61,13 @@ extern "C" { __device__ unsigned long long rt_wave_log[4 * 8192]; }
 #define STAMP_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&rt_stats[50 + k_], rt_tsec[k_]); } while (0)
 #define STAMP_DRY do {} while (0)
 #define STAMP_ROUND do {} while (0)
+#ifdef RT_STATS_STAMPS_ONLY     /* the per-site atomics distort the section times: this build keeps the stamps only */
+#define STAT(site) do {} while (0)
+#else
 #define STAT(site) do { const unsigned long long m_ = __ballot(true); \
 	if (__builtin_amdgcn_mbcnt_hi((unsigned int) (m_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_, 0u)) == 0) { \
 		atomicAdd(&rt_stats[2 * (site)], 1ull); atomicAdd(&rt_stats[2 * (site) + 1], (unsigned long long) __popcll(m_)); } } while (0)
+#endif
 #endif
 #else
 #define STAT(site) do {} while (0)
@@ -783,7 +787,14 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	const int n = L.num_objects;
 	const SceneLDS sc = stage_scene(L, lds);
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + 6 * n)[wave];
+	/* the grids of the "taps certainly lit" table (rt_lit.h), when the launcher found room for them: 3 x float4 per object */
+	if (L.lit_grids_in_lds) {
+		const float4 *gsrc = reinterpret_cast<const float4*>(L.lit_grids);
+		for (int i = threadIdx.x; i < 3 * n; i += RT_BLOCK) lds[6 * n + i] = gsrc[i];
+		__syncthreads();
+	}
+	const rt_lit_grid *lit_grids = L.lit_grids_in_lds ? reinterpret_cast<const rt_lit_grid*>(lds + 6 * n) : reinterpret_cast<const rt_lit_grid*>(L.lit_grids);
+	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (L.lit_grids_in_lds ? 9 : 6) * n)[wave];
 
 	const float inv_spp = 1.0f / (float) L.spp;
 	const unsigned int spp = (unsigned int) L.spp;
@@ -840,6 +851,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	uint32_t sky1 = 0, sky2 = 0;            /* sky texel that ends the sample of rec1 / rec2 (REC_SKY): fetched when the bounce ray
 	                                         * is found to have left the scene, converted two rounds later when it is used */
 	int   hobj = -1;
+	uint32_t lit_next = 0;                  /* != 0: the taps from the pending hit point certainly reach the emitter, none is traced (rt_lit.h) */
 	int   rec1 = 0, rec2 = 0;               /* REC_* | tapmask << 4 | object << 8 of the bounces shaded one and two rounds ago */
 	uint64_t rng = 0;
 	/* the tap queue persists across rounds: taps that do not fill a batch wait, at most two rounds */
@@ -969,7 +981,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 						f_slot = px.off; f_live = true;
 						rng = path_seed(L.seed, px.index, (uint32_t) L.sample_base);
 						bounce = 0;
-						hp = px.a; hn = px.n; hobj = px.obj; hdir = px.dir;
+						hp = px.a; hn = px.n; hobj = px.obj & (RT_PIX_TAPS_LIT - 1); hdir = px.dir;
+						lit_next = (uint32_t) px.obj & RT_PIX_TAPS_LIT;
 						has_hit = true;
 					} else {
 						W.rec[0][sg] = px.a.x;   W.rec[1][sg] = px.a.y;   W.rec[2][sg] = px.a.z;
@@ -1002,7 +1015,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					bounce = 0;
 					hp = mk3(W.rec[0][sg], W.rec[1][sg], W.rec[2][sg]);
 					hn = mk3(W.rec[3][sg], W.rec[4][sg], W.rec[5][sg]);
-					hobj = __float_as_int(W.rec[6][sg]);
+					hobj = __float_as_int(W.rec[6][sg]) & (RT_PIX_TAPS_LIT - 1);
+					lit_next = __float_as_uint(W.rec[6][sg]) & RT_PIX_TAPS_LIT;
 					hdir = mk3(W.rec[7][sg], W.rec[8][sg], W.rec[9][sg]);
 					has_hit = true; f_live = true;
 				}
@@ -1037,13 +1051,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			STAT(8);
 			/* a camera-ray hit point from which every tap certainly reaches the emitter (flagged by rt_primary_pass): the taps
 			 * are drawn and accepted as always (main.c:193-195), but not traced */
-			bool taps_lit = (hobj & RT_PIX_TAPS_LIT) != 0;
-			hobj &= RT_PIX_TAPS_LIT - 1;
-			/* ... or a hit point of any bounce in a cell of the scene's table all of whose surface points are such points */
-			if (FAST && L.lit_words != nullptr && hobj != light_obj) {
-				const int bit = rt_lit_bit_of(reinterpret_cast<const rt_lit_grid*>(L.lit_grids) + hobj, hp.x, hp.y, hp.z);
-				taps_lit = taps_lit || ((L.lit_words[bit >> 5] >> (bit & 31)) & 1u) != 0u;
-			}
+			const bool taps_lit = lit_next != 0u;      /* ... or a hit point of a later bounce in such a cell of the scene's table (section 4) */
 			if (have_light) {
 				/* main.c:191-195: three rand_dir draws, a tap is skipped when it points into the surface.  Only the sign of
 				 * dot(rand_dir, normal) is needed here, and random_vector() has it before normalize() does (rt_math.hip.h:
@@ -1150,6 +1158,12 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				hobj = hit.obj; hn = hit.n;
 				hp = hit.obj >= 0 ? madd3(ray_o, dn, hit.t)                               /* scene.c:186 */
 				                  : dn;                 /* left the scene: the sky is looked up in that direction (main.c:170) */
+				/* will the taps from this hit point need tracing?  The scene's table (rt_lit.h) has one entry per cell of a grid
+				 * over every object: 1 = every surface point in the cell certainly sees the emitter.  The load is in flight
+				 * until the next round's front asks */
+				lit_next = 0u;
+				if (FAST && L.lit_cells != nullptr && hit.obj >= 0 && hit.obj != light_obj)
+					lit_next = L.lit_cells[rt_lit_bit_of(lit_grids + hit.obj, hp.x, hp.y, hp.z)];
 			}
 		}
 		/* the bounces retired below were shaded two rounds ago: whatever is left of their taps (the oldest in the queue) is
@@ -1576,17 +1590,23 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 		return e != hipSuccess ? e : hipEventRecord(primary_done, stream);
 	}
 	/* persistent waves: as many workgroups as fit on the chip at once, capped by the work */
-	const size_t lds = rt_wavefront_lds_bytes(L.num_objects);
+	size_t lds = rt_wavefront_lds_bytes(L.num_objects);
 	int per_cu = (int) ((160u * 1024u) / lds);
 	if (per_cu < 1) per_cu = 1;
 	if (per_cu > 4) per_cu = 4;
+	/* the grids of the lit-taps table go into LDS as well if that costs no workgroup per CU (else they are read from memory) */
+	rt_launch Lq = L;
+	Lq.lit_grids_in_lds = 0;
+	if (L.lit_cells != nullptr) {
+		const size_t with = lds + (size_t) L.num_objects * 48;
+		if (with <= 160u * 1024u && (int) ((160u * 1024u) / with) >= per_cu) { Lq.lit_grids_in_lds = 1; lds = with; }
+	}
 	if (workgroups_per_cu >= 1 && workgroups_per_cu < per_cu) per_cu = workgroups_per_cu;     /* rt_tuning */
 	const long long blocks = (long long) ((L.width + 7) / 8) * ((L.local_rows + 7) / 8);
 	long long grid = (long long) num_cus * per_cu;
 	const long long useful = (blocks + (RT_BLOCK / 64) - 1) / (RT_BLOCK / 64);
 	if (grid > useful) grid = useful;
 	if (grid < 1) grid = 1;
-	const rt_launch &Lq = L;
 	hipError_t e = hipMemsetAsync(block_counter, 0, RT_COUNTER_BYTES, stream);
 	if (e == hipSuccess && cleared) e = hipEventRecord(cleared, stream);
 	if (e != hipSuccess) return e;

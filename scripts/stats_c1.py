@@ -3,14 +3,15 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ray_tracing_amd as rt
 scene = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-jit = len(sys.argv) > 2 and sys.argv[2] == "jit"      # the scene-specialised kernel, instrumented through jit_flags
+jit = len(sys.argv) > 2 and sys.argv[2] in ("jit", "stamps")      # the scene-specialised kernel, instrumented through jit_flags
+stamps = len(sys.argv) > 2 and sys.argv[2] == "stamps"              # section time stamps only (the per-site atomics distort them)
 if not jit: rt.LIB_PATH = os.path.join(os.path.dirname(rt.LIB_PATH), "librt_hip_stats.so")
 W, H, spp, nb = (1920, 1080, 64, 4) if scene == 0 else (1920, 1080, 256, 8)
 g = rt.Renderer(0)
 g.set_skybox(rt.load_skybox()); g.set_scene(f"{rt.DATA_DIR}/scene_{scene}.txt")
 out = (C.c_ulonglong * 64)()
 if jit:
-    g.set_tuning(jit_flags="-DRT_STATS"); g.compile_scene()
+    g.set_tuning(jit_flags="-DRT_STATS -DRT_STATS_STAMPS_ONLY" if stamps else "-DRT_STATS"); g.compile_scene()
     rt.lib().rt_spec_stats_read.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
     read = lambda: rt.lib().rt_spec_stats_read(g._ctx, out, 1)
 else:
@@ -27,7 +28,7 @@ for k in sorted(names):
     if n:
         print(f"{names[k]:32s} execs/sample*64 {n * 64 / samples:8.3f}   avg active lanes {lanes / n:5.1f} ({lanes / n / 64 * 100:4.1f}%)")
 
-sec = ["1 supply: ballots, stream state, exit", "2 shade", "3+4 push + trace", "5 back", "6 in-order sum", "1 supply: pixel fetch", "1 supply: hand-out", "loop top / idle"]
+sec = ["1 supply: ballots, stream state, exit", "2 shade", "3+4 taps: push + trace; bounce rays", "5 back", "6 in-order sum", "1 supply: pixel fetch", "1 supply: hand-out", "loop top / idle"]
 tot = sum(out[50 + k] for k in range(8))
 if tot:
     print("share of wave time (s_memtime stamps at the section boundaries):")
