@@ -684,15 +684,16 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
  *     counters); inside a wave every free lane takes the next SAMPLE of a pixel the wave is working on
  *     (ballot + mbcnt prefix), so a lane never waits for its neighbours and a pixel's samples run on several
  *     lanes at once (a 1080p frame has about as many object pixels as the chip has lanes);
- *   - a path lives in its lane's registers, but the RAYS it needs traced (next bounce ray +
- *     up to three shadow taps, all known right after shading because the taps only feed the
- *     light term that is added afterwards, main.c:257-261) are compacted into a per-wave LDS
- *     queue with ballot/mbcnt prefix sums and traced in full batches of 64 by whichever lane
- *     gets them -- trace_ray() runs on full waves;
+ *   - a path lives in its lane's registers, and so does its next bounce ray: every lane traces its own, once per
+ *     round.  The up to three shadow taps of a bounce (known right after shading: they only feed the light term that is
+ *     added afterwards, main.c:257-261) are compacted into a per-wave LDS queue with ballot/mbcnt prefix sums and
+ *     traced in full batches of 64 by whichever lane gets them -- unless their answer is known without tracing
+ *     (rt_lit.h: the camera ray's hit point was flagged by rt_primary_pass, or the hit point of a later bounce lies in a
+ *     flagged cell of the scene's table): 69 % of the taps of the shipped scene_0;
  *   - the radiance arithmetic of a bounce (emission, albedo, light term: main.c:232,248,257-261) needs
- *     the bounce's tap results but nothing else does, so it runs one round behind the ray generation
- *     (the "back" and the "front" of a lane): taps that do not fill a batch simply wait in the queue
- *     for the next round's rays, and 99 % of the traced batches are full;
+ *     the bounce's tap results but nothing else does, so it runs two rounds behind the ray generation
+ *     (the "back" and the "front" of a lane): taps that do not fill a batch simply wait in the queue, up to two
+ *     rounds, and tap batches are full;
  *   - the primary hit is traced once per pixel, by rt_primary_pass, and re-used by all samples (the
  *     reference has no sub-pixel jitter, main.c:293-296, so bounce 0 of every sample is the same ray):
  *     bit-exact; sky-only pixels never reach this kernel;
@@ -706,7 +707,7 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 
 #define WF_SHARDS  64                  /* pixel lists (at most); each has a fill counter and a dequeue counter, 128 B apart */
 #define RT_COUNTER_BYTES ((2 * WF_SHARDS + 1) * 128)   /* + one line of launch control words (rt_launch.control) */
-#define WF_QUEUE   128                 /* ring: at most 63 waiting + 64 pushed at a time */
+#define WF_QUEUE   128                 /* tap ring: at most 63 waiting + 64 pushed at a time */
 #define WF_STREAMS 8                   /* pixels a wave adds up concurrently (at most) */
 #define WF_WINDOW  384                 /* sample slots per wave, shared equally by its streams */
 #define WF_EMPTY   0xffffffffu         /* window slot not written yet (a colour channel is in [0,1]: never this pattern) */
@@ -714,12 +715,11 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 #define REC_VALID    1                /* per-bounce record handed from the front to the back (wavefront_body) */
 #define REC_SPECULAR 2
 #define REC_LAST     4                /* the path ends after this bounce ...               */
-#define REC_SKY      8                /* ... because its bounce ray left the scene (end_sky) */
+#define REC_SKY      8                /* ... because its bounce ray left the scene (sky1 / sky2) */
 #define REC_TAPS_LIT 128              /* the bounce's accepted taps are known to hit the emitter (rt_lit.h): none was queued */
-#define WF_KIND_MAIN    1              /* next bounce ray of lane `owner`; kinds 2..4 = its shadow tap 0..2 */
 
 struct WaveLDS {
-	float q[6][WF_QUEUE];              /* ray queue SoA: o.xyz, d.xyz (un-normalised)                */
+	float q[6][WF_QUEUE];              /* tap queue SoA: hit point xyz, random_vector() xyz (kinds 2..4 = tap 0..2 of lane `owner`) */
 	unsigned short qmeta[WF_QUEUE];    /* owner lane | kind << 8 | round mod 3 << 12                 */
 	short tap[3][3][64];               /* shadow tap results per owner lane (object index < 1024 or -1), by the round (mod 3) that queued them */
 	/* Sample window.  Stream g (one pixel at a time, pixels one after another) owns slots [g*WF_WINDOW/P, (g+1)*WF_WINDOW/P)
@@ -836,12 +836,12 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	bool exhausted = false;                 /* no pixels left to fetch */
 	bool cancelled = false;                 /* rt_cancel(): nothing more is handed out, the paths in flight finish, the wave leaves */
 
-	/* per-lane path state.  A path is worked on at two places one round apart.  The FRONT (section 2) turns the
+	/* per-lane path state.  A path is worked on at two places two rounds apart.  The FRONT (section 2) turns the
 	 * pending hit into the next rays: it owns rng, bounce, the hit and f_slot.  The BACK (section 5) does the
-	 * radiance arithmetic of a bounce (main.c:232,248,257-261) one round later, when its shadow taps are certainly
-	 * traced: it owns rad, carry and b_slot.  `prev` is the record of the bounce the front shaded in the previous
-	 * round.  A slot word is the window slot the sample's colour goes to (| WF_LAST); in direct mode, the pixel's
-	 * frame offset. */
+	 * radiance arithmetic of a bounce (main.c:232,248,257-261) two rounds later, when its shadow taps are certainly
+	 * traced: it owns rad and carry.  rec1 / rec2 are the records of the bounces the front shaded one and two rounds
+	 * ago, with their slot words and sky texels.  A slot word is the window slot the sample's colour goes to
+	 * (| WF_LAST); in direct mode, the pixel's frame offset. */
 	bool  f_live = false;                   /* the front is on a sample */
 	int   f_slot = 0, slot1 = 0, slot2 = 0;
 	int   bounce = 0;
