@@ -7,13 +7,14 @@ rank renders its blocks into a compact strip (kernel side: rt_device.h `rt_launc
 all strips with a single gather and de-interleaves them.  One process per GPU, `torch.distributed`
 supplies the communicator (backend "nccl" = RCCL on ROCm; "gloo" on CPU for the tests).
 
-Stream discipline (GPU): every stage of a frame -- strip render, gather, de-interleave -- is issued from ONE
-stream (its handle is what the C ABI receives, so the kernels, torch's collective hand-off events and the
-de-interleave are ordered by construction); the copy of the finished frame to pinned host memory runs on a
-copy stream behind an event.  Consecutive frames alternate between the renderer's two streams (rt_stream: different
-priorities, hence different hardware queues) and are double-buffered, so the waves of frame k+1 fill the compute units
-as the waves of frame k run out of pixels, and the gather / copy of frame k overlaps the render of frame k+1 -- the
-way the reference's workers keep accumulating while its main thread presents (main.c:354-408 vs 450-482).
+Stream discipline (GPU): a frame's strip render and the hand-off to its gather are issued from ONE stream (its handle
+is what the C ABI receives, so the kernels and torch's collective hand-off event are ordered by construction); what
+follows the gather -- the wait for it, the de-interleave -- runs on a second stream and the copy of the finished frame
+to pinned host memory on a third, each behind events (class TiledFrame).  Consecutive frames alternate between the
+renderer's two streams (rt_stream: different priorities, hence different hardware queues) and rotate through three
+strip buffers, so the waves of frame k+1 fill the compute units as the waves of frame k run out of pixels, and the
+gather / de-interleave / copy of frame k overlap the render of frames k+1 and k+2 -- the way the reference's workers
+keep accumulating while its main thread presents (main.c:354-408 vs 450-482).
 """
 import numpy as np
 import torch
@@ -93,9 +94,17 @@ class TiledFrame:
     """The N-GPU frame loop of bench.py: render own strip -> gather -> de-interleave on rank 0 -> frame in
     pinned host memory on rank 0 (what update_frame() hands to the presenter, main.c:467-479).
 
-    step() enqueues one frame and returns at once; up to two frames are in flight.  flush() completes
+    step() enqueues one frame and returns at once; up to three frames are in flight.  flush() completes
     everything and leaves the last frame in `host_frame` (rank 0).  `seed` may be changed between steps
     (`step(seed=...)`): every frame is rendered from scratch, nothing is reused across frames.
+
+    Streams (N > 1).  Frame k is rendered on streams[k & 1] (the renderer's two streams: consecutive strips overlap on
+    the GPU) into strip buffer k % 3, and its gather is issued behind it.  What FOLLOWS the gather -- waiting for it,
+    the de-interleave, handing the frame to the copy stream -- is enqueued on a third stream (`post`): the render
+    streams never wait for a collective of the last two frames, only (through an event) for the one three frames back
+    whose strip buffer they reuse.  The collective's kernels only get compute units when the persistent trace kernel
+    of the next frame starts to drain, so a render stream that waited for the previous gather would lose the overlap
+    of consecutive strips.
     """
 
     def __init__(self, renderer, width, height, spp, max_bounces, seed=0, row_block=8, rank=0, world=1,
@@ -106,8 +115,8 @@ class TiledFrame:
         self.to_host = to_host and rank == 0
         self.device = device
         rows = strip_rows(height, row_block, world)
-        # render, collective hand-off, de-interleave: frame k on streams[k & 1].  The library's own two streams, wrapped: they
-        # have different priorities, so they never share a hardware queue and consecutive frames overlap on the GPU
+        # render + collective hand-off: frame k on streams[k & 1].  The library's own two streams, wrapped: they have
+        # different priorities, so they never share a hardware queue and consecutive frames overlap on the GPU
         # (two torch streams of equal priority were seen to share one: then nothing overlaps)
         if overlap_frames:
             self.streams = [torch.cuda.ExternalStream(renderer.stream(w), device=device) for w in (0, 1)]
@@ -118,18 +127,22 @@ class TiledFrame:
         # queues, and two streams on one queue run in enqueue order: the copy of frame k would then sit between render k and
         # render k+1 instead of beside the latter), and its copy kernel is dispatched ahead of the next frame's kernels.
         self.copy_stream = torch.cuda.Stream(device, priority=-1)
+        # what follows a gather (N > 1): see the class comment
+        self.post = torch.cuda.Stream(device, priority=-1) if world > 1 else None
         assert all(s.cuda_stream != 0 for s in self.streams)
         self.primitive = collective_for() if world > 1 else None
+        self.depth = 3 if world > 1 else 2            # strip buffers in rotation
         with torch.cuda.stream(self.stream):
-            self.strip = [torch.empty((rows, width, 3), dtype=torch.float32, device=device) for _ in range(2)]
+            self.strip = [torch.empty((rows, width, 3), dtype=torch.float32, device=device) for _ in range(self.depth)]
             self.strips = self.frame = None
             if world > 1 and (rank == 0 or self.primitive == "all_gather"):
-                self.strips = [torch.empty((world, rows, width, 3), dtype=torch.float32, device=device) for _ in range(2)]
+                self.strips = [torch.empty((world, rows, width, 3), dtype=torch.float32, device=device) for _ in range(self.depth)]
             if world > 1 and rank == 0:
                 self.frame = [torch.empty((height, width, 3), dtype=torch.float32, device=device) for _ in range(2)]
         self.host_frame = torch.empty((height, width, 3), dtype=torch.float32, pin_memory=True) if self.to_host else None
-        self.copied = [None, None]        # event: the host copy that read buffer k has finished
-        self.pending = None               # (work, k) of the frame whose gather is in flight
+        self.copied = [None, None]        # event: the host copy that read frame / strip buffer k & 1 has finished
+        self.gathered = [None] * self.depth    # event (post): the gather that read strip[j] (and wrote strips[j]) is complete
+        self.assembled = [None] * self.depth   # event (post): the de-interleave that read strips[j] is complete
         self.k = 0
         self.done_events = []             # one per completed frame when record_events is set
         self.render_events = []           # one behind every strip render when record_events is set
@@ -137,65 +150,72 @@ class TiledFrame:
 
     # -- one frame ---------------------------------------------------------------------------------
     def step(self, seed=None):
-        k = self.k & 1
+        k = self.k
         self.k += 1
-        s = self.streams[k]
+        s = self.streams[k & 1]
+        j = k % self.depth
         with torch.cuda.stream(s):
-            if self.copied[k] is not None and self.world == 1:
-                s.wait_event(self.copied[k])           # the copy two frames ago still reads strip[k]
+            if self.world == 1:
+                if self.copied[j] is not None:
+                    s.wait_event(self.copied[j])           # the copy two frames ago still reads strip[j]
+            else:
+                if self.gathered[j] is not None:
+                    s.wait_event(self.gathered[j])         # the gather three frames ago still reads strip[j] ...
+                if self.assembled[j] is not None:
+                    s.wait_event(self.assembled[j])        # ... and its de-interleave reads strips[j], which this gather overwrites
             p = self.r.params(self.W, self.H, self.spp, self.max_bounces, seed=self.seed if seed is None else seed,
                               row_block=self.row_block, rank=self.rank, world=self.world, kernel=self.kernel)
-            self.r.render_device(p, self.strip[k].data_ptr(), s.cuda_stream)
+            self.r.render_device(p, self.strip[j].data_ptr(), s.cuda_stream)
             if self.record_events:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(s)
                 self.render_events.append(ev)
             if self.world == 1:
-                self._deliver(self.strip[k][:self.H], k)
+                self._deliver(self.strip[j][:self.H], j, s)
                 return
-            _, work = gather_strips(self.strip[k], self.rank, self.world, dst=0,
-                                    out=self.strips[k] if self.strips is not None else None,
+            # the collective is ordered behind everything enqueued on s so far (torch hands its stream an event of s)
+            _, work = gather_strips(self.strip[j], self.rank, self.world, dst=0,
+                                    out=self.strips[j] if self.strips is not None else None,
                                     primitive=self.primitive, async_op=True)
-        prev, self.pending = self.pending, (work, k)
-        if prev is not None:
-            self._finish(prev)
-
-    def _finish(self, pending):
-        work, k = pending
-        s = self.streams[k]                                    # the frame's own stream
-        with torch.cuda.stream(s):
-            work.wait()                                        # s waits for the collective (no host block on nccl)
+        with torch.cuda.stream(self.post):
+            work.wait()                                    # post waits for the collective (no host block on nccl)
+            done = torch.cuda.Event()
+            done.record(self.post)
+            self.gathered[j] = done
             if self.rank == 0:
-                if self.copied[k] is not None:
-                    s.wait_event(self.copied[k])               # frame[k] is still being copied out
-                frame = assemble(self.strips[k], self.H, self.row_block, self.world, renderer=self.r,
-                                 out=self.frame[k], stream=s)
-                self._deliver(frame, k)
+                f = k & 1
+                if self.copied[f] is not None:
+                    self.post.wait_event(self.copied[f])   # frame[f] is still being copied out
+                frame = assemble(self.strips[j], self.H, self.row_block, self.world, renderer=self.r,
+                                 out=self.frame[f], stream=self.post)
+                read = torch.cuda.Event()
+                read.record(self.post)
+                self.assembled[j] = read
+                self._deliver(frame, f, self.post)
 
-    def _deliver(self, frame, k):
-        """frame (device, on the frame's stream) -> pinned host memory, on the copy stream."""
+    def _deliver(self, frame, slot, source):
+        """frame (device, complete on stream `source`) -> pinned host memory, on the copy stream."""
         if self.to_host:
             ready = torch.cuda.Event()
-            ready.record(self.streams[k])
+            ready.record(source)
             self.copy_stream.wait_event(ready)
             with torch.cuda.stream(self.copy_stream):
                 self.host_frame.copy_(frame, non_blocking=True)
                 done = torch.cuda.Event(enable_timing=self.record_events)
                 done.record(self.copy_stream)
-            self.copied[k] = done
+            self.copied[slot] = done
         else:
             done = torch.cuda.Event(enable_timing=self.record_events)
-            done.record(self.streams[k])
+            done.record(source)
         if self.record_events:
             self.done_events.append(done)
 
     def flush(self):
         """Complete every frame in flight; afterwards host_frame (rank 0) holds the last one."""
-        prev, self.pending = self.pending, None
-        if prev is not None:
-            self._finish(prev)
         for s in self.streams:
             s.synchronize()
+        if self.post is not None:
+            self.post.synchronize()
         self.copy_stream.synchronize()
 
     def render_now(self, seed=None):

@@ -68,11 +68,16 @@ def _nccl_worker(rank, world, port, q, backend="nccl", share_gpu=False):
         got = t.render_now(seed=s)
         if rank == 0:
             ok = ok and bool((bits(got.numpy()) == bits(g.render(W, H, spp, nb, seed=s))).all())
-    for s in (4, 5, 6, 7):
-        t.step(seed=s)
-    t.flush()
+    # pipelined: up to three frames in flight, three strip buffers and two frame buffers in rotation -- runs of 4, 5, 6 and 9
+    # frames end on every combination of them; a different seed per frame, so that a stale or overwritten buffer shows
+    seed = 4
+    for run in (4, 5, 6, 9):
+        for _ in range(run):
+            t.step(seed=seed); seed += 1
+        t.flush()
+        if rank == 0:
+            ok = ok and bool((bits(t.host_frame.numpy()) == bits(g.render(W, H, spp, nb, seed=seed - 1))).all())
     if rank == 0:
-        ok = ok and bool((bits(t.host_frame.numpy()) == bits(g.render(W, H, spp, nb, seed=7))).all())
         q.put(ok)
     dist.barrier()
     g.close()
