@@ -14,8 +14,8 @@ A step = one full frame through the hot path, ending where the reference's updat
 (main.c:467-479): every rank renders its interleaved row blocks with the HIP kernels (librt_hip.so, C ABI),
 then -- for N > 1 -- ONE RCCL gather of the finished strips to rank 0 and a de-interleave kernel there, then
 the resolved Vector3[W*H] frame is copied to (pinned) HOST memory on rank 0.  Inputs (scene, skybox,
-camera) are resident in HBM before the timed region.  Two frames are in flight: the gather / host copy of
-frame k overlaps the render of frame k+1 (ray_tracing_amd/multi_gpu.py); `frame_latency` reports the same
+camera) are resident in HBM before the timed region.  Two frames are in flight (three for N > 1): the gather / host
+copy of frame k overlaps the render of the following frames (ray_tracing_amd/multi_gpu.py); `frame_latency` reports the same
 frame with nothing overlapped (first launch -> frame on the host, median of 7).  The same frame is split
 over N GPUs, so scaling is "strong".
 
@@ -322,7 +322,7 @@ def main():
                                    f"counter-mode RNG seed {seed}, shipped skybox (6x2048x2048)",
                        "timed_region": "K frames, each: strip render -> "
                                        + ("one RCCL gather to rank 0 -> de-interleave -> " if world > 1 else "")
-                                       + "resolved frame copied to pinned host memory; two frames in flight",
+                                       + "resolved frame copied to pinned host memory; " + ("three" if world > 1 else "two") + " frames in flight",
                        "partition": f"interleaved blocks of {ROW_BLOCK} rows over {world} " + ("rank(s) SHARING ONE GPU (testing aid)" if args.share_gpu else "GPU(s)")
                                     + (f"; collective: {tiled.primitive}" if world > 1 else ""),
                        "kernel": {0: "wavefront" + ("+scene-specialised (hiprtc)" if compiled else ""), 1: "simple",
