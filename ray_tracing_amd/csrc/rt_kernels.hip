@@ -1162,7 +1162,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				 * over every object: 1 = every surface point in the cell certainly sees the emitter.  The load is in flight
 				 * until the next round's front asks */
 				lit_next = 0u;
-				if (FAST && L.lit_cells != nullptr && hit.obj >= 0 && hit.obj != light_obj)
+				if (FAST && L.lit_cells != nullptr && hit.obj >= 0 && hit.obj != light_obj &&
+				    rt_lit_point_on_surface(reinterpret_cast<const float*>(sc.geom) + 8 * hit.obj, hp.x, hp.y, hp.z, hn.x, hn.y, hn.z))
 					lit_next = L.lit_cells[rt_lit_bit_of(lit_grids + hit.obj, hp.x, hp.y, hp.z)];
 			}
 		}

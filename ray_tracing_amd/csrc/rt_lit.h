@@ -11,9 +11,11 @@
  *     above the tangent plane and moves away cannot come back);
  *   - every other object is missed by the cone -- cut off behind the emitter -- by at least 0.01 scene units:
  *     either its bounding box is clear of the cone's bounding box, or its bounding sphere is clear of the cone.
- * The margins are four or more orders of magnitude above the rounding errors of the reference's slab and
- * discriminant tests at the coordinate sizes accepted here (|coordinates| <= 32), so "certainly lit" means the
- * reference's trace_ray() returns the emitter for every such tap; anything doubtful answers 0 and is traced.
+ * The clearances are two or more orders of magnitude above the rounding errors of the reference's slab and
+ * discriminant tests at the coordinate sizes accepted here (|coordinates| <= 32, emitter within 50 radii); the one
+ * assumption that is not a clearance -- that the hit point lies on its object's surface -- is measured for every point
+ * (rt_lit_point_on_surface).  "Certainly lit" then means the reference's trace_ray() returns the emitter for every
+ * such tap; anything doubtful answers 0 and is traced.
  * When it answers 1 for the camera ray's hit point, the taps of bounce 0 of all the pixel's samples are known
  * without being traced (rt_primary_pass sets the flag, the trace kernel honours it): same object index, same
  * emission added in the same order -- bit-identical frames, fewer rays.
@@ -58,7 +60,9 @@ RT_LIT_FN int rt_region_certainly_lit(const float *geom, int num_objects, int li
 	const float lx = cx - px, ly = cy - py, lz = cz - pz;
 	const float D = RT_LIT_SQRT(lx * lx + ly * ly + lz * lz);
 	const float Dmin = D - sl, Dmax = D + sl;
-	if (!(Dmin >= R + 0.75f) || !(R >= 0.05f)) { RT_LIT_REFUSE(-2); return 0; }
+	/* (the emitter's own discriminant -- b*b - 4ac with |c - o| = D -- carries an error of a few 1e-6 D^2 against the
+	 * >= 0.39 R^2 the 5 % margin below leaves it: D <= 50 R keeps two orders of magnitude between them) */
+	if (!(Dmin >= R + 0.75f) || !(R >= 0.05f) || !(Dmax <= 50.0f * R)) { RT_LIT_REFUSE(-2); return 0; }
 	const float inv = 1.0f / D;
 	const float ax = lx * inv, ay = ly * inv, az = lz * inv;
 	const float s1 = 0.505f / (Dmin - 0.5f);             /* sin of the half-angle of one point's cone, 1 % over */
@@ -112,10 +116,29 @@ RT_LIT_FN int rt_region_certainly_lit(const float *geom, int num_objects, int li
 	return 1;
 }
 
+/* Is the hit point a ray reported really on the object's surface, to within the 1e-4 by which a tap's origin is moved
+ * off it (main.c:198 with a direction that leans >= 0.1 away)?  trace_ray()'s hit point is origin + direction * t in
+ * float: on a cube face it is off the plane by a few ulps of the ray's extent, but a sphere's t comes out of a
+ * discriminant whose error grows with the SQUARE of the distance to the ray's origin -- 2e-4 inside a sphere of radius
+ * 2.25 hit from 40 units away (found by scripts/lit_fuzz.py at scale 4.5): a tap from there starts INSIDE and hits the
+ * sphere itself.  So the deviation is measured, not assumed: g = the 8 words of the hit object, n its normal at P. */
+RT_LIT_FN int rt_lit_point_on_surface(const float *g, float px, float py, float pz, float nx, float ny, float nz)
+{
+	if (((const int *) g)[6] == 1) {                     /* sphere: |P - centre|^2 - r^2 = 2 r x (radial offset), at most 5e-5 inside */
+		const float vx = px - g[0], vy = py - g[1], vz = pz - g[2];
+		const float dev2 = vx * vx + vy * vy + vz * vz - g[3];
+		return dev2 >= 0.0f || dev2 * dev2 <= 1e-8f * g[3];
+	}
+	/* cube: the face is the one the normal names; P within 2e-5 of its plane */
+	const float off = nx != 0.0f ? px - (nx > 0.0f ? g[3] : g[0]) : (ny != 0.0f ? py - (ny > 0.0f ? g[4] : g[1]) : pz - (nz > 0.0f ? g[5] : g[2]));
+	return __builtin_fabsf(off) <= 2e-5f;
+}
+
 /* one point: the hit point of a ray, with the normal trace_ray() reports there */
 RT_LIT_FN int rt_taps_certainly_lit(const float *geom, int num_objects, int light, float cx, float cy, float cz,
                                     int hobj, float px, float py, float pz, float nx, float ny, float nz)
 {
+	if (hobj < 0 || hobj >= num_objects || !rt_lit_point_on_surface(geom + 8 * hobj, px, py, pz, nx, ny, nz)) return 0;
 	return rt_region_certainly_lit(geom, num_objects, light, cx, cy, cz, hobj, px, py, pz, 0.0f, 0.0f, 0.0f, nx, ny, nz, 0.0f);
 }
 
@@ -125,8 +148,9 @@ RT_LIT_FN int rt_taps_certainly_lit(const float *geom, int num_objects, int ligh
  * every point of the object's SURFACE inside that cell, with the normal the surface has there, is a point whose taps
  * certainly reach the emitter (rt_region_certainly_lit over the cell, per cube face that touches it).  Built once per
  * scene on the host (rt_set_scene); the trace kernel turns a hit point into its cell with three multiplies and reads
- * one bit.  Cells are inflated by a thousandth of their size before they are classified, so that a hit point whose
- * index rounds into the neighbouring cell is still covered. */
+ * one entry.  Cells are inflated by a thousandth of their size before they are classified, so that a hit point whose
+ * index rounds into the neighbouring cell is still covered.  An entry speaks for points ON the surface: whoever reads
+ * it for a hit point checks rt_lit_point_on_surface() for that point first. */
 typedef struct { float lo[3]; float scale[3]; int res[3]; int base; int pad[2]; } rt_lit_grid;   /* 48 bytes */
 
 #define RT_LIT_MAX_RES 256

@@ -1,5 +1,5 @@
 """Development aid (CPU only): random scenes with a sphere emitter through scripts/lit_probe.c -- the shipped rt_lit.h against
-the oracle's trace at every shading point of every bounce.  usage: lit_fuzz.py [cases] [seed]   (exit status 1 on a violation)"""
+the oracle's trace at every shading point of every bounce.  usage: lit_fuzz.py [cases] [seed] [scale] [camera distance]   (exit status 1 on a violation; scale multiplies every coordinate and size)"""
 import os, subprocess, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,6 +7,8 @@ exe = os.path.join(tempfile.gettempdir(), "lit_probe")
 subprocess.check_call(["gcc", "-O2", "-std=c11", "-o", exe, os.path.join(ROOT, "scripts", "lit_probe.c"), "-lm", "-lpthread"])
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+scale = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+far = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0      # > 0: the camera stands this many scene sizes away and looks at the scene
 def num(x): return "%.9f" % float(x)
 def vec(v): return "{%s}" % " ".join(num(x) for x in v)
 bad = taps = known = tabled = 0
@@ -22,16 +24,19 @@ for case in range(cases):
         if k == light or rng.random() < 0.4:
             c = rng.integers(-3, 7, 3).astype(float) if tight else rng.uniform(-3, 7, 3)
             r = float(rng.choice([0.25, 0.5, 1.0, 2.0])) if tight else float(rng.uniform(0.06, 2.0))
-            txt += ["sphere"] + ["\t" + m for m in mat] + ["\t" + P("center", vec(c)), "\t" + P("radius", num(r)), ""]
+            txt += ["sphere"] + ["\t" + m for m in mat] + ["\t" + P("center", vec(c * scale)), "\t" + P("radius", num(r * scale)), ""]
         else:
             o = rng.integers(-3, 7, 3).astype(float) if tight else rng.uniform(-3, 7, 3)
             sz = rng.choice([0.1, 0.5, 1.0, 3.0, 9.0], 3) if tight else rng.uniform(0.05, 5, 3)
-            txt += ["cube"] + ["\t" + m for m in mat] + ["\t" + P("origin", vec(o)), "\t" + P("size", vec(sz)), ""]
+            txt += ["cube"] + ["\t" + m for m in mat] + ["\t" + P("origin", vec(o * scale)), "\t" + P("size", vec(np.asarray(sz) * scale)), ""]
     path = os.path.join(tempfile.gettempdir(), "lit_fuzz_scene.txt")
     open(path, "w").write("\n".join(txt))
     pos = rng.integers(-2, 9, 3).astype(float) if rng.random() < 0.3 else rng.uniform(-2, 9, 3)
     front = rng.uniform(-1, 1, 3)
-    r = subprocess.run([exe, path, "160", "120", "4", "6"] + [repr(float(x)) for x in list(pos) + list(front)], capture_output=True, text=True)
+    if far > 0:
+        pos = rng.normal(size=3); pos = pos / np.linalg.norm(pos) * 10.0 * far
+        front = (np.array([2.0, 2.0, 2.0]) + rng.uniform(-3, 3, 3)) - pos
+    r = subprocess.run([exe, path, "160", "120", "4", "6"] + [repr(float(x)) for x in list(pos * scale) + list(front)], capture_output=True, text=True)
     last = [l for l in r.stdout.splitlines() if l.startswith("all:")]
     if last:
         w = last[0].split()

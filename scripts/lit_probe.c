@@ -59,7 +59,7 @@ static void lit_probe_tap(const void *hit, int light, int blocker, int bounce)
 	}
 	if (table_bits && h->object != light) {              /* the table of rt_lit_build, read as the trace kernel reads it */
 		const int b = rt_lit_bit_of(&grids[h->object], h->point.x, h->point.y, h->point.z);
-		if ((table[b >> 5] >> (b & 31)) & 1u) {
+		if (((table[b >> 5] >> (b & 31)) & 1u) && rt_lit_point_on_surface(packed + 8 * h->object, h->point.x, h->point.y, h->point.z, h->normal.x, h->normal.y, h->normal.z)) {
 			n_table[bounce]++;
 			if (blocker != light && n_table_viol++ < 10)
 				fprintf(stderr, "TABLE VIOLATION: point %.9g %.9g %.9g object %d: tap hit %d, not the emitter\n", h->point.x, h->point.y, h->point.z, h->object, blocker);

@@ -33,7 +33,11 @@ def test_scenes_without_a_sphere_emitter_are_never_answered(probe):
         assert not [l for l in r.stdout.splitlines() if l.startswith("all:") and " answered 0.0 %" not in l], r.stdout
 
 
-def test_random_scenes(probe):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "lit_fuzz.py"), "150", "11"], capture_output=True, text=True)
+@pytest.mark.parametrize("cases,seed,scale", [("150", "11", "1"), ("400", "8", "4.5")])
+def test_random_scenes(probe, cases, seed, scale):
+    """scale 4.5, seed 8, scene 239: a sphere of radius 2.25 hit from 40 units away -- the reference's float discriminant
+    puts the hit point 2e-4 INSIDE the sphere, and a tap from there hits the sphere itself.  The classifier measures how
+    far a hit point is off its surface (rt_lit_point_on_surface) instead of assuming it is on it."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "lit_fuzz.py"), cases, seed, scale], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " 0 scenes with violations" in r.stdout
