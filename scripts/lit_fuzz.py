@@ -3,7 +3,7 @@ the oracle's trace at every shading point of every bounce.  usage: lit_fuzz.py [
 import os, subprocess, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-exe = os.path.join(tempfile.gettempdir(), "lit_probe")
+exe = os.path.join(tempfile.gettempdir(), f"lit_probe_{os.getpid()}")
 subprocess.check_call(["gcc", "-O2", "-std=c11", "-o", exe, os.path.join(ROOT, "scripts", "lit_probe.c"), "-lm", "-lpthread"])
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -29,7 +29,7 @@ for case in range(cases):
             o = rng.integers(-3, 7, 3).astype(float) if tight else rng.uniform(-3, 7, 3)
             sz = rng.choice([0.1, 0.5, 1.0, 3.0, 9.0], 3) if tight else rng.uniform(0.05, 5, 3)
             txt += ["cube"] + ["\t" + m for m in mat] + ["\t" + P("origin", vec(o * scale)), "\t" + P("size", vec(np.asarray(sz) * scale)), ""]
-    path = os.path.join(tempfile.gettempdir(), "lit_fuzz_scene.txt")
+    path = os.path.join(tempfile.gettempdir(), f"lit_fuzz_scene_{os.getpid()}.txt")
     open(path, "w").write("\n".join(txt))
     pos = rng.integers(-2, 9, 3).astype(float) if rng.random() < 0.3 else rng.uniform(-2, 9, 3)
     front = rng.uniform(-1, 1, 3)
@@ -47,5 +47,7 @@ for case in range(cases):
         bad += 1
         print(f"case {case}: rc={r.returncode}\n{r.stdout}{r.stderr}", flush=True)
         os.replace(path, os.path.join(tempfile.gettempdir(), f"lit_fuzz_bad_{case}.txt"))
+for f in (path, exe):
+    if os.path.exists(f): os.remove(f)
 print(f"{cases} scenes, {taps} taps checked, {known} answered without tracing ({100.0 * known / max(taps, 1):.1f} %), {tabled} by the per-scene table ({100.0 * tabled / max(taps, 1):.1f} %), {bad} scenes with violations")
 sys.exit(1 if bad else 0)
