@@ -97,7 +97,12 @@ RT_LIT_FN int rt_region_certainly_lit(const float *geom, int num_objects, int li
 			q[0] = blo[0] + 0.5f * ex; q[1] = blo[1] + 0.5f * ey; q[2] = blo[2] + 0.5f * ez;
 			rho = 0.5f * RT_LIT_SQRT(ex * ex + ey * ey + ez * ez);
 		} else if (type == 1) {
-			rho = RT_LIT_SQRT(g[3]);
+			/* a sphere is "missed" by the reference when its float discriminant b*b - 4ac is not positive, and that
+			 * carries an error of about 2.4e-6 |centre - origin|^2: the sphere is taken larger by enough that a line
+			 * clear of it has a discriminant below -8e-4 of that square */
+			const float wx = g[0] - px, wy = g[1] - py, wz = g[2] - pz;
+			const float far = RT_LIT_SQRT(wx * wx + wy * wy + wz * wz) + sl;
+			rho = RT_LIT_SQRT(g[3] + 2e-4f * far * far + 1e-4f);
 			for (int k = 0; k < 3; k++) { q[k] = g[k]; blo[k] = g[k] - 1.001f * rho; bhi[k] = g[k] + 1.001f * rho; }
 		} else
 			continue;
