@@ -51,11 +51,12 @@ def collective_for(backend=None):
     return "gather" if str(backend).lower() in ("nccl", "gloo") else "all_gather"
 
 
-def gather_strips(strip, rank, world, dst=0, out=None, primitive=None, async_op=False):
+def gather_strips(strip, rank, world, dst=0, out=None, primitive=None, async_op=False, force=False):
     """One collective of equally-sized strips to `dst`.  Returns (result, work): result is [world, rows, W, 3] on
     dst and None elsewhere; work is the torch Work handle when async_op is set (wait() on it before touching
-    the result), else None.  `out` must be passed on dst when the call is asynchronous or repeated."""
-    if world == 1:
+    the result), else None.  `out` must be passed on dst when the call is asynchronous or repeated.  force: run the
+    collective on a one-rank group too (testing aid: the real backend's stream semantics on a 1-GPU box)."""
+    if world == 1 and not force:
         return strip.unsqueeze(0), None
     primitive = primitive or collective_for()
     if primitive == "gather":
@@ -108,12 +109,15 @@ class TiledFrame:
     """
 
     def __init__(self, renderer, width, height, spp, max_bounces, seed=0, row_block=8, rank=0, world=1,
-                 kernel=0, device=None, to_host=True, overlap_frames=True):
+                 kernel=0, device=None, to_host=True, overlap_frames=True, force_collective=False):
         self.r, self.W, self.H = renderer, width, height
         self.row_block, self.rank, self.world = row_block, rank, world
         self.spp, self.max_bounces, self.kernel, self.seed = spp, max_bounces, kernel, seed
         self.to_host = to_host and rank == 0
         self.device = device
+        # N > 1, or (testing aid) one rank that runs the N > 1 loop all the same -- gather, de-interleave, three buffers --
+        # on a one-rank process group: all of the real backend's stream semantics that a 1-GPU box can show
+        self.multi = world > 1 or force_collective
         rows = strip_rows(height, row_block, world)
         # render + collective hand-off: frame k on streams[k & 1].  The library's own two streams, wrapped: they have
         # different priorities, so they never share a hardware queue and consecutive frames overlap on the GPU
@@ -128,16 +132,16 @@ class TiledFrame:
         # render k+1 instead of beside the latter), and its copy kernel is dispatched ahead of the next frame's kernels.
         self.copy_stream = torch.cuda.Stream(device, priority=-1)
         # what follows a gather (N > 1): see the class comment
-        self.post = torch.cuda.Stream(device, priority=-1) if world > 1 else None
+        self.post = torch.cuda.Stream(device, priority=-1) if self.multi else None
         assert all(s.cuda_stream != 0 for s in self.streams)
-        self.primitive = collective_for() if world > 1 else None
-        self.depth = 3 if world > 1 else 2            # strip buffers in rotation
+        self.primitive = collective_for() if self.multi else None
+        self.depth = 3 if self.multi else 2            # strip buffers in rotation
         with torch.cuda.stream(self.stream):
             self.strip = [torch.empty((rows, width, 3), dtype=torch.float32, device=device) for _ in range(self.depth)]
             self.strips = self.frame = None
-            if world > 1 and (rank == 0 or self.primitive == "all_gather"):
+            if self.multi and (rank == 0 or self.primitive == "all_gather"):
                 self.strips = [torch.empty((world, rows, width, 3), dtype=torch.float32, device=device) for _ in range(self.depth)]
-            if world > 1 and rank == 0:
+            if self.multi and rank == 0:
                 self.frame = [torch.empty((height, width, 3), dtype=torch.float32, device=device) for _ in range(2)]
         self.host_frame = torch.empty((height, width, 3), dtype=torch.float32, pin_memory=True) if self.to_host else None
         self.copied = [None, None]        # event: the host copy that read frame / strip buffer k & 1 has finished
@@ -155,7 +159,7 @@ class TiledFrame:
         s = self.streams[k & 1]
         j = k % self.depth
         with torch.cuda.stream(s):
-            if self.world == 1:
+            if not self.multi:
                 if self.copied[j] is not None:
                     s.wait_event(self.copied[j])           # the copy two frames ago still reads strip[j]
             else:
@@ -170,13 +174,13 @@ class TiledFrame:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(s)
                 self.render_events.append(ev)
-            if self.world == 1:
+            if not self.multi:
                 self._deliver(self.strip[j][:self.H], j, s)
                 return
             # the collective is ordered behind everything enqueued on s so far (torch hands its stream an event of s)
             _, work = gather_strips(self.strip[j], self.rank, self.world, dst=0,
                                     out=self.strips[j] if self.strips is not None else None,
-                                    primitive=self.primitive, async_op=True)
+                                    primitive=self.primitive, async_op=True, force=True)
         with torch.cuda.stream(self.post):
             work.wait()                                    # post waits for the collective (no host block on nccl)
             done = torch.cuda.Event()

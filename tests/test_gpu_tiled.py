@@ -141,6 +141,45 @@ def test_pipelined_frames_ranks_sharing_one_gpu_over_gloo(world):
     assert q.get(timeout=5) is True
 
 
+def _one_rank_rccl_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+    import torch.distributed as dist
+    from ray_tracing_amd.multi_gpu import TiledFrame
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    g = rt.Renderer(0)
+    g.set_tuning(poison_frame=True)
+    g.set_skybox(rt.load_skybox()); g.set_scene(os.path.join(rt.DATA_DIR, "scene_0.txt")); g.set_camera()
+    W, H, spp, nb = 640, 360, 8, 4
+    t = TiledFrame(g, W, H, spp, nb, rank=0, world=1, device=dev, force_collective=True)
+    ok = t.primitive == "gather" and t.post is not None
+    seed = 1
+    for run in (1, 2, 3, 4, 7, 12):                 # frames in flight: asynchronous RCCL gathers, nothing blocks the host
+        for _ in range(run):
+            t.step(seed=seed); seed += 1
+        t.flush()
+        ok = ok and bool((bits(t.host_frame.numpy()) == bits(g.render(W, H, spp, nb, seed=seed - 1))).all())
+    q.put(ok)
+    g.close()
+    dist.destroy_process_group()
+
+
+def test_pipelined_frames_one_rank_over_rccl():
+    """The N > 1 frame loop with the REAL backend on the one GPU of a test box: a one-rank RCCL group runs the gather
+    (asynchronous, on RCCL's own stream), the wait for it on the post stream, the de-interleave and the rotation of
+    three strip and two frame buffers exactly as N ranks would; a different seed per frame."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_rccl_worker, args=(_free_port(), q))
+    p.start(); p.join(600)
+    assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL gather between ranks)")
 def test_pipelined_frames_two_ranks_over_rccl():
     import torch.multiprocessing as mp
