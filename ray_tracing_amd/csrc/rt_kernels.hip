@@ -1059,7 +1059,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				 * where it is traced, on a full batch, if it is traced at all. */
 				tap_j0 = rng_vector(rng); tap_j1 = rng_vector(rng); tap_j2 = rng_vector(rng);
 				const float side0 = dot3(tap_j0, hn), side1 = dot3(tap_j1, hn), side2 = dot3(tap_j2, hn);
-				if (FAST && wave_all(side_is_certain(tap_j0, side0) && side_is_certain(tap_j1, side1) && side_is_certain(tap_j2, side2)))
+				if (FAST && wave_all(side_is_certain(side0) && side_is_certain(side1) && side_is_certain(side2)))
 					tapmask = (side0 > 0 ? 1 : 0) | (side1 > 0 ? 2 : 0) | (side2 > 0 ? 4 : 0);
 				else
 					tapmask = (dot3(unit3_of_vector<FAST>(tap_j0), hn) > 0 ? 1 : 0) | (dot3(unit3_of_vector<FAST>(tap_j1), hn) > 0 ? 2 : 0) |
@@ -1471,7 +1471,7 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 				nn = unit3(madd3(unit3(c), v, eps));
 			}
 			const float side = dot3(v, nn);
-			if (side_is_certain(v, side) && (side > 0) != (dot3(unit3(v), nn) > 0)) {
+			if (side_is_certain(side) && (side > 0) != (dot3(unit3(v), nn) > 0)) {
 				bad++;
 				out[1] = __float_as_uint(v.x); out[2] = __float_as_uint(v.y); out[3] = __float_as_uint(v.z);
 				out[4] = __float_as_uint(nn.x); out[5] = __float_as_uint(nn.y);

@@ -229,8 +229,9 @@ RT_DEV V3 rng_direction(uint64_t &state) { return unit3_of_vector<FAST>(rng_vect
 /* The sign of dot(normalize(v), n) without normalising: `dot(rand_dir, hit.normal) <= 0` (main.c:194) only needs it.
  * With u = normalize(v) as the reference computes it (vector.c:129-138: three correctly rounded quotients by the rounded
  * length, or v itself below the epsilon), float dot(u, n) is within 1e-6 of (v.n)/|v| for a unit normal, and float
- * dot(v, n) within 4e-7 |v| of v.n: where dot(v, n)^2 > 1e-10 |v|^2 both have the sign of v.n.  Answers whether that
- * holds; the caller falls back to the real thing for the whole wave otherwise (one tap in 10^5). */
-RT_DEV bool side_is_certain(V3 v, float dot_vn) { return dot_vn * dot_vn > 1e-10f * (v.x * v.x + v.y * v.y + v.z * v.z); }
+ * dot(v, n) within 4e-7 |v| of v.n: where |dot(v, n)| > 1e-5 |v| both have the sign of v.n.  v = random_vector() has
+ * components in [-1, 1], so |v| <= sqrt(3) and |dot(v, n)| > 1.75e-5 is enough.  Answers whether that holds; the
+ * caller falls back to the real thing for the whole wave otherwise (one tap in 3 x 10^4). */
+RT_DEV bool side_is_certain(float dot_vn) { return dot_vn * dot_vn > 3.1e-10f; }
 
 #endif
