@@ -66,6 +66,9 @@ def parse_args(argv=None):
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing aid for 1-GPU boxes: all ranks use GPU 0 and the strips travel over gloo "
                          "(RCCL refuses two ranks on one device); not a performance configuration")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="testing aid for 1-GPU boxes: one rank runs the N > 1 frame loop (RCCL gather on a one-rank group, "
+                         "de-interleave, three strip buffers) so that loop's cost shows beside the plain N = 1 line")
     return ap.parse_args(argv)
 
 
@@ -215,15 +218,16 @@ def main():
         args.backend = args.backend or "gloo"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         # the collective's internal stream on its own (high-priority) hardware queue: streams of equal priority share a
         # handful of queues, and the gather of frame k must run beside render k+1, not between render k and render k+1
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         if (args.backend or "nccl") == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     w = WORKLOADS[args.config]
     W, H, spp, nb, seed = w["width"], w["height"], w["spp"], w["max_bounces"], w["seed"]
@@ -247,7 +251,7 @@ def main():
 
     from ray_tracing_amd.multi_gpu import TiledFrame
     tiled = TiledFrame(gpu, W, H, spp, nb, seed=seed, row_block=ROW_BLOCK, rank=rank, world=world,
-                       kernel=args.kernel, device=dev, to_host=True)
+                       kernel=args.kernel, device=dev, to_host=True, force_collective=args.force_collective)
 
     def fence():
         torch.cuda.synchronize()
@@ -321,10 +325,11 @@ def main():
             "config": {"workload": f"{w['name']}: {w['scene']} {W}x{H}, {spp} spp, {nb} bounces, default camera, "
                                    f"counter-mode RNG seed {seed}, shipped skybox (6x2048x2048)",
                        "timed_region": "K frames, each: strip render -> "
-                                       + ("one RCCL gather to rank 0 -> de-interleave -> " if world > 1 else "")
-                                       + "resolved frame copied to pinned host memory; " + ("three" if world > 1 else "two") + " frames in flight",
+                                       + ("one RCCL gather to rank 0 -> de-interleave -> " if tiled.multi else "")
+                                       + "resolved frame copied to pinned host memory; " + ("three" if tiled.multi else "two") + " frames in flight",
                        "partition": f"interleaved blocks of {ROW_BLOCK} rows over {world} " + ("rank(s) SHARING ONE GPU (testing aid)" if args.share_gpu else "GPU(s)")
-                                    + (f"; collective: {tiled.primitive}" if world > 1 else ""),
+                                    + (f"; collective: {tiled.primitive}" if tiled.multi else "")
+                                    + (" (one-rank group: testing aid)" if args.force_collective and world == 1 else ""),
                        "kernel": {0: "wavefront" + ("+scene-specialised (hiprtc)" if compiled else ""), 1: "simple",
                                   2: "wavefront, plain IEEE ops"}.get(args.kernel, str(args.kernel))},
         }
@@ -413,7 +418,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     gpu.close()
-    if world > 1:
+    if world > 1 or args.force_collective:
         dist.barrier()
         dist.destroy_process_group()
 
