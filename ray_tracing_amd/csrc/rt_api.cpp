@@ -80,6 +80,7 @@ struct rt_context {
 	size_t       lit_cells_capacity = 0;
 	int          lit_grids_capacity = 0;
 	bool         have_lit = false;
+	uint64_t     input_version = 1;      /* bumped by rt_set_scene / rt_set_skybox: part of launch_slot::lists_key */
 
 	uint32_t    *d_sky = nullptr;
 	size_t       sky_bytes = 0;
@@ -100,6 +101,7 @@ struct rt_context {
 		hipEvent_t   started = nullptr;      /* recorded behind that launch's primary pass, i.e. in front of its trace kernel */
 		hipStream_t  stream = nullptr;
 		bool         used = false;
+		uint64_t     lists_key = 0;          /* what rt_primary_pass's output in this set belongs to (0: nothing reusable) */
 		std::atomic<bool> cancel_pending{false};  /* a stop request was sent since the set's last launch: see begin_launch() */
 	} slot[2];
 	unsigned     launches = 0;           /* launch n uses slot[n & 1] */
@@ -408,6 +410,7 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 	}
 	ctx->num_objects = n;
 	ctx->have_scene = true;
+	ctx->input_version++;
 	return RT_OK;
 }
 
@@ -499,6 +502,7 @@ int rt_set_skybox(rt_context *ctx, const Cubemap *sky)
 	if (e != hipSuccess) return fail(RT_ERR_DEVICE, "hipMemcpy(skybox): %s", hipGetErrorString(e));
 	ctx->sky_w = sky->w; ctx->sky_h = sky->h;
 	ctx->have_sky = true;
+	ctx->input_version++;
 	return RT_OK;
 }
 
@@ -560,6 +564,7 @@ static int prepare_launch(rt_context *ctx, rt_launch &L, unsigned which)
 	if (cap > (size_t) 0x7fffffff) return fail(RT_ERR_ARGUMENT, "render: frame too large");
 	if (records > sl.pix_capacity) {
 		(void) hipFree(sl.d_pix); sl.d_pix = nullptr; sl.pix_capacity = 0;    /* (hipFree waits for the device: nothing still reads it) */
+		sl.lists_key = 0;
 		HIP_TRY(hipMalloc((void**) &sl.d_pix, records * 12 * sizeof(float)));
 		sl.pix_capacity = records;
 	}
@@ -636,6 +641,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 		e0 = take_event(ctx); e1 = take_event(ctx);
 		if (!e0 || !e1) { give_event(ctx, e0); give_event(ctx, e1); return fail(RT_ERR_DEVICE, "rt_render_device: hipEventCreate failed"); }
 	}
+	ctx->slot[ctx->launches & 1u].lists_key = 0;
 	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->slot[ctx->launches & 1u].d_counter, e0, ctx->slot[ctx->launches & 1u].started, ctx->num_cus, ctx->tuning.workgroups_per_cu, stream);
 	if (le == hipSuccess && ctx->profiling) le = hipEventRecord(e1, stream);
 	if (ctx->profiling) {
@@ -792,7 +798,30 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	{ const int rc = prepare_launch(ctx, L, ctx->launches); if (rc != RT_OK) return rc; }
 	{ const int rc = order_behind_previous(ctx, ctx->stream); if (rc != RT_OK) return rc; }
 	if (ctx->tuning.poison_frame) HIP_TRY(hipMemsetAsync(g.d_low, 0xff, g.low_bytes, ctx->stream));
-	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, ctx->slot[ctx->launches & 1u].d_counter, nullptr, ctx->slot[ctx->launches & 1u].started, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream));
+	/* A pass differs from the pass before last (same scratch set) in its sample number only, once the scale ladder has
+	 * reached full resolution and until the camera moves: the camera rays, their hits and the sky pixels in the
+	 * low-resolution frame are the same, so rt_primary_pass's output is kept (a sixth of a 1080p pass).  The key is
+	 * everything that output depends on. */
+	uint64_t key = 0;
+	{
+		rt_launch K = L;
+		K.seed = 0; K.sample_base = 0; K.max_bounces = 0; K.lit_cells = nullptr; K.lit_grids = nullptr; K.lit_grids_in_lds = 0;
+		key = 0xcbf29ce484222325ull ^ ctx->input_version;
+		const unsigned char *b = reinterpret_cast<const unsigned char*>(&K);
+		for (size_t i = 0; i < sizeof(K); i++) key = (key ^ b[i]) * 0x100000001b3ull;
+		if (key == 0) key = 1;
+	}
+	rt_context::launch_slot &sl = ctx->slot[ctx->launches & 1u];
+	const bool reuse = !ctx->tuning.poison_frame && sl.lists_key == key;
+	sl.lists_key = 0;
+	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, sl.d_counter, nullptr, sl.started, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream, reuse));
+	sl.lists_key = ctx->tuning.poison_frame ? 0 : key;
+	/* the low-resolution frame now holds THIS launch's sky pixels: lists of the other set that belong to anything else
+	 * (a pass at another scale before the ladder came back to this one) no longer have theirs */
+	{
+		rt_context::launch_slot &other = ctx->slot[(ctx->launches & 1u) ^ 1u];
+		if (other.lists_key != key) other.lists_key = 0;
+	}
 	const float weight = 1.0f / (s * s);                                         /* main.c:278 */
 	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), L.control + 1, ctx->stream));
 	{ const int rc = mark_launch(ctx, ctx->stream); if (rc != RT_OK) return rc; }

@@ -1572,7 +1572,8 @@ size_t rt_pixel_list_capacity(int width, int local_rows, int num_cus, int num_sh
 }
 
 hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, hipFunction_t spec_fn,
-                           unsigned int *block_counter, hipEvent_t cleared, hipEvent_t primary_done, int num_cus, int workgroups_per_cu, hipStream_t stream)
+                           unsigned int *block_counter, hipEvent_t cleared, hipEvent_t primary_done, int num_cus, int workgroups_per_cu, hipStream_t stream,
+                           bool reuse_pixel_lists)
 {
 	if (L.local_rows <= 0 || L.width <= 0) {
 		hipError_t e = cleared ? hipEventRecord(cleared, stream) : hipSuccess;
@@ -1608,10 +1609,17 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	const long long useful = (blocks + (RT_BLOCK / 64) - 1) / (RT_BLOCK / 64);
 	if (grid > useful) grid = useful;
 	if (grid < 1) grid = 1;
-	hipError_t e = hipMemsetAsync(block_counter, 0, RT_COUNTER_BYTES, stream);
+	/* counter block: WF_SHARDS dequeue counters, WF_SHARDS fill counters, one line of control words.  When the lists of the
+	 * previous launch of this scratch set are this launch's lists (an interactive pass with nothing changed but the
+	 * sample number: rt_api.cpp), the fill counters and the records stay and rt_primary_pass is not run */
+	hipError_t e = hipMemsetAsync(block_counter, 0, reuse_pixel_lists ? (size_t) WF_SHARDS * 128 : (size_t) RT_COUNTER_BYTES, stream);
+	if (e == hipSuccess && reuse_pixel_lists) e = hipMemsetAsync(block_counter + 2 * WF_SHARDS * 32, 0, 128, stream);
 	if (e == hipSuccess && cleared) e = hipEventRecord(cleared, stream);
 	if (e != hipSuccess) return e;
-	{
+	if (reuse_pixel_lists) {
+		e = hipEventRecord(primary_done, stream);
+		if (e != hipSuccess) return e;
+	} else {
 		unsigned int groups; int per_group;
 		rt_primary_geometry(L.width, L.local_rows, num_cus, &groups, &per_group);
 		const size_t plds = rt_scene_lds_bytes(L.num_objects);

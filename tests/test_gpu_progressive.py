@@ -136,3 +136,65 @@ def test_cancel_reaches_both_launches_in_flight(scene_paths):
     for k in range(4):
         assert (small[k].cpu().numpy().view(np.uint32) == want.view(np.uint32)).all(), k
     g.close()
+
+
+def test_kept_pixel_lists_change_no_bit(oracle, scene_paths):
+    """Once the scale ladder has reached full resolution, a pass differs from the pass before last (same scratch set)
+    in its sample number only, and rt_progressive_pass keeps rt_primary_pass's output -- pixel lists and the sky pixels of
+    the low-resolution frame -- instead of recomputing it (never with poison_frame, which would wipe those sky pixels:
+    hence no poisoning here).  Whatever that output depends on must invalidate it: camera, scene, skybox, frame size, an
+    ordinary rt_render() through the same scratch sets in between."""
+    sky = synthetic_skybox(32, seed=7)
+    sky2 = synthetic_skybox(16, seed=9)
+    g = rt.Renderer(0)
+    g.set_skybox(sky); oracle.set_skybox(sky)
+    g.set_scene(scene_paths[0]); oracle.load_scene(scene_paths[0])
+    g.set_camera(); oracle.set_camera()
+    W, H = 96, 54
+
+    def check(init_scale, passes, what):
+        g.progressive_begin(W, H, init_scale=init_scale, max_bounces=6, seed=3)
+        for _ in range(passes):
+            g.progressive_pass()
+        want, _, _, _ = oracle_progressive(oracle, W, H, init_scale, passes, 6, 3)
+        assert (bits(g.progressive_resolve()) == bits(want)).all(), what
+
+    check(1, 7, "seven full-resolution passes: five of them on kept lists")
+    check(4, 8, "ladder 4, 2, 1 and five more passes")
+    cam = dict(pos=(2, 3, 9), front=(0.1, -0.3, -1), up=(0, 1, 0), fov=30.0)
+    g.set_camera(**cam); oracle.set_camera(**cam)
+    check(1, 5, "camera moved")
+    g.set_scene(scene_paths[1]); oracle.load_scene(scene_paths[1])
+    check(1, 5, "scene replaced")
+    g.set_skybox(sky2); oracle.set_skybox(sky2)
+    g.set_scene(scene_paths[2]); oracle.load_scene(scene_paths[2])
+    check(1, 5, "skybox and scene replaced (scene_2 is mostly sky)")
+    # an ordinary frame through the same scratch sets between two passes
+    g.progressive_begin(W, H, init_scale=1, max_bounces=6, seed=3)
+    for k in range(6):
+        g.progressive_pass()
+        if k in (2, 3):
+            g.render(64, 40, 2, 3, seed=k)
+    want, _, _, _ = oracle_progressive(oracle, W, H, 1, 6, 6, 3)
+    assert (bits(g.progressive_resolve()) == bits(want)).all()
+    # a camera move in the middle of the full-resolution passes (main.c:522-570 -> invalidate_accumulation())
+    g.progressive_begin(W, H, init_scale=1, max_bounces=6, seed=3)
+    for _ in range(4):
+        g.progressive_pass()
+    g.set_camera(); oracle.set_camera()
+    g.progressive_invalidate()
+    for _ in range(4):
+        g.progressive_pass()
+    want, _, _, _ = oracle_progressive(oracle, W, H, 1, 4, 6, 3)
+    assert (bits(g.progressive_resolve()) == bits(want)).all()
+    # the ladder restarted from half resolution with nothing else changed: the pass at scale 2 overwrites part of the
+    # low-resolution frame, so the full-resolution lists of the other scratch set have lost their sky pixels
+    g.progressive_begin(W, H, init_scale=1, max_bounces=6, seed=3)
+    for _ in range(4):
+        g.progressive_pass()
+    g.progressive_begin(W, H, init_scale=2, max_bounces=6, seed=3)
+    for _ in range(4):
+        g.progressive_pass()
+    want, _, _, _ = oracle_progressive(oracle, W, H, 2, 4, 6, 3)
+    assert (bits(g.progressive_resolve()) == bits(want)).all()
+    oracle.set_camera(); oracle.set_skybox(sky); g.close()
