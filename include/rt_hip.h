@@ -195,6 +195,9 @@ RT_API int  rt_multi_render(rt_multi *m, const rt_render_params *params, Vector3
  * with rt_path_seed(seed, (j*s)*w + i*s, p).  init_scale must be 1, 2, 4, 8 or 16 (main.c:611-621). */
 RT_API int rt_progressive_begin(rt_context *ctx, int width, int height, int init_scale, int max_bounces, uint64_t seed);
 RT_API int rt_progressive_pass(rt_context *ctx, float *weight_out);
+/* Development / test aid: how many of this context's launches ran rt_primary_pass (camera rays) -- an interactive pass that
+ * differs from the pass before last in its sample number only keeps that pass's camera rays instead. */
+RT_API long long rt_primary_passes_run(rt_context *ctx);
 RT_API int rt_progressive_resolve(rt_context *ctx, Vector3 *frame_out);
 RT_API int rt_progressive_invalidate(rt_context *ctx);
 RT_API int rt_progressive_state(rt_context *ctx, int *next_scale, float *count, uint32_t *generation, int *passes);

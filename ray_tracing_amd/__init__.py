@@ -65,7 +65,7 @@ class MouseState(C.Structure):
 EXPORTS = [
     "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
     "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_spec_stats_read", "rt_spec_symbol_read", "rt_render", "rt_render_device", "rt_stream", "rt_reserve", "rt_strip_rows", "rt_deinterleave_device",
-    "rt_synchronize", "rt_cancel", "rt_was_cancelled", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
+    "rt_synchronize", "rt_cancel", "rt_was_cancelled", "rt_primary_passes_run", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
     "rt_progressive_invalidate", "rt_progressive_state", "rt_selftest", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
     "rt_parse_scene_string", "rt_load_cubemap", "rt_free_cubemap", "rt_decode_jpeg_file",
     "rt_camera_default", "rt_camera_basis_for", "rt_mouse_state_default", "rt_move_camera",
@@ -118,6 +118,7 @@ def lib():
     if hasattr(L, "rt_cancel"):
         L.rt_cancel.argtypes = [C.c_void_p]
         L.rt_was_cancelled.argtypes = [C.c_void_p]
+        L.rt_primary_passes_run.argtypes = [C.c_void_p]; L.rt_primary_passes_run.restype = C.c_longlong
     if hasattr(L, "rt_multi_create"):       # (scripts/ab.py also loads older builds of the library)
         L.rt_multi_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
         L.rt_multi_destroy.argtypes = [C.c_void_p]

@@ -80,6 +80,7 @@ struct rt_context {
 	size_t       lit_cells_capacity = 0;
 	int          lit_grids_capacity = 0;
 	bool         have_lit = false;
+	long long    primary_passes = 0;     /* launches that ran rt_primary_pass (rt_primary_passes_run) */
 	uint64_t     input_version = 1;      /* bumped by rt_set_scene / rt_set_skybox: part of launch_slot::lists_key */
 
 	uint32_t    *d_sky = nullptr;
@@ -642,6 +643,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 		if (!e0 || !e1) { give_event(ctx, e0); give_event(ctx, e1); return fail(RT_ERR_DEVICE, "rt_render_device: hipEventCreate failed"); }
 	}
 	ctx->slot[ctx->launches & 1u].lists_key = 0;
+	ctx->primary_passes++;
 	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->slot[ctx->launches & 1u].d_counter, e0, ctx->slot[ctx->launches & 1u].started, ctx->num_cus, ctx->tuning.workgroups_per_cu, stream);
 	if (le == hipSuccess && ctx->profiling) le = hipEventRecord(e1, stream);
 	if (ctx->profiling) {
@@ -696,6 +698,8 @@ int rt_cancel(rt_context *ctx)
 	for (auto &sl : ctx->slot) sl.cancel_pending.store(true);
 	return RT_OK;
 }
+
+long long rt_primary_passes_run(rt_context *ctx) { return ctx ? ctx->primary_passes : -1; }
 
 int rt_was_cancelled(rt_context *ctx)
 {
@@ -791,7 +795,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	L.row_block = 8; L.rank = 0; L.world = 1;
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.sky_wm1 = (float) (ctx->sky_w - 1); L.sky_hm1 = (float) (ctx->sky_h - 1);
 	L.frame = g.d_low;
-	L.skip_known_taps = 0;      /* one sample per pixel and pass: see rt_render_device */
+	L.skip_known_taps = ctx->tuning.trace_known_taps ? 0 : 1;   /* the flags are kept with the lists: paid once per camera position */
 	L.lit_cells = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_cells : nullptr;
 	L.lit_grids = ctx->d_lit_grids;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
@@ -806,6 +810,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	{
 		rt_launch K = L;
 		K.seed = 0; K.sample_base = 0; K.max_bounces = 0; K.lit_cells = nullptr; K.lit_grids = nullptr; K.lit_grids_in_lds = 0;
+		K.pix = nullptr; K.pix_count = nullptr; K.control = nullptr;      /* the scratch set's own addresses: the same output in either set has the same key */
 		key = 0xcbf29ce484222325ull ^ ctx->input_version;
 		const unsigned char *b = reinterpret_cast<const unsigned char*>(&K);
 		for (size_t i = 0; i < sizeof(K); i++) key = (key ^ b[i]) * 0x100000001b3ull;
@@ -815,6 +820,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	const bool reuse = !ctx->tuning.poison_frame && sl.lists_key == key;
 	sl.lists_key = 0;
 	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, sl.d_counter, nullptr, sl.started, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream, reuse));
+	if (!reuse) ctx->primary_passes++;
 	sl.lists_key = ctx->tuning.poison_frame ? 0 : key;
 	/* the low-resolution frame now holds THIS launch's sky pixels: lists of the other set that belong to anything else
 	 * (a pass at another scale before the ladder came back to this one) no longer have theirs */
