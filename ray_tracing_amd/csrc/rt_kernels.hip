@@ -1101,9 +1101,9 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 
 		STAMP(1);
 		/* ---- 3. the shadow taps go into the wave's ring (ballot + mbcnt prefix), one kind at a time; whenever 64 are
-		 * queued, any lane traces any tap (scene.c:156-190 on full waves).  A tap is queued as (hit point, rand_dir); its
-		 * direction and origin (main.c:197-198) are formed where it is traced.  Taps that do not fill a batch wait: the
-		 * bounce they belong to is retired two rounds from now ------------------------------------------------------- */
+		 * queued, any lane traces any tap (scene.c:156-190 on full waves).  A tap is queued as (hit point, random_vector());
+		 * its normalisation, direction and origin (main.c:193-198) are formed where it is traced.  Taps that do not fill a
+		 * batch wait: the bounce they belong to is retired two rounds from now ------------------------------------------------------- */
 		auto push = [&](bool on, V3 qo, V3 qd, int k) {
 			const unsigned long long m = __ballot(on);
 			if (on) {
