@@ -401,7 +401,7 @@ static V3 shade_path(float px, float py, float aspect, int max_bounces, uint64_t
 				V3 sd = unit(lin2(jitter, to_light, 0.5f, 1));
 				Ray shadow = { lin2(hit.point, sd, 1, 0.001f), sd };
 				Hit blocker = nearest_hit(shadow);
-				ORC_TAP_HOOK(&hit, light, blocker.object, bounce);      /* development probes (scripts/lit_probe.c); nothing by default */
+				ORC_TAP_HOOK(&hit, light, blocker.object, bounce);      /* development probes (tests/lit_probe.c); nothing by default */
 				if (blocker.object >= 0) {
 					const Material *bm = &sc->objects[blocker.object].material;
 					lit = lin2(lit, bm->emission_color, 1, bm->emission_power);

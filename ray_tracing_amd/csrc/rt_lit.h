@@ -20,7 +20,7 @@
  * without being traced (rt_primary_pass sets the flag, the trace kernel honours it): same object index, same
  * emission added in the same order -- bit-identical frames, fewer rays.
  *
- * Plain C99 / HIP, float only, no FMA dependence (every comparison has margins).  scripts/lit_probe.c runs this
+ * Plain C99 / HIP, float only, no FMA dependence (every comparison has margins).  tests/lit_probe.c runs this
  * very function on the CPU at every shading point of a frame and checks each answer against the oracle's trace;
  * tests/test_gpu_parity.py compares frames with the flag honoured and ignored (rt_tuning.trace_known_taps).
  */
@@ -35,7 +35,7 @@
 #endif
 
 #ifndef RT_LIT_REFUSE
-#define RT_LIT_REFUSE(why) ((void) 0)      /* scripts/lit_probe.c counts the reasons */
+#define RT_LIT_REFUSE(why) ((void) 0)      /* tests/lit_probe.c counts the reasons */
 #endif
 #define RT_LIT_MARGIN 0.01f          /* clearance demanded of every other object, scene units */
 
@@ -125,7 +125,7 @@ RT_LIT_FN int rt_region_certainly_lit(const float *geom, int num_objects, int li
  * off it (main.c:198 with a direction that leans >= 0.1 away)?  trace_ray()'s hit point is origin + direction * t in
  * float: on a cube face it is off the plane by a few ulps of the ray's extent, but a sphere's t comes out of a
  * discriminant whose error grows with the SQUARE of the distance to the ray's origin -- 2e-4 inside a sphere of radius
- * 2.25 hit from 40 units away (found by scripts/lit_fuzz.py at scale 4.5): a tap from there starts INSIDE and hits the
+ * 2.25 hit from 40 units away (found by tests/lit_fuzz.py at scale 4.5): a tap from there starts INSIDE and hits the
  * sphere itself.  So the deviation is measured, not assumed: g = the 8 words of the hit object, n its normal at P. */
 RT_LIT_FN int rt_lit_point_on_surface(const float *g, float px, float py, float pz, float nx, float ny, float nz)
 {

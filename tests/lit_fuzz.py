@@ -1,10 +1,10 @@
-"""Development aid (CPU only): random scenes with a sphere emitter through scripts/lit_probe.c -- the shipped rt_lit.h against
+"""Development aid (CPU only): random scenes with a sphere emitter through tests/lit_probe.c -- the shipped rt_lit.h against
 the oracle's trace at every shading point of every bounce.  usage: lit_fuzz.py [cases] [seed] [scale] [camera distance]   (exit status 1 on a violation; scale multiplies every coordinate and size)"""
 import os, subprocess, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 exe = os.path.join(tempfile.gettempdir(), f"lit_probe_{os.getpid()}")
-subprocess.check_call(["gcc", "-O2", "-std=c11", "-o", exe, os.path.join(ROOT, "scripts", "lit_probe.c"), "-lm", "-lpthread"])
+subprocess.check_call(["gcc", "-O2", "-std=c11", "-o", exe, os.path.join(ROOT, "tests", "lit_probe.c"), "-lm", "-lpthread"])
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 scale = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0

@@ -5,7 +5,7 @@
  * calls the SHIPPED function at every shading point (all bounces, although rt_primary_pass only uses it for the camera
  * ray's hit), counts the taps it would answer and compares each answer with the real trace: violations must be 0.
  *
- * build: gcc -O2 -std=c11 -o /tmp/lit_probe scripts/lit_probe.c -lm -lpthread
+ * build: gcc -O2 -std=c11 -o /tmp/lit_probe tests/lit_probe.c -lm -lpthread
  * usage: /tmp/lit_probe scene.txt W H spp bounces [pos.x pos.y pos.z yaw pitch fov]      exit status 1 on a violation */
 #include <stdio.h>
 #include <stdint.h>

@@ -1,4 +1,4 @@
-"""rt_lit.h (which soft-shadow taps need no trace) against the oracle, on the CPU: scripts/lit_probe.c calls the shipped
+"""rt_lit.h (which soft-shadow taps need no trace) against the oracle, on the CPU: tests/lit_probe.c calls the shipped
 function at every shading point of a frame -- every bounce, although the kernels only use it for camera-ray hits -- and
 compares each "certainly lit" with the oracle's trace_ray() result for that tap (main.c:191-206)."""
 import os
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def probe(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("lit") / "lit_probe")
-    subprocess.check_call(["gcc", "-O2", "-std=c11", "-o", exe, os.path.join(ROOT, "scripts", "lit_probe.c"), "-lm", "-lpthread"])
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-o", exe, os.path.join(ROOT, "tests", "lit_probe.c"), "-lm", "-lpthread"])
     return exe
 
 
@@ -38,6 +38,6 @@ def test_random_scenes(probe, cases, seed, scale):
     """scale 4.5, seed 8, scene 239: a sphere of radius 2.25 hit from 40 units away -- the reference's float discriminant
     puts the hit point 2e-4 INSIDE the sphere, and a tap from there hits the sphere itself.  The classifier measures how
     far a hit point is off its surface (rt_lit_point_on_surface) instead of assuming it is on it."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "lit_fuzz.py"), cases, seed, scale], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "lit_fuzz.py"), cases, seed, scale], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " 0 scenes with violations" in r.stdout
