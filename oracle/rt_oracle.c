@@ -362,7 +362,7 @@ void orc_sample_cubemap(const float d[3], float out[3])
 }
 
 #ifndef ORC_TAP_HOOK
-#define ORC_TAP_HOOK(hit, light, blocker, bounce) ((void) 0)
+#define ORC_TAP_HOOK(hit, light, blocker, bounce, ray) ((void) 0)
 #endif
 
 /* ------------------------------------------------------------------------------------------ */
@@ -401,7 +401,7 @@ static V3 shade_path(float px, float py, float aspect, int max_bounces, uint64_t
 				V3 sd = unit(lin2(jitter, to_light, 0.5f, 1));
 				Ray shadow = { lin2(hit.point, sd, 1, 0.001f), sd };
 				Hit blocker = nearest_hit(shadow);
-				ORC_TAP_HOOK(&hit, light, blocker.object, bounce);      /* development probes (tests/lit_probe.c); nothing by default */
+				ORC_TAP_HOOK(&hit, light, blocker.object, bounce, &shadow);      /* development probes (tests/lit_probe.c); nothing by default */
 				if (blocker.object >= 0) {
 					const Material *bm = &sc->objects[blocker.object].material;
 					lit = lin2(lit, bm->emission_color, 1, bm->emission_power);

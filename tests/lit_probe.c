@@ -9,8 +9,8 @@
  * usage: /tmp/lit_probe scene.txt W H spp bounces [pos.x pos.y pos.z yaw pitch fov]      exit status 1 on a violation */
 #include <stdio.h>
 #include <stdint.h>
-static void lit_probe_tap(const void *hit, int light, int blocker, int bounce);
-#define ORC_TAP_HOOK(hit, light, blocker, bounce) lit_probe_tap(hit, light, blocker, bounce)
+static void lit_probe_tap(const void *hit, int light, int blocker, int bounce, const void *ray);
+#define ORC_TAP_HOOK(hit, light, blocker, bounce, ray) lit_probe_tap(hit, light, blocker, bounce, ray)
 #include "../oracle/rt_oracle.c"
 static _Atomic uint64_t n_why[1024 + 8];
 static int why_bounce;
@@ -44,7 +44,69 @@ static void pack_scene(void)          /* as rt_set_scene packs rt_geom (rt_api.c
 	}
 }
 
-static void lit_probe_tap(const void *hit, int light, int blocker, int bounce)
+/* ---- a look ahead (not in the product): taps that can only hit the EMITTER first, or nothing that matters ------------
+ * With one emissive object in the scene a tap contributes nothing unless the emitter is its nearest hit.  If the cone of
+ * all taps from P is clear of every other object -- in front of the emitter; an object wholly beyond the emitter's far
+ * plane along an axis every tap direction moves along cannot be reached before the emitter -- then "is the emitter the
+ * nearest hit" is the reference's test of the emitter ALONE: one box or sphere instead of the whole scene, whatever the
+ * emitter's shape or size (scene_1's thin panel, which a third of the taps miss).  Counted here to size the idea. */
+static _Atomic uint64_t n_only[16], n_only_viol;
+static int emitter_only_would_do(const Hit *h, int light)
+{
+	const Scene *sc = &G.scene;
+	int emitters = 0;
+	for (int i = 0; i < sc->num_objects; i++) emitters += sc->objects[i].material.emission_power > 0;
+	if (emitters != 1 || h->object == light) return 0;
+	const float *ge = packed + 8 * light;
+	float elo[3], ehi[3];
+	rt_lit_object_box(ge, elo, ehi);
+	const V3 c = centre_of(&sc->objects[light]);
+	const float Rb = ((const int *) ge)[6] == 1 ? sqrtf(ge[3]) : 0.5f * sqrtf((ehi[0] - elo[0]) * (ehi[0] - elo[0]) + (ehi[1] - elo[1]) * (ehi[1] - elo[1]) + (ehi[2] - elo[2]) * (ehi[2] - elo[2]));
+	const float p[3] = { h->point.x, h->point.y, h->point.z }, n[3] = { h->normal.x, h->normal.y, h->normal.z };
+	if (!rt_lit_point_on_surface(packed + 8 * h->object, p[0], p[1], p[2], n[0], n[1], n[2])) return 0;
+	const float l[3] = { c.x - p[0], c.y - p[1], c.z - p[2] };
+	const float D = sqrtf(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+	if (!(D >= Rb + 0.75f) || fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fabsf(p[2])) > 32.0f) return 0;
+	const float a[3] = { l[0] / D, l[1] / D, l[2] / D };
+	const float s = 0.505f / (D - 0.5f);
+	if (!(s <= 0.7f)) return 0;
+	const float cs = sqrtf(1.0f - s * s), tau = 1.01f * s / cs, icos = 1.01f / cs, lean = 1.1f * s + 0.1f;
+	if (!(a[0] * n[0] + a[1] * n[1] + a[2] * n[2] >= lean)) return 0;
+	const float T = 1.01f * (D + Rb), m = RT_LIT_MARGIN;
+	float lo[3], hi[3];
+	for (int k = 0; k < 3; k++) {
+		const float w = sqrtf(fmaxf(0.0f, 1.0f - a[k] * a[k])), r = T * tau * w + m, q = p[k] + T * a[k];
+		lo[k] = fminf(a[k] >= lean ? p[k] + 2e-5f : p[k] - m, q - r);
+		hi[k] = fmaxf(-a[k] >= lean ? p[k] - 2e-5f : p[k] + m, q + r);
+	}
+	for (int i = 0; i < sc->num_objects; i++) {
+		if (i == light || i == h->object) continue;
+		const float *g = packed + 8 * i;
+		float blo[3], bhi[3], q[3], rho;
+		rt_lit_object_box(g, blo, bhi);
+		int behind = 0;                       /* wholly beyond the emitter along an axis all taps move along */
+		for (int k = 0; k < 3; k++) behind |= (a[k] >= lean && blo[k] >= ehi[k]) || (-a[k] >= lean && bhi[k] <= elo[k]);
+		if (behind) continue;
+		if (((const int *) g)[6] == 1) {
+			const float wx = g[0] - p[0], wy = g[1] - p[1], wz = g[2] - p[2], far = sqrtf(wx * wx + wy * wy + wz * wz);
+			rho = sqrtf(g[3] + 2e-4f * far * far + 1e-4f);
+			for (int k = 0; k < 3; k++) { q[k] = g[k]; blo[k] = g[k] - 1.001f * rho; bhi[k] = g[k] + 1.001f * rho; }
+		} else {
+			for (int k = 0; k < 3; k++) q[k] = 0.5f * (blo[k] + bhi[k]);
+			rho = 0.5f * sqrtf((bhi[0] - blo[0]) * (bhi[0] - blo[0]) + (bhi[1] - blo[1]) * (bhi[1] - blo[1]) + (bhi[2] - blo[2]) * (bhi[2] - blo[2]));
+		}
+		if (lo[0] > bhi[0] || hi[0] < blo[0] || lo[1] > bhi[1] || hi[1] < blo[1] || lo[2] > bhi[2] || hi[2] < blo[2]) continue;
+		const float v[3] = { q[0] - p[0], q[1] - p[1], q[2] - p[2] };
+		const float along = v[0] * a[0] + v[1] * a[1] + v[2] * a[2], vv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], rr = 1.001f * rho + m;
+		if (along < -rr || along - rr > T) continue;
+		const float lim = fmaxf(along, 0.0f) * tau + rr * icos;
+		if (vv - along * along > lim * lim + 1e-4f * vv + 1e-4f) continue;
+		return 0;
+	}
+	return 1;
+}
+
+static void lit_probe_tap(const void *hit, int light, int blocker, int bounce, const void *ray)
 {
 	const Hit *h = (const Hit *) hit;
 	const V3 c = centre_of(&G.scene.objects[light]);
@@ -56,6 +118,16 @@ static void lit_probe_tap(const void *hit, int light, int blocker, int bounce)
 		n_known[bounce]++;
 		if (blocker != light && n_viol++ < 10)
 			fprintf(stderr, "VIOLATION: point %.9g %.9g %.9g object %d: tap hit %d, not the emitter\n", h->point.x, h->point.y, h->point.z, h->object, blocker);
+	}
+	if (emitter_only_would_do(h, light)) {
+		const Ray *r = (const Ray *) ray;
+		const Object *em = &G.scene.objects[light];
+		const V3 d = unit(r->direction);
+		float t = 0; V3 nn;
+		const int hits = em->type == OBJECT_CUBE ? box_entry(r->origin, d, &em->cube, &t, &nn) : ball_entry(r->origin, d, &em->sphere, &t);
+		n_only[bounce]++;
+		if ((hits && t >= 0) != (blocker == light) && n_only_viol++ < 10)
+			fprintf(stderr, "EMITTER-ONLY VIOLATION: point %.9g %.9g %.9g object %d: the emitter alone says %d, the scene says object %d\n", h->point.x, h->point.y, h->point.z, h->object, hits && t >= 0, blocker);
 	}
 	if (table_bits && h->object != light) {              /* the table of rt_lit_build, read as the trace kernel reads it */
 		const int b = rt_lit_bit_of(&grids[h->object], h->point.x, h->point.y, h->point.z);
@@ -103,10 +175,16 @@ int main(int argc, char **argv)
 		kt += n_table[b];
 		t += n_taps[b]; k += n_known[b]; l += n_lit[b];
 	}
+	{
+		uint64_t o = 0;
+		for (int b = 0; b < 16; b++) o += n_only[b];
+		if (t) printf("look ahead: %.1f %% of the taps (bounce 0: %.1f %%) would need the emitter tested alone; disagreements with the full trace: %llu\n",
+		              100.0 * o / t, n_taps[0] ? 100.0 * n_only[0] / n_taps[0] : 0.0, (unsigned long long) n_only_viol);
+	}
 	if (t) printf("all: taps %llu  lit %.1f %%  answered %.1f %%  violations %llu  table %.1f %%  table violations %llu\n", (unsigned long long) t, 100.0 * l / t, 100.0 * k / t,
 	              (unsigned long long) (n_viol + n_table_viol), 100.0 * kt / t, (unsigned long long) n_table_viol);
 	printf("bounce-0 taps refused: coordinates %llu, emitter too near %llu, cone wider than the emitter %llu, own surface %llu", (unsigned long long) n_why[7], (unsigned long long) n_why[6], (unsigned long long) n_why[5], (unsigned long long) n_why[4]);
 	for (int i = 0; i < sc.num_objects; i++) if (n_why[8 + i]) printf(", object %d: %llu", i, (unsigned long long) n_why[8 + i]);
 	printf("\n");
-	return n_viol != 0 || n_table_viol != 0;
+	return n_viol != 0 || n_table_viol != 0 || n_only_viol != 0;
 }
