@@ -1,5 +1,5 @@
 """Development aid: randomised GPU-vs-oracle parity sweep (bit-exact) over scenes, cameras, frame sizes, sample
-counts, bounce limits, schedules, compiled/generic kernels and strips.  usage: fuzz_parity.py [cases] [seed]"""
+counts, bounce limits, schedules, compiled/generic kernels and strips.  usage: fuzz_parity.py [cases] [seed] [scale]   (scale multiplies every coordinate and size)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,6 +10,7 @@ from rtlibs import Oracle, bits, make_scene, synthetic_skybox
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+scale = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 gpu, orc = rt.Renderer(0), Oracle()
 gpu.set_tuning(poison_frame=True)
 bad = 0
@@ -20,17 +21,17 @@ for case in range(cases):
         mat = dict(albedo=rng.uniform(0, 1, 3), roughness=float(rng.choice([0, 0.3, 1.0])), reflectance=float(rng.uniform(0, 1)),
                    metallic=float(rng.choice([0, 0, 1])), emission_power=float(rng.choice([0, 0, 0, 3.0])))
         if rng.random() < 0.4:
-            objs.append(dict(type="sphere", center=rng.uniform(-3, 6, 3), radius=float(rng.uniform(0.3, 1.5)), **mat))
+            objs.append(dict(type="sphere", center=rng.uniform(-3, 6, 3) * scale, radius=float(rng.uniform(0.3, 1.5)) * scale, **mat))
         else:
             grid = rng.random() < 0.5
             o = rng.integers(-3, 6, 3).astype(float) if grid else rng.uniform(-3, 6, 3)
             sz = rng.choice([0.1, 0.5, 1.0, 3.0, 9.0], 3) if grid else rng.uniform(0.05, 4, 3)
-            objs.append(dict(type="cube", origin=o, size=sz, **mat))
+            objs.append(dict(type="cube", origin=o * scale, size=np.asarray(sz, dtype=float) * scale, **mat))
     scene = make_scene(objs)
     sky = synthetic_skybox(int(rng.choice([8, 16, 33])), seed=int(rng.integers(1 << 30)))
     pos = rng.integers(-2, 8, 3).astype(float) if rng.random() < 0.3 else rng.uniform(-2, 8, 3)
     front = rng.uniform(-1, 1, 3); front[2] -= 0.5
-    cam = dict(pos=tuple(pos), front=tuple(front), up=(0, 1, 0), fov=float(rng.uniform(0.5, 1.4)))
+    cam = dict(pos=tuple(pos * scale), front=tuple(front), up=(0, 1, 0), fov=float(rng.uniform(0.5, 1.4)))
     W, H = int(rng.integers(2, 90)), int(rng.integers(2, 70))     # the reference divides by W-1 and H-1
     spp, nb, seed = int(rng.choice([1, 2, 3, 5, 16, 37])), int(rng.choice([1, 2, 4, 8, 10])), int(rng.integers(0, 1 << 62))
     print(f"case {case}: n={n} {W}x{H} spp={spp} nb={nb}", flush=True)
