@@ -181,8 +181,15 @@ class TiledFrame:
             _, work = gather_strips(self.strip[j], self.rank, self.world, dst=0,
                                     out=self.strips[j] if self.strips is not None else None,
                                     primitive=self.primitive, async_op=True, force=True)
+            issued = torch.cuda.Event()
+            issued.record(s)
         with torch.cuda.stream(self.post):
-            work.wait()                                    # post waits for the collective (no host block on nccl)
+            # post waits for the collective (no host block on nccl) -- AND for s itself up to here: torch's NCCL gather copies
+            # the root's own contribution on the CALLING stream, not on the collective's, and Work.wait() does not cover
+            # that copy (measured on a one-rank RCCL group: a consumer on another stream that only waits for the Work
+            # reads the old bytes every time)
+            self.post.wait_event(issued)
+            work.wait()
             done = torch.cuda.Event()
             done.record(self.post)
             self.gathered[j] = done
