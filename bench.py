@@ -213,6 +213,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
+    # The contract is ONE line on stdout: the JSON.  RCCL prints a version banner and gloo its connection messages to the
+    # process's stdout (file descriptor 1, from C): everything written to descriptor 1 from here on goes to stderr, and the
+    # JSON line is written to the original descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if args.share_gpu:
         local_rank = 0
         args.backend = args.backend or "gloo"
@@ -415,7 +421,8 @@ def main():
                 out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
             except Exception as e:
                 out["cpu_baseline_error"] = repr(e)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
     gpu.close()
     if world > 1 or args.force_collective:
