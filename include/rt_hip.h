@@ -34,6 +34,7 @@ extern "C" {
 #define RT_API __attribute__((visibility("default")))
 
 typedef enum {
+	RT_PENDING       =  2,   /* not an error: rt_frame_poll() -- the frame is not in host memory yet */
 	RT_CANCELLED     =  1,   /* not an error: the launch was cut short by rt_cancel(); the frame is incomplete */
 	RT_OK            =  0,
 	RT_ERR_ARGUMENT  = -1,   /* NULL / out-of-range argument                     */
@@ -150,6 +151,34 @@ RT_API int rt_deinterleave_device(rt_context *ctx, const void *d_strips, void *d
 
 RT_API int rt_synchronize(rt_context *ctx);
 
+/* ---- frames in flight: the reference's workers keep rendering while its main thread presents -------------------
+ * (main.c:354-408 vs main.c:450-482).  rt_render() above is one blocking call per frame; here a frame is SUBMITTED --
+ * the call only enqueues: render into the slot's device buffer, copy to `frame_out` on a copy stream of its own -- and
+ * WAITED for later, so that the copy of frame k to the host overlaps the render of frame k+1, and consecutive renders
+ * overlap each other on the context's two streams (the waves of frame k+1 fill the compute units as the waves of frame
+ * k run out of pixels).  A slot holds one frame at a time; RT_FRAME_SLOTS of them can be in flight:
+ *
+ *     rt_frame_submit(ctx, &p0, 0, frame[0]);
+ *     for (k = 0; ; k++) {
+ *         rt_frame_submit(ctx, &p_next, (k + 1) % 2, frame[(k + 1) % 2]);     // frame k+1 starts behind frame k
+ *         rt_frame_wait(ctx, k % 2);                                          // frame k is in frame[k % 2]
+ *         move_frame_to_the_gpu(w, h, frame[k % 2]);                          // main.c:479
+ *     }
+ *
+ * frame_out is caller-owned and must stay valid until the slot has been waited for; memory from rt_host_alloc()
+ * (page-locked) lets the copy run beside the next render -- with ordinary malloc()ed memory the runtime stages the copy
+ * and the submit call may block for it.  Frames are bit-identical to rt_render()'s.  rt_frame_wait() returns RT_OK, or
+ * RT_CANCELLED when rt_cancel() cut the frame short; rt_frame_poll() never blocks: RT_PENDING while the frame is not
+ * there yet.  Submitting into a slot that holds a frame nobody waited for is an error (RT_ERR_STATE); params->world
+ * must be 1.  rt_set_scene / rt_set_skybox / rt_destroy wait for the frames in flight. */
+#define RT_FRAME_SLOTS 4
+RT_API int rt_frame_submit(rt_context *ctx, const rt_render_params *params, int slot, Vector3 *frame_out);
+RT_API int rt_frame_wait(rt_context *ctx, int slot);
+RT_API int rt_frame_poll(rt_context *ctx, int slot);
+/* page-locked host memory for frame_out (hipHostMalloc): any thread, no context needed */
+RT_API int  rt_host_alloc(void **out, size_t bytes);
+RT_API void rt_host_free(void *p);
+
 /* Giving up a frame, as the reference's workers do when the camera moves mid-pass (main.c:316-317): rt_cancel()
  * asks the launch that is running (or already enqueued) on this context to stop -- its waves hand out no more
  * samples, finish the paths in flight and leave, within a few hundred microseconds.  It may be called from ANY
@@ -179,6 +208,16 @@ RT_API int  rt_multi_set_camera(rt_multi *m, const rt_camera *camera);
 RT_API int  rt_multi_set_tuning(rt_multi *m, const rt_tuning *tuning);
 RT_API int  rt_multi_compile_scene(rt_multi *m);
 RT_API int  rt_multi_render(rt_multi *m, const rt_render_params *params, Vector3 *frame_out);
+/* The same with frames in flight (rt_frame_submit / rt_frame_wait above, same rules): every device renders frame k's
+ * strip on its context's streams alternately, into one of three strip buffers; the grouped ncclGather of frame k, the
+ * de-interleave on the first device and the copy to frame_out run on streams of their own behind events, beside the
+ * renders of frames k+1 and k+2 -- a render stream only ever waits for the gather three frames back, whose strip buffer
+ * it reuses.  (The persistent trace kernel of the next frame holds every compute unit until it drains, so a render
+ * stream that waited for the previous frame's collective would lose the overlap of consecutive strips.)  With one
+ * device and no rt_tuning.force_collective this is rt_frame_submit() on that device's context. */
+RT_API int  rt_multi_frame_submit(rt_multi *m, const rt_render_params *params, int slot, Vector3 *frame_out);
+RT_API int  rt_multi_frame_wait(rt_multi *m, int slot);
+RT_API int  rt_multi_frame_poll(rt_multi *m, int slot);
 
 /* ---- progressive accumulation: the reference's interactive protocol ----------------------------
  * worker() renders passes of 1 sample per (low-resolution) pixel, starting at 1/init_scale resolution
@@ -210,6 +249,9 @@ RT_API int rt_progressive_state(rt_context *ctx, int *next_scale, float *count, 
  * on the GPU together is counted in both.) */
 RT_API int rt_profile_enable(rt_context *ctx, int on);
 RT_API int rt_profile_collect(rt_context *ctx, double *kernel_ms_total, int *launches);
+/* the same, plus the time from the first of those launches getting its first compute unit to the end of the last one's
+ * trace kernel (no double counting of the time overlapping launches share, but idle time between launches is in it) */
+RT_API int rt_profile_collect_span(rt_context *ctx, double *kernel_ms_total, int *launches, double *span_ms);
 
 /* On-GPU self-test of the exact-arithmetic shortcuts the tuned kernel uses (shared-reciprocal
  * division, vector normalisation): compares them bit-for-bit with the plain IEEE forms on

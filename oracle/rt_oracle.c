@@ -565,6 +565,7 @@ typedef struct {
 	uint64_t seed;
 	float *frame;
 	atomic_int *next_row;
+	const int *row_list;             /* NULL: rows next_row .. row1-1; else row_list[next_row .. row1-1] */
 } CounterJob;
 
 static void *counter_worker(void *arg)
@@ -576,6 +577,7 @@ static void *counter_worker(void *arg)
 	for (;;) {
 		int j = atomic_fetch_add(job->next_row, 1);
 		if (j >= job->row1) break;
+		if (job->row_list) j = job->row_list[j];
 		for (int i = 0; i < W; i++) {
 			COUNT(flops, 4);
 			float u = (float) i / (W - 1);                           /* main.c:293-296 at scale 1 */
@@ -604,7 +606,23 @@ void orc_render_counter(int W, int H, int spp, int max_bounces, uint64_t seed,
 	if (threads < 1) threads = 1;
 	if (threads > 256) threads = 256;
 	atomic_int next_row = row0;
-	CounterJob job = { W, H, spp, max_bounces, row1, seed, frame_out, &next_row };
+	CounterJob job = { W, H, spp, max_bounces, row1, seed, frame_out, &next_row, NULL };
+	if (threads == 1) { counter_worker(&job); return; }
+	pthread_t tid[256];
+	for (int t = 0; t < threads; t++) pthread_create(&tid[t], NULL, counter_worker, &job);
+	for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+}
+
+/* the same for an arbitrary list of frame rows (every row in [0, H)), dealt to the threads one at a time: what the
+ * full-size GPU parity tests use to check rows spread over a whole frame */
+void orc_render_counter_rows(int W, int H, int spp, int max_bounces, uint64_t seed,
+                             const int *rows, int num_rows, int threads, float *frame_out)
+{
+	if (threads < 1) threads = 1;
+	if (threads > 256) threads = 256;
+	if (threads > num_rows) threads = num_rows > 0 ? num_rows : 1;
+	atomic_int next_row = 0;
+	CounterJob job = { W, H, spp, max_bounces, num_rows, seed, frame_out, &next_row, rows };
 	if (threads == 1) { counter_worker(&job); return; }
 	pthread_t tid[256];
 	for (int t = 0; t < threads; t++) pthread_create(&tid[t], NULL, counter_worker, &job);

@@ -103,6 +103,8 @@ struct rt_context {
 		hipStream_t  stream = nullptr;
 		bool         used = false;
 		uint64_t     lists_key = 0;          /* what rt_primary_pass's output in this set belongs to (0: nothing reusable) */
+		hipEvent_t   readback = nullptr;     /* a copy stream still has to read this set's control words (rt_frame_submit): the set's
+		                                      * next launch, which clears them, waits for it.  Owned by a frame slot. */
 		std::atomic<bool> cancel_pending{false};  /* a stop request was sent since the set's last launch: see begin_launch() */
 	} slot[2];
 	unsigned     launches = 0;           /* launch n uses slot[n & 1] */
@@ -121,14 +123,24 @@ struct rt_context {
 	float       *d_frame = nullptr;      /* scratch for rt_render() */
 	size_t       frame_bytes = 0;
 
+	/* frames in flight (rt_frame_submit / rt_frame_wait): a device frame per slot, one copy stream for all */
+	struct frame_slot {
+		float     *d_buf = nullptr;
+		size_t     bytes = 0;
+		hipEvent_t copied = nullptr;     /* behind the copy of the frame (and of the launch's control word) to the host */
+		bool       busy = false;         /* submitted and not waited for yet */
+	} fq[RT_FRAME_SLOTS];
+	unsigned long long frames_submitted = 0;   /* frame n renders on the context's stream n & 1 */
+	hipStream_t  copy_stream = nullptr;  /* made by the first rt_frame_submit() */
+
 	/* progressive accumulation (rt_progressive_*) */
 	struct {
 		bool     active = false;
 		int      width = 0, height = 0, init_scale = 1, scale = 1, max_bounces = 10, passes = 0;
 		uint64_t seed = 0;
-		float    count = 0;
 		uint32_t generation = 0;
 		float   *d_accum = nullptr, *d_low = nullptr, *d_out = nullptr;
+		float   *d_count = nullptr;          /* sum of the published passes' weights (accum_counts[], main.c:396): written by rt_accumulate */
 		size_t   accum_bytes = 0, low_bytes = 0;
 	} prog;
 
@@ -146,6 +158,7 @@ static int wait_for_launches(rt_context *ctx)
 	for (auto &sl : ctx->slot)
 		if (sl.used) HIP_TRY(hipEventSynchronize(sl.done));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	if (ctx->copy_stream) HIP_TRY(hipStreamSynchronize(ctx->copy_stream));   /* frames on their way to the host */
 	return RT_OK;
 }
 
@@ -164,6 +177,8 @@ static int order_behind_previous(rt_context *ctx, hipStream_t stream)
 	if (prev.used && prev.stream != stream) HIP_TRY(hipStreamWaitEvent(stream, prev.started, 0));
 	/* a stop request meant for earlier launches must have landed before this launch clears the set's control words */
 	if (sl.cancel_pending.exchange(false)) HIP_TRY(hipStreamWaitEvent(stream, ctx->cancel_event, 0));
+	/* ... and a frame in flight must have read them (rt_frame_submit) */
+	if (sl.readback) { HIP_TRY(hipStreamWaitEvent(stream, sl.readback, 0)); sl.readback = nullptr; }
 	return RT_OK;
 }
 
@@ -281,6 +296,8 @@ void rt_destroy(rt_context *ctx)
 		if (sl.started) (void) hipEventDestroy(sl.started);
 		(void) hipFree(sl.d_counter); (void) hipFree(sl.d_pix);
 	}
+	if (ctx->copy_stream) { (void) hipStreamSynchronize(ctx->copy_stream); (void) hipStreamDestroy(ctx->copy_stream); }
+	for (auto &f : ctx->fq) { if (f.copied) (void) hipEventDestroy(f.copied); (void) hipFree(f.d_buf); }
 	if (ctx->stream2) { (void) hipStreamSynchronize(ctx->stream2); (void) hipStreamDestroy(ctx->stream2); }
 	if (ctx->cancel_stream) { (void) hipStreamSynchronize(ctx->cancel_stream); (void) hipStreamDestroy(ctx->cancel_stream); }
 	if (ctx->cancel_event) (void) hipEventDestroy(ctx->cancel_event);
@@ -289,7 +306,7 @@ void rt_destroy(rt_context *ctx)
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
 	(void) hipFree(ctx->d_lit_cells); (void) hipFree(ctx->d_lit_grids);
 	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame);
-	(void) hipFree(ctx->prog.d_accum); (void) hipFree(ctx->prog.d_low); (void) hipFree(ctx->prog.d_out);
+	(void) hipFree(ctx->prog.d_accum); (void) hipFree(ctx->prog.d_low); (void) hipFree(ctx->prog.d_out); (void) hipFree(ctx->prog.d_count);
 	(void) hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -677,6 +694,90 @@ int rt_render(rt_context *ctx, const rt_render_params *p, Vector3 *frame_out)
 	return ctx->h_words[0] ? RT_CANCELLED : RT_OK;
 }
 
+/* ---- frames in flight (include/rt_hip.h): the reference's workers keep accumulating while its main thread presents
+ * (main.c:354-408 vs 450-482).  Frame n is rendered on the context's stream n & 1 -- consecutive launches sit in two
+ * hardware queues and overlap on the GPU, see order_behind_previous() -- into its slot's device frame; the copy to the
+ * caller's memory runs on a third, high-priority stream (a queue of its own: streams of equal priority share a handful
+ * of queues in creation order, and a copy queued behind the next render would not overlap it). */
+static int frame_copy_stream(rt_context *ctx)
+{
+	if (ctx->copy_stream) return RT_OK;
+	int least = 0, greatest = 0;
+	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) greatest = 0;
+	if (hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, greatest) != hipSuccess)
+		HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+	return RT_OK;
+}
+
+int rt_frame_submit(rt_context *ctx, const rt_render_params *p, int slot, Vector3 *frame_out)
+{
+	int rc = check_params(ctx, p);
+	if (rc != RT_OK) return rc;
+	if (!frame_out) return fail(RT_ERR_ARGUMENT, "rt_frame_submit: frame_out is NULL");
+	if (slot < 0 || slot >= RT_FRAME_SLOTS) return fail(RT_ERR_ARGUMENT, "rt_frame_submit: slot %d not in [0,%d)", slot, RT_FRAME_SLOTS);
+	if (p->world != 1) return fail(RT_ERR_ARGUMENT, "rt_frame_submit: world must be 1 (rt_multi_frame_submit renders on several GPUs)");
+	rt_context::frame_slot &f = ctx->fq[slot];
+	if (f.busy) return fail(RT_ERR_STATE, "rt_frame_submit: slot %d holds a frame that has not been waited for", slot);
+	HIP_TRY(hipSetDevice(ctx->device));
+	rc = frame_copy_stream(ctx);
+	if (rc != RT_OK) return rc;
+	if (!f.copied) HIP_TRY(hipEventCreateWithFlags(&f.copied, hipEventDisableTiming));
+	const size_t need = (size_t) rt_strip_rows(p->height, p->row_block, 1) * p->width * 3 * sizeof(float);
+	if (need > f.bytes) {
+		(void) hipFree(f.d_buf); f.d_buf = nullptr; f.bytes = 0;       /* (the slot is idle: its last copy was waited for) */
+		HIP_TRY(hipMalloc((void**) &f.d_buf, need));
+		f.bytes = need;
+	}
+	hipStream_t stream = (ctx->frames_submitted & 1ull) ? (hipStream_t) rt_stream(ctx, 1) : ctx->stream;
+	if (!stream) return RT_ERR_DEVICE;                                  /* rt_stream() left the text */
+	rc = rt_render_device(ctx, p, f.d_buf, stream);
+	if (rc != RT_OK) return rc;
+	ctx->frames_submitted++;
+	rt_context::launch_slot &sl = ctx->slot[ctx->cur];
+	/* the copy waits for the render (sl.done was recorded behind it on `stream`), nothing waits for the copy but the slot */
+	HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, sl.done, 0));
+	HIP_TRY(hipMemcpyAsync(frame_out, f.d_buf, (size_t) p->height * p->width * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->copy_stream));
+	HIP_TRY(hipMemcpyAsync(&ctx->h_words[1 + slot], sl.d_counter + 128 * 32 + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->copy_stream));
+	HIP_TRY(hipEventRecord(f.copied, ctx->copy_stream));
+	sl.readback = f.copied;
+	f.busy = true;
+	return RT_OK;
+}
+
+int rt_frame_wait(rt_context *ctx, int slot)
+{
+	if (!ctx || slot < 0 || slot >= RT_FRAME_SLOTS) return fail(RT_ERR_ARGUMENT, "rt_frame_wait: bad argument");
+	rt_context::frame_slot &f = ctx->fq[slot];
+	if (!f.busy) return fail(RT_ERR_STATE, "rt_frame_wait: nothing was submitted into slot %d", slot);
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipEventSynchronize(f.copied));
+	f.busy = false;
+	return ctx->h_words[1 + slot] ? RT_CANCELLED : RT_OK;
+}
+
+int rt_frame_poll(rt_context *ctx, int slot)
+{
+	if (!ctx || slot < 0 || slot >= RT_FRAME_SLOTS) return fail(RT_ERR_ARGUMENT, "rt_frame_poll: bad argument");
+	rt_context::frame_slot &f = ctx->fq[slot];
+	if (!f.busy) return fail(RT_ERR_STATE, "rt_frame_poll: nothing was submitted into slot %d", slot);
+	HIP_TRY(hipSetDevice(ctx->device));
+	const hipError_t e = hipEventQuery(f.copied);
+	if (e == hipErrorNotReady) return RT_PENDING;
+	if (e != hipSuccess) return fail(RT_ERR_DEVICE, "rt_frame_poll: %s", hipGetErrorString(e));
+	return rt_frame_wait(ctx, slot);
+}
+
+int rt_host_alloc(void **out, size_t bytes)
+{
+	if (!out || bytes == 0) return fail(RT_ERR_ARGUMENT, "rt_host_alloc: bad argument");
+	*out = nullptr;
+	const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+	if (e != hipSuccess) { *out = nullptr; return fail(RT_ERR_MEMORY, "rt_host_alloc(%zu): %s", bytes, hipGetErrorString(e)); }
+	return RT_OK;
+}
+
+void rt_host_free(void *p) { if (p) (void) hipHostFree(p); }
+
 /* The stop request travels on its own stream, so it overtakes the kernel it is meant for; the counter block is
  * cleared at the start of every launch.  Uses nothing of the context that a render call on
  * another thread changes. */
@@ -744,6 +845,7 @@ int rt_progressive_begin(rt_context *ctx, int width, int height, int init_scale,
 		HIP_TRY(hipMalloc((void**) &g.d_out, accum_bytes));
 		g.accum_bytes = accum_bytes;
 	}
+	if (!g.d_count) HIP_TRY(hipMalloc((void**) &g.d_count, sizeof(float)));
 	if (low_bytes != g.low_bytes) {
 		(void) hipFree(g.d_low); g.d_low = nullptr; g.low_bytes = 0;
 		HIP_TRY(hipMalloc((void**) &g.d_low, low_bytes));
@@ -751,6 +853,9 @@ int rt_progressive_begin(rt_context *ctx, int width, int height, int init_scale,
 	}
 	g.width = width; g.height = height; g.init_scale = init_scale; g.max_bounces = max_bounces; g.seed = seed;
 	g.active = true;
+	/* whatever rt_primary_pass left in the scratch sets belongs to an earlier low-resolution buffer (which may even have had
+	 * this one's address: the key hashes the pointer, not the contents) */
+	for (auto &sl : ctx->slot) sl.lists_key = 0;
 	return rt_progressive_invalidate(ctx);
 }
 
@@ -765,7 +870,8 @@ int rt_progressive_invalidate(rt_context *ctx)
 	 * (main.c:382: rt_accumulate looks at control[1]); the clear below is ordered behind it */
 	if (ctx->launches) { const int rc = rt_cancel(ctx); if (rc != RT_OK) return rc; }
 	HIP_TRY(hipMemsetAsync(g.d_accum, 0, g.accum_bytes, ctx->stream));
-	g.count = 0; g.passes = 0; g.scale = g.init_scale; g.generation++;
+	HIP_TRY(hipMemsetAsync(g.d_count, 0, sizeof(float), ctx->stream));
+	g.passes = 0; g.scale = g.init_scale; g.generation++;
 	return RT_OK;
 }
 
@@ -829,9 +935,10 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 		if (other.lists_key != key) other.lists_key = 0;
 	}
 	const float weight = 1.0f / (s * s);                                         /* main.c:278 */
-	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), L.control + 1, ctx->stream));
+	/* accum += pass * weight and accum_counts += weight (main.c:394-396), both on the device and both skipped for a pass
+	 * that rt_cancel() cut short (main.c:382): the count can never include a pass the buffer does not */
+	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), L.control + 1, g.d_count, ctx->stream));
 	{ const int rc = mark_launch(ctx, ctx->stream); if (rc != RT_OK) return rc; }
-	g.count += weight;                                                           /* main.c:396 */
 	g.passes++;
 	if (g.scale > 1) g.scale >>= 1;                                              /* main.c:402-403 */
 	if (weight_out) *weight_out = weight;
@@ -843,12 +950,16 @@ int rt_progressive_resolve(rt_context *ctx, Vector3 *frame_out)
 	if (!ctx || !ctx->prog.active) return fail(RT_ERR_STATE, "rt_progressive_resolve: call rt_progressive_begin first");
 	if (!frame_out) return fail(RT_ERR_ARGUMENT, "rt_progressive_resolve: frame_out is NULL");
 	auto &g = ctx->prog;
-	if (g.count < 0.0001)                                                        /* update_frame() waits for this, main.c:462 */
-		return fail(RT_ERR_STATE, "rt_progressive_resolve: nothing accumulated yet");
+	if (g.passes == 0) return fail(RT_ERR_STATE, "rt_progressive_resolve: nothing accumulated yet");
 	HIP_TRY(hipSetDevice(ctx->device));
-	HIP_TRY(rt_launch_resolve(g.d_accum, g.d_out, (size_t) g.width * g.height * 3, 1.0f / g.count, ctx->stream));
+	/* frame = accum * (1 / count) with the count the device holds (main.c:467-477) */
+	HIP_TRY(rt_launch_resolve(g.d_accum, g.d_out, (size_t) g.width * g.height * 3, g.d_count, ctx->stream));
 	HIP_TRY(hipMemcpyAsync(frame_out, g.d_out, g.accum_bytes, hipMemcpyDeviceToHost, ctx->stream));
+	float *h_count = reinterpret_cast<float*>(&ctx->h_words[8]);
+	HIP_TRY(hipMemcpyAsync(h_count, g.d_count, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	if ((double) *h_count < 0.0001)                                              /* update_frame() waits for this, main.c:462 */
+		return fail(RT_ERR_STATE, "rt_progressive_resolve: nothing accumulated yet (every pass so far was cancelled)");
 	return RT_OK;
 }
 
@@ -856,7 +967,13 @@ int rt_progressive_state(rt_context *ctx, int *next_scale, float *count, uint32_
 {
 	if (!ctx || !ctx->prog.active) return fail(RT_ERR_STATE, "rt_progressive_state: call rt_progressive_begin first");
 	if (next_scale) *next_scale = ctx->prog.scale;
-	if (count) *count = ctx->prog.count;
+	if (count) {          /* the passes enqueued so far, as far as they were published: waits for them */
+		HIP_TRY(hipSetDevice(ctx->device));
+		float *h_count = reinterpret_cast<float*>(&ctx->h_words[8]);
+		HIP_TRY(hipMemcpyAsync(h_count, ctx->prog.d_count, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		*count = *h_count;
+	}
 	if (generation) *generation = ctx->prog.generation;
 	if (passes) *passes = ctx->prog.passes;
 	return RT_OK;
@@ -894,10 +1011,24 @@ int rt_profile_enable(rt_context *ctx, int on)
 
 int rt_profile_collect(rt_context *ctx, double *kernel_ms_total, int *launches)
 {
+	return rt_profile_collect_span(ctx, kernel_ms_total, launches, nullptr);
+}
+
+int rt_profile_collect_span(rt_context *ctx, double *kernel_ms_total, int *launches, double *span_ms)
+{
 	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_profile_collect: NULL context");
 	HIP_TRY(hipSetDevice(ctx->device));
 	double total = 0;
 	int n = 0;
+	if (span_ms) {
+		*span_ms = 0;
+		if (!ctx->events.empty()) {
+			float ms = 0;
+			HIP_TRY(hipEventSynchronize(ctx->events.back().second));
+			HIP_TRY(hipEventElapsedTime(&ms, ctx->events.front().first, ctx->events.back().second));
+			*span_ms = ms;
+		}
+	}
 	for (auto &p : ctx->events) {
 		HIP_TRY(hipEventSynchronize(p.second));
 		float ms = 0;

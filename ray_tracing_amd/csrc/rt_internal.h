@@ -27,8 +27,8 @@ hipError_t rt_launch_deinterleave(const float *strips, float *frame, int width, 
                                   int row_block, int world, int rows_per_rank, hipStream_t stream);
 
 hipError_t rt_launch_accumulate(float *accum, const float *lowres, int width, int height, int scale,
-                                int low_w, int low_h, float k, const unsigned int *cancelled, hipStream_t stream);
-hipError_t rt_launch_resolve(const float *accum, float *frame, size_t floats, float inv_count, hipStream_t stream);
+                                int low_w, int low_h, float k, const unsigned int *cancelled, float *count, hipStream_t stream);
+hipError_t rt_launch_resolve(const float *accum, float *frame, size_t floats, const float *count, hipStream_t stream);
 hipError_t rt_launch_selftest(int which, uint64_t seed, int blocks, int iters, unsigned long long *d_out, hipStream_t stream);
 
 #endif

@@ -1265,9 +1265,12 @@ rt_trace_spec(const rt_launch L, unsigned int *block_counter)
 /* ---- progressive accumulation: worker()'s publish step (main.c:387-396) and update_frame()'s
  * resolve (main.c:467-477) ------------------------------------------------------------------ */
 extern "C" __global__ void __launch_bounds__(RT_BLOCK)
-rt_accumulate(float *accum, const float *lowres, int width, int height, int scale, int low_w, int low_h, float k, const unsigned int *cancelled)
+rt_accumulate(float *accum, const float *lowres, int width, int height, int scale, int low_w, int low_h, float k, const unsigned int *cancelled, float *count)
 {
 	if (*cancelled) return;               /* the pass was given up: it is not published (main.c:382) */
+	/* accum_counts[] += weight (main.c:396) lives beside the buffer it describes: a pass that rt_cancel() cut short
+	 * leaves both untouched, whatever the host believed when it enqueued the pass */
+	if (blockIdx.x == 0 && threadIdx.x == 0) *count = *count + k;
 	const size_t total = (size_t) width * height;
 	for (size_t p = (size_t) blockIdx.x * RT_BLOCK + threadIdx.x; p < total; p += (size_t) gridDim.x * RT_BLOCK) {
 		const int y = (int) (p / (size_t) width), x = (int) (p % (size_t) width);
@@ -1280,8 +1283,9 @@ rt_accumulate(float *accum, const float *lowres, int width, int height, int scal
 }
 
 extern "C" __global__ void __launch_bounds__(RT_BLOCK)
-rt_resolve(const float *accum, float *frame, size_t floats, float inv_count)
+rt_resolve(const float *accum, float *frame, size_t floats, const float *count)
 {
+	const float inv_count = 1.0f / *count;                                       /* main.c:476 */
 	for (size_t p = (size_t) blockIdx.x * RT_BLOCK + threadIdx.x; p < floats; p += (size_t) gridDim.x * RT_BLOCK)
 		frame[p] = accum[p] * inv_count;
 }
@@ -1511,15 +1515,15 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 }
 
 hipError_t rt_launch_accumulate(float *accum, const float *lowres, int width, int height, int scale,
-                                int low_w, int low_h, float k, const unsigned int *cancelled, hipStream_t stream)
+                                int low_w, int low_h, float k, const unsigned int *cancelled, float *count, hipStream_t stream)
 {
-	hipLaunchKernelGGL(rt_accumulate, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, lowres, width, height, scale, low_w, low_h, k, cancelled);
+	hipLaunchKernelGGL(rt_accumulate, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, lowres, width, height, scale, low_w, low_h, k, cancelled, count);
 	return hipGetLastError();
 }
 
-hipError_t rt_launch_resolve(const float *accum, float *frame, size_t floats, float inv_count, hipStream_t stream)
+hipError_t rt_launch_resolve(const float *accum, float *frame, size_t floats, const float *count, hipStream_t stream)
 {
-	hipLaunchKernelGGL(rt_resolve, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, frame, floats, inv_count);
+	hipLaunchKernelGGL(rt_resolve, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, frame, floats, count);
 	return hipGetLastError();
 }
 

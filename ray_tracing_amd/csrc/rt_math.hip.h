@@ -165,27 +165,40 @@ RT_DEV V3 unit3_fast(V3 v)
 
 /* ---- RNG: utils.c:60-75 ---------------------------------------------------------------- */
 
-/* hi64(a*b) ^ lo64(a*b) with the four 32x32 partial products formed once (each line is one
- * v_mad_u64_u32); written out because `__umul64hi(a,b) ^ (a*b)` makes the compiler form them twice */
-RT_DEV uint64_t fold_mul(uint64_t a, uint64_t b)
+/* hi64(a*B) ^ lo64(a*B) with the four 32x32 partial products formed once (each line is one
+ * v_mad_u64_u32); written out because `__umul64hi(a,b) ^ (a*b)` makes the compiler form them twice.
+ * The multiplier is a template argument: the two the generator uses (utils.c:64,67) are literals, and the inline asm
+ * below takes the multiplier's low word in a SCALAR register -- a lane-varying value there would silently be replaced
+ * by its first lane's. */
+template <uint64_t B>
+RT_DEV uint64_t fold_mul(uint64_t a)
 {
-	const uint32_t a0 = (uint32_t) a, a1 = (uint32_t) (a >> 32), b0 = (uint32_t) b, b1 = (uint32_t) (b >> 32);
+	constexpr uint32_t b0 = (uint32_t) B, b1 = (uint32_t) (B >> 32);
+	const uint32_t a0 = (uint32_t) a, a1 = (uint32_t) (a >> 32);
 	const uint64_t p0 = (uint64_t) a0 * b0;
 	const uint64_t x  = (uint64_t) a0 * b1 + (p0 >> 32);          /* fits 64 bits */
-	/* a1*b0 + x can carry out of 64 bits: v_mad_u64_u32 reports it (the compiler has no pattern for that carry, so it
-	 * would split x into halves and add them separately: two moves and a 64-bit add more per product) */
+#if defined(__gfx950__) || defined(__gfx942__) || defined(__gfx90a__)
+	/* a1*b0 + x can carry out of 64 bits: v_mad_u64_u32 reports it in its wave64 carry mask (the compiler has no
+	 * pattern for that carry, so it would split x into halves and add them separately: two moves and a 64-bit add
+	 * more per product) */
 	uint64_t y, carry, unused;
 	asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(y), "=&s"(carry) : "v"(a1), "s"(b0), "v"(x));
-	const uint64_t h = (uint64_t) a1 * b1 + (y >> 32);            /* high 64 bits of a*b, but for that carry (weight 2^96) */
+	const uint64_t h = (uint64_t) a1 * b1 + (y >> 32);            /* high 64 bits of a*B, but for that carry (weight 2^96) */
 	uint32_t h1;
 	asm("v_addc_co_u32 %0, %1, 0, %2, %3" : "=v"(h1), "=&s"(unused) : "v"((uint32_t) (h >> 32)), "s"(carry));
 	return ((uint64_t) (h1 ^ (uint32_t) y) << 32) | (uint64_t) ((uint32_t) h ^ (uint32_t) p0);
+#else
+	const uint64_t m = (uint64_t) a1 * b0;
+	const uint64_t y = m + x;                                     /* may wrap: the carry has weight 2^96 */
+	const uint64_t h = (uint64_t) a1 * b1 + (y >> 32) + ((uint64_t) (y < m) << 32);
+	return ((uint64_t) ((uint32_t) (h >> 32) ^ (uint32_t) y) << 32) | (uint64_t) ((uint32_t) h ^ (uint32_t) p0);
+#endif
 }
 
 RT_DEV float rng_draw(uint64_t &state)
 {
 	state += 0x60bee2bee120fc15ull;
-	uint64_t bits = fold_mul(fold_mul(state, 0xa3b195354a39b70dull), 0x1b03738712fad5c9ull);
+	uint64_t bits = fold_mul<0x1b03738712fad5c9ull>(fold_mul<0xa3b195354a39b70dull>(state));
 	return (float) bits * 0x1p-64f;       /* == (float)bits / (float)UINT64_MAX, the divisor is 2^64 */
 }
 

@@ -131,6 +131,7 @@ class Oracle:
         L.orc_pixel.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_uint64), C.c_void_p]
         L.orc_render_stream.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]
         L.orc_render_counter.argtypes = [C.c_int] * 4 + [C.c_uint64] + [C.c_int] * 3 + [C.c_void_p]
+        L.orc_render_counter_rows.argtypes = [C.c_int] * 4 + [C.c_uint64, C.c_void_p] + [C.c_int] * 2 + [C.c_void_p]
         L.orc_time_columns.argtypes = [C.c_int] * 5
         L.orc_parse_scene_file.argtypes = [C.c_char_p, C.c_void_p]
         L.orc_parse_scene_string.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
@@ -245,6 +246,16 @@ class Oracle:
         frame = np.zeros((H, W, 3), np.float32)
         self.L.orc_render_counter(W, H, spp, max_bounces, seed, r0, r1, threads, _fp(frame))
         return frame
+
+    def render_counter_rows(self, W, H, spp, max_bounces, rows, seed=0, threads=None):
+        """Only the listed frame rows (dealt dynamically to the threads); returns {row: [W, 3] array}."""
+        rows = np.ascontiguousarray(sorted(set(int(r) for r in rows)), dtype=np.int32)
+        assert len(rows) and rows[0] >= 0 and rows[-1] < H
+        if threads is None:
+            threads = min(os.cpu_count() or 1, 32)
+        frame = np.zeros((H, W, 3), np.float32)
+        self.L.orc_render_counter_rows(W, H, spp, max_bounces, seed, rows.ctypes.data_as(C.c_void_p), len(rows), threads, _fp(frame))
+        return {int(r): frame[int(r)] for r in rows}
 
     def time_columns(self, W, H, passes, max_bounces, threads):
         self.L.orc_time_columns(W, H, passes, max_bounces, threads)
