@@ -15,9 +15,13 @@ A step = one full frame through the hot path, ending where the reference's updat
 then -- for N > 1 -- ONE RCCL gather of the finished strips to rank 0 and a de-interleave kernel there, then
 the resolved Vector3[W*H] frame is copied to (pinned) HOST memory on rank 0.  Inputs (scene, skybox,
 camera) are resident in HBM before the timed region.  Two frames are in flight (three for N > 1): the gather / host
-copy of frame k overlaps the render of the following frames (ray_tracing_amd/multi_gpu.py); `frame_latency` reports the same
-frame with nothing overlapped (first launch -> frame on the host, median of 7).  The same frame is split
-over N GPUs, so scaling is "strong".
+copy of frame k overlaps the render of the following frames; `frame_latency` reports the same frame with nothing
+overlapped (first launch -> frame on the host, median of 7).  The same frame is split over N GPUs, so scaling is "strong".
+At N = 1 the frame loop is the library's own, behind the C ABI (rt_frame_submit / rt_frame_wait through ctypes:
+ray_tracing_amd/frames.py); under torch.distributed.run (N > 1, one process per GPU) the collective is torch's, so the
+loop is ray_tracing_amd/multi_gpu.py on top of rt_render_device.  Step k renders seed k, and after the timed region the
+last frame is compared bit for bit with a blocking rt_render() of its seed and with rows of the CPU oracle
+("verified"); a mismatch makes the process exit non-zero.
 
 Rank 0 prints ONE JSON line; `roofline` is computed from HIP-event kernel times measured over the timed
 region and from ALGORITHMIC flops/bytes counted by the CPU oracle's instrumented build; `cpu_baseline` times
@@ -69,6 +73,9 @@ def parse_args(argv=None):
     ap.add_argument("--force-collective", action="store_true",
                     help="testing aid for 1-GPU boxes: one rank runs the N > 1 frame loop (RCCL gather on a one-rank group, "
                          "de-interleave, three strip buffers) so that loop's cost shows beside the plain N = 1 line")
+    ap.add_argument("--torch-loop", action="store_true",
+                    help="N = 1: run the torch-side frame loop (multi_gpu.TiledFrame) instead of the C ABI's frame queue")
+    ap.add_argument("--depth", type=int, default=0, help="frames in flight in the C ABI's frame queue (default 2; 3 with --force-collective)")
     return ap.parse_args(argv)
 
 
@@ -84,6 +91,14 @@ def self_launch(args, argv):
     """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: start the N ranks as a CHILD
     process tree.  Nothing in this process has touched the GPU (torch is not even imported yet), and it is never
     replaced by exec: it waits for the child and exits with its status."""
+    # Under rocprofv3 the profiler's preloaded library has initialised the GPU before main() runs, and starting another
+    # program from a GPU-initialised process is what this pool forbids: profiled runs are single-rank (bench.py --gpus 1,
+    # scripts/render_cfg.py), see profiles/README.md.
+    preload = os.environ.get("LD_PRELOAD", "")
+    if "rocprof" in preload or any(k.startswith(("ROCPROFILER_", "ROCP_")) for k in os.environ):
+        print("[bench] --gpus N > 1 cannot self-launch under a profiler (the parent has initialised the GPU); "
+              "profile a single rank with --gpus 1", file=sys.stderr)
+        return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
@@ -224,7 +239,7 @@ def main():
         args.backend = args.backend or "gloo"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or args.force_collective:
+    if world > 1 or (args.force_collective and args.torch_loop):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
         # the collective's internal stream on its own (high-priority) hardware queue: streams of equal priority share a
@@ -255,52 +270,123 @@ def main():
         except rt.RtError as e:
             print(f"[bench] scene not specialised, using the generic kernel: {e}", file=sys.stderr)
 
-    from ray_tracing_amd.multi_gpu import TiledFrame
-    tiled = TiledFrame(gpu, W, H, spp, nb, seed=seed, row_block=ROW_BLOCK, rank=rank, world=world,
-                       kernel=args.kernel, device=dev, to_host=True, force_collective=args.force_collective)
-
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        tiled.step()
-    tiled.flush()
+    # ---- the frame loop: the library's own frame queue behind the C ABI at N = 1 (rt_frame_submit / rt_frame_wait; with
+    # --force-collective the N-GPU path of rt_multi_frame_* over a one-rank RCCL communicator), torch.distributed's
+    # collective around rt_render_device when every GPU has its own process (N > 1) -----------------------------------
+    native = world == 1 and not args.torch_loop
+    multi_path = world > 1 or args.force_collective
+    if native:
+        from ray_tracing_amd.frames import FrameLoop
+        queue = gpu
+        if args.force_collective:
+            queue = rt.MultiRenderer([local_rank])
+            queue.set_tuning(force_collective=1)
+            queue.set_scene(scene_path); queue.set_skybox(sky); queue.set_camera()
+            if compiled:
+                queue.compile_scene()
+            prof = queue.context(0)
+        else:
+            prof = gpu
+        depth = args.depth or (3 if args.force_collective else 2)
+        loop = FrameLoop(queue, W, H, spp, nb, depth=depth, row_block=ROW_BLOCK, kernel=args.kernel)
+        primitive = "ncclGather (native, one process)" if args.force_collective else None
+
+        def run_steps(first_seed, n):
+            t0 = time.perf_counter()
+            stamps = loop.run(range(first_seed, first_seed + n))
+            return t0, stamps
+
+        def one_frame(seed_):
+            return loop.render_now(seed_)
+
+        def last_frame():
+            return loop.last
+    else:
+        from ray_tracing_amd.multi_gpu import TiledFrame
+        tiled = TiledFrame(gpu, W, H, spp, nb, seed=seed, row_block=ROW_BLOCK, rank=rank, world=world,
+                           kernel=args.kernel, device=dev, to_host=True, force_collective=args.force_collective)
+        prof = gpu
+        depth = 3 if tiled.multi else 2
+        primitive = tiled.primitive
+
+        def run_steps(first_seed, n):
+            t0 = time.perf_counter()
+            for k in range(n):
+                tiled.step(seed=first_seed + k)
+            tiled.flush()                   # every frame gathered, de-interleaved and resident in host memory
+            return t0, None
+
+        def one_frame(seed_):
+            return tiled.render_now(seed=seed_)
+
+        def last_frame():
+            return tiled.host_frame.numpy() if tiled.host_frame is not None else None
+
+    # step k of the run renders seed k (warm-up first): a stale or re-ordered frame cannot hide behind equal seeds
+    run_steps(seed, args.warmup)
     fence()
-    gpu.profile(True)
-    tiled.record_events = True
-    start = torch.cuda.Event(enable_timing=True)
-    start.record(tiled.streams[tiled.k & 1])
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tiled.step()
-    tiled.flush()                       # every frame gathered, de-interleaved and resident in host memory
+    prof.profile(True)
+    first_timed = seed + args.warmup
+    if not native:
+        tiled.record_events = True
+        start = torch.cuda.Event(enable_timing=True)
+        start.record(tiled.streams[tiled.k & 1])
+    t0, stamps = run_steps(first_timed, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    tiled.record_events = False
-    # Kernel time of a launch, two ways (HIP events, all launches of the timed region).  (a) per launch: from its first
-    # compute unit (behind the clearing of its counters) to the end of its trace kernel, summed -- consecutive launches
-    # are enqueued on two streams and overlap on the GPU (the next frame's waves fill the compute units while this
+    last_seed = first_timed + args.steps - 1
+    # Kernel time of a launch, two ways (HIP events inside the library, all launches of the timed region).  (a) per launch:
+    # from its first compute unit (behind the clearing of its counters) to the end of its trace kernel, summed -- consecutive
+    # launches are enqueued on two streams and overlap on the GPU (the next frame's waves fill the compute units while this
     # frame's run out of pixels), and the ~0.1 ms two launches share is in both of them, as it is in rocprofv3's
-    # per-kernel durations.  (b) the span from before the first launch to behind the last trace kernel, over the
-    # launches in it: no double counting, but it contains idle time when the launches wait for something else (C3:
+    # per-kernel durations.  (b) the span from the first launch's first compute unit to the end of the last trace kernel,
+    # over the launches in it: no double counting, but it contains idle time when the launches wait for something else (C3:
     # for the host copy of the frame before last).  Both are upper bounds of the time the GPU needs per launch.
-    per_launch_ms, launches = gpu.profile_collect()
-    gpu.profile(False)
-    span_ms = start.elapsed_time(tiled.render_events[-1]) if tiled.render_events else 0.0
-    span_launches = len(tiled.render_events)
-    tiled.render_events = []
-    kernel_ms = min(per_launch_ms, span_ms * launches / span_launches) if span_launches and launches else per_launch_ms
-    marks = [start] + tiled.done_events
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)) if len(marks) > 1 else []
-    tiled.done_events = []
+    per_launch_ms, launches, span_ms = prof.profile_collect_span()
+    prof.profile(False)
+    span_launches = launches
+    kernel_ms = min(per_launch_ms, span_ms) if launches and span_ms > 0 else per_launch_ms
+    if native:
+        marks = [t0] + stamps
+        step_ms = sorted((marks[i + 1] - marks[i]) * 1e3 for i in range(1, len(marks) - 1))   # (the first interval holds the pipeline fill)
+    else:
+        tiled.record_events = False
+        marks = [start] + tiled.done_events
+        step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)) if len(marks) > 1 else []
+        tiled.done_events = []; tiled.render_events = []
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+
+    # ---- what was timed is what was asked for: the last frame of the timed region against a blocking rt_render() of its
+    # seed (whole frame, bit for bit) and against rows of the CPU oracle.  Outside the timed region. -------------------
+    verified = None
+    if rank == 0:
+        got = np.array(last_frame(), copy=True)
+        check = rt.Renderer(local_rank)
+        check.set_scene(scene_path); check.set_skybox(sky); check.set_camera()
+        want = check.render(W, H, spp, nb, seed=last_seed)          # generic kernel, one GPU, blocking
+        check.close()
+        same = bool((got.view(np.uint32) == want.view(np.uint32)).all())
+        verified = {"last_frame_seed": last_seed, "equals_blocking_rt_render": same, "frame_mean": round(float(got.mean()), 6)}
+        try:
+            from rtlibs import Oracle
+            o = Oracle(); o.load_scene(scene_path); o.set_skybox(sky); o.set_camera()
+            rows = [H // 3, (2 * H) // 3 + 1]
+            ref_rows = o.render_counter_rows(W, H, spp, nb, rows, seed=last_seed)
+            verified["oracle_rows"] = rows
+            verified["equals_oracle_rows"] = bool(all((got[r].view(np.uint32) == v.view(np.uint32)).all() for r, v in ref_rows.items()))
+        except Exception as e:       # the oracle is a checker that may be absent; the GPU-vs-GPU check above stands
+            verified["oracle_error"] = repr(e)
+        verified["ok"] = same and verified.get("equals_oracle_rows", True)
 
     # ---- the same frame with nothing overlapped: first launch -> frame on the host (SURVEY.md 8d protocol)
     latency = None
@@ -309,7 +395,7 @@ def main():
         for _ in range(7):
             fence()
             t1 = time.perf_counter()
-            tiled.render_now()
+            one_frame(seed)
             if world > 1:
                 dist.barrier()
             runs.append((time.perf_counter() - t1) * 1e3)
@@ -327,14 +413,17 @@ def main():
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "verified": bool(verified and verified["ok"]), "verification": verified,
             "config": {"workload": f"{w['name']}: {w['scene']} {W}x{H}, {spp} spp, {nb} bounces, default camera, "
-                                   f"counter-mode RNG seed {seed}, shipped skybox (6x2048x2048)",
+                                   f"counter-mode RNG seeds {seed}.. (one per step), shipped skybox (6x2048x2048)",
                        "timed_region": "K frames, each: strip render -> "
-                                       + ("one RCCL gather to rank 0 -> de-interleave -> " if tiled.multi else "")
-                                       + "resolved frame copied to pinned host memory; " + ("three" if tiled.multi else "two") + " frames in flight",
+                                       + ("one RCCL gather to rank 0 -> de-interleave -> " if multi_path else "")
+                                       + f"resolved frame copied to pinned host memory; {depth} frames in flight; step k renders seed k",
+                       "frame_loop": "C ABI frame queue (rt_frame_submit / rt_frame_wait)" if native and not args.force_collective
+                                     else "C ABI frame queue of the device group (rt_multi_frame_submit / rt_multi_frame_wait)" if native
+                                     else "multi_gpu.TiledFrame: rt_render_device + torch.distributed collective, one process per GPU",
                        "partition": f"interleaved blocks of {ROW_BLOCK} rows over {world} " + ("rank(s) SHARING ONE GPU (testing aid)" if args.share_gpu else "GPU(s)")
-                                    + (f"; collective: {tiled.primitive}" if tiled.multi else "")
+                                    + (f"; collective: {primitive}" if multi_path else "")
                                     + (" (one-rank group: testing aid)" if args.force_collective and world == 1 else ""),
                        "kernel": {0: "wavefront" + ("+scene-specialised (hiprtc)" if compiled else ""), 1: "simple",
                                   2: "wavefront, plain IEEE ops"}.get(args.kernel, str(args.kernel))},
@@ -360,6 +449,7 @@ def main():
             out["roofline_error"] = repr(e)
         if work and launches:
             avg_ms = kernel_ms / launches
+            span_launches = launches
             samples_per_launch = samples_per_step / world
             flops = work["flops"] * samples_per_launch
             # algorithmic bytes: 3 B per skybox fetch + 12 B per pixel written once per launch
@@ -398,23 +488,16 @@ def main():
             if tr:
                 out["roofline"]["traffic"] = round(tr["fetch_bytes"] + tr["write_bytes"])
                 out["roofline"]["traffic_note"] = tr.get("source", "")
-        # ---- the generic kernel (no hiprtc): same frame, same events
-        if world == 1 and compiled and not args.no_extras:
+        # ---- the generic kernel (no hiprtc): same frames, same events
+        if native and not args.force_collective and compiled and not args.no_extras:
             gpu.set_scene(scene_path)                 # drops the compiled kernel
-            tiled.render_now()
+            one_frame(seed)
             gpu.profile(True)
-            tiled.record_events = True
-            g_start = torch.cuda.Event(enable_timing=True)
-            g_start.record(tiled.streams[tiled.k & 1])
-            for _ in range(5):
-                tiled.step()
-            tiled.flush()
-            tiled.record_events = False
-            g_ms, g_n = gpu.profile_collect()
+            run_steps(seed, 5)
+            g_ms, g_n, g_span = gpu.profile_collect_span()
             gpu.profile(False)
-            if tiled.render_events and g_n:
-                g_span = g_start.elapsed_time(tiled.render_events[-1]) / len(tiled.render_events)
-                out.setdefault("roofline", {})["generic_kernel_ms"] = round(min(g_ms / g_n, g_span), 4)
+            if g_n:
+                out.setdefault("roofline", {})["generic_kernel_ms"] = round(min(g_ms, g_span) / g_n, 4)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(rt, w, sky)
@@ -424,10 +507,17 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
+    if native:
+        loop.close()
+        if queue is not gpu:
+            queue.close()
     gpu.close()
-    if world > 1 or args.force_collective:
+    if world > 1 or (args.force_collective and not native):
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and not (verified and verified["ok"]):
+        print(f"[bench] VERIFICATION FAILED: {verified}", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -65,6 +65,8 @@ class MouseState(C.Structure):
 EXPORTS = [
     "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
     "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_spec_stats_read", "rt_spec_symbol_read", "rt_render", "rt_render_device", "rt_stream", "rt_reserve", "rt_strip_rows", "rt_deinterleave_device",
+    "rt_frame_submit", "rt_frame_wait", "rt_frame_poll", "rt_host_alloc", "rt_host_free",
+    "rt_multi_frame_submit", "rt_multi_frame_wait", "rt_multi_frame_poll", "rt_profile_collect_span",
     "rt_synchronize", "rt_cancel", "rt_was_cancelled", "rt_primary_passes_run", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
     "rt_progressive_invalidate", "rt_progressive_state", "rt_selftest", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
     "rt_parse_scene_string", "rt_load_cubemap", "rt_free_cubemap", "rt_decode_jpeg_file",
@@ -131,6 +133,16 @@ def lib():
         L.rt_multi_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
         L.rt_multi_compile_scene.argtypes = [C.c_void_p]
         L.rt_multi_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p]
+    if hasattr(L, "rt_frame_submit"):
+        L.rt_frame_submit.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_int, C.c_void_p]
+        L.rt_frame_wait.argtypes = [C.c_void_p, C.c_int]
+        L.rt_frame_poll.argtypes = [C.c_void_p, C.c_int]
+        L.rt_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        L.rt_host_free.argtypes = [C.c_void_p]
+        L.rt_multi_frame_submit.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_int, C.c_void_p]
+        L.rt_multi_frame_wait.argtypes = [C.c_void_p, C.c_int]
+        L.rt_multi_frame_poll.argtypes = [C.c_void_p, C.c_int]
+        L.rt_profile_collect_span.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.rt_progressive_begin.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
     L.rt_progressive_pass.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.rt_progressive_resolve.argtypes = [C.c_void_p, C.c_void_p]
@@ -222,9 +234,62 @@ def strip_rows(height, row_block, world):
 
 # ---- the GPU path ---------------------------------------------------------------------------------
 
-class Renderer:
+FRAME_SLOTS = 4          # RT_FRAME_SLOTS
+PENDING, CANCELLED = 2, 1
+
+
+class HostFrame:
+    """Page-locked host memory for one frame (rt_host_alloc), viewed as a float32 array (height, width, 3)."""
+
+    def __init__(self, width, height):
+        self._p = C.c_void_p()
+        _check(lib().rt_host_alloc(C.byref(self._p), width * height * 12), "rt_host_alloc")
+        self.ptr = self._p.value
+        self.array = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_float)), shape=(height, width, 3))
+
+    def free(self):
+        if self._p:
+            self.array = None
+            lib().rt_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class _FrameQueue:
+    """rt_frame_submit / rt_frame_wait / rt_frame_poll of a Renderer or MultiRenderer."""
+
+    def frame_submit(self, params, slot, host):
+        """host: a HostFrame (or any writable float32 array of the frame's size; page-locked memory lets the copy overlap)."""
+        ptr = host.ptr if isinstance(host, HostFrame) else host.ctypes.data
+        _check(getattr(lib(), self._prefix + "frame_submit")(self._handle(), C.byref(params), slot, C.c_void_p(ptr)), self._prefix + "frame_submit")
+
+    def frame_wait(self, slot):
+        """Blocks until the slot's frame is in host memory; True if it is complete, False if rt_cancel() cut it short."""
+        rc = getattr(lib(), self._prefix + "frame_wait")(self._handle(), slot)
+        if rc < 0:
+            _check(rc, self._prefix + "frame_wait")
+        return rc == 0
+
+    def frame_poll(self, slot):
+        """None while the frame is on its way; otherwise as frame_wait()."""
+        rc = getattr(lib(), self._prefix + "frame_poll")(self._handle(), slot)
+        if rc < 0:
+            _check(rc, self._prefix + "frame_poll")
+        return None if rc == PENDING else rc == 0
+
+
+class Renderer(_FrameQueue):
     """One rt_context = one GPU.  Mirrors the life cycle of the reference's main(): set scene,
     skybox and camera once, then render frames."""
+    _prefix = "rt_"
+
+    def _handle(self):
+        return self._ctx
 
     def __init__(self, device=0):
         self._ctx = C.c_void_p()
@@ -233,9 +298,9 @@ class Renderer:
         self._keep = {}
 
     def close(self):
-        if self._ctx:
+        if self._ctx and not getattr(self, "_borrowed", False):
             lib().rt_destroy(self._ctx)
-            self._ctx = C.c_void_p()
+        self._ctx = C.c_void_p()
 
     def __del__(self):
         try:
@@ -393,9 +458,26 @@ class Renderer:
         _check(lib().rt_profile_collect(self._ctx, C.byref(ms), C.byref(n)), "rt_profile_collect")
         return ms.value, n.value
 
+    def profile_collect_span(self):
+        """(summed per-launch kernel ms, launches, ms from the first launch's start to the end of the last one's trace kernel)"""
+        ms, n, span = C.c_double(), C.c_int(), C.c_double()
+        _check(lib().rt_profile_collect_span(self._ctx, C.byref(ms), C.byref(n), C.byref(span)), "rt_profile_collect_span")
+        return ms.value, n.value, span.value
 
-class MultiRenderer:
+
+class MultiRenderer(_FrameQueue):
     """rt_multi_*: one frame on several GPUs of this node from one process (native RCCL gather, no torch)."""
+    _prefix = "rt_multi_"
+
+    def _handle(self):
+        return self._m
+
+    def context(self, i):
+        """Device i's rt_context as a Renderer view (owned by the group: do not close it)."""
+        r = Renderer.__new__(Renderer)
+        r._ctx = C.c_void_p(lib().rt_multi_context(self._m, i))
+        r.device, r._keep, r._borrowed = i, {}, True
+        return r
 
     def __init__(self, devices):
         devices = list(devices)

@@ -16,6 +16,13 @@
  *   --gpus <n>           render on GPUs 0..n-1 of this node at once (row blocks interleaved over them, one RCCL
  *                        gather of the strips): the counterpart of the reference's --threads
  *   --out <file>         where the presenter hook writes the frame: .png or .ppm (default frame.ppm)
+ *   --frames <k>         render k frames (seeds seed, seed+1, ...) with two in flight -- rt_multi_frame_submit /
+ *                        rt_multi_frame_wait: the copy of a frame to the host runs beside the render of the next, as the
+ *                        reference's workers keep rendering while its main thread presents (main.c:354-408 vs 450-482) --
+ *                        and print the rate; the last frame goes to the presenter hook
+ *   --compile            specialise the trace kernel for the scene first (rt_compile_scene; same pixels)
+ *   --force-collective   testing aid for 1-GPU boxes: one device runs the N-GPU path all the same (RCCL gather on a one-rank
+ *                        communicator, de-interleave, three strip buffers)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -46,7 +53,7 @@ static double now_s(void)
 int main(int argc, char **argv)
 {
 	const char *scene_file = NULL, *sky_dir = "assets/skybox";
-	int width = 1280, height = 960, spp = 16, bounces = 10, device = 0, gpus = 0;
+	int width = 1280, height = 960, spp = 16, bounces = 10, device = 0, gpus = 0, frames = 0, compile = 0, force_collective = 0;
 	unsigned long long seed = 0;
 
 	for (int i = 1; i < argc; i++) {
@@ -65,6 +72,9 @@ int main(int argc, char **argv)
 		else if (!strcmp(a, "--device"))     { NEED_VALUE(); device = atoi(v); }
 		else if (!strcmp(a, "--gpus"))       { NEED_VALUE(); gpus = atoi(v); }
 		else if (!strcmp(a, "--out"))        { NEED_VALUE(); out_file = v; }
+		else if (!strcmp(a, "--frames"))     { NEED_VALUE(); frames = atoi(v); }
+		else if (!strcmp(a, "--compile"))    { compile = 1; }
+		else if (!strcmp(a, "--force-collective")) { force_collective = 1; }
 		else fprintf(stderr, "Warning: Ignoring option %s\n", a);
 #undef NEED_VALUE
 	}
@@ -106,12 +116,62 @@ int main(int argc, char **argv)
 	rt_camera_default(&cam);
 	rt_multi_set_camera(group, &cam);
 
-	Vector3 *frame = malloc(sizeof(Vector3) * (size_t) width * height);
-	if (!frame) { printf("OUT OF MEMORY\n"); return -1; }
+	if (force_collective) {
+		rt_tuning t;
+		rt_default_tuning(&t);
+		t.force_collective = 1;
+		rt_multi_set_tuning(group, &t);
+	}
+	if (compile && rt_multi_compile_scene(group) != RT_OK)
+		fprintf(stderr, "Warning: %s (continuing with the generic kernel)\n", rt_last_error());
 
 	rt_render_params p;
 	rt_default_params(&p, width, height, spp, bounces);
 	p.seed = seed;
+	rt_set_frame_sink(write_frame, NULL);
+
+	if (frames > 0) {
+		/* the presenter's loop with two frames in flight: submit k+1, wait for k, hand k on */
+		Vector3 *buf[2] = { NULL, NULL };
+		for (int s = 0; s < 2; s++)
+			if (rt_host_alloc((void **) &buf[s], sizeof(Vector3) * (size_t) width * height) != RT_OK) {
+				fprintf(stderr, "Error: %s\n", rt_last_error());
+				return -1;
+			}
+		if (rt_multi_frame_submit(group, &p, 0, buf[0]) != RT_OK || rt_multi_frame_wait(group, 0) < 0) {    /* warm-up: allocations, first launches */
+			fprintf(stderr, "Error: %s\n", rt_last_error());
+			return -1;
+		}
+		double t0 = now_s();
+		int rc = rt_multi_frame_submit(group, &p, 0, buf[0]);
+		for (int k = 0; k < frames && rc >= 0; k++) {
+			if (k + 1 < frames) {
+				rt_render_params q = p;
+				q.seed = seed + (unsigned long long) (k + 1);
+				rc = rt_multi_frame_submit(group, &q, (k + 1) & 1, buf[(k + 1) & 1]);
+				if (rc < 0) break;
+			}
+			rc = rt_multi_frame_wait(group, k & 1);       /* frame k is in buf[k & 1]: update_frame() would present it now */
+		}
+		if (rc < 0) {
+			fprintf(stderr, "Error: %s\n", rt_last_error());
+			return -1;
+		}
+		double dt = now_s() - t0;
+		fprintf(stderr, "Rendered %d frames of %dx%d, %d spp, %d bounces on %d GPU(s), two in flight: %.3f ms per frame, %.1f Msamples/s (frames in host memory)\n",
+		        frames, width, height, spp, bounces, rt_multi_size(group), dt / frames * 1e3, (double) width * height * spp * frames / dt / 1e6);
+		printf("{\"frames\": %d, \"ms_per_frame\": %.4f, \"msamples_per_s\": %.2f, \"gpus\": %d}\n",
+		       frames, dt / frames * 1e3, (double) width * height * spp * frames / dt / 1e6, rt_multi_size(group));
+		rt_move_frame_to_the_gpu(width, height, buf[(frames - 1) & 1]);   /* where update_frame() hands off, main.c:479 */
+		rt_host_free(buf[0]); rt_host_free(buf[1]);
+		rt_free_cubemap(&skybox);
+		rt_multi_destroy(group);
+		return 0;
+	}
+
+	Vector3 *frame = malloc(sizeof(Vector3) * (size_t) width * height);
+	if (!frame) { printf("OUT OF MEMORY\n"); return -1; }
+
 	double t0 = now_s();
 	if (rt_multi_render(group, &p, frame) != RT_OK) {
 		fprintf(stderr, "Error: %s\n", rt_last_error());
@@ -121,7 +181,6 @@ int main(int argc, char **argv)
 	fprintf(stderr, "Rendered %dx%d, %d spp, %d bounces on %d GPU(s) in %.3f s (%.1f Msamples/s incl. copy-back)\n",
 	        width, height, spp, bounces, rt_multi_size(group), dt, (double) width * height * spp / dt / 1e6);
 
-	rt_set_frame_sink(write_frame, NULL);
 	rt_move_frame_to_the_gpu(width, height, frame);   /* where update_frame() hands off, main.c:479 */
 
 	free(frame);

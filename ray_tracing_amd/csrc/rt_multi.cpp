@@ -3,19 +3,29 @@
  * (include/rt_hip.h, rt_multi_*).
  *
  * The reference fans its work out inside the host binary: start_workers() creates one pthread per image
- * column and every worker adds its passes into the shared accumulation buffer (main.c:695-718, 324-414).
- * Here the fan-out is over GPUs: rt_multi_render() gives device i the row blocks b with b % n == i (the same
- * interleaved partition rt_render_device() implements for one rank), every device renders its strip
- * concurrently on its own stream, ONE grouped ncclGather over xGMI brings the strips to device 0, a
- * de-interleave kernel there puts the rows in frame order and the frame is copied to the caller's host
- * buffer -- what update_frame() hands to move_frame_to_the_gpu() (main.c:467-479).
+ * column and every worker adds its passes into the shared accumulation buffer (main.c:695-718, 324-414),
+ * while the main thread presents what has been accumulated so far (main.c:450-482).
+ * Here the fan-out is over GPUs: device i gets the row blocks b with b % n == i (the same interleaved partition
+ * rt_render_device() implements for one rank), every device renders its strip concurrently, ONE grouped
+ * ncclGather over xGMI brings the strips to device 0, a de-interleave kernel there puts the rows in frame order
+ * and the frame is copied to the caller's host buffer -- what update_frame() hands to move_frame_to_the_gpu()
+ * (main.c:467-479).  Frames are SUBMITTED and WAITED for (rt_multi_frame_submit / rt_multi_frame_wait), so that
+ * the gather, the de-interleave and the copy of frame k run beside the renders of frames k+1 and k+2;
+ * rt_multi_render() is submit + wait.
  *
- * RCCL is loaded with dlopen() on the first multi-device create (as rt_jit.cpp does for hiprtc), so the library
- * has no link-time dependency on it and single-GPU hosts never touch it.  There is no fallback: if RCCL cannot
- * be loaded or initialised, rt_multi_create() with n > 1 fails with RT_ERR_DEVICE.
+ * Streams per device: the context's two render streams (frame k on stream k & 1: consecutive strips overlap on the
+ * GPU, rt_api.cpp) and one high-priority stream for the collective (and, on device 0, the de-interleave); device 0
+ * has one more for the copy to the host.  Strips rotate through three buffers per device: the persistent trace kernel of
+ * frame k+1 holds every compute unit until it drains, so the collective of frame k only gets to run then, and a render
+ * stream must not wait for it -- it waits (through an event) for the gather three frames back, whose strip buffer it
+ * reuses.
+ *
+ * RCCL is loaded with dlopen() on the first multi-device create (as rt_jit.cpp does for hiprtc) and the handful of
+ * entry points used are declared here, so the library needs neither RCCL's headers nor its .so at build or load time,
+ * and single-GPU hosts never touch it.  There is no fallback: if RCCL cannot be loaded or initialised,
+ * rt_multi_create() with n > 1 fails with RT_ERR_DEVICE.
  */
 #include <hip/hip_runtime_api.h>
-#include <rccl/rccl.h>
 #include <dlfcn.h>
 
 #include <cstdio>
@@ -28,14 +38,20 @@
 
 namespace {
 
+/* the part of RCCL's C API (rccl.h, NCCL 2.x ABI) this file calls */
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;                    /* ncclSuccess = 0 */
+enum { ncclSuccess_ = 0, ncclFloat_ = 7 };   /* ncclDataType_t: ncclFloat32 = 7 */
+
 struct Rccl {
 	void *lib = nullptr;
-	decltype(&ncclCommInitAll)    comm_init_all = nullptr;
-	decltype(&ncclCommDestroy)    comm_destroy = nullptr;
-	decltype(&ncclGather)         gather = nullptr;
-	decltype(&ncclGroupStart)     group_start = nullptr;
-	decltype(&ncclGroupEnd)       group_end = nullptr;
-	decltype(&ncclGetErrorString) error_string = nullptr;
+	ncclResult_t (*comm_init_all)(ncclComm_t *comms, int ndev, const int *devlist) = nullptr;
+	ncclResult_t (*comm_destroy)(ncclComm_t comm) = nullptr;
+	ncclResult_t (*gather)(const void *sendbuff, void *recvbuff, size_t sendcount, int datatype, int root,
+	                       ncclComm_t comm, hipStream_t stream) = nullptr;
+	ncclResult_t (*group_start)() = nullptr;
+	ncclResult_t (*group_end)() = nullptr;
+	const char  *(*error_string)(ncclResult_t) = nullptr;
 	bool ok = false;
 };
 
@@ -57,6 +73,8 @@ Rccl &rccl()
 	return r;
 }
 
+constexpr int STRIP_BUFFERS = 3;
+
 } // namespace
 
 struct rt_multi {
@@ -64,12 +82,32 @@ struct rt_multi {
 	bool force_collective = false;              /* rt_tuning.force_collective: gather + de-interleave even with one device */
 	std::vector<int>          devices;
 	std::vector<rt_context *> ctx;
-	std::vector<ncclComm_t>   comms;            /* n > 1 only */
-	std::vector<float *>      d_strip;          /* one strip per device */
-	size_t strip_floats = 0;                    /* capacity of each */
-	float *d_strips = nullptr;                  /* device 0: n strips back to back (the gather's destination) */
-	float *d_frame = nullptr;                   /* device 0: the frame in row order */
-	size_t strips_floats = 0, frame_floats = 0;
+	std::vector<ncclComm_t>   comms;            /* made on first use of the collective */
+
+	struct per_device {
+		float      *d_strip[STRIP_BUFFERS] = { nullptr, nullptr, nullptr };
+		hipEvent_t  rendered[STRIP_BUFFERS] = { nullptr, nullptr, nullptr };   /* behind the render into d_strip[j], on its render stream */
+		hipEvent_t  gathered[STRIP_BUFFERS] = { nullptr, nullptr, nullptr };   /* behind the gather that read d_strip[j] */
+		bool        gathered_set[STRIP_BUFFERS] = { false, false, false };
+		hipStream_t gather_stream = nullptr;    /* the collective (device 0: and the de-interleave) */
+	};
+	std::vector<per_device> dev;
+	size_t strip_floats = 0;                    /* capacity of every strip buffer */
+
+	/* device 0 */
+	float *d_strips[STRIP_BUFFERS] = { nullptr, nullptr, nullptr };   /* n strips back to back: the gather's destination */
+	size_t strips_floats = 0;
+	hipStream_t copy_stream = nullptr;
+	unsigned int *h_cancel = nullptr;           /* pinned: [slot * 64 + device] = that launch's control word */
+	struct frame_slot {
+		float     *d_frame = nullptr;           /* the frame in row order */
+		size_t     floats = 0;
+		hipEvent_t assembled = nullptr;         /* behind the de-interleave into d_frame */
+		hipEvent_t copied = nullptr;            /* behind the copy to the caller's memory */
+		bool       busy = false;
+		bool       plain = false;               /* the frame went through rt_frame_submit() of the only context */
+	} fq[RT_FRAME_SLOTS];
+	unsigned long long frames = 0;              /* frame k: render streams k & 1, strip buffers k % 3 */
 };
 
 #define MULTI_HIP(expr)                                                                      \
@@ -87,9 +125,86 @@ static int init_communicators(rt_multi *m)
 	if (!r.ok) return rt_fail(RT_ERR_DEVICE, "rt_multi: RCCL is not available (dlopen librccl.so failed)");
 	m->comms.assign((size_t) m->n, nullptr);
 	const ncclResult_t rc = r.comm_init_all(m->comms.data(), m->n, m->devices.data());
-	if (rc != ncclSuccess) {
+	if (rc != ncclSuccess_) {
 		m->comms.clear();
 		return rt_fail(RT_ERR_DEVICE, "ncclCommInitAll: %s", r.error_string(rc));
+	}
+	return RT_OK;
+}
+
+/* Everything the handle has enqueued on any device has finished (error paths: nothing may still read or write the
+ * buffers the handle owns when a call returns a failure). */
+static void drain(rt_multi *m)
+{
+	for (int i = 0; i < m->n; i++) {
+		if (!m->ctx[(size_t) i]) continue;
+		(void) rt_synchronize(m->ctx[(size_t) i]);
+		(void) hipSetDevice(m->devices[(size_t) i]);
+		if (m->dev[(size_t) i].gather_stream) (void) hipStreamSynchronize(m->dev[(size_t) i].gather_stream);
+	}
+	if (m->copy_stream) { (void) hipSetDevice(m->devices[0]); (void) hipStreamSynchronize(m->copy_stream); }
+}
+
+/* streams, events and buffers of the pipelined frame loop for frames of W x H, made or grown on demand */
+static int prepare(rt_multi *m, int W, int H, int rb, int slot)
+{
+	const int n = m->n;
+	const size_t strip_floats = (size_t) rt_strip_rows(H, rb, n) * W * 3, frame_floats = (size_t) H * W * 3;
+	int least = 0, greatest = 0;
+	for (int i = 0; i < n; i++) {
+		rt_multi::per_device &d = m->dev[(size_t) i];
+		MULTI_HIP(hipSetDevice(m->devices[(size_t) i]));
+		if (!d.gather_stream) {
+			if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) greatest = 0;
+			if (hipStreamCreateWithPriority(&d.gather_stream, hipStreamNonBlocking, greatest) != hipSuccess)
+				MULTI_HIP(hipStreamCreateWithFlags(&d.gather_stream, hipStreamNonBlocking));
+			for (int j = 0; j < STRIP_BUFFERS; j++) {
+				MULTI_HIP(hipEventCreateWithFlags(&d.rendered[j], hipEventDisableTiming));
+				MULTI_HIP(hipEventCreateWithFlags(&d.gathered[j], hipEventDisableTiming));
+			}
+		}
+	}
+	if (strip_floats > m->strip_floats) {
+		drain(m);                                   /* nothing in flight reads the buffers that are replaced */
+		for (int i = 0; i < n; i++) {
+			rt_multi::per_device &d = m->dev[(size_t) i];
+			MULTI_HIP(hipSetDevice(m->devices[(size_t) i]));
+			for (int j = 0; j < STRIP_BUFFERS; j++) { (void) hipFree(d.d_strip[j]); d.d_strip[j] = nullptr; d.gathered_set[j] = false; }
+		}
+		m->strip_floats = 0;
+		for (int i = 0; i < n; i++)
+			for (int j = 0; j < STRIP_BUFFERS; j++) {
+				MULTI_HIP(hipSetDevice(m->devices[(size_t) i]));
+				MULTI_HIP(hipMalloc((void **) &m->dev[(size_t) i].d_strip[j], strip_floats * sizeof(float)));
+			}
+		m->strip_floats = strip_floats;
+	}
+	MULTI_HIP(hipSetDevice(m->devices[0]));
+	if (strip_floats * (size_t) n > m->strips_floats) {
+		drain(m);
+		MULTI_HIP(hipSetDevice(m->devices[0]));
+		for (int j = 0; j < STRIP_BUFFERS; j++) { (void) hipFree(m->d_strips[j]); m->d_strips[j] = nullptr; }
+		m->strips_floats = 0;
+		for (int j = 0; j < STRIP_BUFFERS; j++)
+			MULTI_HIP(hipMalloc((void **) &m->d_strips[j], strip_floats * (size_t) n * sizeof(float)));
+		m->strips_floats = strip_floats * (size_t) n;
+	}
+	if (!m->copy_stream) {
+		if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) greatest = 0;
+		if (hipStreamCreateWithPriority(&m->copy_stream, hipStreamNonBlocking, greatest) != hipSuccess)
+			MULTI_HIP(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+	}
+	if (!m->h_cancel) {
+		MULTI_HIP(hipHostMalloc((void **) &m->h_cancel, (size_t) RT_FRAME_SLOTS * 64 * sizeof(unsigned int), hipHostMallocDefault));
+		memset(m->h_cancel, 0, (size_t) RT_FRAME_SLOTS * 64 * sizeof(unsigned int));
+	}
+	rt_multi::frame_slot &f = m->fq[slot];
+	if (!f.copied) MULTI_HIP(hipEventCreateWithFlags(&f.copied, hipEventDisableTiming));
+	if (!f.assembled) MULTI_HIP(hipEventCreateWithFlags(&f.assembled, hipEventDisableTiming));
+	if (frame_floats > f.floats) {
+		(void) hipFree(f.d_frame); f.d_frame = nullptr; f.floats = 0;   /* (the slot is idle: its last copy was waited for) */
+		MULTI_HIP(hipMalloc((void **) &f.d_frame, frame_floats * sizeof(float)));
+		f.floats = frame_floats;
 	}
 	return RT_OK;
 }
@@ -110,7 +225,7 @@ int rt_multi_create(rt_multi **out, const int *device_ids, int n)
 	m->n = n;
 	m->devices.assign(device_ids, device_ids + n);
 	m->ctx.assign((size_t) n, nullptr);
-	m->d_strip.assign((size_t) n, nullptr);
+	m->dev.resize((size_t) n);
 	for (int i = 0; i < n; i++) {
 		const int rc = rt_create(&m->ctx[(size_t) i], device_ids[i]);
 		if (rc != RT_OK) { rt_multi_destroy(m); return rc; }          /* rt_last_error() holds rt_create's text */
@@ -126,12 +241,23 @@ int rt_multi_create(rt_multi **out, const int *device_ids, int n)
 void rt_multi_destroy(rt_multi *m)
 {
 	if (!m) return;
+	drain(m);
 	for (int i = 0; i < m->n; i++) {
 		if (!m->ctx[(size_t) i]) continue;
-		(void) rt_synchronize(m->ctx[(size_t) i]);
+		rt_multi::per_device &d = m->dev[(size_t) i];
 		(void) hipSetDevice(m->devices[(size_t) i]);
-		(void) hipFree(m->d_strip[(size_t) i]);
-		if (i == 0) { (void) hipFree(m->d_strips); (void) hipFree(m->d_frame); }
+		for (int j = 0; j < STRIP_BUFFERS; j++) {
+			(void) hipFree(d.d_strip[j]);
+			if (d.rendered[j]) (void) hipEventDestroy(d.rendered[j]);
+			if (d.gathered[j]) (void) hipEventDestroy(d.gathered[j]);
+		}
+		if (d.gather_stream) (void) hipStreamDestroy(d.gather_stream);
+		if (i == 0) {
+			for (int j = 0; j < STRIP_BUFFERS; j++) (void) hipFree(m->d_strips[j]);
+			for (auto &f : m->fq) { (void) hipFree(f.d_frame); if (f.copied) (void) hipEventDestroy(f.copied); if (f.assembled) (void) hipEventDestroy(f.assembled); }
+			if (m->copy_stream) (void) hipStreamDestroy(m->copy_stream);
+			if (m->h_cancel) (void) hipHostFree(m->h_cancel);
+		}
 	}
 	for (ncclComm_t c : m->comms) if (c) (void) rccl().comm_destroy(c);
 	for (rt_context *c : m->ctx) rt_destroy(c);
@@ -164,75 +290,142 @@ int rt_multi_set_tuning(rt_multi *m, const rt_tuning *tuning)
 }
 int rt_multi_compile_scene(rt_multi *m)                       { FOR_ALL(rt_compile_scene(ctx)); }
 
+int rt_multi_frame_submit(rt_multi *m, const rt_render_params *params, int slot, Vector3 *frame_out)
+{
+	if (!m || !params || !frame_out) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_frame_submit: NULL argument");
+	if (slot < 0 || slot >= RT_FRAME_SLOTS) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_frame_submit: slot %d not in [0,%d)", slot, RT_FRAME_SLOTS);
+	rt_multi::frame_slot &f = m->fq[slot];
+	if (f.busy) return rt_fail(RT_ERR_STATE, "rt_multi_frame_submit: slot %d holds a frame that has not been waited for", slot);
+	if (m->n == 1 && !m->force_collective) {    /* one device: the strip is the frame */
+		rt_render_params p = *params;
+		p.rank = 0; p.world = 1;
+		const int rc = rt_frame_submit(m->ctx[0], &p, slot, frame_out);
+		if (rc == RT_OK) { f.busy = true; f.plain = true; }
+		return rc;
+	}
+	if (params->width < 2 || params->height < 2 || params->row_block < 1)
+		return rt_fail(RT_ERR_ARGUMENT, "rt_multi_frame_submit: bad frame %dx%d / row_block %d", params->width, params->height, params->row_block);
+	const int n = m->n, W = params->width, H = params->height, rb = params->row_block;
+	{ const int rc = init_communicators(m); if (rc != RT_OK) return rc; }
+	{ const int rc = prepare(m, W, H, rb, slot); if (rc != RT_OK) return rc; }
+	const size_t strip_floats = (size_t) rt_strip_rows(H, rb, n) * W * 3, frame_floats = (size_t) H * W * 3;
+	const int j = (int) (m->frames % STRIP_BUFFERS), which = (int) (m->frames & 1ull);
+
+	/* every device renders its interleaved row blocks, concurrently (the calls only enqueue); its collective stream
+	 * takes over behind the render */
+	int rc = RT_OK;
+	int enqueued = 0;
+	for (int i = 0; i < n && rc == RT_OK; i++) {
+		rt_multi::per_device &d = m->dev[(size_t) i];
+		rt_context *ctx = m->ctx[(size_t) i];
+		hipStream_t rs = (hipStream_t) rt_stream(ctx, which);
+		hipError_t e = rs ? hipSetDevice(m->devices[(size_t) i]) : hipErrorInvalidValue;
+		/* the gather three frames back still reads d_strip[j] */
+		if (e == hipSuccess && d.gathered_set[j]) e = hipStreamWaitEvent(rs, d.gathered[j], 0);
+		if (e != hipSuccess) { rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: device %d: %s", m->devices[(size_t) i], hipGetErrorString(e)); break; }
+		rt_render_params p = *params;
+		p.rank = i; p.world = n;
+		rc = rt_render_device(ctx, &p, d.d_strip[j], rs);
+		if (rc != RT_OK) break;
+		enqueued++;
+		/* this launch's control word (set by a wave that rt_cancel() stopped), for rt_multi_frame_wait() */
+		rc = rt_context_read_control(ctx, &m->h_cancel[slot * 64 + i], rs, nullptr);
+		if (rc != RT_OK) break;
+		e = hipEventRecord(d.rendered[j], rs);
+		if (e == hipSuccess) e = hipStreamWaitEvent(d.gather_stream, d.rendered[j], 0);
+		if (e != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: device %d: %s", m->devices[(size_t) i], hipGetErrorString(e));
+	}
+	/* ONE gather of the finished strips to device 0, each rank's part on its own collective stream */
+	Rccl &r = rccl();
+	if (rc == RT_OK) {
+		ncclResult_t nrc = r.group_start();
+		for (int i = 0; i < n && nrc == ncclSuccess_; i++)
+			nrc = r.gather(m->dev[(size_t) i].d_strip[j], i == 0 ? m->d_strips[j] : nullptr, strip_floats, ncclFloat_, 0,
+			               m->comms[(size_t) i], m->dev[(size_t) i].gather_stream);
+		{ const ncclResult_t end = r.group_end(); if (nrc == ncclSuccess_) nrc = end; }
+		if (nrc != ncclSuccess_) rc = rt_fail(RT_ERR_DEVICE, "ncclGather: %s", r.error_string(nrc));
+	}
+	for (int i = 0; i < n && rc == RT_OK; i++) {
+		rt_multi::per_device &d = m->dev[(size_t) i];
+		hipError_t e = hipSetDevice(m->devices[(size_t) i]);
+		if (e == hipSuccess) e = hipEventRecord(d.gathered[j], d.gather_stream);
+		if (e != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: device %d: %s", m->devices[(size_t) i], hipGetErrorString(e));
+		else d.gathered_set[j] = true;
+	}
+	/* device 0: rows back into frame order (behind the gather, on its stream), then the frame to the caller on the
+	 * copy stream (main.c:467-479) */
+	if (rc == RT_OK) {
+		hipError_t e = hipSetDevice(m->devices[0]);
+		if (e == hipSuccess)
+			rc = rt_deinterleave_device(m->ctx[0], m->d_strips[j], f.d_frame, W, H, rb, n, m->dev[0].gather_stream);
+		if (rc == RT_OK && e == hipSuccess) e = hipEventRecord(f.assembled, m->dev[0].gather_stream);
+		if (rc == RT_OK && e == hipSuccess) e = hipStreamWaitEvent(m->copy_stream, f.assembled, 0);
+		if (rc == RT_OK && e == hipSuccess) e = hipMemcpyAsync(frame_out, f.d_frame, frame_floats * sizeof(float), hipMemcpyDeviceToHost, m->copy_stream);
+		if (rc == RT_OK && e == hipSuccess) e = hipEventRecord(f.copied, m->copy_stream);
+		if (rc == RT_OK && e != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: %s", hipGetErrorString(e));
+	}
+	if (rc != RT_OK) {
+		/* some devices may have renders or a partial collective enqueued on buffers the handle owns: nothing of it is
+		 * left running when the failure is reported (the error text survives: drain() sets none on success) */
+		if (enqueued) drain(m);
+		return rc;
+	}
+	m->frames++;
+	f.busy = true; f.plain = false;
+	return RT_OK;
+}
+
+static int finish_slot(rt_multi *m, int slot)
+{
+	rt_multi::frame_slot &f = m->fq[slot];
+	f.busy = false;
+	if (f.plain) return rt_frame_wait(m->ctx[0], slot);
+	MULTI_HIP(hipSetDevice(m->devices[0]));
+	MULTI_HIP(hipEventSynchronize(f.copied));      /* behind the gather, hence behind every device's render and control-word copy ... */
+	int cancelled = 0;
+	for (int i = 0; i < m->n; i++) cancelled |= m->h_cancel[slot * 64 + i] != 0u;
+	return cancelled ? RT_CANCELLED : RT_OK;
+}
+
+int rt_multi_frame_wait(rt_multi *m, int slot)
+{
+	if (!m || slot < 0 || slot >= RT_FRAME_SLOTS) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_frame_wait: bad argument");
+	if (!m->fq[slot].busy) return rt_fail(RT_ERR_STATE, "rt_multi_frame_wait: nothing was submitted into slot %d", slot);
+	return finish_slot(m, slot);
+}
+
+int rt_multi_frame_poll(rt_multi *m, int slot)
+{
+	if (!m || slot < 0 || slot >= RT_FRAME_SLOTS) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_frame_poll: bad argument");
+	rt_multi::frame_slot &f = m->fq[slot];
+	if (!f.busy) return rt_fail(RT_ERR_STATE, "rt_multi_frame_poll: nothing was submitted into slot %d", slot);
+	if (f.plain) {
+		const int rc = rt_frame_poll(m->ctx[0], slot);
+		if (rc != RT_PENDING) f.busy = false;
+		return rc;
+	}
+	MULTI_HIP(hipSetDevice(m->devices[0]));
+	const hipError_t e = hipEventQuery(f.copied);
+	if (e == hipErrorNotReady) return RT_PENDING;
+	if (e != hipSuccess) return rt_fail(RT_ERR_DEVICE, "rt_multi_frame_poll: %s", hipGetErrorString(e));
+	return finish_slot(m, slot);
+}
+
+/* one frame, start to finish: submit + wait (what rt_render() is for one device) */
 int rt_multi_render(rt_multi *m, const rt_render_params *params, Vector3 *frame_out)
 {
 	if (!m || !params || !frame_out) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_render: NULL argument");
-	if (m->n == 1 && !m->force_collective) {    /* one device: the strip is the frame */
+	if (m->n == 1 && !m->force_collective) {
 		rt_render_params p = *params;
 		p.rank = 0; p.world = 1;
 		return rt_render(m->ctx[0], &p, frame_out);
 	}
-	if (params->width < 2 || params->height < 2 || params->row_block < 1)
-		return rt_fail(RT_ERR_ARGUMENT, "rt_multi_render: bad frame %dx%d / row_block %d", params->width, params->height, params->row_block);
-	const int n = m->n, W = params->width, H = params->height, rb = params->row_block;
-	const int rows = rt_strip_rows(H, rb, n);
-	const size_t strip_floats = (size_t) rows * W * 3, frame_floats = (size_t) H * W * 3;
-
-	/* buffers, grown on demand */
-	if (strip_floats > m->strip_floats) {
-		for (int i = 0; i < n; i++) {
-			MULTI_HIP(hipSetDevice(m->devices[(size_t) i]));
-			{ const int rc = rt_synchronize(m->ctx[(size_t) i]); if (rc != RT_OK) return rc; }
-			(void) hipFree(m->d_strip[(size_t) i]); m->d_strip[(size_t) i] = nullptr;
-		}
-		m->strip_floats = 0;
-		for (int i = 0; i < n; i++) {
-			MULTI_HIP(hipSetDevice(m->devices[(size_t) i]));
-			MULTI_HIP(hipMalloc((void **) &m->d_strip[(size_t) i], strip_floats * sizeof(float)));
-		}
-		m->strip_floats = strip_floats;
-	}
-	MULTI_HIP(hipSetDevice(m->devices[0]));
-	if (strip_floats * (size_t) n > m->strips_floats) {
-		(void) hipFree(m->d_strips); m->d_strips = nullptr; m->strips_floats = 0;
-		MULTI_HIP(hipMalloc((void **) &m->d_strips, strip_floats * (size_t) n * sizeof(float)));
-		m->strips_floats = strip_floats * (size_t) n;
-	}
-	if (frame_floats > m->frame_floats) {
-		(void) hipFree(m->d_frame); m->d_frame = nullptr; m->frame_floats = 0;
-		MULTI_HIP(hipMalloc((void **) &m->d_frame, frame_floats * sizeof(float)));
-		m->frame_floats = frame_floats;
-	}
-
-	{ const int rc = init_communicators(m); if (rc != RT_OK) return rc; }
-	/* every device renders its interleaved row blocks, concurrently (the calls only enqueue) */
-	for (int i = 0; i < n; i++) {
-		rt_render_params p = *params;
-		p.rank = i; p.world = n;
-		const int rc = rt_render_device(m->ctx[(size_t) i], &p, m->d_strip[(size_t) i], nullptr);
-		if (rc != RT_OK) return rc;
-	}
-	/* ONE gather of the finished strips to device 0, each rank's part on its own stream behind its render */
-	Rccl &r = rccl();
-	ncclResult_t nrc = r.group_start();
-	for (int i = 0; i < n && nrc == ncclSuccess; i++)
-		nrc = r.gather(m->d_strip[(size_t) i], i == 0 ? m->d_strips : nullptr, strip_floats, ncclFloat, 0,
-		               m->comms[(size_t) i], (hipStream_t) rt_context_stream(m->ctx[(size_t) i]));
-	{ const ncclResult_t end = r.group_end(); if (nrc == ncclSuccess) nrc = end; }
-	if (nrc != ncclSuccess) return rt_fail(RT_ERR_DEVICE, "ncclGather: %s", r.error_string(nrc));
-	/* device 0: rows back into frame order, then the frame to the caller (main.c:467-479) */
-	{
-		const int rc = rt_deinterleave_device(m->ctx[0], m->d_strips, m->d_frame, W, H, rb, n, nullptr);
-		if (rc != RT_OK) return rc;
-	}
-	MULTI_HIP(hipSetDevice(m->devices[0]));
-	MULTI_HIP(hipMemcpyAsync(frame_out, m->d_frame, frame_floats * sizeof(float), hipMemcpyDeviceToHost,
-	                         (hipStream_t) rt_context_stream(m->ctx[0])));
-	for (int i = 0; i < n; i++) {
-		const int rc = rt_synchronize(m->ctx[(size_t) i]);
-		if (rc != RT_OK) return rc;
-	}
-	return RT_OK;
+	int slot = -1;
+	for (int s = 0; s < RT_FRAME_SLOTS; s++) if (!m->fq[s].busy) { slot = s; break; }
+	if (slot < 0) return rt_fail(RT_ERR_STATE, "rt_multi_render: every frame slot holds a frame that has not been waited for");
+	const int rc = rt_multi_frame_submit(m, params, slot, frame_out);
+	if (rc != RT_OK) return rc;
+	return rt_multi_frame_wait(m, slot);
 }
 
 } /* extern "C" */

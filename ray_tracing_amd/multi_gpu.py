@@ -143,7 +143,11 @@ class TiledFrame:
                 self.strips = [torch.empty((world, rows, width, 3), dtype=torch.float32, device=device) for _ in range(self.depth)]
             if self.multi and rank == 0:
                 self.frame = [torch.empty((height, width, 3), dtype=torch.float32, device=device) for _ in range(2)]
-        self.host_frame = torch.empty((height, width, 3), dtype=torch.float32, pin_memory=True) if self.to_host else None
+        # two pinned destinations, used alternately: a consumer of frame k (host_frame after flush(), or the frame a
+        # done event announces) is not overwritten by the copy of frame k+1
+        self.host_frames = [torch.empty((height, width, 3), dtype=torch.float32, pin_memory=True) for _ in range(2)] if self.to_host else None
+        self.host_frame = self.host_frames[0] if self.to_host else None     # the most recently delivered frame
+        self.delivered = 0
         self.copied = [None, None]        # event: the host copy that read frame / strip buffer k & 1 has finished
         self.gathered = [None] * self.depth    # event (post): the gather that read strip[j] (and wrote strips[j]) is complete
         self.assembled = [None] * self.depth   # event (post): the de-interleave that read strips[j] is complete
@@ -211,6 +215,8 @@ class TiledFrame:
             ready.record(source)
             self.copy_stream.wait_event(ready)
             with torch.cuda.stream(self.copy_stream):
+                self.host_frame = self.host_frames[self.delivered & 1]
+                self.delivered += 1
                 self.host_frame.copy_(frame, non_blocking=True)
                 done = torch.cuda.Event(enable_timing=self.record_events)
                 done.record(self.copy_stream)
