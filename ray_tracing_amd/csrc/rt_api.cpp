@@ -103,7 +103,8 @@ struct rt_context {
 		hipStream_t  stream = nullptr;
 		bool         used = false;
 		uint64_t     lists_key = 0;          /* what rt_primary_pass's output in this set belongs to (0: nothing reusable) */
-		hipEvent_t   readback = nullptr;     /* behind the copy of this set's control word to the host (read_control_word) */
+		hipEvent_t   readback = nullptr;     /* behind the copy of this set's control word to the host (rt_context_read_control) */
+		hipStream_t  readback_stream = nullptr;
 		bool         readback_pending = false; /* ... which the set's next launch, which clears the word, has to wait for */
 		std::atomic<bool> cancel_pending{false};  /* a stop request was sent since the set's last launch: see begin_launch() */
 	} slot[2];
@@ -178,7 +179,7 @@ static int order_behind_previous(rt_context *ctx, hipStream_t stream)
 	/* a stop request meant for earlier launches must have landed before this launch clears the set's control words */
 	if (sl.cancel_pending.exchange(false)) HIP_TRY(hipStreamWaitEvent(stream, ctx->cancel_event, 0));
 	/* ... and a frame in flight must have read them (rt_frame_submit) */
-	if (sl.readback_pending) { sl.readback_pending = false; if (sl.stream != stream) HIP_TRY(hipStreamWaitEvent(stream, sl.readback, 0)); }
+	if (sl.readback_pending) { sl.readback_pending = false; if (sl.readback_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, sl.readback, 0)); }
 	return RT_OK;
 }
 
@@ -201,18 +202,23 @@ static hipStream_t pick_stream(rt_context *ctx, void *hip_stream)
 void *rt_context_stream(rt_context *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
 
 /* The control word of the context's most recent launch (non-zero: rt_cancel() cut it short) is copied to *h_dst (pinned)
- * on `stream`, which must be the stream that launch was enqueued on.  The scratch set's next launch clears the word: it
- * is ordered behind this copy.  *behind (optional) = an event recorded behind the copy. */
+ * on `stream`, which the caller has already ordered behind that launch -- NOT the launch's own stream: a copy between
+ * two kernels of a render stream costs the overlap of consecutive launches (measured: +0.15 ms per C1 frame).  The
+ * scratch set's next launch clears the word: it is ordered behind this copy.  *behind (optional) = an event recorded
+ * behind the copy. */
 int rt_context_read_control(rt_context *ctx, unsigned int *h_dst, hipStream_t stream, hipEvent_t *behind)
 {
 	rt_context::launch_slot &sl = ctx->slot[ctx->cur];
 	if (!sl.readback) HIP_TRY(hipEventCreateWithFlags(&sl.readback, hipEventDisableTiming));
 	HIP_TRY(hipMemcpyAsync(h_dst, sl.d_counter + 128 * 32 + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
 	HIP_TRY(hipEventRecord(sl.readback, stream));
-	sl.readback_pending = true;
+	sl.readback_pending = true; sl.readback_stream = stream;
 	if (behind) *behind = sl.readback;
 	return RT_OK;
 }
+
+/* an event recorded behind the context's most recent launch, on that launch's stream */
+void *rt_context_launch_done(rt_context *ctx) { return ctx ? (void *) ctx->slot[ctx->cur].done : nullptr; }
 
 extern "C" void *rt_stream(rt_context *ctx, int which)
 {
@@ -748,13 +754,13 @@ int rt_frame_submit(rt_context *ctx, const rt_render_params *p, int slot, Vector
 	rc = rt_render_device(ctx, p, f.d_buf, stream);
 	if (rc != RT_OK) return rc;
 	ctx->frames_submitted++;
-	/* the launch's control word (rt_cancel) follows the render on its own stream; the copy of the frame waits for both and
-	 * nothing waits for the copy but the slot */
-	hipEvent_t rendered = nullptr;
-	rc = rt_context_read_control(ctx, &ctx->h_words[1 + slot], stream, &rendered);
-	if (rc != RT_OK) return rc;
-	HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, rendered, 0));
+	/* the copy waits for the render (an event recorded behind it on `stream`); the launch's control word (rt_cancel) follows
+	 * the frame on the copy stream, and nothing waits for either but the slot -- and the scratch set's launch after next,
+	 * which clears that word */
+	HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->slot[ctx->cur].done, 0));
 	HIP_TRY(hipMemcpyAsync(frame_out, f.d_buf, (size_t) p->height * p->width * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->copy_stream));
+	rc = rt_context_read_control(ctx, &ctx->h_words[1 + slot], ctx->copy_stream, nullptr);
+	if (rc != RT_OK) return rc;
 	HIP_TRY(hipEventRecord(f.copied, ctx->copy_stream));
 	f.busy = true;
 	return RT_OK;

@@ -10,9 +10,10 @@ struct rt_context;
 /* rt_api.cpp: sets the thread's error text (rt_last_error()) and returns `code`; the context's own stream */
 int        rt_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 void      *rt_context_stream(rt_context *ctx);
-/* copies the control word of the context's most recent launch (non-zero: cut short by rt_cancel) to pinned *h_dst on `stream`
- * (the stream of that launch); *behind (optional) = an event recorded behind the copy */
+/* copies the control word of the context's most recent launch (non-zero: cut short by rt_cancel) to pinned *h_dst on `stream`,
+ * which the caller has ordered behind that launch (not the launch's own stream); *behind (optional) = an event behind the copy */
 int        rt_context_read_control(rt_context *ctx, unsigned int *h_dst, hipStream_t stream, hipEvent_t *behind);
+void      *rt_context_launch_done(rt_context *ctx);      /* hipEvent_t recorded behind the context's most recent launch */
 
 size_t     rt_counter_bytes();
 size_t     rt_scene_lds_bytes(int num_objects);

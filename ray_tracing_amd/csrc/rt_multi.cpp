@@ -86,7 +86,6 @@ struct rt_multi {
 
 	struct per_device {
 		float      *d_strip[STRIP_BUFFERS] = { nullptr, nullptr, nullptr };
-		hipEvent_t  rendered[STRIP_BUFFERS] = { nullptr, nullptr, nullptr };   /* behind the render into d_strip[j], on its render stream */
 		hipEvent_t  gathered[STRIP_BUFFERS] = { nullptr, nullptr, nullptr };   /* behind the gather that read d_strip[j] */
 		bool        gathered_set[STRIP_BUFFERS] = { false, false, false };
 		hipStream_t gather_stream = nullptr;    /* the collective (device 0: and the de-interleave) */
@@ -159,7 +158,6 @@ static int prepare(rt_multi *m, int W, int H, int rb, int slot)
 			if (hipStreamCreateWithPriority(&d.gather_stream, hipStreamNonBlocking, greatest) != hipSuccess)
 				MULTI_HIP(hipStreamCreateWithFlags(&d.gather_stream, hipStreamNonBlocking));
 			for (int j = 0; j < STRIP_BUFFERS; j++) {
-				MULTI_HIP(hipEventCreateWithFlags(&d.rendered[j], hipEventDisableTiming));
 				MULTI_HIP(hipEventCreateWithFlags(&d.gathered[j], hipEventDisableTiming));
 			}
 		}
@@ -248,7 +246,6 @@ void rt_multi_destroy(rt_multi *m)
 		(void) hipSetDevice(m->devices[(size_t) i]);
 		for (int j = 0; j < STRIP_BUFFERS; j++) {
 			(void) hipFree(d.d_strip[j]);
-			if (d.rendered[j]) (void) hipEventDestroy(d.rendered[j]);
 			if (d.gathered[j]) (void) hipEventDestroy(d.gathered[j]);
 		}
 		if (d.gather_stream) (void) hipStreamDestroy(d.gather_stream);
@@ -328,11 +325,11 @@ int rt_multi_frame_submit(rt_multi *m, const rt_render_params *params, int slot,
 		rc = rt_render_device(ctx, &p, d.d_strip[j], rs);
 		if (rc != RT_OK) break;
 		enqueued++;
-		/* this launch's control word (set by a wave that rt_cancel() stopped), for rt_multi_frame_wait() */
-		rc = rt_context_read_control(ctx, &m->h_cancel[slot * 64 + i], rs, nullptr);
-		if (rc != RT_OK) break;
-		e = hipEventRecord(d.rendered[j], rs);
-		if (e == hipSuccess) e = hipStreamWaitEvent(d.gather_stream, d.rendered[j], 0);
+		/* the collective stream takes over behind the render; first this launch's control word (set by a wave that
+		 * rt_cancel() stopped), for rt_multi_frame_wait() -- not on the render stream: a copy between two kernels there costs
+		 * the overlap of consecutive launches */
+		e = hipStreamWaitEvent(d.gather_stream, (hipEvent_t) rt_context_launch_done(ctx), 0);
+		if (e == hipSuccess) { rc = rt_context_read_control(ctx, &m->h_cancel[slot * 64 + i], d.gather_stream, nullptr); if (rc != RT_OK) break; }
 		if (e != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: device %d: %s", m->devices[(size_t) i], hipGetErrorString(e));
 	}
 	/* ONE gather of the finished strips to device 0, each rank's part on its own collective stream */
