@@ -240,6 +240,30 @@ RT_API long long rt_primary_passes_run(rt_context *ctx);
 RT_API int rt_progressive_resolve(rt_context *ctx, Vector3 *frame_out);
 RT_API int rt_progressive_invalidate(rt_context *ctx);
 RT_API int rt_progressive_state(rt_context *ctx, int *next_scale, float *count, uint32_t *generation, int *passes);
+/* (`count` is read from the device, where rt_accumulate keeps it beside the accumulation buffer: a pass that a bare
+ * rt_cancel() cut short -- without rt_progressive_invalidate() -- is neither added nor counted, main.c:382.  The ladder
+ * and the sample numbering go on: that pass's sample number stays unused.)
+ *
+ * One rank of several (hosts with one process per GPU and a collective of their own): rt_progressive_begin_rank() makes
+ * the context accumulate only the frame rows of the row blocks b with b % world == rank -- blocks of
+ * RT_PROGRESSIVE_ROW_BLOCK frame rows, a multiple of every scale of the ladder, so that a low-resolution row never
+ * straddles two ranks; rt_progressive_pass() then renders the low-resolution rows that cover them.  rt_progressive_resolve()
+ * returns those rows, resolved: rt_strip_rows(height, RT_PROGRESSIVE_ROW_BLOCK, world) x width Vector3 (padding rows are
+ * zero); rt_progressive_resolve_device() leaves them in device memory instead (*d_rows, owned by the context, valid until
+ * the next resolve; enqueued on the context's stream, no sync) for the host's gather + rt_deinterleave_device().
+ *
+ * The same protocol on a device group (all workers run the ladder, main.c:354-408): every device accumulates the frame
+ * rows of its own row blocks (16 frame rows each, dealt round-robin) pass after pass with nothing exchanged; a displayed
+ * frame costs one resolve per device, ONE gather to the first device, a de-interleave and the copy to the host.  Frames
+ * are bit-identical to the single-device ladder's. */
+#define RT_PROGRESSIVE_ROW_BLOCK 16
+RT_API int rt_progressive_begin_rank(rt_context *ctx, int width, int height, int init_scale, int max_bounces, uint64_t seed, int rank, int world);
+RT_API int rt_progressive_resolve_device(rt_context *ctx, void **d_rows);
+RT_API int rt_multi_progressive_begin(rt_multi *m, int width, int height, int init_scale, int max_bounces, uint64_t seed);
+RT_API int rt_multi_progressive_pass(rt_multi *m, float *weight_out);
+RT_API int rt_multi_progressive_resolve(rt_multi *m, Vector3 *frame_out);
+RT_API int rt_multi_progressive_invalidate(rt_multi *m);
+RT_API int rt_multi_progressive_state(rt_multi *m, int *next_scale, float *count, uint32_t *generation, int *passes);
 
 /* ---- measurement --------------------------------------------------------------------------- */
 /* When enabled, every rt_render_device()/rt_render() brackets its kernels (rt_primary_pass and the trace kernel) with

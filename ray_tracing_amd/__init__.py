@@ -67,6 +67,8 @@ EXPORTS = [
     "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_spec_stats_read", "rt_spec_symbol_read", "rt_render", "rt_render_device", "rt_stream", "rt_reserve", "rt_strip_rows", "rt_deinterleave_device",
     "rt_frame_submit", "rt_frame_wait", "rt_frame_poll", "rt_host_alloc", "rt_host_free",
     "rt_multi_frame_submit", "rt_multi_frame_wait", "rt_multi_frame_poll", "rt_profile_collect_span",
+    "rt_progressive_begin_rank", "rt_progressive_resolve_device", "rt_multi_progressive_begin", "rt_multi_progressive_pass",
+    "rt_multi_progressive_resolve", "rt_multi_progressive_invalidate", "rt_multi_progressive_state",
     "rt_synchronize", "rt_cancel", "rt_was_cancelled", "rt_primary_passes_run", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
     "rt_progressive_invalidate", "rt_progressive_state", "rt_selftest", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
     "rt_parse_scene_string", "rt_load_cubemap", "rt_free_cubemap", "rt_decode_jpeg_file",
@@ -143,6 +145,14 @@ def lib():
         L.rt_multi_frame_wait.argtypes = [C.c_void_p, C.c_int]
         L.rt_multi_frame_poll.argtypes = [C.c_void_p, C.c_int]
         L.rt_profile_collect_span.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    if hasattr(L, "rt_progressive_begin_rank"):
+        L.rt_progressive_begin_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int]
+        L.rt_progressive_resolve_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.rt_multi_progressive_begin.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
+        L.rt_multi_progressive_pass.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.rt_multi_progressive_resolve.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_multi_progressive_invalidate.argtypes = [C.c_void_p]
+        L.rt_multi_progressive_state.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
     L.rt_progressive_begin.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
     L.rt_progressive_pass.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.rt_progressive_resolve.argtypes = [C.c_void_p, C.c_void_p]
@@ -410,9 +420,15 @@ class Renderer(_FrameQueue):
                "rt_deinterleave_device")
 
     # -- progressive accumulation (reference worker()/update_frame() protocol)
-    def progressive_begin(self, width, height, init_scale=8, max_bounces=10, seed=0):
-        _check(lib().rt_progressive_begin(self._ctx, width, height, init_scale, max_bounces, seed), "rt_progressive_begin")
-        self._prog_shape = (height, width, 3)
+    def progressive_begin(self, width, height, init_scale=8, max_bounces=10, seed=0, rank=0, world=1):
+        """world > 1: this context accumulates only the rows of its row blocks (rt_progressive_begin_rank) and
+        progressive_resolve() returns those rows, (rt_strip_rows(height, 16, world), width, 3)."""
+        if world == 1:
+            _check(lib().rt_progressive_begin(self._ctx, width, height, init_scale, max_bounces, seed), "rt_progressive_begin")
+            self._prog_shape = (height, width, 3)
+        else:
+            _check(lib().rt_progressive_begin_rank(self._ctx, width, height, init_scale, max_bounces, seed, rank, world), "rt_progressive_begin_rank")
+            self._prog_shape = (strip_rows(height, 16, world), width, 3)
 
     def progressive_pass(self):
         w = C.c_float()
@@ -515,8 +531,16 @@ class MultiRenderer(_FrameQueue):
         cm.h, cm.w, cm.chan = faces.shape[1], faces.shape[2], faces.shape[3]
         _check(lib().rt_multi_set_skybox(self._m, C.byref(cm)), "rt_multi_set_skybox")
 
-    def set_camera(self):
+    def set_camera(self, pos=None, front=None, up=None, fov=None):
         cam = default_camera()
+        if pos is not None:
+            cam.pos = Vector3(*pos)
+        if front is not None:
+            cam.front = Vector3(*front)
+        if up is not None:
+            cam.up = Vector3(*up)
+        if fov is not None:
+            cam.fov = fov
         _check(lib().rt_multi_set_camera(self._m, C.byref(cam)), "rt_multi_set_camera")
 
     def set_tuning(self, **kw):
@@ -528,6 +552,29 @@ class MultiRenderer(_FrameQueue):
 
     def compile_scene(self):
         _check(lib().rt_multi_compile_scene(self._m), "rt_multi_compile_scene")
+
+    # -- the interactive protocol on the group (rt_multi_progressive_*)
+    def progressive_begin(self, width, height, init_scale=8, max_bounces=10, seed=0):
+        _check(lib().rt_multi_progressive_begin(self._m, width, height, init_scale, max_bounces, seed), "rt_multi_progressive_begin")
+        self._prog_shape = (height, width, 3)
+
+    def progressive_pass(self):
+        w = C.c_float()
+        _check(lib().rt_multi_progressive_pass(self._m, C.byref(w)), "rt_multi_progressive_pass")
+        return w.value
+
+    def progressive_resolve(self):
+        out = np.empty(self._prog_shape, dtype=np.float32)
+        _check(lib().rt_multi_progressive_resolve(self._m, out.ctypes.data_as(C.c_void_p)), "rt_multi_progressive_resolve")
+        return out
+
+    def progressive_invalidate(self):
+        _check(lib().rt_multi_progressive_invalidate(self._m), "rt_multi_progressive_invalidate")
+
+    def progressive_state(self):
+        s, c, g, n = C.c_int(), C.c_float(), C.c_uint32(), C.c_int()
+        _check(lib().rt_multi_progressive_state(self._m, C.byref(s), C.byref(c), C.byref(g), C.byref(n)), "rt_multi_progressive_state")
+        return dict(next_scale=s.value, count=c.value, generation=g.value, passes=n.value)
 
     def render(self, width, height, spp, max_bounces, seed=0, row_block=8):
         p = Renderer.params(width, height, spp, max_bounces, seed=seed, row_block=row_block)

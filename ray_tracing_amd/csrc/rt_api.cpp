@@ -138,6 +138,7 @@ struct rt_context {
 	struct {
 		bool     active = false;
 		int      width = 0, height = 0, init_scale = 1, scale = 1, max_bounces = 10, passes = 0;
+		int      rank = 0, world = 1, rows = 0;   /* this context accumulates the frame rows of the row blocks b % world == rank: `rows` of them */
 		uint64_t seed = 0;
 		uint32_t generation = 0;
 		float   *d_accum = nullptr, *d_low = nullptr, *d_out = nullptr;
@@ -851,29 +852,38 @@ int rt_deinterleave_device(rt_context *ctx, const void *d_strips, void *d_frame,
 
 int rt_progressive_begin(rt_context *ctx, int width, int height, int init_scale, int max_bounces, uint64_t seed)
 {
+	return rt_progressive_begin_rank(ctx, width, height, init_scale, max_bounces, seed, 0, 1);
+}
+
+int rt_progressive_begin_rank(rt_context *ctx, int width, int height, int init_scale, int max_bounces, uint64_t seed, int rank, int world)
+{
 	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_progressive_begin: NULL context");
 	if (init_scale != 1 && init_scale != 2 && init_scale != 4 && init_scale != 8 && init_scale != 16)
 		return fail(RT_ERR_ARGUMENT, "rt_progressive_begin: init_scale %d not in {1,2,4,8,16}", init_scale);   /* main.c:611-621 */
 	if (width / init_scale < 2 || height / init_scale < 2 || (int64_t) width * height > (int64_t) 1 << 30)
 		return fail(RT_ERR_ARGUMENT, "rt_progressive_begin: frame %dx%d too small for scale %d (or too large)", width, height, init_scale);
 	if (max_bounces < 1) return fail(RT_ERR_ARGUMENT, "rt_progressive_begin: max_bounces %d < 1", max_bounces);
+	if (world < 1 || rank < 0 || rank >= world) return fail(RT_ERR_ARGUMENT, "rt_progressive_begin: bad partition rank=%d world=%d", rank, world);
 	HIP_TRY(hipSetDevice(ctx->device));
 	auto &g = ctx->prog;
-	const size_t accum_bytes = (size_t) width * height * 3 * sizeof(float);
-	const size_t low_bytes = (size_t) (width + 1) * height * 3 * sizeof(float);
+	/* one rank: the whole frame; several: this rank's row blocks, padded like a strip (rt_strip_rows) */
+	const int rows = world == 1 ? height : rt_strip_rows(height, RT_PROGRESSIVE_ROW_BLOCK, world);
+	const size_t accum_bytes = (size_t) width * rows * 3 * sizeof(float);
+	const size_t low_bytes = (size_t) (width + 1) * rows * 3 * sizeof(float);
 	if (accum_bytes != g.accum_bytes) {
 		(void) hipFree(g.d_accum); (void) hipFree(g.d_out); g.d_accum = g.d_out = nullptr; g.accum_bytes = 0;
 		HIP_TRY(hipMalloc((void**) &g.d_accum, accum_bytes));
 		HIP_TRY(hipMalloc((void**) &g.d_out, accum_bytes));
 		g.accum_bytes = accum_bytes;
 	}
-	if (!g.d_count) HIP_TRY(hipMalloc((void**) &g.d_count, sizeof(float)));
+	if (!g.d_count) HIP_TRY(hipMalloc((void**) &g.d_count, 2 * sizeof(float)));     /* [1]: a word that stays zero */
 	if (low_bytes != g.low_bytes) {
 		(void) hipFree(g.d_low); g.d_low = nullptr; g.low_bytes = 0;
 		HIP_TRY(hipMalloc((void**) &g.d_low, low_bytes));
 		g.low_bytes = low_bytes;
 	}
 	g.width = width; g.height = height; g.init_scale = init_scale; g.max_bounces = max_bounces; g.seed = seed;
+	g.rank = rank; g.world = world; g.rows = rows;
 	g.active = true;
 	/* whatever rt_primary_pass left in the scratch sets belongs to an earlier low-resolution buffer (which may even have had
 	 * this one's address: the key hashes the pointer, not the contents) */
@@ -892,7 +902,7 @@ int rt_progressive_invalidate(rt_context *ctx)
 	 * (main.c:382: rt_accumulate looks at control[1]); the clear below is ordered behind it */
 	if (ctx->launches) { const int rc = rt_cancel(ctx); if (rc != RT_OK) return rc; }
 	HIP_TRY(hipMemsetAsync(g.d_accum, 0, g.accum_bytes, ctx->stream));
-	HIP_TRY(hipMemsetAsync(g.d_count, 0, sizeof(float), ctx->stream));
+	HIP_TRY(hipMemsetAsync(g.d_count, 0, 2 * sizeof(float), ctx->stream));
 	g.passes = 0; g.scale = g.init_scale; g.generation++;
 	return RT_OK;
 }
@@ -921,6 +931,13 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	L.spp = 1; L.max_bounces = g.max_bounces; L.seed = g.seed;
 	L.u_den = lw - 1; L.v_den = lh - 1; L.pix_scale = s; L.pix_width = g.width; L.sample_base = g.passes;
 	L.row_block = 8; L.rank = 0; L.world = 1;
+	if (g.world > 1) {
+		/* this rank's share of the low-resolution rows: the rows that cover its blocks of 16 frame rows */
+		L.row_block = RT_PROGRESSIVE_ROW_BLOCK / s; L.rank = g.rank; L.world = g.world;
+		const int blocks = (lh + L.row_block - 1) / L.row_block;
+		const int mine = blocks > g.rank ? (blocks - g.rank + g.world - 1) / g.world : 0;
+		L.local_rows = mine * L.row_block;
+	}
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.sky_wm1 = (float) (ctx->sky_w - 1); L.sky_hm1 = (float) (ctx->sky_h - 1);
 	L.frame = g.d_low;
 	L.skip_known_taps = ctx->tuning.trace_known_taps ? 0 : 1;   /* the flags are kept with the lists: paid once per camera position */
@@ -930,6 +947,16 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	{ const int rc = prepare_launch(ctx, L, ctx->launches); if (rc != RT_OK) return rc; }
 	{ const int rc = order_behind_previous(ctx, ctx->stream); if (rc != RT_OK) return rc; }
 	if (ctx->tuning.poison_frame) HIP_TRY(hipMemsetAsync(g.d_low, 0xff, g.low_bytes, ctx->stream));
+	if (L.local_rows <= 0) {
+		/* a rank without rows at this scale -- its few frame rows lie below the last whole low-resolution row -- renders
+		 * nothing and adds nothing, but the pass counts (main.c:396): those rows are divided by the same count as all others */
+		HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), reinterpret_cast<unsigned int*>(g.d_count + 1), g.d_count,
+		                             RT_PROGRESSIVE_ROW_BLOCK, g.rank, g.world, 0, ctx->stream));
+		g.passes++;
+		if (g.scale > 1) g.scale >>= 1;
+		if (weight_out) *weight_out = 1.0f / (s * s);
+		return RT_OK;
+	}
 	/* A pass differs from the pass before last (same scratch set) in its sample number only, once the scale ladder has
 	 * reached full resolution and until the camera moves: the camera rays, their hits and the sky pixels in the
 	 * low-resolution frame are the same, so rt_primary_pass's output is kept (a sixth of a 1080p pass).  The key is
@@ -959,7 +986,8 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	const float weight = 1.0f / (s * s);                                         /* main.c:278 */
 	/* accum += pass * weight and accum_counts += weight (main.c:394-396), both on the device and both skipped for a pass
 	 * that rt_cancel() cut short (main.c:382): the count can never include a pass the buffer does not */
-	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), L.control + 1, g.d_count, ctx->stream));
+	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), L.control + 1, g.d_count,
+	                             RT_PROGRESSIVE_ROW_BLOCK, g.rank, g.world, g.rows, ctx->stream));
 	{ const int rc = mark_launch(ctx, ctx->stream); if (rc != RT_OK) return rc; }
 	g.passes++;
 	if (g.scale > 1) g.scale >>= 1;                                              /* main.c:402-403 */
@@ -975,8 +1003,8 @@ int rt_progressive_resolve(rt_context *ctx, Vector3 *frame_out)
 	if (g.passes == 0) return fail(RT_ERR_STATE, "rt_progressive_resolve: nothing accumulated yet");
 	HIP_TRY(hipSetDevice(ctx->device));
 	/* frame = accum * (1 / count) with the count the device holds (main.c:467-477) */
-	HIP_TRY(rt_launch_resolve(g.d_accum, g.d_out, (size_t) g.width * g.height * 3, g.d_count, ctx->stream));
-	HIP_TRY(hipMemcpyAsync(frame_out, g.d_out, g.accum_bytes, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(rt_launch_resolve(g.d_accum, g.d_out, (size_t) g.width * g.rows * 3, g.d_count, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(frame_out, g.d_out, g.accum_bytes, hipMemcpyDeviceToHost, ctx->stream));     /* one rank of several: its rows */
 	float *h_count = reinterpret_cast<float*>(&ctx->h_words[8]);
 	HIP_TRY(hipMemcpyAsync(h_count, g.d_count, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -985,16 +1013,39 @@ int rt_progressive_resolve(rt_context *ctx, Vector3 *frame_out)
 	return RT_OK;
 }
 
+/* one rank's rows, resolved, left on the device (rt_multi_progressive_resolve, or the host's own collective, gathers them) */
+int rt_progressive_resolve_device(rt_context *ctx, void **d_strip)
+{
+	if (!ctx || !ctx->prog.active || !d_strip) return fail(RT_ERR_STATE, "rt_progressive_resolve: call rt_progressive_begin first");
+	auto &g = ctx->prog;
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(rt_launch_resolve(g.d_accum, g.d_out, (size_t) g.width * g.rows * 3, g.d_count, ctx->stream));
+	*d_strip = g.d_out;
+	return RT_OK;
+}
+
+} /* extern "C" */
+
+int rt_progressive_count(rt_context *ctx, float *count)
+{
+	if (!ctx || !ctx->prog.active || !count) return fail(RT_ERR_STATE, "rt_progressive_state: call rt_progressive_begin first");
+	HIP_TRY(hipSetDevice(ctx->device));
+	float *h_count = reinterpret_cast<float*>(&ctx->h_words[8]);
+	HIP_TRY(hipMemcpyAsync(h_count, ctx->prog.d_count, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	*count = *h_count;
+	return RT_OK;
+}
+
+extern "C" {
+
 int rt_progressive_state(rt_context *ctx, int *next_scale, float *count, uint32_t *generation, int *passes)
 {
 	if (!ctx || !ctx->prog.active) return fail(RT_ERR_STATE, "rt_progressive_state: call rt_progressive_begin first");
 	if (next_scale) *next_scale = ctx->prog.scale;
 	if (count) {          /* the passes enqueued so far, as far as they were published: waits for them */
-		HIP_TRY(hipSetDevice(ctx->device));
-		float *h_count = reinterpret_cast<float*>(&ctx->h_words[8]);
-		HIP_TRY(hipMemcpyAsync(h_count, ctx->prog.d_count, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(hipStreamSynchronize(ctx->stream));
-		*count = *h_count;
+		const int rc = rt_progressive_count(ctx, count);
+		if (rc != RT_OK) return rc;
 	}
 	if (generation) *generation = ctx->prog.generation;
 	if (passes) *passes = ctx->prog.passes;

@@ -13,7 +13,9 @@ void      *rt_context_stream(rt_context *ctx);
 /* copies the control word of the context's most recent launch (non-zero: cut short by rt_cancel) to pinned *h_dst on `stream`,
  * which the caller has ordered behind that launch (not the launch's own stream); *behind (optional) = an event behind the copy */
 int        rt_context_read_control(rt_context *ctx, unsigned int *h_dst, hipStream_t stream, hipEvent_t *behind);
-void      *rt_context_launch_done(rt_context *ctx);      /* hipEvent_t recorded behind the context's most recent launch */
+void      *rt_context_launch_done(rt_context *ctx);
+#define RT_PROGRESSIVE_ROW_BLOCK 16      /* == the header's: a multiple of every scale of the ladder */
+int        rt_progressive_count(rt_context *ctx, float *count);      /* hipEvent_t recorded behind the context's most recent launch */
 
 size_t     rt_counter_bytes();
 size_t     rt_scene_lds_bytes(int num_objects);
@@ -31,7 +33,8 @@ hipError_t rt_launch_deinterleave(const float *strips, float *frame, int width, 
                                   int row_block, int world, int rows_per_rank, hipStream_t stream);
 
 hipError_t rt_launch_accumulate(float *accum, const float *lowres, int width, int height, int scale,
-                                int low_w, int low_h, float k, const unsigned int *cancelled, float *count, hipStream_t stream);
+                                int low_w, int low_h, float k, const unsigned int *cancelled, float *count,
+                                int row_block, int rank, int world, int local_rows, hipStream_t stream);
 hipError_t rt_launch_resolve(const float *accum, float *frame, size_t floats, const float *count, hipStream_t stream);
 hipError_t rt_launch_selftest(int which, uint64_t seed, int blocks, int iters, unsigned long long *d_out, hipStream_t stream);
 

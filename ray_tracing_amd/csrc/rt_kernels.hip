@@ -1265,18 +1265,25 @@ rt_trace_spec(const rt_launch L, unsigned int *block_counter)
 /* ---- progressive accumulation: worker()'s publish step (main.c:387-396) and update_frame()'s
  * resolve (main.c:467-477) ------------------------------------------------------------------ */
 extern "C" __global__ void __launch_bounds__(RT_BLOCK)
-rt_accumulate(float *accum, const float *lowres, int width, int height, int scale, int low_w, int low_h, float k, const unsigned int *cancelled, float *count)
+rt_accumulate(float *accum, const float *lowres, int width, int height, int scale, int low_w, int low_h, float k, const unsigned int *cancelled, float *count,
+              int row_block, int rank, int world, int local_rows)
 {
 	if (*cancelled) return;               /* the pass was given up: it is not published (main.c:382) */
 	/* accum_counts[] += weight (main.c:396) lives beside the buffer it describes: a pass that rt_cancel() cut short
 	 * leaves both untouched, whatever the host believed when it enqueued the pass */
 	if (blockIdx.x == 0 && threadIdx.x == 0) *count = *count + k;
-	const size_t total = (size_t) width * height;
+	/* `accum` holds the frame rows of this rank's row blocks (blocks of `row_block` frame rows dealt round-robin: one rank,
+	 * the whole frame), `lowres` the low-resolution rows that cover them: blocks of row_block / scale rows, same deal */
+	const size_t total = (size_t) width * local_rows;
+	const int low_block = row_block / scale;
 	for (size_t p = (size_t) blockIdx.x * RT_BLOCK + threadIdx.x; p < total; p += (size_t) gridDim.x * RT_BLOCK) {
-		const int y = (int) (p / (size_t) width), x = (int) (p % (size_t) width);
+		const int ly = (int) (p / (size_t) width), x = (int) (p % (size_t) width);
+		const int y = world == 1 ? ly : global_row(row_block, rank, world, ly);
+		if (y >= height) continue;            /* padding rows of the last block */
 		const int j = y / scale, i = x / scale;
 		if (j >= low_h) continue;             /* rows the low-resolution pass did not paint */
-		const float *c = lowres + ((size_t) j * low_w + i) * 3;
+		const int lj = world == 1 ? j : (j / low_block / world) * low_block + j % low_block;
+		const float *c = lowres + ((size_t) lj * low_w + i) * 3;
 		float *a = accum + p * 3;
 		a[0] = a[0] + c[0] * k; a[1] = a[1] + c[1] * k; a[2] = a[2] + c[2] * k;
 	}
@@ -1515,9 +1522,11 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 }
 
 hipError_t rt_launch_accumulate(float *accum, const float *lowres, int width, int height, int scale,
-                                int low_w, int low_h, float k, const unsigned int *cancelled, float *count, hipStream_t stream)
+                                int low_w, int low_h, float k, const unsigned int *cancelled, float *count,
+                                int row_block, int rank, int world, int local_rows, hipStream_t stream)
 {
-	hipLaunchKernelGGL(rt_accumulate, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, lowres, width, height, scale, low_w, low_h, k, cancelled, count);
+	hipLaunchKernelGGL(rt_accumulate, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, lowres, width, height, scale, low_w, low_h, k, cancelled, count,
+	                   row_block, rank, world, local_rows);
 	return hipGetLastError();
 }
 

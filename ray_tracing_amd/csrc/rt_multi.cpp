@@ -107,6 +107,7 @@ struct rt_multi {
 		bool       plain = false;               /* the frame went through rt_frame_submit() of the only context */
 	} fq[RT_FRAME_SLOTS];
 	unsigned long long frames = 0;              /* frame k: render streams k & 1, strip buffers k % 3 */
+	int prog_w = 0, prog_h = 0;                 /* rt_multi_progressive_begin's frame */
 };
 
 #define MULTI_HIP(expr)                                                                      \
@@ -406,6 +407,95 @@ int rt_multi_frame_poll(rt_multi *m, int slot)
 	if (e == hipErrorNotReady) return RT_PENDING;
 	if (e != hipSuccess) return rt_fail(RT_ERR_DEVICE, "rt_multi_frame_poll: %s", hipGetErrorString(e));
 	return finish_slot(m, slot);
+}
+
+/* ---- the reference's interactive protocol on the device group (main.c:354-408, 450-482, 115-124) ------------------------
+ * Every device accumulates the frame rows of ITS row blocks (blocks of 16 frame rows dealt round-robin: a multiple of every
+ * scale of the ladder, so a low-resolution row never straddles two devices) through the whole ladder: a pass renders the
+ * low-resolution rows that cover them and adds them in place, nothing is exchanged.  Only a displayed frame costs a
+ * collective: every device resolves its rows, ONE gather brings them to the first device, de-interleave, copy to the host.
+ * Pass p of every device uses the same seeds as the single-device ladder: frames are bit-identical to rt_progressive_*'s. */
+int rt_multi_progressive_begin(rt_multi *m, int width, int height, int init_scale, int max_bounces, uint64_t seed)
+{
+	if (!m) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_progressive_begin: NULL handle");
+	for (int i = 0; i < m->n; i++) {
+		const int rc = rt_progressive_begin_rank(m->ctx[(size_t) i], width, height, init_scale, max_bounces, seed, i, m->n);
+		if (rc != RT_OK) return rc;
+	}
+	m->prog_w = width; m->prog_h = height;
+	return RT_OK;
+}
+
+int rt_multi_progressive_pass(rt_multi *m, float *weight_out)
+{
+	if (!m) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_progressive_pass: NULL handle");
+	for (int i = 0; i < m->n; i++) {       /* the calls only enqueue: the devices render side by side */
+		const int rc = rt_progressive_pass(m->ctx[(size_t) i], weight_out);
+		if (rc != RT_OK) return rc;
+	}
+	return RT_OK;
+}
+
+int rt_multi_progressive_invalidate(rt_multi *m)
+{
+	if (!m) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_progressive_invalidate: NULL handle");
+	for (int i = 0; i < m->n; i++) {
+		const int rc = rt_progressive_invalidate(m->ctx[(size_t) i]);
+		if (rc != RT_OK) return rc;
+	}
+	return RT_OK;
+}
+
+int rt_multi_progressive_state(rt_multi *m, int *next_scale, float *count, uint32_t *generation, int *passes)
+{
+	if (!m) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_progressive_state: NULL handle");
+	return rt_progressive_state(m->ctx[0], next_scale, count, generation, passes);    /* the first device always has rows */
+}
+
+int rt_multi_progressive_resolve(rt_multi *m, Vector3 *frame_out)
+{
+	if (!m || !frame_out) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_progressive_resolve: NULL argument");
+	if (m->prog_w == 0) return rt_fail(RT_ERR_STATE, "rt_multi_progressive_resolve: call rt_multi_progressive_begin first");
+	if (m->n == 1 && !m->force_collective) return rt_progressive_resolve(m->ctx[0], frame_out);
+	const int n = m->n, W = m->prog_w, H = m->prog_h, rb = RT_PROGRESSIVE_ROW_BLOCK;
+	int slot = -1;
+	for (int s = 0; s < RT_FRAME_SLOTS; s++) if (!m->fq[s].busy) { slot = s; break; }
+	if (slot < 0) return rt_fail(RT_ERR_STATE, "rt_multi_progressive_resolve: every frame slot holds a frame that has not been waited for");
+	{ const int rc = init_communicators(m); if (rc != RT_OK) return rc; }
+	{ const int rc = prepare(m, W, H, rb, slot); if (rc != RT_OK) return rc; }
+	rt_multi::frame_slot &f = m->fq[slot];
+	/* what one rank sends: its rows, padded like a strip -- one rank alone holds exactly the frame */
+	const size_t strip_floats = (size_t) (n == 1 ? H : rt_strip_rows(H, rb, n)) * W * 3, frame_floats = (size_t) H * W * 3;
+	std::vector<void *> d_rows((size_t) n, nullptr);
+	int rc = RT_OK;
+	for (int i = 0; i < n && rc == RT_OK; i++)          /* frame = accum * (1 / count) (main.c:467-477), every device its own rows */
+		rc = rt_progressive_resolve_device(m->ctx[(size_t) i], &d_rows[(size_t) i]);
+	Rccl &r = rccl();
+	if (rc == RT_OK) {                                  /* ONE gather per displayed frame, behind the resolves on the contexts' streams */
+		ncclResult_t nrc = r.group_start();
+		for (int i = 0; i < n && nrc == ncclSuccess_; i++)
+			nrc = r.gather(d_rows[(size_t) i], i == 0 ? m->d_strips[0] : nullptr, strip_floats, ncclFloat_, 0,
+			               m->comms[(size_t) i], (hipStream_t) rt_context_stream(m->ctx[(size_t) i]));
+		{ const ncclResult_t end = r.group_end(); if (nrc == ncclSuccess_) nrc = end; }
+		if (nrc != ncclSuccess_) rc = rt_fail(RT_ERR_DEVICE, "ncclGather: %s", r.error_string(nrc));
+	}
+	if (rc == RT_OK) rc = rt_deinterleave_device(m->ctx[0], m->d_strips[0], f.d_frame, W, H, rb, n, nullptr);
+	if (rc == RT_OK) {
+		hipError_t e = hipSetDevice(m->devices[0]);
+		if (e == hipSuccess) e = hipMemcpyAsync(frame_out, f.d_frame, frame_floats * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t) rt_context_stream(m->ctx[0]));
+		if (e != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_multi_progressive_resolve: %s", hipGetErrorString(e));
+	}
+	if (rc != RT_OK) { drain(m); return rc; }
+	for (int i = 0; i < n; i++) {
+		const int src = rt_synchronize(m->ctx[(size_t) i]);
+		if (src != RT_OK) return src;
+	}
+	float count = 0;
+	rc = rt_progressive_count(m->ctx[0], &count);
+	if (rc != RT_OK) return rc;
+	if ((double) count < 0.0001)                        /* update_frame() waits for this, main.c:462 */
+		return rt_fail(RT_ERR_STATE, "rt_multi_progressive_resolve: nothing accumulated yet");
+	return RT_OK;
 }
 
 /* one frame, start to finish: submit + wait (what rt_render() is for one device) */

@@ -13,6 +13,7 @@ generic = len(sys.argv) > 3 and sys.argv[3] == "generic"
 scene, W, H, spp, nb, world, rank = CFG[name]
 g = rt.Renderer(0)
 g.set_skybox(rt.load_skybox()); g.set_scene(f"{rt.DATA_DIR}/scene_{scene}.txt")
+if os.environ.get("RT_JIT_FLAGS"): g.set_tuning(jit_flags=os.environ["RT_JIT_FLAGS"])     # e.g. -gline-tables-only for PC sampling
 if not generic:
     g.compile_scene()
 strip = torch.empty((rt.strip_rows(H, 8, world), W, 3), dtype=torch.float32, device="cuda:0")

@@ -53,15 +53,16 @@ def _worker(rank, world, port, W, H, rb, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,H,rb", [(2, 36, 8), (3, 29, 4)])
-def test_gather_and_deinterleave_over_gloo(world, H, rb):
+@pytest.mark.parametrize("world,H,rb,W", [(2, 36, 8, 48), (3, 29, 4, 48),
+                                         (8, 1080, 8, 12)])      # the 8-GPU partition of a 1080-row frame: 135 blocks, strips of 136 rows
+def test_gather_and_deinterleave_over_gloo(world, H, rb, W):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 48, H, rb, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, rb, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(300)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True

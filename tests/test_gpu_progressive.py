@@ -200,3 +200,62 @@ def test_kept_pixel_lists_change_no_bit(oracle, scene_paths):
     want, _, _, _ = oracle_progressive(oracle, W, H, 2, 4, 6, 3)
     assert (bits(g.progressive_resolve()) == bits(want)).all()
     oracle.set_camera(); oracle.set_skybox(sky); g.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_rank_ladders_reassemble_to_the_single_device_ladder(oracle, scene_paths, world):
+    """rt_progressive_begin_rank(): `world` contexts (here all on the one GPU of the box, as the ranks of a one-process-per-GPU
+    host would each have) accumulate the rows of their own 16-row blocks through the whole scale ladder with nothing
+    exchanged; their resolved rows, put back in frame order, are the single-device ladder's frame and the oracle's."""
+    from ray_tracing_amd.multi_gpu import frame_index
+    sky = synthetic_skybox(32, seed=7)
+    oracle.set_skybox(sky); oracle.set_camera()
+    for (W, H, init_scale, passes, si) in [(96, 70, 8, 6, 0), (64, 130, 16, 7, 1), (50, 33, 4, 4, 0), (40, 24, 1, 3, 0)]:
+        oracle.load_scene(scene_paths[si])
+        want, _, count, next_scale = oracle_progressive(oracle, W, H, init_scale, passes, 10, 5)
+        ranks = []
+        for r in range(world):
+            g = rt.Renderer(0)
+            g.set_tuning(poison_frame=True)
+            g.set_skybox(sky); g.set_scene(scene_paths[si])
+            g.progressive_begin(W, H, init_scale=init_scale, max_bounces=10, seed=5, rank=r, world=world)
+            ranks.append(g)
+        for _ in range(passes):
+            for g in ranks:
+                g.progressive_pass()
+        rows = np.concatenate([g.progressive_resolve() for g in ranks])          # what one gather delivers
+        frame = rows[frame_index(H, 16, world)]
+        st = ranks[0].progressive_state()
+        assert st["passes"] == passes and st["next_scale"] == next_scale and np.float32(st["count"]) == np.float32(count)
+        assert (bits(frame) == bits(want)).all(), (world, W, H, init_scale)
+        for g in ranks:
+            g.close()
+
+
+def test_group_ladder_over_a_one_rank_rccl_communicator(oracle, scene_paths):
+    """rt_multi_progressive_*: the group's ladder, its ONE gather per displayed frame and the de-interleave on the one GPU of
+    the box (rt_tuning.force_collective); invalidation with a moved camera restarts it (main.c:115-124)."""
+    sky = synthetic_skybox(32, seed=7)
+    oracle.set_skybox(sky); oracle.load_scene(scene_paths[0]); oracle.set_camera()
+    m = rt.MultiRenderer([0])
+    m.set_tuning(force_collective=1, poison_frame=1)
+    m.set_scene(scene_paths[0]); m.set_skybox(sky); m.set_camera()
+    W, H = 96, 70
+    m.progressive_begin(W, H, init_scale=8, max_bounces=10, seed=5)
+    for p in range(1, 7):
+        m.progressive_pass()
+        if p in (1, 4, 6):           # frames are displayed while the ladder runs (update_frame(), main.c:450-482)
+            want, _, count, next_scale = oracle_progressive(oracle, W, H, 8, p, 10, 5)
+            assert (bits(m.progressive_resolve()) == bits(want)).all(), p
+    st = m.progressive_state()
+    assert st["passes"] == 6 and st["next_scale"] == next_scale and np.float32(st["count"]) == np.float32(count)
+    cam = dict(pos=(2, 3, 9), front=(0.1, -0.3, -1), up=(0, 1, 0), fov=30.0)
+    m.set_camera(**cam); oracle.set_camera(**cam)
+    m.progressive_invalidate()
+    with pytest.raises(rt.RtError):
+        m.progressive_resolve()
+    for _ in range(3):
+        m.progressive_pass()
+    want, _, _, _ = oracle_progressive(oracle, W, H, 8, 3, 10, 5)
+    assert (bits(m.progressive_resolve()) == bits(want)).all()
+    oracle.set_camera(); m.close()
