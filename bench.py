@@ -388,6 +388,29 @@ def main():
             verified["oracle_error"] = repr(e)
         verified["ok"] = same and verified.get("equals_oracle_rows", True)
 
+    # ---- the host hand-off by itself: the frame's bytes from HBM to pinned host memory, nothing else on the GPU (torch is the
+    # plumbing here; the loop's own copies are hipMemcpyAsync on the library's copy stream).  The only device crossing of the
+    # reference is the opposite one: glTexImage2D of the finished frame (gpu_and_windowing.c:371-376).
+    host_copy = None
+    if rank == 0 and not args.no_extras:
+        nfl = W * H * 3
+        src_t = torch.empty(nfl, dtype=torch.float32, device=dev)
+        dst_t = torch.empty(nfl, dtype=torch.float32, pin_memory=True)
+        cs = torch.cuda.Stream(dev, priority=-1)
+        with torch.cuda.stream(cs):
+            dst_t.copy_(src_t, non_blocking=True)
+        cs.synchronize()
+        tc = time.perf_counter()
+        with torch.cuda.stream(cs):
+            for _ in range(10):
+                dst_t.copy_(src_t, non_blocking=True)
+        cs.synchronize()
+        copy_ms = (time.perf_counter() - tc) * 1e2
+        host_copy = {"bytes": nfl * 4, "ms": round(copy_ms, 4), "GBps": round(nfl * 4 / copy_ms / 1e6, 2), "link_peak_GBps": 63.0,
+                     "frac_of_link": round(nfl * 4 / copy_ms / 1e6 / 63.0, 3),
+                     "note": "frame -> pinned host memory alone on the GPU, mean of 10; link peak = PCIe 5.0 x16, 32 GT/s x 16 lanes x 128/130"}
+        del src_t, dst_t
+
     # ---- the same frame with nothing overlapped: first launch -> frame on the host (SURVEY.md 8d protocol)
     latency = None
     if not args.no_extras:
@@ -431,6 +454,7 @@ def main():
         if step_ms:
             med = step_ms[len(step_ms) // 2]
             out["ms_per_step_median"] = round(med, 4)
+            out["ms_per_step_p90_max"] = [round(step_ms[(len(step_ms) * 9) // 10], 4), round(step_ms[-1], 4)]
             out["value_at_median_step"] = round(samples_per_step / med / 1e3, 2)
         if latency is not None:
             out["frame_latency"] = {"median_ms": round(latency, 4), "runs": 7,
@@ -438,6 +462,8 @@ def main():
                                     "region": "first launch -> gathered, resolved frame resident in host memory, nothing overlapped"}
         if jit_s is not None:
             out["jit_compile_s"] = round(jit_s, 3)
+        if host_copy is not None:
+            out["host_copy"] = host_copy
         # ---- roofline of the dominant kernel (rank 0's launches; every rank runs the same kernel on 1/N of the rows)
         from rtlibs import Oracle
         try:

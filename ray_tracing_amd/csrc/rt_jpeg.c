@@ -6,8 +6,18 @@
  * JPEG decoders differ in their inverse DCT, chroma upsampling and colour conversion, so "the
  * skybox" is defined by that decoder's integer arithmetic (libjpeg differs in 1-3 % of the bytes).
  * This file restates stb_image v2.29's published (public-domain) algorithm for the baseline, Huffman,
- * 8-bit path (the IDCT butterfly, the resamplers and the YCbCr row follow stb's statement order, which
- * byte-identical texels require):
+ * 8-bit path.
+ *
+ * PROVENANCE.  stb_image.h is third-party code (Sean Barrett et al., public domain / MIT, v2.29), not the
+ * reference's own; the reference vendors it unmodified under 3p/stb.  The fixed-point IDCT butterfly below keeps
+ * stb's temporaries and statement order (STBI__IDCT_1D, stb_image.h:2429-2464), and the resampler and YCbCr rows follow
+ * stb__resample_row_* / stbi__YCbCr_to_RGB_row -- a deliberate restatement of that public-domain arithmetic, kept
+ * recognisable so that it can be checked against the original line by line.  What byte-identical texels require is
+ * the arithmetic -- the constants, the rounding offsets, the shifts and where values are truncated to 16 or 8 bits --
+ * not the order of the (commutative, overflow-free) integer additions.  A host that prefers to may link stb_image.h
+ * itself and hand its bytes to rt_set_skybox(): the Cubemap struct is the seam.
+ *
+ * What is restated:
  *   - entropy decoding per ITU T.81 annex F (any conforming decoder yields the same coefficients),
  *     each coefficient multiplied by its quantiser and kept as int16;
  *   - 2-D IDCT: column pass then row pass of the 12-bit fixed-point LLM butterfly

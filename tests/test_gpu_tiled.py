@@ -46,7 +46,7 @@ def _free_port():
     return p
 
 
-def _nccl_worker(rank, world, port, q, backend="nccl", share_gpu=False):
+def _nccl_worker(rank, world, port, q, backend="nccl", share_gpu=False, size=(320, 180, 8)):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
@@ -61,7 +61,7 @@ def _nccl_worker(rank, world, port, q, backend="nccl", share_gpu=False):
     g = rt.Renderer(device)
     g.set_tuning(poison_frame=True)
     g.set_skybox(rt.load_skybox()); g.set_scene(os.path.join(rt.DATA_DIR, "scene_0.txt")); g.set_camera()
-    W, H, spp, nb = 320, 180, 8, 4
+    (W, H, spp), nb = size, 4
     t = TiledFrame(g, W, H, spp, nb, rank=rank, world=world, device=dev)
     ok = True
     for s in (1, 2, 3):
@@ -121,8 +121,11 @@ def test_consecutive_launches_overlap_on_the_two_streams(gpu):
     assert (bits(frame) == bits(want[11])).all()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_pipelined_frames_ranks_sharing_one_gpu_over_gloo(world):
+@pytest.mark.parametrize("world,size", [(2, (320, 180, 8)), (3, (320, 180, 8)),
+                                        (5, (160, 1080, 4))])     # 1080 rows over five ranks: 135 blocks, strips of 216 rows (the pool allows six
+                                                                    # processes on a GPU: five ranks + this test process; world 8 runs over gloo on CPU tensors,
+                                                                    # tests/test_distributed_gloo.py)
+def test_pipelined_frames_ranks_sharing_one_gpu_over_gloo(world, size):
     """The N-rank frame loop of bench.py on the ONE GPU this pool's boxes have: every rank is its own process with
     its own context, streams and strips on GPU 0, the strips travel through gloo (which moves device tensors) instead
     of RCCL (which refuses two ranks on one device).  Everything but the transport is what an N-GPU run executes:
@@ -132,7 +135,7 @@ def test_pipelined_frames_ranks_sharing_one_gpu_over_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q, "gloo", True)) for r in range(world)]
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q, "gloo", True, size)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -230,4 +233,44 @@ def test_native_multi_gpu_entry_two_devices(gpu):
     m.set_skybox(rt.load_skybox()); m.set_scene(os.path.join(rt.DATA_DIR, "scene_0.txt")); m.set_camera()
     for _ in range(2):
         assert (bits(m.render(W, H, spp, nb, seed=9)) == bits(want)).all()
+    m.close()
+
+
+def test_bench_self_launch_four_ranks_sharing_the_gpu():
+    """`python bench.py --gpus 4 --share-gpu`: the self-launched N-rank bench (a child torch.distributed.run, one process per
+    rank) end to end on the one GPU of the box -- strips over gloo -- with its built-in check of the last frame."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--share-gpu", "--steps", "3", "--warmup", "1",
+                        "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 4 and line["verified"] is True and line["verification"]["equals_blocking_rt_render"] is True
+    assert "SHARING ONE GPU" in line["config"]["partition"]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (ncclGather between them)")
+def test_native_multi_gpu_frames_in_flight_two_devices(gpu):
+    """rt_multi_frame_submit / rt_multi_frame_wait over two real devices: three strip buffers per device, grouped ncclGather
+    on the collective streams, a different seed per frame."""
+    W, H, spp, nb = 320, 181, 8, 4
+    seeds = list(range(30, 41))
+    want = {s: gpu.render(W, H, spp, nb, seed=s) for s in seeds}
+    m = rt.MultiRenderer([0, 1])
+    m.set_skybox(rt.load_skybox()); m.set_scene(os.path.join(rt.DATA_DIR, "scene_0.txt")); m.set_camera()
+    from ray_tracing_amd.frames import FrameLoop
+    for depth in (2, 3, 4):
+        loop = FrameLoop(m, W, H, spp, nb, depth=depth)
+        got = []
+        loop.run(seeds, on_frame=lambda k, a: got.append(a.copy()))
+        for k, s in enumerate(seeds):
+            assert (bits(got[k]) == bits(want[s])).all(), (depth, k)
+        loop.close()
+    m.progressive_begin(W, H, init_scale=8, max_bounces=4, seed=1)
+    gpu.progressive_begin(W, H, init_scale=8, max_bounces=4, seed=1)
+    for _ in range(6):
+        m.progressive_pass(); gpu.progressive_pass()
+    assert (bits(m.progressive_resolve()) == bits(gpu.progressive_resolve())).all()
     m.close()
