@@ -5,9 +5,20 @@ import collections, csv, glob, json, os, sys
 root = sys.argv[1]
 config = sys.argv[2] if len(sys.argv) > 2 else "C1"
 lines = []
-for f in sorted(glob.glob(os.path.join(root, "stats", "**", "*_kernel_stats.csv"), recursive=True)):
-    lines.append(f"== kernel stats ({os.path.basename(f)})")
-    lines += [l.rstrip() for l in open(f)]
+for sub, what in (("stats", "bench.py with frames in flight (launches overlap; rocprofv3 serialises what it can)"),
+                  ("stats_serial", "bench.py --depth 1: one frame in flight, launches never overlap")):
+    for f in sorted(glob.glob(os.path.join(root, sub, "**", "*_kernel_stats.csv"), recursive=True)):
+        lines.append(f"== kernel stats, {what} ({os.path.basename(f)})")
+        lines += [l.rstrip() for l in open(f)]
+    j = os.path.join(root, "bench_under_rocprof.json" if sub == "stats" else "bench_under_rocprof_serial.json")
+    if os.path.exists(j):
+        try:
+            d = json.loads(open(j).read().strip().splitlines()[-1])
+            r = d.get("roofline", {})
+            lines.append(f"   the bench line of that same process: ms_per_step {d.get('ms_per_step')}, roofline.avg_kernel_ms {r.get('avg_kernel_ms')} "
+                         f"(per-launch events {r.get('avg_kernel_ms_per_launch_events')}, span {r.get('avg_kernel_ms_span')}), frac {r.get('frac')}")
+        except Exception as e:
+            lines.append(f"   ({j}: {e})")
 totals = {}
 KERNELS = ("rt_trace", "rt_primary_pass")
 for d in ("pmc_valu", "pmc_busy", "pmc_mix1", "pmc_mix2", "pmc_fetch", "pmc_write"):
