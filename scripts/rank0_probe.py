@@ -1,0 +1,54 @@
+"""Development aid: what rank 0 of an 8-GPU run does per frame, on ONE GPU: its own strip (row blocks 0, 8, 16 ...), the
+root's local share of the gather (a device copy of its strip into the gather buffer), the de-interleave of all eight
+strips into the frame and the copy of the frame to pinned host memory -- pipelined as multi_gpu.TiledFrame pipelines
+them (render streams k & 1, post stream, copy stream, three strip buffers).  Only the xGMI transfer of the seven peer
+strips is missing.  Prints ms per step for: strips alone, + gather stand-in and de-interleave, + host copy.
+usage: rank0_probe.py [C1|C4] [world]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ray_tracing_amd as rt
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C1"
+world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+W, H, spp, nb = {"C1": (1920, 1080, 64, 4), "C4": (3840, 2160, 1024, 8)}[cfg]
+N = 40 if cfg == "C1" else 6
+dev = torch.device("cuda", 0)
+g = rt.Renderer(0)
+g.set_skybox(rt.load_skybox()); g.set_scene(f"{rt.DATA_DIR}/scene_0.txt"); g.set_camera(); g.compile_scene()
+rows = rt.strip_rows(H, 8, world)
+streams = [torch.cuda.ExternalStream(g.stream(w), device=dev) for w in (0, 1)]
+post, copy = torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev, priority=-1)
+strip = [torch.empty((rows, W, 3), dtype=torch.float32, device=dev) for _ in range(3)]
+strips = [torch.zeros((world, rows, W, 3), dtype=torch.float32, device=dev) for _ in range(3)]
+frame = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+host = [torch.empty((H, W, 3), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+
+def run(level):
+    gathered, copied = [None] * 3, [None] * 2
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(N):
+        s, j, f = streams[k & 1], k % 3, k & 1
+        with torch.cuda.stream(s):
+            if gathered[j] is not None: s.wait_event(gathered[j])
+            g.render_device(g.params(W, H, spp, nb, seed=k, row_block=8, rank=0, world=world), strip[j].data_ptr(), s.cuda_stream)
+            done = torch.cuda.Event(); done.record(s)
+        if level >= 1:
+            with torch.cuda.stream(post):
+                post.wait_event(done)
+                strips[j][0].copy_(strip[j], non_blocking=True)          # the root's own part of the gather
+                ev = torch.cuda.Event(); ev.record(post); gathered[j] = ev
+                if copied[f] is not None: post.wait_event(copied[f])
+                g.deinterleave_device(strips[j].data_ptr(), frame[f].data_ptr(), W, H, 8, world, post.cuda_stream)
+                ready = torch.cuda.Event(); ready.record(post)
+            if level >= 2:
+                with torch.cuda.stream(copy):
+                    copy.wait_event(ready)
+                    host[f].copy_(frame[f], non_blocking=True)
+                    c = torch.cuda.Event(); c.record(copy); copied[f] = c
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / N * 1e3
+
+for rep in range(3):
+    a, b, c = run(0), run(1), run(2)
+    print(f"{cfg}, rank 0 of {world} on one GPU: strips alone {a:.3f} ms per step | + gather stand-in + de-interleave {b:.3f} | + frame to pinned host memory {c:.3f}", flush=True)
