@@ -458,9 +458,10 @@ int rt_multi_progressive_resolve(rt_multi *m, Vector3 *frame_out)
 	if (m->prog_w == 0) return rt_fail(RT_ERR_STATE, "rt_multi_progressive_resolve: call rt_multi_progressive_begin first");
 	if (m->n == 1 && !m->force_collective) return rt_progressive_resolve(m->ctx[0], frame_out);
 	const int n = m->n, W = m->prog_w, H = m->prog_h, rb = RT_PROGRESSIVE_ROW_BLOCK;
-	int slot = -1;
-	for (int s = 0; s < RT_FRAME_SLOTS; s++) if (!m->fq[s].busy) { slot = s; break; }
-	if (slot < 0) return rt_fail(RT_ERR_STATE, "rt_multi_progressive_resolve: every frame slot holds a frame that has not been waited for");
+	/* the gather lands in the frame queue's first strips buffer: not while frames are in flight */
+	for (int s = 0; s < RT_FRAME_SLOTS; s++)
+		if (m->fq[s].busy) return rt_fail(RT_ERR_STATE, "rt_multi_progressive_resolve: slot %d holds a frame that has not been waited for", s);
+	const int slot = 0;
 	{ const int rc = init_communicators(m); if (rc != RT_OK) return rc; }
 	{ const int rc = prepare(m, W, H, rb, slot); if (rc != RT_OK) return rc; }
 	rt_multi::frame_slot &f = m->fq[slot];
