@@ -33,6 +33,8 @@ for name, scene, W, H, spp, nb, world in cfgs:
     for k, r in enumerate(rs):
         rt._lib = r._L
         r.set_scene(f"{rt.DATA_DIR}/scene_{scene}.txt")
+        jf = os.environ.get("AB_JITFLAGS_A" if k == 0 else "AB_JITFLAGS_B")       # e.g. "-DSOMETHING": the same library built two ways
+        if jf: r.set_tuning(jit_flags=jf)
         if r._jit: r.compile_scene()
     frames = [None, None]
     for it in range(rounds + 1):
