@@ -514,6 +514,19 @@ def main():
             if tr:
                 out["roofline"]["traffic"] = round(tr["fetch_bytes"] + tr["write_bytes"])
                 out["roofline"]["traffic_note"] = tr.get("source", "")
+                if tr.get("valu_instructions"):
+                    # The same launch against the ISSUE ceiling of the SIMDs, which is what binds it: VALU instructions per launch
+                    # (committed rocprofv3 PMC pass of this build) x 2 clk per wave64 instruction -- the guide's rate for the
+                    # cheapest class -- over SIMDs x clock x measured time.  Only ~29 % of these instructions carry a flop of the
+                    # reference's count (the rest: compares, selects, min/max, the generator's 64-bit integer products, fp64
+                    # islands), and most of those issue at 4 clk: VALUBusy reads > 100 %.
+                    simds, clock_hz = 256 * 4, 2.4e9
+                    insts = float(tr["valu_instructions"])
+                    out["roofline"]["issue"] = {
+                        "valu_instructions_per_launch": round(insts), "source": "SQ_INSTS_VALU, " + tr.get("source", "").split(",")[-1].strip().split(";")[0],
+                        "frac_of_issue_peak_at_2clk": round(insts * 2.0 / (simds * clock_hz * avg_ms * 1e-3), 4),
+                        "valu_busy_pct": tr.get("valu_busy_pct"), "valu_lane_utilisation_pct": tr.get("valu_lane_utilisation_pct"),
+                        "note": "instructions x 2 clk / (1024 SIMDs x 2.4 GHz x avg_kernel_ms); VALUBusy / VALUUtilization from the same PMC passes"}
         # ---- the generic kernel (no hiprtc): same frames, same events
         if native and not args.force_collective and compiled and not args.no_extras:
             gpu.set_scene(scene_path)                 # drops the compiled kernel

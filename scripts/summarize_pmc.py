@@ -54,7 +54,10 @@ if len(sys.argv) > 3:
     table = json.load(open(path)) if os.path.exists(path) else {}
     fetch = sum(v.get("FETCH_SIZE", 0.0) for v in totals.values()) * 1024
     write = sum(v.get("WRITE_SIZE", 0.0) for v in totals.values()) * 1024
+    valu = sum(v.get("SQ_INSTS_VALU", 0.0) for v in totals.values())
+    lanes = totals.get("rt_trace", {}).get("VALUUtilization")
     table[config] = {"kernel": "rt_primary_pass + rt_trace_*", "fetch_bytes": fetch, "write_bytes": write,
+                     "valu_instructions": valu, "valu_lane_utilisation_pct": lanes, "valu_busy_pct": totals.get("rt_trace", {}).get("VALUBusy"),
                      "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB x 1024, per frame = all kernels of one launch), {root}; "
                                "reads are scattered 4-byte skybox gathers served by the Infinity Cache, so the x2 streaming correction is not applied"}
     json.dump(table, open(path, "w"), indent=1, sort_keys=True)
