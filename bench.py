@@ -523,7 +523,7 @@ def main():
                     simds, clock_hz = 256 * 4, 2.4e9
                     insts = float(tr["valu_instructions"])
                     out["roofline"]["issue"] = {
-                        "valu_instructions_per_launch": round(insts), "source": "SQ_INSTS_VALU, " + tr.get("source", "").split(",")[-1].strip().split(";")[0],
+                        "valu_instructions_per_launch": round(insts), "source": "SQ_INSTS_VALU, rocprofv3 PMC pass, profiles/pmc_latest.json",
                         "frac_of_issue_peak_at_2clk": round(insts * 2.0 / (simds * clock_hz * avg_ms * 1e-3), 4),
                         "valu_busy_pct": tr.get("valu_busy_pct"), "valu_lane_utilisation_pct": tr.get("valu_lane_utilisation_pct"),
                         "note": "instructions x 2 clk / (1024 SIMDs x 2.4 GHz x avg_kernel_ms); VALUBusy / VALUUtilization from the same PMC passes"}

@@ -106,7 +106,8 @@ RT_API int rt_scene_is_compiled(rt_context *ctx);
 /* development aid: instrumentation counters of a compiled kernel built with jit_flags "-DRT_STATS" (scripts/stats_c1.py) */
 RT_API int rt_spec_stats_read(rt_context *ctx, unsigned long long out[64], int reset);
 /* development aid: copy the named device variable of the compiled kernel's module (e.g. "rt_wave_log" of a build with
- * "-DRT_STATS -DRT_STATS_LIFETIMES_ONLY", scripts/tail_probe.py) to dst, at most `bytes` bytes; *copied = bytes copied */
+ * "-DRT_STATS -DRT_STATS_LIFETIMES_ONLY", scripts/tail_probe.py) to dst, at most `bytes` bytes; *copied = bytes copied.  The
+ * empty name "" stands for the compiled kernel's code object itself (*copied = its full size), for disassembly. */
 RT_API int rt_spec_symbol_read(rt_context *ctx, const char *name, void *dst, size_t bytes, size_t *copied);
 /* chan must be 3 or 4 (what stb_image returns for the shipped JPEGs is 3); all faces w x h */
 RT_API int rt_set_skybox(rt_context *ctx, const Cubemap *skybox);

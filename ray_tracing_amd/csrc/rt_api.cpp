@@ -69,6 +69,7 @@ struct rt_context {
 	bool         have_scene = false;
 	std::vector<rt_geom> h_geom;         /* host copy of the packed geometry (rt_compile_scene) */
 	hipModule_t  spec_module = nullptr;  /* scene-specialised kernel, valid until the scene changes */
+	std::vector<char> spec_code;         /* its code object as hiprtc produced it (rt_spec_symbol_read("") hands it out) */
 	hipFunction_t spec_fn = nullptr;
 	bool         scene_fast_ok = false;  /* every cube has 0 <= size, plane coordinates +0 or 2^-76 <= |x| <= 2^29, sphere data |x| <= 2^29 */
 	int          light_index = -1;
@@ -466,7 +467,7 @@ int rt_compile_scene(rt_context *ctx)
 	HIP_TRY(hipSetDevice(ctx->device));
 	std::string message;
 	const int rc = rt_jit_build(ctx->h_geom.data(), n, ctx->light_index, ctx->light_pos, ctx->tuning.jit_waves_per_simd, ctx->jit_flags.c_str(),
-	                            &ctx->spec_module, &ctx->spec_fn, message);
+	                            &ctx->spec_module, &ctx->spec_fn, message, &ctx->spec_code);
 	if (rc != RT_OK) { ctx->spec_module = nullptr; ctx->spec_fn = nullptr; return fail(rc, "rt_compile_scene: %s", message.c_str()); }
 	return RT_OK;
 }
@@ -495,6 +496,12 @@ int rt_spec_symbol_read(rt_context *ctx, const char *name, void *dst, size_t byt
 {
 	if (!ctx || !name || !dst) return fail(RT_ERR_ARGUMENT, "rt_spec_symbol_read: NULL argument");
 	if (!ctx->spec_module) return fail(RT_ERR_STATE, "rt_spec_symbol_read: no compiled scene");
+	if (name[0] == '\0') {                 /* the empty name: the compiled kernel's code object itself (scripts/runtime_probe.py) */
+		const size_t n = ctx->spec_code.size() < bytes ? ctx->spec_code.size() : bytes;
+		memcpy(dst, ctx->spec_code.data(), n);
+		if (copied) *copied = ctx->spec_code.size();
+		return RT_OK;
+	}
 	HIP_TRY(hipSetDevice(ctx->device));
 	{ const int rc = wait_for_launches(ctx); if (rc != RT_OK) return rc; }
 	hipDeviceptr_t p = nullptr; size_t have = 0;

@@ -85,9 +85,8 @@ struct SceneLDS {
 	const float4 *shade;   /* 4 x float4 per object */
 };
 
-RT_DEV SceneLDS stage_scene(const rt_launch &L, float4 *lds)
+RT_DEV SceneLDS stage_scene(const rt_launch &L, float4 *lds, int n)
 {
-	const int n = L.num_objects;
 	const float4 *g = reinterpret_cast<const float4*>(L.geom);
 	const float4 *s = reinterpret_cast<const float4*>(L.shade);
 	for (int i = threadIdx.x; i < 2 * n; i += RT_BLOCK) lds[i] = g[i];
@@ -479,8 +478,8 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
 rt_trace_simple(const rt_launch L)
 {
 	extern __shared__ float4 lds[];
-	const SceneLDS sc = stage_scene(L, lds);
 	const int n = L.num_objects;
+	const SceneLDS sc = stage_scene(L, lds, n);
 
 	const int tiles_x = (L.width + RT_TILE_W - 1) / RT_TILE_W;
 	const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
@@ -602,8 +601,8 @@ __global__ void __launch_bounds__(RT_BLOCK)
 rt_primary_pass(const rt_launch L, int blocks_per_group)
 {
 	extern __shared__ float4 lds[];
-	const SceneLDS sc = stage_scene(L, lds);
 	const int n = L.num_objects;
+	const SceneLDS sc = stage_scene(L, lds, n);
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int tiles_x = (L.width + 7) >> 3, tiles_y = (L.local_rows + 7) >> 3;
 	const unsigned int total = (unsigned int) (tiles_x * tiles_y);
@@ -769,7 +768,10 @@ struct PixelRec { V3 a, n; int obj; V3 dir; uint32_t index; int off; };
 RT_DEV PixelRec load_pixel(rt_launch_cold C, size_t c)
 {
 	const size_t plane = (size_t) C->pix_shard_cap * (size_t) C->num_shards;
-	const float *src = C->pix + c;
+	/* (the pointer comes out of the launch record in memory: said to be a global one, the twelve loads are global loads off
+	 * one base instead of flat loads with a 64-bit address each) */
+	typedef const __attribute__((address_space(1))) float *gfloat;
+	const gfloat src = (gfloat) C->pix + c;
 	PixelRec p;
 	p.a = mk3(src[0], src[plane], src[2 * plane]);
 	p.n = mk3(src[3 * plane], src[4 * plane], src[5 * plane]);
@@ -784,8 +786,12 @@ template <bool FAST>
 RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 {
 	extern __shared__ float4 lds[];
+#ifdef RT_SPEC_HEADER
+	constexpr int n = SPEC_N;              /* the compiled scene's object count: every LDS offset below is a literal */
+#else
 	const int n = L.num_objects;
-	const SceneLDS sc = stage_scene(L, lds);
+#endif
+	const SceneLDS sc = stage_scene(L, lds, n);
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	/* the grids of the "taps certainly lit" table (rt_lit.h), when the launcher found room for them: 3 x float4 per object */
 	if (L.lit_grids_in_lds) {
@@ -793,7 +799,11 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		for (int i = threadIdx.x; i < 3 * n; i += RT_BLOCK) lds[6 * n + i] = gsrc[i];
 		__syncthreads();
 	}
-	const rt_lit_grid *lit_grids = L.lit_grids_in_lds ? reinterpret_cast<const rt_lit_grid*>(lds + 6 * n) : reinterpret_cast<const rt_lit_grid*>(L.lit_grids);
+	/* (two pointers, not one chosen at run time: a pointer that may be LDS or memory makes every access a flat load with a
+	 * 64-bit address -- ten per bounce ray) */
+	const rt_lit_grid *lit_grids_lds = reinterpret_cast<const rt_lit_grid*>(lds + 6 * n);
+	const rt_lit_grid *lit_grids_mem = reinterpret_cast<const rt_lit_grid*>(L.lit_grids);
+	const bool grids_in_lds = L.lit_grids_in_lds != 0;
 	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (L.lit_grids_in_lds ? 9 : 6) * n)[wave];
 
 	const float inv_spp = 1.0f / (float) L.spp;
@@ -946,7 +956,9 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					unsigned int k = 0;
 					if (lane == 0) k = atomicAdd(block_counter + shard * 32u, (unsigned int) asked);
 					k = (unsigned int) __builtin_amdgcn_readfirstlane((int) k);
-					const unsigned int filled = (unsigned int) __builtin_amdgcn_readfirstlane((int) C->pix_count[shard * 32u]);
+					typedef const __attribute__((address_space(1))) unsigned int *guint;
+					const guint fill_counts = (guint) C->pix_count;
+					const unsigned int filled = (unsigned int) __builtin_amdgcn_readfirstlane((int) fill_counts[shard * 32u]);
 					got = k < filled ? (filled - k < (unsigned int) asked ? (int) (filled - k) : asked) : 0;
 					first = (size_t) shard * (size_t) C->pix_shard_cap + k;
 					if (got < asked) {
@@ -956,7 +968,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 						unsigned int left = 0, taken = 0;
 						if (lane < C->num_shards) {
 							taken = __hip_atomic_load(block_counter + (unsigned int) lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-							const unsigned int have = C->pix_count[(unsigned int) lane * 32u];
+							const unsigned int have = fill_counts[(unsigned int) lane * 32u];
 							left = have > taken ? have - taken : 0u;
 						}
 						/* rt_cancel() makes every list look empty by pushing its dequeue counter beyond any fill count; seeing
@@ -1164,7 +1176,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				lit_next = 0u;
 				if (FAST && L.lit_cells != nullptr && hit.obj >= 0 && hit.obj != light_obj &&
 				    rt_lit_point_on_surface(reinterpret_cast<const float*>(sc.geom) + 8 * hit.obj, hp.x, hp.y, hp.z, hn.x, hn.y, hn.z))
-					lit_next = L.lit_cells[rt_lit_bit_of(lit_grids + hit.obj, hp.x, hp.y, hp.z)];
+					lit_next = L.lit_cells[grids_in_lds ? rt_lit_bit_of(lit_grids_lds + hit.obj, hp.x, hp.y, hp.z)
+					                                    : rt_lit_bit_of(lit_grids_mem + hit.obj, hp.x, hp.y, hp.z)];
 			}
 		}
 		/* the bounces retired below were shaded two rounds ago: whatever is left of their taps (the oldest in the queue) is

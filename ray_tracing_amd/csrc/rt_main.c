@@ -142,6 +142,7 @@ int main(int argc, char **argv)
 			fprintf(stderr, "Error: %s\n", rt_last_error());
 			return -1;
 		}
+		rt_profile_enable(rt_multi_context(group, 0), 1);      /* the library's own per-launch events on the first device */
 		double t0 = now_s();
 		int rc = rt_multi_frame_submit(group, &p, 0, buf[0]);
 		for (int k = 0; k < frames && rc >= 0; k++) {
@@ -158,10 +159,16 @@ int main(int argc, char **argv)
 			return -1;
 		}
 		double dt = now_s() - t0;
-		fprintf(stderr, "Rendered %d frames of %dx%d, %d spp, %d bounces on %d GPU(s), two in flight: %.3f ms per frame, %.1f Msamples/s (frames in host memory)\n",
-		        frames, width, height, spp, bounces, rt_multi_size(group), dt / frames * 1e3, (double) width * height * spp * frames / dt / 1e6);
-		printf("{\"frames\": %d, \"ms_per_frame\": %.4f, \"msamples_per_s\": %.2f, \"gpus\": %d}\n",
-		       frames, dt / frames * 1e3, (double) width * height * spp * frames / dt / 1e6, rt_multi_size(group));
+		double kernel_ms = 0, span_ms = 0;
+		int launches = 0;
+		rt_profile_collect_span(rt_multi_context(group, 0), &kernel_ms, &launches, &span_ms);
+		if (launches < 1) launches = 1;
+		fprintf(stderr, "Rendered %d frames of %dx%d, %d spp, %d bounces on %d GPU(s), two in flight: %.3f ms per frame, %.1f Msamples/s (frames in host memory); "
+		        "kernels of the first device: %.3f ms per launch, %.3f ms of span per launch\n",
+		        frames, width, height, spp, bounces, rt_multi_size(group), dt / frames * 1e3, (double) width * height * spp * frames / dt / 1e6,
+		        kernel_ms / launches, span_ms / launches);
+		printf("{\"frames\": %d, \"ms_per_frame\": %.4f, \"msamples_per_s\": %.2f, \"gpus\": %d, \"kernel_ms_per_launch\": %.4f, \"span_ms_per_launch\": %.4f}\n",
+		       frames, dt / frames * 1e3, (double) width * height * spp * frames / dt / 1e6, rt_multi_size(group), kernel_ms / launches, span_ms / launches);
 		rt_move_frame_to_the_gpu(width, height, buf[(frames - 1) & 1]);   /* where update_frame() hands off, main.c:479 */
 		rt_host_free(buf[0]); rt_host_free(buf[1]);
 		rt_free_cubemap(&skybox);
