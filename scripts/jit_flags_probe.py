@@ -2,7 +2,7 @@
 interleaved in one process.  usage: jit_flags_probe.py "<flags A>" "<flags B>" ..."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
+if os.environ.get("NOTORCH"): sys.modules["torch"] = None     # the system's HIP runtime and compiler instead of torch's bundled ones
 import ray_tracing_amd as rt
 flags = [""] + sys.argv[1:]
 W, H, spp, nb = 1920, 1080, 64, 4
@@ -17,7 +17,14 @@ for f in flags:
         print(f"{f!r}: {e}"); g = None
     if g: g.profile(True)
     rs.append(g)
-strip = torch.empty((H, W, 3), dtype=torch.float32, device="cuda:0")
+import ctypes as C
+_p = C.c_void_p(); rt.lib().hipMalloc = None
+hip = C.CDLL("libamdhip64.so.7" if os.environ.get("NOTORCH") else os.path.join(os.path.dirname(__import__("torch").__file__), "lib", "libamdhip64.so"))
+hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+assert hip.hipMalloc(C.byref(_p), H * W * 12) == 0
+class _S:
+    def data_ptr(self): return _p.value
+strip = _S()
 times = [[] for _ in flags]
 for it in range(8):
     for k, g in enumerate(rs):
