@@ -801,7 +801,7 @@ int rt_host_alloc(void **out, size_t bytes)
 {
 	if (!out || bytes == 0) return fail(RT_ERR_ARGUMENT, "rt_host_alloc: bad argument");
 	*out = nullptr;
-	const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+	const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable);     /* page-locked for every device of the process */
 	if (e != hipSuccess) { *out = nullptr; return fail(RT_ERR_MEMORY, "rt_host_alloc(%zu): %s", bytes, hipGetErrorString(e)); }
 	return RT_OK;
 }

@@ -194,7 +194,7 @@ static int prepare(rt_multi *m, int W, int H, int rb, int slot)
 			MULTI_HIP(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
 	}
 	if (!m->h_cancel) {
-		MULTI_HIP(hipHostMalloc((void **) &m->h_cancel, (size_t) RT_FRAME_SLOTS * 64 * sizeof(unsigned int), hipHostMallocDefault));
+		MULTI_HIP(hipHostMalloc((void **) &m->h_cancel, (size_t) RT_FRAME_SLOTS * 64 * sizeof(unsigned int), hipHostMallocPortable));   /* every device writes its word */
 		memset(m->h_cancel, 0, (size_t) RT_FRAME_SLOTS * 64 * sizeof(unsigned int));
 	}
 	rt_multi::frame_slot &f = m->fq[slot];
