@@ -235,10 +235,12 @@ REF_API void ref_time_columns(int W, int H, int passes, int threads)
 	num_columns = threads; init_scale = 1; frame_w = W; frame_h = H;
 	pthread_t tid[MAX_COLUMNS];
 	ColumnJob jobs[MAX_COLUMNS];
+	int created[MAX_COLUMNS];
 	for (int t = 0; t < threads; t++) {
 		jobs[t] = (ColumnJob) { t, W / threads, W, H, passes };
-		pthread_create(&tid[t], NULL, column_thread, &jobs[t]);
+		created[t] = pthread_create(&tid[t], NULL, column_thread, &jobs[t]) == 0;
+		if (!created[t]) column_thread(&jobs[t]);      /* (a box's thread limit: the column is rendered by the caller) */
 	}
 	for (int t = 0; t < threads; t++)
-		pthread_join(tid[t], NULL);
+		if (created[t]) pthread_join(tid[t], NULL);
 }

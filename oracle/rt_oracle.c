@@ -600,6 +600,18 @@ static void *counter_worker(void *arg)
 	return NULL;
 }
 
+/* rows are dealt through job->next_row, so any number of workers finishes the job: threads that cannot be created (a box's
+ * thread limit) are simply not joined, and the calling thread always works too */
+static void run_counter_workers(CounterJob *job, int threads)
+{
+	pthread_t tid[256];
+	int started = 0;
+	for (int t = 1; t < threads && t < 256; t++)
+		if (pthread_create(&tid[started], NULL, counter_worker, job) == 0) started++;
+	counter_worker(job);
+	for (int t = 0; t < started; t++) pthread_join(tid[t], NULL);
+}
+
 void orc_render_counter(int W, int H, int spp, int max_bounces, uint64_t seed,
                         int row0, int row1, int threads, float *frame_out)
 {
@@ -607,10 +619,7 @@ void orc_render_counter(int W, int H, int spp, int max_bounces, uint64_t seed,
 	if (threads > 256) threads = 256;
 	atomic_int next_row = row0;
 	CounterJob job = { W, H, spp, max_bounces, row1, seed, frame_out, &next_row, NULL };
-	if (threads == 1) { counter_worker(&job); return; }
-	pthread_t tid[256];
-	for (int t = 0; t < threads; t++) pthread_create(&tid[t], NULL, counter_worker, &job);
-	for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+	run_counter_workers(&job, threads);
 }
 
 /* the same for an arbitrary list of frame rows (every row in [0, H)), dealt to the threads one at a time: what the
@@ -623,10 +632,7 @@ void orc_render_counter_rows(int W, int H, int spp, int max_bounces, uint64_t se
 	if (threads > num_rows) threads = num_rows > 0 ? num_rows : 1;
 	atomic_int next_row = 0;
 	CounterJob job = { W, H, spp, max_bounces, num_rows, seed, frame_out, &next_row, rows };
-	if (threads == 1) { counter_worker(&job); return; }
-	pthread_t tid[256];
-	for (int t = 0; t < threads; t++) pthread_create(&tid[t], NULL, counter_worker, &job);
-	for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+	run_counter_workers(&job, threads);
 }
 
 typedef struct { int column_i, column_w, W, H, passes, max_bounces; } ColumnJob;
@@ -649,11 +655,13 @@ void orc_time_columns(int W, int H, int passes, int max_bounces, int threads)
 	if (threads > 32) threads = 32;                                  /* MAX_COLUMNS, main.c:46 */
 	pthread_t tid[32];
 	ColumnJob jobs[32];
+	int created[32];
 	for (int t = 0; t < threads; t++) {
 		jobs[t] = (ColumnJob) { t, W / threads, W, H, passes, max_bounces };
-		pthread_create(&tid[t], NULL, column_worker, &jobs[t]);
+		created[t] = pthread_create(&tid[t], NULL, column_worker, &jobs[t]) == 0;
+		if (!created[t]) column_worker(&jobs[t]);                /* (thread limit of the box: the column is rendered here) */
 	}
-	for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+	for (int t = 0; t < threads; t++) if (created[t]) pthread_join(tid[t], NULL);
 }
 
 /* ------------------------------------------------------------------------------------------ */
