@@ -46,7 +46,24 @@ def _free_port():
     return p
 
 
+def _join_all(procs, seconds):
+    """Wait for the rank processes; one that is still running after `seconds` is killed (it must not outlive the test or hold
+    the suite up -- its own faulthandler timer has dumped its stacks by then) and the test fails."""
+    import time
+    deadline = time.time() + seconds
+    for p in procs:
+        p.join(max(1.0, deadline - time.time()))
+    stuck = [p for p in procs if p.is_alive()]
+    for p in stuck:
+        p.kill(); p.join(10)
+    assert not stuck, f"{len(stuck)} rank process(es) did not finish within {seconds} s"
+    for p in procs:
+        assert p.exitcode == 0, p.exitcode
+
+
 def _nccl_worker(rank, world, port, q, backend="nccl", share_gpu=False, size=(320, 180, 8)):
+    import faulthandler
+    faulthandler.dump_traceback_later(200, exit=True)      # a collective that never completes ends the worker with its stacks on stderr
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
@@ -138,13 +155,13 @@ def test_pipelined_frames_ranks_sharing_one_gpu_over_gloo(world, size):
     procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q, "gloo", True, size)) for r in range(world)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(600)
-        assert p.exitcode == 0
+    _join_all(procs, 300)
     assert q.get(timeout=5) is True
 
 
 def _one_rank_rccl_worker(port, q):
+    import faulthandler
+    faulthandler.dump_traceback_later(150, exit=True)      # a collective that never completes ends the worker with its stacks on stderr
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
@@ -178,8 +195,8 @@ def test_pipelined_frames_one_rank_over_rccl():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     p = ctx.Process(target=_one_rank_rccl_worker, args=(_free_port(), q))
-    p.start(); p.join(600)
-    assert p.exitcode == 0
+    p.start()
+    _join_all([p], 240)
     assert q.get(timeout=5) is True
 
 
@@ -192,9 +209,7 @@ def test_pipelined_frames_two_ranks_over_rccl():
     procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
+    _join_all(procs, 300)
     assert q.get(timeout=5) is True
 
 
