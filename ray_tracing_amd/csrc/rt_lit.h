@@ -7,8 +7,9 @@
  * sin <= 0.5 / (|L| - 0.5).  rt_taps_certainly_lit() decides, conservatively and from P alone, whether EVERY ray of
  * that cone is certain to have the emitter as its nearest hit in the reference's own floating-point tests:
  *   - the emitter is a sphere and every line of the cone passes well inside it (5 % of its radius to spare);
- *   - the whole cone leaves P's own object (cubes and spheres are convex: a ray that starts 0.001 * cos >= 1e-4
- *     above the tangent plane and moves away cannot come back);
+ *   - every ACCEPTED tap (main.c:194: the random unit vector has a positive component along the normal) leaves P's own
+ *     object (cubes and spheres are convex: a ray that starts 0.001 * cos >= 1e-4 above the tangent plane and moves away
+ *     cannot come back): the direction to the emitter leans >= 0.1 (1 + 0.5 / |L|) beyond the tangent plane;
  *   - every other object is missed by the cone -- cut off behind the emitter -- by at least 0.01 scene units:
  *     either its bounding box is clear of the cone's bounding box, or its bounding sphere is clear of the cone.
  * The clearances are two or more orders of magnitude above the rounding errors of the reference's slab and
@@ -72,7 +73,13 @@ RT_LIT_FN int rt_region_certainly_lit(const float *geom, int num_objects, int li
 	const float cs = RT_LIT_SQRT(1.0f - s * s);
 	const float tau = 1.01f * s / cs, icos = 1.01f / cs; /* tan, 1 / cos: 1 % over */
 	const float lean = 1.1f * s + 0.1f;                  /* a component of the axis above this: every cone direction has it >= 0.1 */
-	if (!(ax * nx + ay * ny + az * nz - nslack >= lean)) { RT_LIT_REFUSE(-4); return 0; }
+	/* The taps must leave P's own (convex) object: their origin is moved 0.001 along the tap direction (main.c:198), which
+	 * has to amount to >= 1e-4 along the normal.  Only ACCEPTED taps are ever asked about -- dot(r, n) > 0 for the unit
+	 * vector r (main.c:194) -- and their direction is (0.5 r + L) / |0.5 r + L|: its normal component is above
+	 * (L.n) / (|L| + 0.5), so L^.n >= 0.1 (1 + 0.5 / |L|) is enough, whatever the cone's width (2 % and the region's wobble
+	 * of the direction to the emitter on top) */
+	const float leave = 0.102f * (1.0f + 0.5f / Dmin) + 1.05f * sl / Dmin + 1e-4f;
+	if (!(ax * nx + ay * ny + az * nz - nslack >= leave)) { RT_LIT_REFUSE(-4); return 0; }
 	const float T = 1.01f * (Dmax + R);                  /* axial length of the cone that matters: the emitter ends before it */
 	const float m = RT_LIT_MARGIN;
 	const float p[3] = { px, py, pz }, a[3] = { ax, ay, az }, h[3] = { hx, hy, hz };
