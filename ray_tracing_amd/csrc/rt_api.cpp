@@ -416,17 +416,17 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 		HIP_TRY(hipMemcpy(ctx->d_geom, geom.data(), (size_t) n * sizeof(rt_geom), hipMemcpyHostToDevice));
 		HIP_TRY(hipMemcpy(ctx->d_shade, shade.data(), (size_t) n * sizeof(rt_shade), hipMemcpyHostToDevice));
 	}
-	/* the table of hit points whose soft-shadow taps certainly reach the emitter (rt_lit.h): cells of 1/16 scene unit,
-	 * coarser if that takes more than 2^20 cells; scenes of up to 64 objects with a sphere as the first emitter */
+	/* the table of hit points whose soft-shadow taps certainly reach the emitter (rt_lit.h): cells of 1/32 scene unit,
+	 * coarser if that takes more than 2^21 cells (a byte each); scenes of up to 64 objects with a sphere as the first emitter */
 	ctx->have_lit = false;
 	if (light >= 0 && n <= 64 && fast_ok) {
 		static_assert(sizeof(rt_geom) == 8 * sizeof(float) && sizeof(rt_lit_grid) == 48, "rt_lit.h reads rt_geom as 8 floats");
 		std::vector<rt_lit_grid> grids((size_t) n);
 		const float *words8 = reinterpret_cast<const float*>(geom.data());
 		long long bits = 0;
-		for (float cell = 0.0625f; cell <= 64.0f; cell *= 2.0f) {
+		for (float cell = 0.03125f; cell <= 64.0f; cell *= 2.0f) {
 			bits = rt_lit_layout(words8, n, light, cell, grids.data());
-			if (bits <= (1ll << 20)) break;
+			if (bits <= (1ll << 21)) break;
 			bits = 0;
 		}
 		if (bits > 0) {
