@@ -74,6 +74,7 @@ struct rt_context {
 	bool         scene_fast_ok = false;  /* every cube has 0 <= size, plane coordinates +0 or 2^-76 <= |x| <= 2^29, sphere data |x| <= 2^29 */
 	int          light_index = -1;
 	float        light_pos[3] = {0, 0, 0};
+	bool         only_light_emits = false;   /* no other object has a non-zero emission component (rt_device.h) */
 	/* rt_lit.h: which hit points need no soft-shadow tap traced -- one bit per cell of a grid over every object, built
 	 * by rt_set_scene on the host (a few milliseconds) */
 	unsigned char *d_lit_cells = nullptr;
@@ -391,6 +392,18 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 	}
 	ctx->light_index = light;
 	ctx->scene_fast_ok = fast_ok;
+	{
+		/* emission = emission_color * emission_power, bit pattern by bit pattern: +-0 adds nothing to a tap sum, anything else
+		 * (negative, NaN) does and makes the object one whose index a tap must report */
+		bool only = light >= 0;
+		for (int i = 0; i < n && only; i++)
+			for (int k = 0; k < 3; k++) {
+				uint32_t bits_;
+				memcpy(&bits_, &shade[i].emission[k], 4);
+				if (i != light && (bits_ & 0x7fffffffu) != 0u) only = false;
+			}
+		ctx->only_light_emits = only;
+	}
 	ctx->h_geom.assign(geom.begin(), geom.begin() + n);
 	if (ctx->spec_module) { (void) hipModuleUnload(ctx->spec_module); ctx->spec_module = nullptr; ctx->spec_fn = nullptr; }
 	if (light >= 0) {
@@ -430,10 +443,13 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 			bits = 0;
 		}
 		if (bits > 0) {
-			std::vector<uint32_t> words((size_t) ((bits + 31) / 32));
-			rt_lit_build(words8, n, light, ctx->light_pos[0], ctx->light_pos[1], ctx->light_pos[2], grids.data(), words.data(), bits);
-			std::vector<unsigned char> cells((size_t) bits);          /* a byte per cell on the device: one load, no shift */
-			for (long long b = 0; b < bits; b++) cells[(size_t) b] = (unsigned char) ((words[(size_t) (b >> 5)] >> (b & 31)) & 1u);
+			std::vector<uint32_t> words((size_t) ((bits + 31) / 32)), dark(ctx->only_light_emits ? (size_t) ((bits + 31) / 32) : 0);
+			rt_lit_build(words8, n, light, ctx->light_pos[0], ctx->light_pos[1], ctx->light_pos[2], grids.data(), words.data(),
+			             dark.empty() ? nullptr : dark.data(), bits);
+			std::vector<unsigned char> cells((size_t) bits);          /* a byte per cell on the device: one load, no shift; 1 lit, 2 dark */
+			for (long long b = 0; b < bits; b++)
+				cells[(size_t) b] = (unsigned char) (((words[(size_t) (b >> 5)] >> (b & 31)) & 1u) ? 1u :
+				                                     (!dark.empty() && ((dark[(size_t) (b >> 5)] >> (b & 31)) & 1u)) ? 2u : 0u);
 			if (cells.size() > ctx->lit_cells_capacity) {
 				(void) hipFree(ctx->d_lit_cells); ctx->d_lit_cells = nullptr; ctx->lit_cells_capacity = 0;
 				HIP_TRY(hipMalloc((void**) &ctx->d_lit_cells, cells.size()));
@@ -661,6 +677,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	for (int k = 0; k < 4; k++) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; }
 	L.light_index = ctx->light_index;
 	memcpy(L.light_pos, ctx->light_pos, sizeof(L.light_pos));
+	L.only_light_emits = ctx->only_light_emits ? 1 : 0;
 	L.num_objects = ctx->num_objects;
 	L.width = p->width; L.height = p->height;
 	L.spp = p->spp; L.max_bounces = p->max_bounces; L.seed = p->seed;
@@ -933,6 +950,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	for (int k = 0; k < 4; k++) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; }
 	L.light_index = ctx->light_index;
 	memcpy(L.light_pos, ctx->light_pos, sizeof(L.light_pos));
+	L.only_light_emits = ctx->only_light_emits ? 1 : 0;
 	L.num_objects = ctx->num_objects;
 	L.width = lcw; L.height = lh; L.local_rows = lh;
 	L.spp = 1; L.max_bounces = g.max_bounces; L.seed = g.seed;

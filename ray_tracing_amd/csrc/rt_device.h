@@ -50,6 +50,8 @@ typedef struct {
 	/* first emitter (main.c:140-146) and its origin_of() (scene.c:10-15) */
 	int   light_index;
 	float light_pos[3];
+	int   only_light_emits;    /* that emitter is the only object whose emission is not all zeros: a tap then adds something only if
+	                            * the emitter is its nearest hit, and "certainly not" is as good an answer as "certainly" (rt_lit.h) */
 
 	int   num_objects;
 	int   width, height;       /* full frame                                   */
@@ -75,7 +77,7 @@ typedef struct {
 	int    skip_known_taps;    /* rt_primary_pass flags the pixels whose bounce-0 taps need no tracing (rt_lit.h); 0: every tap is traced */
 	/* the same answer for hit points of any bounce, from a table built once per scene (rt_lit.h: one entry per cell of a grid
 	 * over every object's bounding box, rt_lit_grid per object); NULL: no table (no sphere emitter, or every tap is traced) */
-	const unsigned char *lit_cells;     /* one byte per cell: 1 = every surface point in it is such a point */
+	const unsigned char *lit_cells;     /* one byte per cell: 1 = every surface point in it is such a point, 2 = from every one the accepted taps certainly do NOT reach the emitter first */
 	const void     *lit_grids;
 	int             lit_grids_in_lds;   /* the trace kernel's workgroups keep a copy of the grids behind the scene records */
 	/* scheduling of the wavefront kernels (any values give the same frame):

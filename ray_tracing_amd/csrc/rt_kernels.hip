@@ -37,7 +37,8 @@
 #define RT_TILE_H   8
 
 struct Hit { float t; V3 n; int obj; };
-#define RT_PIX_TAPS_LIT 0x10000      /* flag beside the object index of a pixel record (objects: < 1024) */
+#define RT_PIX_TAPS_LIT  0x10000     /* flags beside the object index of a pixel record (objects: < 1024): every accepted tap from */
+#define RT_PIX_TAPS_DARK 0x20000     /* the hit point certainly reaches the emitter first / certainly does not (rt_lit.h) */
 
 /* Development instrumentation (make stats): per-site counts of executions and of active lanes,
  * accumulated in a device array.  Compiled out of the product build. */
@@ -635,9 +636,11 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 				nn = hit.n;
 				/* every soft-shadow tap from this point certainly hits the emitter first (rt_lit.h): bounce 0 of all the
 				 * pixel's samples needs no tap traced */
-				if (FAST && L.skip_known_taps && rt_taps_certainly_lit(reinterpret_cast<const float*>(sc.geom), n, L.light_index,
-				        L.light_pos[0], L.light_pos[1], L.light_pos[2], obj, a.x, a.y, a.z, nn.x, nn.y, nn.z))
-					known = RT_PIX_TAPS_LIT;
+				if (FAST && L.skip_known_taps) {
+					const int cls = rt_taps_class(reinterpret_cast<const float*>(sc.geom), n, L.light_index, L.light_pos[0], L.light_pos[1], L.light_pos[2],
+					                              L.only_light_emits, obj, a.x, a.y, a.z, nn.x, nn.y, nn.z);
+					known = cls == 1 ? RT_PIX_TAPS_LIT : (cls == 2 ? RT_PIX_TAPS_DARK : 0);
+				}
 			} else {
 				const V3 sky = sky_lookup<FAST>(L, dn);                                  /* main.c:170 */
 				const V3 c = mk3(clamp01(sky.x), clamp01(sky.y), clamp01(sky.z));
@@ -716,6 +719,7 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 #define REC_LAST     4                /* the path ends after this bounce ...               */
 #define REC_SKY      8                /* ... because its bounce ray left the scene (sky1 / sky2) */
 #define REC_TAPS_LIT 128              /* the bounce's accepted taps are known to hit the emitter (rt_lit.h): none was queued */
+#define REC_TAPS_DARK 0x40000         /* ... known NOT to have the emitter as their nearest hit: they add nothing (above the object index, < 1024 << 8) */
 
 struct WaveLDS {
 	float q[6][WF_QUEUE];              /* tap queue SoA: hit point xyz, random_vector() xyz (kinds 2..4 = tap 0..2 of lane `owner`) */
@@ -994,7 +998,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 						rng = path_seed(L.seed, px.index, (uint32_t) L.sample_base);
 						bounce = 0;
 						hp = px.a; hn = px.n; hobj = px.obj & (RT_PIX_TAPS_LIT - 1); hdir = px.dir;
-						lit_next = (uint32_t) px.obj & RT_PIX_TAPS_LIT;
+						lit_next = ((uint32_t) px.obj >> 16) & 3u;
 						has_hit = true;
 					} else {
 						W.rec[0][sg] = px.a.x;   W.rec[1][sg] = px.a.y;   W.rec[2][sg] = px.a.z;
@@ -1028,7 +1032,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					hp = mk3(W.rec[0][sg], W.rec[1][sg], W.rec[2][sg]);
 					hn = mk3(W.rec[3][sg], W.rec[4][sg], W.rec[5][sg]);
 					hobj = __float_as_int(W.rec[6][sg]) & (RT_PIX_TAPS_LIT - 1);
-					lit_next = __float_as_uint(W.rec[6][sg]) & RT_PIX_TAPS_LIT;
+					lit_next = (__float_as_uint(W.rec[6][sg]) >> 16) & 3u;
 					hdir = mk3(W.rec[7][sg], W.rec[8][sg], W.rec[9][sg]);
 					has_hit = true; f_live = true;
 				}
@@ -1063,7 +1067,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			STAT(8);
 			/* a camera-ray hit point from which every tap certainly reaches the emitter (flagged by rt_primary_pass): the taps
 			 * are drawn and accepted as always (main.c:193-195), but not traced */
-			const bool taps_lit = lit_next != 0u;      /* ... or a hit point of a later bounce in such a cell of the scene's table (section 4) */
+			const bool taps_lit = lit_next != 0u;      /* ... or a hit point of a later bounce in such a cell of the scene's table (section 4);
+			                                            * 1: they reach the emitter, 2: they certainly do not (and nothing else emits) */
 			if (have_light) {
 				/* main.c:191-195: three rand_dir draws, a tap is skipped when it points into the surface.  Only the sign of
 				 * dot(rand_dir, normal) is needed here, and random_vector() has it before normalize() does (rt_math.hip.h:
@@ -1108,7 +1113,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			hdir = out_dir;
 			has_hit = false;
 			cur = REC_VALID | (specular ? REC_SPECULAR : 0) | (emit_main ? 0 : REC_LAST) | (tapmask << 4) | (hobj << 8);
-			if (taps_lit) { cur |= REC_TAPS_LIT; tapmask = 0; }      /* the record keeps the accepted taps, the queue gets none */
+			if (taps_lit) { cur |= lit_next == 1u ? REC_TAPS_LIT : REC_TAPS_DARK; tapmask = 0; }      /* the record keeps the accepted taps, the queue gets none */
 		}
 
 		STAMP(1);
@@ -1192,7 +1197,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		STAT(16);
 		if (rec2 & REC_VALID) {
 			STAT(17);
-			const int pobj = rec2 >> 8, ptaps = (rec2 >> 4) & 7;
+			const int pobj = (rec2 >> 8) & 1023, ptaps = (rec2 >> 4) & 7;
 			const float4 m2 = sc.shade[4 * pobj + 2], m3 = sc.shade[4 * pobj + 3];
 			rad = add3(rad, had3(mk3(m3.x, m3.y, m3.z), carry));                    /* main.c:232 */
 			if (!(rec2 & REC_SPECULAR)) carry = had3(carry, mk3(m2.x, m2.y, m2.z));  /* main.c:248 */
@@ -1202,7 +1207,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 #pragma unroll
 				for (int k = 0; k < 3; k++)
 					if ((ptaps >> k) & 1) {
-						const int obj = (rec2 & REC_TAPS_LIT) ? light_obj : W.tap[due][k][lane];
+						const int obj = (rec2 & REC_TAPS_LIT) ? light_obj : ((rec2 & REC_TAPS_DARK) ? -1 : W.tap[due][k][lane]);
 						if (obj >= 0) { const float4 e = sc.shade[4 * obj + 3]; lit = add3(lit, mk3(e.x, e.y, e.z)); }
 						taps++;
 					}

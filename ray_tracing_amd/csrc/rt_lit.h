@@ -128,6 +128,65 @@ RT_LIT_FN int rt_region_certainly_lit(const float *geom, int num_objects, int li
 	return 1;
 }
 
+/* The opposite certainty, for scenes in which the emitter is the ONLY object whose emission is not all zeros (the caller
+ * checks: then a tap adds something only if the emitter is its nearest hit, main.c:200-204): every accepted tap from every
+ * point of the region certainly has some OTHER object as its nearest hit, so it adds nothing and need not be traced.
+ * Two cases, both about spheres:
+ *   - the hit point lies on the far side of its own sphere as seen from the emitter: the direction of every accepted tap
+ *     (0.5 r + L, dot(r, n) > 0) has a normal component of at most (0.5 + L.n) / (|L| + 0.5) <= -0.1, the tap starts
+ *     >= 1e-4 INSIDE the sphere and the reference finds the sphere's far side (one root negative, one positive, the
+ *     constant term of its quadratic a few 1e-4 r below zero against a rounding error of 2.4e-6 r^2) -- or something nearer,
+ *     which is not the emitter either: that lies outside the sphere, with a gap;
+ *   - another sphere stands in the cone's way: every line of the cone passes within 93 % of its radius of its centre
+ *     (a discriminant of >= 0.5 r^2 against an error of 2.4e-6 (distance + r)^2 at up to 50 radii), the sphere is in front
+ *     of every tap's origin and ends before the emitter begins. */
+RT_LIT_FN int rt_region_certainly_dark(const float *geom, int num_objects, int light, float cx, float cy, float cz, int hobj,
+                                       float px, float py, float pz, float hx, float hy, float hz, float nx, float ny, float nz, float nslack)
+{
+	if (light < 0 || hobj == light || hobj < 0 || hobj >= num_objects) return 0;
+	const float *ge = geom + 8 * light;
+	if (((const int *) ge)[6] != 1 /* RT_GEOM_SPHERE */) return 0;
+	const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(px) + hx, __builtin_fabsf(py) + hy), __builtin_fabsf(pz) + hz),
+	                                  __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(cx), __builtin_fabsf(cy)), __builtin_fabsf(cz)));
+	if (!(big <= 32.0f)) return 0;
+	const float sl = 1.001f * RT_LIT_SQRT(hx * hx + hy * hy + hz * hz) + 0.001f;     /* the region's radius and the 0.001 a tap's origin is moved */
+	const float R = RT_LIT_SQRT(ge[3]);
+	const float lx = cx - px, ly = cy - py, lz = cz - pz;
+	const float D = RT_LIT_SQRT(lx * lx + ly * ly + lz * lz);
+	const float Dmin = D - sl, Dmax = D + sl;
+	if (!(Dmin >= R + 0.75f) || !(R >= 0.05f) || !(Dmax <= 50.0f * R)) return 0;
+	const float inv = 1.0f / D;
+	const float ax = lx * inv, ay = ly * inv, az = lz * inv;
+	const float s = 0.505f / (Dmin - 0.5f) + 1.05f * sl / Dmin;      /* sin of the half-angle of the cone that holds every point's taps */
+	if (!(s <= 0.7f)) return 0;
+	const float cs = RT_LIT_SQRT(1.0f - s * s);
+	const float *gh = geom + 8 * hobj;
+	if (((const int *) gh)[6] == 1) {                    /* the own sphere's far side */
+		const float rho = RT_LIT_SQRT(gh[3]);
+		const float ex = cx - gh[0], ey = cy - gh[1], ez = cz - gh[2];
+		if (rho >= 0.05f && rho <= 16.0f && RT_LIT_SQRT(ex * ex + ey * ey + ez * ez) >= rho + R + 0.1f &&
+		    ax * nx + ay * ny + az * nz + 1.05f * sl / Dmin + nslack <= -(0.56f / Dmin + 0.102f))
+			return 1;
+	}
+	for (int i = 0; i < num_objects; i++) {              /* another sphere in the way of the whole cone */
+		if (i == light || i == hobj) continue;
+		const float *g = geom + 8 * i;
+		if (((const int *) g)[6] != 1) continue;
+		const float rho = RT_LIT_SQRT(g[3]);
+		const float wx = g[0] - px, wy = g[1] - py, wz = g[2] - pz;
+		const float dist = RT_LIT_SQRT(wx * wx + wy * wy + wz * wz);
+		if (!(rho >= 0.05f) || !(dist - sl >= rho + 0.01f) || !(dist + sl <= 50.0f * rho)) continue;   /* origins outside it, not too far */
+		if (!(dist + sl + rho <= Dmin - R - 0.1f)) continue;                                          /* it ends before the emitter begins */
+		const float cphi = (wx * ax + wy * ay + wz * az) / dist;
+		if (!(cphi > 0.0f)) continue;
+		const float sphi = RT_LIT_SQRT(__builtin_fmaxf(0.0f, 1.0f - cphi * cphi));
+		const float spsi = 1.05f * sl / (dist - sl);                 /* the direction to its centre wobbles by this much over the region */
+		if (!(cphi * cs - sphi * s >= 0.2f) || !(spsi <= 0.1f)) continue;   /* the angles below add up to less than a right angle */
+		if ((sphi * cs + cphi * s + spsi) * 1.01f * (dist + sl) <= 0.93f * rho) return 1;
+	}
+	return 0;
+}
+
 /* Is the hit point a ray reported really on the object's surface, to within the 1e-4 by which a tap's origin is moved
  * off it (main.c:198 with a direction that leans >= 0.1 away)?  trace_ray()'s hit point is origin + direction * t in
  * float: on a cube face it is off the plane by a few ulps of the ray's extent, but a sphere's t comes out of a
@@ -136,14 +195,26 @@ RT_LIT_FN int rt_region_certainly_lit(const float *geom, int num_objects, int li
  * sphere itself.  So the deviation is measured, not assumed: g = the 8 words of the hit object, n its normal at P. */
 RT_LIT_FN int rt_lit_point_on_surface(const float *g, float px, float py, float pz, float nx, float ny, float nz)
 {
-	if (((const int *) g)[6] == 1) {                     /* sphere: |P - centre|^2 - r^2 = 2 r x (radial offset), at most 5e-5 inside */
+	if (((const int *) g)[6] == 1) {                     /* sphere: |P - centre|^2 - r^2 = 2 r x (radial offset), at most 5e-5 either way */
 		const float vx = px - g[0], vy = py - g[1], vz = pz - g[2];
 		const float dev2 = vx * vx + vy * vy + vz * vz - g[3];
-		return dev2 >= 0.0f || dev2 * dev2 <= 1e-8f * g[3];
+		return dev2 * dev2 <= 1e-8f * g[3];              /* (outside matters too: a tap that is to start INSIDE the sphere, rt_region_certainly_dark) */
 	}
 	/* cube: the face is the one the normal names; P within 2e-5 of its plane */
 	const float off = nx != 0.0f ? px - (nx > 0.0f ? g[3] : g[0]) : (ny != 0.0f ? py - (ny > 0.0f ? g[4] : g[1]) : pz - (nz > 0.0f ? g[5] : g[2]));
 	return __builtin_fabsf(off) <= 2e-5f;
+}
+
+/* one point, both questions: 1 = every accepted tap certainly reaches the emitter first, 2 = certainly none does (asked only
+ * when the caller knows that the emitter alone emits), 0 = trace them */
+RT_LIT_FN int rt_taps_certainly_lit(const float *geom, int num_objects, int light, float cx, float cy, float cz,
+                                    int hobj, float px, float py, float pz, float nx, float ny, float nz);
+RT_LIT_FN int rt_taps_class(const float *geom, int num_objects, int light, float cx, float cy, float cz, int only_light_emits,
+                            int hobj, float px, float py, float pz, float nx, float ny, float nz)
+{
+	if (rt_taps_certainly_lit(geom, num_objects, light, cx, cy, cz, hobj, px, py, pz, nx, ny, nz)) return 1;
+	if (!only_light_emits || hobj < 0 || hobj >= num_objects || !rt_lit_point_on_surface(geom + 8 * hobj, px, py, pz, nx, ny, nz)) return 0;
+	return rt_region_certainly_dark(geom, num_objects, light, cx, cy, cz, hobj, px, py, pz, 0.0f, 0.0f, 0.0f, nx, ny, nz, 0.0f) ? 2 : 0;
 }
 
 /* one point: the hit point of a ray, with the normal trace_ray() reports there */
@@ -209,8 +280,8 @@ RT_LIT_FN int rt_lit_bit_of(const rt_lit_grid *G, float px, float py, float pz)
 	return G->base + (iz * G->res[1] + iy) * G->res[0] + ix;
 }
 
-RT_LIT_FN int rt_lit_cell_certainly_lit(const float *geom, int num_objects, int light, float cx, float cy, float cz,
-                                        int i, const rt_lit_grid *G, int ix, int iy, int iz)
+RT_LIT_FN int rt_lit_cell_certainly(int dark, const float *geom, int num_objects, int light, float cx, float cy, float cz,
+                                    int i, const rt_lit_grid *G, int ix, int iy, int iz)
 {
 	const float *g = geom + 8 * i;
 	const int idx[3] = { ix, iy, iz };
@@ -230,7 +301,8 @@ RT_LIT_FN int rt_lit_cell_certainly_lit(const float *geom, int num_objects, int 
 				p[k] = side ? g[3 + k] : g[k];           /* the face's plane; hit points lie within rounding of it */
 				e[k] = 1e-5f;
 				n[k] = side ? 1.0f : -1.0f;
-				if (!rt_region_certainly_lit(geom, num_objects, light, cx, cy, cz, i, p[0], p[1], p[2], e[0], e[1], e[2], n[0], n[1], n[2], 0.0f)) return 0;
+				if (!(dark ? rt_region_certainly_dark(geom, num_objects, light, cx, cy, cz, i, p[0], p[1], p[2], e[0], e[1], e[2], n[0], n[1], n[2], 0.0f)
+				           : rt_region_certainly_lit(geom, num_objects, light, cx, cy, cz, i, p[0], p[1], p[2], e[0], e[1], e[2], n[0], n[1], n[2], 0.0f))) return 0;
 				faces++;
 			}
 		return faces > 0;
@@ -242,24 +314,31 @@ RT_LIT_FN int rt_lit_cell_certainly_lit(const float *geom, int num_objects, int 
 	const float sl = 1.001f * RT_LIT_SQRT(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
 	if (!(d > 1e-3f * rho) || d - sl > rho || d + sl < rho) return 0;
 	const float inv = 1.0f / d;
-	return rt_region_certainly_lit(geom, num_objects, light, cx, cy, cz, i, c[0], c[1], c[2], h[0], h[1], h[2],
-	                               vx * inv, vy * inv, vz * inv, 2.1f * sl / rho);
+	return dark ? rt_region_certainly_dark(geom, num_objects, light, cx, cy, cz, i, c[0], c[1], c[2], h[0], h[1], h[2], vx * inv, vy * inv, vz * inv, 2.1f * sl / rho)
+	            : rt_region_certainly_lit(geom, num_objects, light, cx, cy, cz, i, c[0], c[1], c[2], h[0], h[1], h[2], vx * inv, vy * inv, vz * inv, 2.1f * sl / rho);
+}
+RT_LIT_FN int rt_lit_cell_certainly_lit(const float *geom, int num_objects, int light, float cx, float cy, float cz,
+                                        int i, const rt_lit_grid *G, int ix, int iy, int iz)
+{
+	return rt_lit_cell_certainly(0, geom, num_objects, light, cx, cy, cz, i, G, ix, iy, iz);
 }
 
-/* the whole table (host side, once per scene); `words` must hold (bits + 31) / 32 words */
+/* the whole table (host side, once per scene); `words` must hold (bits + 31) / 32 words; `dark_words` likewise, or NULL when
+ * other objects emit too (then only "certainly lit" is a usable answer) */
 RT_LIT_FN void rt_lit_build(const float *geom, int num_objects, int light, float cx, float cy, float cz,
-                            const rt_lit_grid *grids, unsigned int *words, long long bits)
+                            const rt_lit_grid *grids, unsigned int *words, unsigned int *dark_words, long long bits)
 {
-	for (long long w = 0; w < (bits + 31) / 32; w++) words[w] = 0u;
+	for (long long w = 0; w < (bits + 31) / 32; w++) { words[w] = 0u; if (dark_words) dark_words[w] = 0u; }
 	for (int i = 0; i < num_objects; i++) {
 		if (i == light) continue;
 		const rt_lit_grid *G = &grids[i];
 		for (int iz = 0; iz < G->res[2]; iz++)
 			for (int iy = 0; iy < G->res[1]; iy++)
 				for (int ix = 0; ix < G->res[0]; ix++)
-					if (rt_lit_cell_certainly_lit(geom, num_objects, light, cx, cy, cz, i, G, ix, iy, iz)) {
+					{
 						const long long b = G->base + ((long long) iz * G->res[1] + iy) * G->res[0] + ix;
-						words[b >> 5] |= 1u << (b & 31);
+						if (rt_lit_cell_certainly(0, geom, num_objects, light, cx, cy, cz, i, G, ix, iy, iz)) words[b >> 5] |= 1u << (b & 31);
+						else if (dark_words && rt_lit_cell_certainly(1, geom, num_objects, light, cx, cy, cz, i, G, ix, iy, iz)) dark_words[b >> 5] |= 1u << (b & 31);
 					}
 	}
 }

@@ -60,7 +60,9 @@ for name, scene, W, H, spp, nb, world in cfgs:
             if it:
                 times[k].append(ms); walls[k].append(wall)
     same = bool((frames[0].view(np.uint32) == frames[1].view(np.uint32)).all())
+    # paired: the two builds ran back to back in every round, so the per-round ratio cancels the drift of the device's clock
+    paired = statistics.median([y / x for x, y in zip(times[0], times[1])])
     a, b = statistics.median(times[0]), statistics.median(times[1])
     wa, wb = statistics.median(walls[0]), statistics.median(walls[1])
-    print(f"{name}: events (primary pass + trace kernel) A {a:.3f} ms (min {min(times[0]):.3f})   B {b:.3f} ms (min {min(times[1]):.3f})   B/A {b / a:.4f} | "
+    print(f"{name}: events (primary pass + trace kernel) A {a:.3f} ms (min {min(times[0]):.3f})   B {b:.3f} ms (min {min(times[1]):.3f})   B/A {b / a:.4f} (median of the per-round ratios {paired:.4f}) | "
           f"whole launch, enqueue -> synchronised: A {wa:.3f}   B {wb:.3f}   B/A {wb / wa:.4f}   identical={same}", flush=True)

@@ -11,7 +11,7 @@ scale = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 far = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0      # > 0: the camera stands this many scene sizes away and looks at the scene
 def num(x): return "%.9f" % float(x)
 def vec(v): return "{%s}" % " ".join(num(x) for x in v)
-bad = taps = known = tabled = 0
+bad = taps = known = tabled = dark = dark_tabled = 0
 for case in range(cases):
     n = int(rng.integers(2, 14))
     light = int(rng.integers(0, n))
@@ -41,6 +41,10 @@ for case in range(cases):
     if last:
         w = last[0].split()
         taps += int(w[2]); known += int(round(float(w[7]) / 100 * int(w[2]))); tabled += int(round(float(w[12]) / 100 * int(w[2])))
+        dl = [l for l in r.stdout.splitlines() if l.startswith("dark:")]       # "dark: x % of the taps ... (bounce 0: y %), z % by the table; violations v"
+        if dl:
+            d = dl[0].split()
+            dark += int(round(float(d[1]) / 100 * int(w[2]))); dark_tabled += int(round(float(d[d.index("%),") + 1]) / 100 * int(w[2])))
     if r.returncode == 2:
         raise SystemExit(f"case {case}: scene file rejected\n{r.stderr}")
     if r.returncode != 0:
@@ -49,5 +53,6 @@ for case in range(cases):
         os.replace(path, os.path.join(tempfile.gettempdir(), f"lit_fuzz_bad_{case}.txt"))
 for f in (path, exe):
     if os.path.exists(f): os.remove(f)
-print(f"{cases} scenes, {taps} taps checked, {known} answered without tracing ({100.0 * known / max(taps, 1):.1f} %), {tabled} by the per-scene table ({100.0 * tabled / max(taps, 1):.1f} %), {bad} scenes with violations")
+print(f"{cases} scenes, {taps} taps checked, {known} answered without tracing ({100.0 * known / max(taps, 1):.1f} %), {tabled} by the per-scene table ({100.0 * tabled / max(taps, 1):.1f} %), "
+      f"{dark} certainly NOT reaching the emitter ({100.0 * dark / max(taps, 1):.1f} %; {dark_tabled} by the table), {bad} scenes with violations")
 sys.exit(1 if bad else 0)

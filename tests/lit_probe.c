@@ -18,6 +18,9 @@ static int why_bounce;
 #include "../ray_tracing_amd/csrc/rt_lit.h"
 
 static _Atomic uint64_t n_taps[16], n_known[16], n_lit[16], n_viol, n_table[16], n_table_viol;
+static _Atomic uint64_t n_dark[16], n_dark_table[16], n_dark_viol;      /* "certainly NOT the emitter" (rt_region_certainly_dark) */
+static unsigned int *dark_table;
+static int only_light_emits;
 static rt_lit_grid grids[1024];
 static unsigned int *table;
 static long long table_bits;
@@ -113,11 +116,16 @@ static void lit_probe_tap(const void *hit, int light, int blocker, int bounce, c
 	n_taps[bounce]++;
 	why_bounce = bounce;
 	if (blocker == light) n_lit[bounce]++;
-	if (rt_taps_certainly_lit(packed, G.scene.num_objects, light, c.x, c.y, c.z, h->object,
-	                          h->point.x, h->point.y, h->point.z, h->normal.x, h->normal.y, h->normal.z)) {
+	const int cls = rt_taps_class(packed, G.scene.num_objects, light, c.x, c.y, c.z, only_light_emits, h->object,
+	                              h->point.x, h->point.y, h->point.z, h->normal.x, h->normal.y, h->normal.z);
+	if (cls == 1) {
 		n_known[bounce]++;
 		if (blocker != light && n_viol++ < 10)
 			fprintf(stderr, "VIOLATION: point %.9g %.9g %.9g object %d: tap hit %d, not the emitter\n", h->point.x, h->point.y, h->point.z, h->object, blocker);
+	} else if (cls == 2) {
+		n_dark[bounce]++;
+		if (blocker == light && n_dark_viol++ < 10)
+			fprintf(stderr, "DARK VIOLATION: point %.9g %.9g %.9g object %d: the tap reaches the emitter\n", h->point.x, h->point.y, h->point.z, h->object);
 	}
 	if (emitter_only_would_do(h, light)) {
 		const Ray *r = (const Ray *) ray;
@@ -131,10 +139,15 @@ static void lit_probe_tap(const void *hit, int light, int blocker, int bounce, c
 	}
 	if (table_bits && h->object != light) {              /* the table of rt_lit_build, read as the trace kernel reads it */
 		const int b = rt_lit_bit_of(&grids[h->object], h->point.x, h->point.y, h->point.z);
-		if (((table[b >> 5] >> (b & 31)) & 1u) && rt_lit_point_on_surface(packed + 8 * h->object, h->point.x, h->point.y, h->point.z, h->normal.x, h->normal.y, h->normal.z)) {
+		const int on = rt_lit_point_on_surface(packed + 8 * h->object, h->point.x, h->point.y, h->point.z, h->normal.x, h->normal.y, h->normal.z);
+		if (((table[b >> 5] >> (b & 31)) & 1u) && on) {
 			n_table[bounce]++;
 			if (blocker != light && n_table_viol++ < 10)
 				fprintf(stderr, "TABLE VIOLATION: point %.9g %.9g %.9g object %d: tap hit %d, not the emitter\n", h->point.x, h->point.y, h->point.z, h->object, blocker);
+		} else if (dark_table && ((dark_table[b >> 5] >> (b & 31)) & 1u) && on) {
+			n_dark_table[bounce]++;
+			if (blocker == light && n_dark_viol++ < 10)
+				fprintf(stderr, "DARK TABLE VIOLATION: point %.9g %.9g %.9g object %d: the tap reaches the emitter\n", h->point.x, h->point.y, h->point.z, h->object);
 		}
 	}
 }
@@ -159,10 +172,18 @@ int main(int argc, char **argv)
 		if (table_bits) {
 			const V3 c = centre_of(&G.scene.objects[light]);
 			table = malloc(sizeof(unsigned int) * (size_t) ((table_bits + 31) / 32));
-			rt_lit_build(packed, sc.num_objects, light, c.x, c.y, c.z, grids, table, table_bits);
-			long long set = 0;
-			for (long long w = 0; w < (table_bits + 31) / 32; w++) set += __builtin_popcount(table[w]);
-			printf("table: %lld cells of %g, %lld set\n", table_bits, probe_cell, set);
+			/* as rt_set_scene decides: "certainly dark" is an answer only when no other object's emission is non-zero */
+			only_light_emits = 1;
+			for (int i = 0; i < sc.num_objects; i++) {
+				const Material *mt = &sc.objects[i].material;
+				const float e[3] = { mt->emission_color.x * mt->emission_power, mt->emission_color.y * mt->emission_power, mt->emission_color.z * mt->emission_power };
+				if (i != light && (e[0] != 0.0f || e[1] != 0.0f || e[2] != 0.0f || e[0] != e[0] || e[1] != e[1] || e[2] != e[2])) only_light_emits = 0;
+			}
+			if (only_light_emits) dark_table = malloc(sizeof(unsigned int) * (size_t) ((table_bits + 31) / 32));
+			rt_lit_build(packed, sc.num_objects, light, c.x, c.y, c.z, grids, table, dark_table, table_bits);
+			long long set = 0, dset = 0;
+			for (long long w = 0; w < (table_bits + 31) / 32; w++) { set += __builtin_popcount(table[w]); if (dark_table) dset += __builtin_popcount(dark_table[w]); }
+			printf("table: %lld cells of %g, %lld lit, %lld dark\n", table_bits, probe_cell, set, dset);
 		}
 	}
 	const int W = atoi(argv[2]), H = atoi(argv[3]), spp = atoi(argv[4]), nb = atoi(argv[5]);
@@ -183,8 +204,14 @@ int main(int argc, char **argv)
 	}
 	if (t) printf("all: taps %llu  lit %.1f %%  answered %.1f %%  violations %llu  table %.1f %%  table violations %llu\n", (unsigned long long) t, 100.0 * l / t, 100.0 * k / t,
 	              (unsigned long long) (n_viol + n_table_viol), 100.0 * kt / t, (unsigned long long) n_table_viol);
+	{
+		uint64_t d = 0, dt = 0;
+		for (int b = 0; b < 16; b++) { d += n_dark[b]; dt += n_dark_table[b]; }
+		if (t) printf("dark: %.1f %% of the taps certainly miss the emitter by the point classifier (bounce 0: %.1f %%), %.1f %% by the table; violations %llu\n",
+		              100.0 * d / t, n_taps[0] ? 100.0 * n_dark[0] / n_taps[0] : 0.0, 100.0 * dt / t, (unsigned long long) n_dark_viol);
+	}
 	printf("bounce-0 taps refused: coordinates %llu, emitter too near %llu, cone wider than the emitter %llu, own surface %llu", (unsigned long long) n_why[7], (unsigned long long) n_why[6], (unsigned long long) n_why[5], (unsigned long long) n_why[4]);
 	for (int i = 0; i < sc.num_objects; i++) if (n_why[8 + i]) printf(", object %d: %llu", i, (unsigned long long) n_why[8 + i]);
 	printf("\n");
-	return n_viol != 0 || n_table_viol != 0 || n_only_viol != 0;
+	return n_viol != 0 || n_table_viol != 0 || n_only_viol != 0 || n_dark_viol != 0;
 }
