@@ -78,7 +78,8 @@ RT_API void rt_default_params(rt_render_params *p, int width, int height, int sp
  * library never reads environment variables. */
 typedef struct {
 	int    dequeue_shards;      /* lists the object pixels are dealt from: 1 or 64 */
-	int    workgroups_per_cu;   /* resident workgroups per CU, 1..4 */
+	int    workgroups_per_cu;   /* resident workgroups per CU, 1..4 (0: all that fit -- half of them for a launch enqueued before the
+	                             * previous one, on the context's other stream, has started: the two are resident side by side) */
 	int    jit_waves_per_simd;  /* rt_compile_scene: register budget = 512 / this many VGPRs (default 4) */
 	const char *jit_flags;      /* rt_compile_scene: extra hiprtc options, space separated (copied) */
 	int    force_collective;    /* testing aid: rt_multi_render() runs its ncclGather + de-interleave path even for a
@@ -149,6 +150,17 @@ RT_API int rt_strip_rows(int height, int row_block, int world);
  * gather / all-gather delivers) -> d_frame = height*width Vector3 in frame order. */
 RT_API int rt_deinterleave_device(rt_context *ctx, const void *d_strips, void *d_frame,
                                   int width, int height, int row_block, int world, void *hip_stream);
+
+/* Which strip each rank renders is the host's choice (rt_render_params.rank names the STRIP: row blocks b with
+ * b % world == rank).  Strips differ by one row block when the blocks do not divide evenly -- the last strip is never
+ * longer than any other -- and the root has work the others do not (gather, de-interleave, the copy to the host), so
+ * both hosts of this library hand the strips out rotated by one: rank r renders strip rt_strip_of_rank(r, world) =
+ * (r + world - 1) % world, the root the last one (1080 rows in blocks of 8 over 8 ranks: 16 blocks instead of 17).
+ * The gathered buffer then holds strip s at position (s + first) % world with first = 1:
+ * rt_deinterleave_rotated_device() takes that `first` (0: rt_deinterleave_device()). */
+RT_API int rt_strip_of_rank(int rank, int world);
+RT_API int rt_deinterleave_rotated_device(rt_context *ctx, const void *d_strips, void *d_frame,
+                                          int width, int height, int row_block, int world, int first, void *hip_stream);
 
 RT_API int rt_synchronize(rt_context *ctx);
 

@@ -64,7 +64,7 @@ class MouseState(C.Structure):
 # every symbol include/rt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
-    "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_spec_stats_read", "rt_spec_symbol_read", "rt_render", "rt_render_device", "rt_stream", "rt_reserve", "rt_strip_rows", "rt_deinterleave_device",
+    "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_spec_stats_read", "rt_spec_symbol_read", "rt_render", "rt_render_device", "rt_stream", "rt_reserve", "rt_strip_rows", "rt_deinterleave_device", "rt_deinterleave_rotated_device", "rt_strip_of_rank",
     "rt_frame_submit", "rt_frame_wait", "rt_frame_poll", "rt_host_alloc", "rt_host_free",
     "rt_multi_frame_submit", "rt_multi_frame_wait", "rt_multi_frame_poll", "rt_profile_collect_span",
     "rt_progressive_begin_rank", "rt_progressive_resolve_device", "rt_multi_progressive_begin", "rt_multi_progressive_pass",
@@ -118,6 +118,8 @@ def lib():
         L.rt_stream.argtypes = [C.c_void_p, C.c_int]
         L.rt_stream.restype = C.c_void_p
     L.rt_deinterleave_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
+    L.rt_deinterleave_rotated_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+    L.rt_strip_of_rank.argtypes = [C.c_int, C.c_int]
     L.rt_synchronize.argtypes = [C.c_void_p]
     if hasattr(L, "rt_cancel"):
         L.rt_cancel.argtypes = [C.c_void_p]
@@ -414,10 +416,11 @@ class Renderer(_FrameQueue):
         _check(lib().rt_render_device(self._ctx, C.byref(params), C.c_void_p(device_ptr), self._stream_arg(stream)),
                "rt_render_device")
 
-    def deinterleave_device(self, strips_ptr, frame_ptr, width, height, row_block, world, stream=None):
-        _check(lib().rt_deinterleave_device(self._ctx, C.c_void_p(strips_ptr), C.c_void_p(frame_ptr), width, height,
-                                            row_block, world, self._stream_arg(stream)),
-               "rt_deinterleave_device")
+    def deinterleave_device(self, strips_ptr, frame_ptr, width, height, row_block, world, stream=None, first=0):
+        """first: position of strip 0 in the gathered buffer (1 when the strips were handed out by rt_strip_of_rank)."""
+        _check(lib().rt_deinterleave_rotated_device(self._ctx, C.c_void_p(strips_ptr), C.c_void_p(frame_ptr), width, height,
+                                                    row_block, world, first, self._stream_arg(stream)),
+               "rt_deinterleave_rotated_device")
 
     # -- progressive accumulation (reference worker()/update_frame() protocol)
     def progressive_begin(self, width, height, init_scale=8, max_bounces=10, seed=0, rank=0, world=1):

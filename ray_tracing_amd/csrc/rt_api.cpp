@@ -186,6 +186,26 @@ static int order_behind_previous(rt_context *ctx, hipStream_t stream)
 	return RT_OK;
 }
 
+/* Resident workgroups per CU for the launch about to be enqueued on `stream`.  rt_tuning.workgroups_per_cu, if set.  Else: a
+ * launch enqueued while the previous one, on the context's OTHER stream, has not even started takes half the chip's
+ * workgroup slots (2 of 4 per CU).  In a run of such launches two are resident side by side, half a launch apart, and the
+ * compute units a launch's last waves leave idle belong to waves of the next one that are already there, not to workgroups
+ * that have yet to start (C1: strips of 8 ranks -4.6 %, of 4 -4.4 %, of 2 -3 %, whole frames the same; scripts/wg_probe.py).
+ * It only pays when the host keeps two launches resident at all times, i.e. enqueues more than a launch ahead -- the N-GPU
+ * loops do (three frames in flight) -- and costs when it does not: a loop with two frames in flight submits frame k+2 when
+ * frame k has been delivered, and until then frame k+1 would have half a chip to itself (C1 whole frames +2.7 %).  That is
+ * what the test tells apart: such a host finds the previous launch running.  A launch with nothing beside it (rt_render(),
+ * the first frame of a run, every launch of a host that uses one stream) takes all the slots. */
+static int workgroups_per_cu_for(rt_context *ctx, hipStream_t stream)
+{
+	if (ctx->tuning.workgroups_per_cu > 0) return ctx->tuning.workgroups_per_cu;
+	const rt_context::launch_slot &prev = ctx->slot[(ctx->launches + 1u) & 1u];
+	if (!prev.used || prev.stream == stream) return 0;
+	const hipError_t q = hipEventQuery(prev.started);
+	(void) hipGetLastError();           /* "not ready" is an answer, not an error the launch below should find */
+	return q == hipErrorNotReady ? 2 : 0;
+}
+
 static int mark_launch(rt_context *ctx, hipStream_t stream)
 {
 	rt_context::launch_slot &sl = ctx->slot[ctx->launches & 1u];
@@ -707,7 +727,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	}
 	ctx->slot[ctx->launches & 1u].lists_key = 0;
 	ctx->primary_passes++;
-	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->slot[ctx->launches & 1u].d_counter, e0, ctx->slot[ctx->launches & 1u].started, ctx->num_cus, ctx->tuning.workgroups_per_cu, stream);
+	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->slot[ctx->launches & 1u].d_counter, e0, ctx->slot[ctx->launches & 1u].started, ctx->num_cus, workgroups_per_cu_for(ctx, stream), stream);
 	if (le == hipSuccess && ctx->profiling) le = hipEventRecord(e1, stream);
 	if (ctx->profiling) {
 		if (le == hipSuccess) ctx->events.emplace_back(e0, e1);
@@ -859,17 +879,28 @@ int rt_was_cancelled(rt_context *ctx)
 	return w ? RT_CANCELLED : RT_OK;
 }
 
-int rt_deinterleave_device(rt_context *ctx, const void *d_strips, void *d_frame,
-                           int width, int height, int row_block, int world, void *hip_stream)
+int rt_deinterleave_rotated_device(rt_context *ctx, const void *d_strips, void *d_frame,
+                                   int width, int height, int row_block, int world, int first, void *hip_stream)
 {
 	if (!ctx || !d_strips || !d_frame) return fail(RT_ERR_ARGUMENT, "rt_deinterleave_device: NULL argument");
-	if (width < 1 || height < 1 || row_block < 1 || world < 1)
+	if (width < 1 || height < 1 || row_block < 1 || world < 1 || first < 0 || first >= world)
 		return fail(RT_ERR_ARGUMENT, "rt_deinterleave_device: bad geometry");
 	HIP_TRY(hipSetDevice(ctx->device));
 	hipStream_t stream = pick_stream(ctx, hip_stream);
 	HIP_TRY(rt_launch_deinterleave((const float*) d_strips, (float*) d_frame, width, height, row_block, world,
-	                               rt_strip_rows(height, row_block, world), stream));
+	                               rt_strip_rows(height, row_block, world), first, stream));
 	return RT_OK;
+}
+
+int rt_deinterleave_device(rt_context *ctx, const void *d_strips, void *d_frame,
+                           int width, int height, int row_block, int world, void *hip_stream)
+{
+	return rt_deinterleave_rotated_device(ctx, d_strips, d_frame, width, height, row_block, world, 0, hip_stream);
+}
+
+int rt_strip_of_rank(int rank, int world)
+{
+	return world > 1 ? (rank + world - 1) % world : 0;
 }
 
 /* ---- progressive accumulation: worker() scale ladder + update_frame() (main.c:354-408, 450-482) ---- */

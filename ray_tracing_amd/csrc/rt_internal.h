@@ -32,7 +32,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 int        rt_jit_build(const rt_geom *geom, int n, int light_index, const float light_pos[3], int waves_per_simd, const char *extra_flags, hipModule_t *module, hipFunction_t *function, std::string &message,
                         std::vector<char> *code_out = nullptr);   /* the code object hiprtc produced (development aid) */
 hipError_t rt_launch_deinterleave(const float *strips, float *frame, int width, int height,
-                                  int row_block, int world, int rows_per_rank, hipStream_t stream);
+                                  int row_block, int world, int rows_per_rank, int first, hipStream_t stream);
 
 hipError_t rt_launch_accumulate(float *accum, const float *lowres, int width, int height, int scale,
                                 int low_w, int low_h, float k, const unsigned int *cancelled, float *count,

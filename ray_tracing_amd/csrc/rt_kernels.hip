@@ -1317,14 +1317,16 @@ rt_resolve(const float *accum, float *frame, size_t floats, const float *count)
 
 /* ---- de-interleave: gathered per-rank strips -> full frame (multi-GPU root) ------------------- */
 extern "C" __global__ void __launch_bounds__(RT_BLOCK)
-rt_deinterleave(const float *strips, float *frame, int width, int height, int row_block, int world, int rows_per_rank)
+rt_deinterleave(const float *strips, float *frame, int width, int height, int row_block, int world, int rows_per_rank, int first)
 {
 	const size_t row_floats = (size_t) width * 3;
 	const size_t total = (size_t) height * row_floats;
 	for (size_t k = (size_t) blockIdx.x * RT_BLOCK + threadIdx.x; k < total; k += (size_t) gridDim.x * RT_BLOCK) {
 		const int j = (int) (k / row_floats);
 		const size_t c = k % row_floats;
-		const int blk = j / row_block, rank = blk % world, lblk = blk / world;
+		/* strip s = blk % world sits at position (s + first) % world of the gathered buffer: the host may hand the strips out
+		 * rotated, so that the root renders the shortest one (first = 1: rank r renders strip r - 1, rank 0 the last) */
+		const int blk = j / row_block, rank = (blk % world + first) % world, lblk = blk / world;
 		const int lr = lblk * row_block + j % row_block;
 		frame[k] = strips[((size_t) rank * rows_per_rank + lr) * row_floats + c];
 	}
@@ -1677,10 +1679,10 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 }
 
 hipError_t rt_launch_deinterleave(const float *strips, float *frame, int width, int height,
-                                  int row_block, int world, int rows_per_rank, hipStream_t stream)
+                                  int row_block, int world, int rows_per_rank, int first, hipStream_t stream)
 {
 	hipLaunchKernelGGL(rt_deinterleave, dim3(2048), dim3(RT_BLOCK), 0, stream,
-	                   strips, frame, width, height, row_block, world, rows_per_rank);
+	                   strips, frame, width, height, row_block, world, rows_per_rank, first);
 	return hipGetLastError();
 }
 #endif /* RT_SPEC_ONLY */

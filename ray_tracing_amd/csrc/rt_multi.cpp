@@ -322,7 +322,7 @@ int rt_multi_frame_submit(rt_multi *m, const rt_render_params *params, int slot,
 		if (e == hipSuccess && d.gathered_set[j]) e = hipStreamWaitEvent(rs, d.gathered[j], 0);
 		if (e != hipSuccess) { rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: device %d: %s", m->devices[(size_t) i], hipGetErrorString(e)); break; }
 		rt_render_params p = *params;
-		p.rank = i; p.world = n;
+		p.rank = rt_strip_of_rank(i, n); p.world = n;     /* rotated by one: device 0, the root, renders the last strip -- never the longest (rt_hip.h) */
 		rc = rt_render_device(ctx, &p, d.d_strip[j], rs);
 		if (rc != RT_OK) break;
 		enqueued++;
@@ -355,7 +355,7 @@ int rt_multi_frame_submit(rt_multi *m, const rt_render_params *params, int slot,
 	if (rc == RT_OK) {
 		hipError_t e = hipSetDevice(m->devices[0]);
 		if (e == hipSuccess)
-			rc = rt_deinterleave_device(m->ctx[0], m->d_strips[j], f.d_frame, W, H, rb, n, m->dev[0].gather_stream);
+			rc = rt_deinterleave_rotated_device(m->ctx[0], m->d_strips[j], f.d_frame, W, H, rb, n, n > 1 ? 1 : 0, m->dev[0].gather_stream);
 		if (rc == RT_OK && e == hipSuccess) e = hipEventRecord(f.assembled, m->dev[0].gather_stream);
 		if (rc == RT_OK && e == hipSuccess) e = hipStreamWaitEvent(m->copy_stream, f.assembled, 0);
 		if (rc == RT_OK && e == hipSuccess) e = hipMemcpyAsync(frame_out, f.d_frame, frame_floats * sizeof(float), hipMemcpyDeviceToHost, m->copy_stream);

@@ -2,8 +2,8 @@
 
 The reference parallelises by giving each CPU thread one contiguous image column (main.c:333,363),
 which is badly load-imbalanced (sky columns finish long before object columns).  Here block b of
-`row_block` rows goes to rank b % world, so every rank sees the same mix of sky and geometry; each
-rank renders its blocks into a compact strip (kernel side: rt_device.h `rt_launch`), rank 0 receives
+`row_block` rows goes to strip b % world, so every strip has the same mix of sky and geometry; each
+rank renders one strip (rank r strip r - 1, the root the last one: strip_of_rank) into a compact buffer (kernel side: rt_device.h `rt_launch`), rank 0 receives
 all strips with a single gather and de-interleaves them.  One process per GPU, `torch.distributed`
 supplies the communicator (backend "nccl" = RCCL on ROCm; "gloo" on CPU for the tests).
 
@@ -35,12 +35,20 @@ def owned_rows(height, row_block, rank, world):
     return np.where(g < height, g, -1)
 
 
-def frame_index(height, row_block, world):
-    """For every frame row: position in the gathered [world * strip_rows] row array."""
+def strip_of_rank(rank, world):
+    """The strip rank `rank` renders (== rt_strip_of_rank in the C ABI): handed out rotated by one, so that the root --
+    which also gathers, de-interleaves and copies the frame out -- has the last strip, which is never the longest
+    (1080 rows in blocks of 8 over 8 ranks: 16 blocks instead of 17)."""
+    return (rank + world - 1) % world if world > 1 else 0
+
+
+def frame_index(height, row_block, world, first=0):
+    """For every frame row: position in the gathered [world * strip_rows] row array; strip s sits at position
+    (s + first) % world (first = 1 when the strips were handed out by strip_of_rank)."""
     n = strip_rows(height, row_block, world)
     j = np.arange(height)
     blk = j // row_block
-    return (blk % world) * n + (blk // world) * row_block + j % row_block
+    return ((blk % world + first) % world) * n + (blk // world) * row_block + j % row_block
 
 
 def collective_for(backend=None):
@@ -73,10 +81,10 @@ def gather_strips(strip, rank, world, dst=0, out=None, primitive=None, async_op=
     return (out if rank == dst else None), work
 
 
-def assemble(strips, height, row_block, world, renderer=None, out=None, stream=None):
+def assemble(strips, height, row_block, world, renderer=None, out=None, stream=None, first=0):
     """De-interleave gathered strips into the frame [height, W, 3].  On a GPU tensor this is the
     library's rt_deinterleave kernel, enqueued on `stream` (a torch stream; default: the current one);
-    on CPU tensors (gloo tests) an index_select."""
+    on CPU tensors (gloo tests) an index_select.  first: see frame_index."""
     W = strips.shape[2]
     if strips.is_cuda:
         if renderer is None:
@@ -84,9 +92,9 @@ def assemble(strips, height, row_block, world, renderer=None, out=None, stream=N
         if out is None:
             out = torch.empty((height, W, 3), dtype=torch.float32, device=strips.device)
         s = stream if stream is not None else torch.cuda.current_stream(strips.device)
-        renderer.deinterleave_device(strips.data_ptr(), out.data_ptr(), W, height, row_block, world, s.cuda_stream)
+        renderer.deinterleave_device(strips.data_ptr(), out.data_ptr(), W, height, row_block, world, s.cuda_stream, first=first)
         return out
-    idx = torch.from_numpy(frame_index(height, row_block, world))
+    idx = torch.from_numpy(frame_index(height, row_block, world, first))
     flat = strips.reshape(-1, W, 3)
     return flat.index_select(0, idx)
 
@@ -112,6 +120,8 @@ class TiledFrame:
                  kernel=0, device=None, to_host=True, overlap_frames=True, force_collective=False):
         self.r, self.W, self.H = renderer, width, height
         self.row_block, self.rank, self.world = row_block, rank, world
+        self.strip_index = strip_of_rank(rank, world)      # the strip this rank renders; the gathered buffer holds strip s at (s + 1) % world
+        self.first = 1 if world > 1 else 0
         self.spp, self.max_bounces, self.kernel, self.seed = spp, max_bounces, kernel, seed
         self.to_host = to_host and rank == 0
         self.device = device
@@ -172,7 +182,7 @@ class TiledFrame:
                 if self.assembled[j] is not None:
                     s.wait_event(self.assembled[j])        # ... and its de-interleave reads strips[j], which this gather overwrites
             p = self.r.params(self.W, self.H, self.spp, self.max_bounces, seed=self.seed if seed is None else seed,
-                              row_block=self.row_block, rank=self.rank, world=self.world, kernel=self.kernel)
+                              row_block=self.row_block, rank=self.strip_index, world=self.world, kernel=self.kernel)
             self.r.render_device(p, self.strip[j].data_ptr(), s.cuda_stream)
             if self.record_events:
                 ev = torch.cuda.Event(enable_timing=True)
@@ -202,7 +212,7 @@ class TiledFrame:
                 if self.copied[f] is not None:
                     self.post.wait_event(self.copied[f])   # frame[f] is still being copied out
                 frame = assemble(self.strips[j], self.H, self.row_block, self.world, renderer=self.r,
-                                 out=self.frame[f], stream=self.post)
+                                 out=self.frame[f], stream=self.post, first=self.first)
                 read = torch.cuda.Event()
                 read.record(self.post)
                 self.assembled[j] = read

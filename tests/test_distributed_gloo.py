@@ -28,12 +28,16 @@ def _worker(rank, world, port, W, H, rb, q):
     from ray_tracing_amd import multi_gpu as mg
     o = Oracle(); o.set_skybox(synthetic_skybox(32, seed=7)); o.load_scene(os.path.join(DATA_DIR, "scene_0.txt"))
     assert mg.collective_for() == "gather"
-    rows = mg.owned_rows(H, rb, rank, world)
     ok = True
-    out = torch.empty((world, len(rows), W, 3), dtype=torch.float32) if rank == 0 else None
+    out = torch.empty((world, mg.strip_rows(H, rb, world), W, 3), dtype=torch.float32) if rank == 0 else None
     # two consecutive frames with different seeds through the same buffers (a stale strip would show), the
-    # first with the blocking call, the second with the asynchronous one TiledFrame uses
+    # first with the blocking call and rank r holding strip r, the second with the asynchronous call and the strips
+    # handed out rotated by one (the root has the last, never the longest), as TiledFrame does both
     for frame_no, seed in enumerate((3, 4)):
+        first = frame_no
+        rows = mg.owned_rows(H, rb, mg.strip_of_rank(rank, world) if first else rank, world)
+        if first and rank == 0:
+            assert (rows >= 0).sum() == min((mg.owned_rows(H, rb, s, world) >= 0).sum() for s in range(world))
         strip = torch.zeros((len(rows), W, 3), dtype=torch.float32)
         for lr, j in enumerate(rows):
             if j >= 0:
@@ -42,7 +46,7 @@ def _worker(rank, world, port, W, H, rb, q):
         if work is not None:
             work.wait()
         if rank == 0:
-            frame = mg.assemble(got, H, rb, world)
+            frame = mg.assemble(got, H, rb, world, first=first)
             full = o.render_counter(W, H, 2, 4, seed=seed, threads=2)
             ok = ok and bool((frame.numpy().view(np.uint32) == full.view(np.uint32)).all())
         else:

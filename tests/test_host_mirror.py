@@ -202,6 +202,14 @@ def test_strip_rows_and_partition_cover_every_row_once():
                 assert sorted(real.tolist()) == list(range(H))
                 idx = mg.frame_index(H, rb, world)
                 assert (rows[idx] == np.arange(H)).all()
+                # the strips handed out rotated by one (what both hosts do): a permutation of the ranks, the root's strip
+                # is never longer than another, and frame_index(first=1) finds every row
+                strips = [mg.strip_of_rank(r, world) for r in range(world)]
+                assert sorted(strips) == list(range(world))
+                assert all(rt.lib().rt_strip_of_rank(r, world) == strips[r] for r in range(world))
+                held = [mg.owned_rows(H, rb, s, world) for s in strips]
+                assert (held[0] >= 0).sum() == min((h >= 0).sum() for h in held)
+                assert (np.concatenate(held)[mg.frame_index(H, rb, world, first=1 if world > 1 else 0)] == np.arange(H)).all()
 
 
 def test_frame_sink_and_ppm(tmp_path):
