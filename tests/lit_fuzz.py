@@ -1,5 +1,7 @@
-"""Development aid (CPU only): random scenes with a sphere emitter through tests/lit_probe.c -- the shipped rt_lit.h against
-the oracle's trace at every shading point of every bounce.  usage: lit_fuzz.py [cases] [seed] [scale] [camera distance]   (exit status 1 on a violation; scale multiplies every coordinate and size)"""
+"""Development aid (CPU only): random scenes with one emitter -- a sphere or a cube, thin panels and cubes that touch their
+neighbours among them -- through tests/lit_probe.c: the shipped rt_lit.h against the oracle's trace at every shading point of
+every bounce.  usage: lit_fuzz.py [cases] [seed] [scale] [camera distance] [sphere|box|mixed]   (exit status 1 on a violation;
+scale multiplies every coordinate and size)"""
 import os, subprocess, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,9 +11,10 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 scale = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 far = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0      # > 0: the camera stands this many scene sizes away and looks at the scene
+emitters = sys.argv[5] if len(sys.argv) > 5 else "mixed"
 def num(x): return "%.9f" % float(x)
 def vec(v): return "{%s}" % " ".join(num(x) for x in v)
-bad = taps = known = tabled = dark = dark_tabled = 0
+bad = taps = known = tabled = dark = dark_tabled = alone = 0
 for case in range(cases):
     n = int(rng.integers(2, 14))
     light = int(rng.integers(0, n))
@@ -21,13 +24,17 @@ for case in range(cases):
         mat = [P("emission_color", "{1.0 1.0 1.0}"), P("emission_power", num(4.0 if k == light else 0.0)), P("metallic", num(rng.choice([0, 0, 1]))),
                P("reflectance", num(rng.uniform(0, 1))), P("roughness", num(rng.choice([0, 0.3, 1.0]))), P("albedo", vec(rng.uniform(0, 1, 3)))]
         tight = rng.random() < 0.5          # objects that touch: shared planes, spheres resting on slabs
-        if k == light or rng.random() < 0.4:
+        ball = rng.random() < 0.4
+        if k == light: ball = emitters == "sphere" or (emitters == "mixed" and rng.random() < 0.5)
+        if ball:
             c = rng.integers(-3, 7, 3).astype(float) if tight else rng.uniform(-3, 7, 3)
             r = float(rng.choice([0.25, 0.5, 1.0, 2.0])) if tight else float(rng.uniform(0.06, 2.0))
             txt += ["sphere"] + ["\t" + m for m in mat] + ["\t" + P("center", vec(c * scale)), "\t" + P("radius", num(r * scale)), ""]
         else:
             o = rng.integers(-3, 7, 3).astype(float) if tight else rng.uniform(-3, 7, 3)
             sz = rng.choice([0.1, 0.5, 1.0, 3.0, 9.0], 3) if tight else rng.uniform(0.05, 5, 3)
+            if k == light and rng.random() < 0.6: sz = np.minimum(np.asarray(sz, dtype=float), rng.choice([0.1, 0.5, 1.0, 2.0]))     # emitters are seldom huge
+            if k == light and rng.random() < 0.5: sz = np.asarray(sz, dtype=float); sz[int(rng.integers(0, 3))] = 0.1          # a panel
             txt += ["cube"] + ["\t" + m for m in mat] + ["\t" + P("origin", vec(o * scale)), "\t" + P("size", vec(np.asarray(sz) * scale)), ""]
     path = os.path.join(tempfile.gettempdir(), f"lit_fuzz_scene_{os.getpid()}.txt")
     open(path, "w").write("\n".join(txt))
@@ -45,6 +52,10 @@ for case in range(cases):
         if dl:
             d = dl[0].split()
             dark += int(round(float(d[1]) / 100 * int(w[2]))); dark_tabled += int(round(float(d[d.index("%),") + 1]) / 100 * int(w[2])))
+        al = [l for l in r.stdout.splitlines() if l.startswith("alone:")]     # "alone: x % of the taps (bounce 0: y %), ...; violations v"
+        if al:
+            d = al[0].split()
+            alone += int(round(float(d[1]) / 100 * int(w[2])))
     if r.returncode == 2:
         raise SystemExit(f"case {case}: scene file rejected\n{r.stderr}")
     if r.returncode != 0:
@@ -54,5 +65,6 @@ for case in range(cases):
 for f in (path, exe):
     if os.path.exists(f): os.remove(f)
 print(f"{cases} scenes, {taps} taps checked, {known} answered without tracing ({100.0 * known / max(taps, 1):.1f} %), {tabled} by the per-scene table ({100.0 * tabled / max(taps, 1):.1f} %), "
-      f"{dark} certainly NOT reaching the emitter ({100.0 * dark / max(taps, 1):.1f} %; {dark_tabled} by the table), {bad} scenes with violations")
+      f"{dark} certainly NOT reaching the emitter ({100.0 * dark / max(taps, 1):.1f} %; {dark_tabled} by the table), "
+      f"{alone} more that would need only the emitter and what touches it intersected (a look ahead, not in the product: {100.0 * alone / max(taps, 1):.1f} %), {bad} scenes with violations")
 sys.exit(1 if bad else 0)
