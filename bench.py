@@ -377,6 +377,11 @@ def main():
         check.close()
         same = bool((got.view(np.uint32) == want.view(np.uint32)).all())
         verified = {"last_frame_seed": last_seed, "equals_blocking_rt_render": same, "frame_mean": round(float(got.mean()), 6)}
+        if not same:                  # where: enough to tell a stale strip from a stray pixel
+            bad = (got.view(np.uint32) != want.view(np.uint32)).any(axis=2)
+            rows_bad = np.flatnonzero(bad.any(axis=1))
+            verified["mismatch"] = {"pixels": int(bad.sum()), "rows": int(rows_bad.size), "first_rows": [int(r) for r in rows_bad[:12]],
+                                    "pixels_in_first_row": int(bad[rows_bad[0]].sum()) if rows_bad.size else 0}
         try:
             from rtlibs import Oracle
             o = Oracle(); o.load_scene(scene_path); o.set_skybox(sky); o.set_camera()

@@ -192,15 +192,16 @@ RT_API int rt_frame_poll(rt_context *ctx, int slot);
 RT_API int  rt_host_alloc(void **out, size_t bytes);
 RT_API void rt_host_free(void *p);
 
-/* Giving up a frame, as the reference's workers do when the camera moves mid-pass (main.c:316-317): rt_cancel()
- * asks the launch that is RUNNING on this context to stop -- its waves hand out no more samples, finish the paths in
- * flight and leave, within a few hundred microseconds.  It may be called from ANY host thread while another one is inside
- * rt_render*() for the same context; it returns at once.  rt_render() then returns RT_CANCELLED and its frame is
- * incomplete; after rt_render_device(), rt_was_cancelled() (which waits for the launch) tells; rt_frame_wait() reports it
- * for a submitted frame.  A launch that was enqueued before the request but has not started yet (the second of two frames
- * in flight) clears the request's marks when it starts and runs to the end; launches enqueued after the request are
- * ordered behind it and are not affected either.  rt_progressive_invalidate() does this by itself for a pass in flight,
- * and that pass is not accumulated. */
+/* Giving up what has been asked for, as the reference's workers do when the camera moves mid-pass (main.c:316-317, where
+ * the generation counter invalidates whatever every worker is doing): rt_cancel() asks EVERY launch enqueued on this
+ * context so far -- the one that is running and those still queued behind it (the second of two frames in flight) -- to
+ * stop: its waves hand out no more samples, finish the paths in flight and leave, within a millisecond or two of the call
+ * (a wave looks for the request every 32 rounds) or of their start.  The request is one store into host memory that the
+ * kernels read: the call returns at once, enqueues nothing, and may come from ANY host thread while another one is inside
+ * rt_render*() for the same context.  rt_render() then returns RT_CANCELLED and its frame is incomplete; after
+ * rt_render_device(), rt_was_cancelled() (which waits for the launch) tells; rt_frame_wait() reports it for a submitted
+ * frame.  Launches enqueued after the call are not affected.  rt_progressive_invalidate() does this by itself for a pass
+ * in flight, and that pass is not accumulated. */
 RT_API int rt_cancel(rt_context *ctx);
 RT_API int rt_was_cancelled(rt_context *ctx);
 

@@ -58,6 +58,8 @@ int rt_fail(int code, const char *fmt, ...)      /* for the library's other tran
 			return fail(RT_ERR_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
 	} while (0)
 
+#define RT_STOP_WORD 16
+
 struct rt_context {
 	int          device = 0;
 	hipStream_t  stream = nullptr;
@@ -108,19 +110,15 @@ struct rt_context {
 		hipEvent_t   readback = nullptr;     /* behind the copy of this set's control word to the host (rt_context_read_control) */
 		hipStream_t  readback_stream = nullptr;
 		bool         readback_pending = false; /* ... which the set's next launch, which clears the word, has to wait for */
-		std::atomic<bool> cancel_pending{false};  /* a stop request was sent since the set's last launch: see begin_launch() */
 	} slot[2];
 	unsigned     launches = 0;           /* launch n uses slot[n & 1] */
 	int          cur = 0;                /* set of the most recent launch */
 	hipStream_t  stream2 = nullptr;      /* rt_stream(ctx, 1): made on first request */
 	std::once_flag stream2_once;
-	hipStream_t  cancel_stream = nullptr; /* rt_cancel(): a copy that overtakes the running kernel */
-	hipEvent_t   cancel_event = nullptr;  /* recorded behind that copy: the next launches' clearing of the control words waits for it */
-	std::once_flag cancel_once;          /* the stream and event are made by the first rt_cancel(): HIP maps streams onto a
-	                                      * handful of hardware queues, and a stream nobody uses would only make two busy ones
-	                                      * share a queue (measured: the host copy of a frame then no longer overlaps the next render) */
-	hipError_t   cancel_setup = hipSuccess;
-	unsigned int *h_words = nullptr;     /* pinned: [0] = read-back of control[1]; [32 ...] = 64 x 128 bytes of 0x80000000 (source of the stop request) */
+	std::atomic<unsigned int> enqueued{0}; /* = launches, for rt_cancel() on another thread: the launches enqueued so far are numbers 1 ... enqueued */
+	unsigned int *h_words = nullptr;     /* pinned: [0] = read-back of control[1], [1 ...] = per frame slot, [8] = the ladder's count;
+	                                      * [RT_STOP_WORD] = rt_cancel()'s request, read by the trace kernels (rt_launch.stop): "launches up to this number stop" */
+	unsigned int *d_stop = nullptr;      /* the device's address of that word */
 	int          num_cus = 256;
 
 	float       *d_frame = nullptr;      /* scratch for rt_render() */
@@ -179,8 +177,6 @@ static int order_behind_previous(rt_context *ctx, hipStream_t stream)
 	 * half of either grid finds no pixels left.) */
 	rt_context::launch_slot &prev = ctx->slot[(ctx->launches + 1u) & 1u];
 	if (prev.used && prev.stream != stream) HIP_TRY(hipStreamWaitEvent(stream, prev.started, 0));
-	/* a stop request meant for earlier launches must have landed before this launch clears the set's control words */
-	if (sl.cancel_pending.exchange(false)) HIP_TRY(hipStreamWaitEvent(stream, ctx->cancel_event, 0));
 	/* ... and a frame in flight must have read them (rt_frame_submit) */
 	if (sl.readback_pending) { sl.readback_pending = false; if (sl.readback_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, sl.readback, 0)); }
 	return RT_OK;
@@ -213,6 +209,7 @@ static int mark_launch(rt_context *ctx, hipStream_t stream)
 	sl.stream = stream; sl.used = true;
 	ctx->cur = (int) (ctx->launches & 1u);
 	ctx->launches++;
+	ctx->enqueued.store(ctx->launches, std::memory_order_release);
 	return RT_OK;
 }
 
@@ -310,8 +307,9 @@ int rt_create(rt_context **out, int device_id)
 			if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
 			if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.started, hipEventDisableTiming);
 		}
-		if (e == hipSuccess) e = hipHostMalloc((void**) &ctx->h_words, (size_t) (32 + 64 * 32) * sizeof(unsigned int), hipHostMallocDefault);
-		if (e == hipSuccess) { ctx->h_words[0] = 0u; for (int k = 0; k < 64 * 32; k++) ctx->h_words[32 + k] = 0x80000000u; }
+		if (e == hipSuccess) e = hipHostMalloc((void**) &ctx->h_words, (size_t) 64 * sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent);
+		if (e == hipSuccess) { for (int k = 0; k < 64; k++) ctx->h_words[k] = 0u; }
+		if (e == hipSuccess) e = hipHostGetDevicePointer((void**) &ctx->d_stop, &ctx->h_words[RT_STOP_WORD], 0);
 		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 		if (e != hipSuccess) {
 			for (auto &sl : ctx->slot) { (void) hipFree(sl.d_counter); if (sl.done) (void) hipEventDestroy(sl.done); if (sl.started) (void) hipEventDestroy(sl.started); }
@@ -343,10 +341,8 @@ void rt_destroy(rt_context *ctx)
 	if (ctx->copy_stream) { (void) hipStreamSynchronize(ctx->copy_stream); (void) hipStreamDestroy(ctx->copy_stream); }
 	for (auto &f : ctx->fq) { if (f.copied) (void) hipEventDestroy(f.copied); (void) hipFree(f.d_buf); }
 	if (ctx->stream2) { (void) hipStreamSynchronize(ctx->stream2); (void) hipStreamDestroy(ctx->stream2); }
-	if (ctx->cancel_stream) { (void) hipStreamSynchronize(ctx->cancel_stream); (void) hipStreamDestroy(ctx->cancel_stream); }
-	if (ctx->cancel_event) (void) hipEventDestroy(ctx->cancel_event);
 	if (ctx->h_words) (void) hipHostFree(ctx->h_words);
-	if (ctx->spec_module) (void) hipModuleUnload(ctx->spec_module);
+	/* (the compiled scene's module belongs to the process-wide cache of rt_jit.cpp: never unloaded) */
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
 	(void) hipFree(ctx->d_lit_cells); (void) hipFree(ctx->d_lit_grids);
 	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame);
@@ -425,7 +421,7 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 		ctx->only_light_emits = only;
 	}
 	ctx->h_geom.assign(geom.begin(), geom.begin() + n);
-	if (ctx->spec_module) { (void) hipModuleUnload(ctx->spec_module); ctx->spec_module = nullptr; ctx->spec_fn = nullptr; }
+	ctx->spec_module = nullptr; ctx->spec_fn = nullptr;      /* (not unloaded: rt_jit.cpp keeps compiled scenes for the life of the process) */
 	if (light >= 0) {
 		const Object &o = scene->objects[light];
 		if (o.type == OBJECT_SPHERE) {
@@ -655,6 +651,8 @@ static int prepare_launch(rt_context *ctx, rt_launch &L, unsigned which)
 	L.pix_shard_cap = (int) cap;
 	L.pix_count = sl.d_counter + 64 * 32;      /* counter block: 64 dequeue counters, 64 fill counters, one control line */
 	L.control = sl.d_counter + 128 * 32;
+	L.stop = ctx->d_stop;
+	L.launch_id = ctx->launches + 1u;              /* mark_launch() counts it */
 	return RT_OK;
 }
 
@@ -845,25 +843,16 @@ int rt_host_alloc(void **out, size_t bytes)
 
 void rt_host_free(void *p) { if (p) (void) hipHostFree(p); }
 
-/* The stop request travels on its own stream, so it overtakes the kernel it is meant for; the counter block is
- * cleared at the start of every launch.  Uses nothing of the context that a render call on
- * another thread changes. */
+/* Every launch enqueued so far -- running or still queued -- is asked to stop; launches enqueued later have higher numbers and
+ * are not affected.  Uses nothing of the context that a render call on another thread changes. */
 int rt_cancel(rt_context *ctx)
 {
 	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_cancel: NULL context");
-	HIP_TRY(hipSetDevice(ctx->device));
-	std::call_once(ctx->cancel_once, [ctx]() {
-		hipError_t e = hipStreamCreateWithPriority(&ctx->cancel_stream, hipStreamNonBlocking, -1);     /* high priority: it must overtake */
-		if (e != hipSuccess) e = hipStreamCreateWithFlags(&ctx->cancel_stream, hipStreamNonBlocking);
-		if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->cancel_event, hipEventDisableTiming);
-		ctx->cancel_setup = e;
-	});
-	if (ctx->cancel_setup != hipSuccess) return fail(RT_ERR_DEVICE, "rt_cancel: %s", hipGetErrorString(ctx->cancel_setup));
-	/* every dequeue counter jumps beyond any fill count: from now on no fetch returns a pixel (rt_kernels.hip) */
-	for (auto &sl : ctx->slot)
-		HIP_TRY(hipMemcpyAsync(sl.d_counter, &ctx->h_words[32], (size_t) 64 * 32 * sizeof(unsigned int), hipMemcpyHostToDevice, ctx->cancel_stream));
-	HIP_TRY(hipEventRecord(ctx->cancel_event, ctx->cancel_stream));
-	for (auto &sl : ctx->slot) sl.cancel_pending.store(true);
+	/* one store into host memory the trace kernels poll (rt_kernels.hip, top of a round): nothing is enqueued, nothing has to
+	 * find room on a GPU whose every wave slot the persistent kernel holds.  (Rounds 1-2 sent a copy down a stream of its own:
+	 * the runtime does small copies with a kernel, and beside the compiled trace kernel -- 4 x 128 registers per SIMD -- that
+	 * kernel only got to run when the launch it was meant to stop had finished.) */
+	__atomic_store_n(&ctx->h_words[RT_STOP_WORD], ctx->enqueued.load(std::memory_order_acquire), __ATOMIC_RELEASE);
 	return RT_OK;
 }
 
@@ -1021,6 +1010,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	{
 		rt_launch K = L;
 		K.seed = 0; K.sample_base = 0; K.max_bounces = 0; K.lit_cells = nullptr; K.lit_grids = nullptr; K.lit_grids_in_lds = 0;
+		K.launch_id = 0;
 		K.pix = nullptr; K.pix_count = nullptr; K.control = nullptr;      /* the scratch set's own addresses: the same output in either set has the same key */
 		key = 0xcbf29ce484222325ull ^ ctx->input_version;
 		const unsigned char *b = reinterpret_cast<const unsigned char*>(&K);

@@ -89,9 +89,12 @@ typedef struct {
 	float *pix;
 	unsigned int *pix_count;   /* one fill counter per list, 128 bytes apart */
 	int    pix_shard_cap;
-	/* control[1]: set by a wave that gave up because of rt_cancel() (which pushes the lists' dequeue counters beyond
-	 * any fill count, so that no fetch returns a pixel) -- the frame is incomplete */
+	/* control[1]: set by a wave that gave up because of rt_cancel() -- the frame is incomplete.  The request itself is a word
+	 * in host memory the device can read (`stop`, written by a plain store of the calling thread: nothing has to get past the
+	 * kernel that fills the chip): "the launches up to this number are to stop"; this launch is number launch_id. */
 	unsigned int *control;
+	const unsigned int *stop;
+	unsigned int launch_id;
 	const rt_geom  *geom;      /* num_objects records (global; staged to LDS)  */
 	const rt_shade *shade;
 } rt_launch;

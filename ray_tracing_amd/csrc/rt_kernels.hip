@@ -707,6 +707,9 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
  * Results are bit-identical to rt_trace_simple and to the CPU oracle.
  * ============================================================================================= */
 
+#ifndef RT_SUM_EVERY
+#define RT_SUM_EVERY 2                 /* rounds between two passes of the in-order sum (section 6) when a pixel has >= 32 samples */
+#endif
 #define WF_SHARDS  64                  /* pixel lists (at most); each has a fill counter and a dequeue counter, 128 B apart */
 #define RT_COUNTER_BYTES ((2 * WF_SHARDS + 1) * 128)   /* + one line of launch control words (rt_launch.control) */
 #define WF_QUEUE   128                 /* tap ring: at most 63 waiting + 64 pushed at a time */
@@ -870,6 +873,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	uint64_t rng = 0;
 	/* the tap queue persists across rounds: taps that do not fill a batch wait, at most two rounds */
 	unsigned int q_head = 0, q_tail = 0, phase = 0;     /* phase = round number mod 3 */
+	unsigned int sum_tick = 0;
+	const unsigned int sum_every = L.spp >= 32 ? RT_SUM_EVERY : 1u;
 
 	/* Section 6 of a round: adding the finished samples in sample order (main.c:394).  Lane j of a stream looks at
 	 * the j-th slot after the stream's last added one.  The slots that are filled without a gap from the first form
@@ -957,13 +962,29 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				int got = 0;
 				size_t first = 0;
 				if (!exhausted) {
-					unsigned int k = 0;
-					if (lane == 0) k = atomicAdd(block_counter + shard * 32u, (unsigned int) asked);
-					k = (unsigned int) __builtin_amdgcn_readfirstlane((int) k);
 					typedef const __attribute__((address_space(1))) unsigned int *guint;
+					typedef __attribute__((address_space(1))) unsigned int *gwuint;
+					/* rt_cancel() (main.c:316-317: the frame has been invalidated).  The host stores its request in a word of host
+					 * memory: "the launches up to this number are to stop".  Reading that is slow (a read over the link takes the
+					 * place of 75 ns of everybody else's: 4 096 waves asking at once cost a strip a third of its time), so only eight
+					 * waves of the launch do, when they fetch pixels, and pass the news on through control[2] in device memory, which
+					 * every other wave reads when it fetches pixels.  Told to stop, a wave hands out nothing more, lets the paths in
+					 * flight finish and leaves; the launch is marked incomplete.  (A wave that has no pixels left to fetch does not
+					 * ask any more: it is about to leave anyway.) */
+					unsigned int word = 0u, k = 0u;
+					if (lane == 0) {
+						word = (blockIdx.x < 8u && wave == 0) ? __hip_atomic_load((guint) C->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - C->launch_id
+						                                      : __hip_atomic_load((guint) C->control + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
+						k = atomicAdd(block_counter + shard * 32u, (unsigned int) asked);
+					}
+					k = (unsigned int) __builtin_amdgcn_readfirstlane((int) k);
+					if ((int) __builtin_amdgcn_readfirstlane((int) word) >= 0) {      /* the request covers this launch / another wave has seen it */
+						cancelled = true;
+						if (lane == 0) { C->control[1] = 1u; __hip_atomic_store((gwuint) C->control + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+					}
 					const guint fill_counts = (guint) C->pix_count;
 					const unsigned int filled = (unsigned int) __builtin_amdgcn_readfirstlane((int) fill_counts[shard * 32u]);
-					got = k < filled ? (filled - k < (unsigned int) asked ? (int) (filled - k) : asked) : 0;
+					got = k < filled && !cancelled ? (filled - k < (unsigned int) asked ? (int) (filled - k) : asked) : 0;
 					first = (size_t) shard * (size_t) C->pix_shard_cap + k;
 					if (got < asked) {
 						/* This list has run out: look at all of them at once (lane s reads list s's two counters; a stale
@@ -974,13 +995,6 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 							taken = __hip_atomic_load(block_counter + (unsigned int) lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 							const unsigned int have = fill_counts[(unsigned int) lane * 32u];
 							left = have > taken ? have - taken : 0u;
-						}
-						/* rt_cancel() makes every list look empty by pushing its dequeue counter beyond any fill count; seeing
-						 * that here (main.c:316-317: the frame has been invalidated) the wave gives up: nothing more is handed
-						 * out, the paths in flight finish, and the launch is marked incomplete */
-						if (__ballot(taken >= 0x80000000u) != 0ull) {
-							cancelled = true;
-							if (lane == 0) C->control[1] = 1u;
 						}
 						const unsigned long long some = __ballot(left != 0u);
 						if (some == 0ull || cancelled) { exhausted = true; STAMP_DRY; }
@@ -995,7 +1009,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					const PixelRec px = load_pixel(C, first + (size_t) rr);
 					if (direct) {
 						f_slot = px.off; f_live = true;
-						rng = path_seed(L.seed, px.index, (uint32_t) L.sample_base);
+						rng = (uint64_t) px.index;                /* (pixel index, sample 0): seeded where the sample is first shaded (section 2) */
 						bounce = 0;
 						hp = px.a; hn = px.n; hobj = px.obj & (RT_PIX_TAPS_LIT - 1); hdir = px.dir;
 						lit_next = ((uint32_t) px.obj >> 16) & 3u;
@@ -1027,7 +1041,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					const bool last = s + 1u == spp;
 					f_slot = (int) ((unsigned int) sg * wn + (slot % wn)) | (last ? WF_LAST : 0);
 					if (last) W.win[0][(unsigned int) sg * wn + ((slot + 1u) % wn)] = W.rec[11][sg];
-					rng = path_seed(L.seed, __float_as_uint(W.rec[10][sg]), (uint32_t) L.sample_base + s);
+					rng = ((uint64_t) s << 32) | (uint64_t) __float_as_uint(W.rec[10][sg]);   /* (pixel index, sample): seeded where the sample is first shaded (section 2) */
 					bounce = 0;
 					hp = mk3(W.rec[0][sg], W.rec[1][sg], W.rec[2][sg]);
 					hn = mk3(W.rec[3][sg], W.rec[4][sg], W.rec[5][sg]);
@@ -1067,6 +1081,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			STAT(8);
 			/* a camera-ray hit point from which every tap certainly reaches the emitter (flagged by rt_primary_pass): the taps
 			 * are drawn and accepted as always (main.c:193-195), but not traced */
+			/* a sample's first bounce: its path is seeded here, once per round for all the lanes that start one, not once per hand-out attempt */
+			if (bounce == 0) rng = path_seed(L.seed, (uint32_t) rng, (uint32_t) L.sample_base + (uint32_t) (rng >> 32));
 			const bool taps_lit = lit_next != 0u;      /* ... or a hit point of a later bounce in such a cell of the scene's table (section 4);
 			                                            * 1: they reach the emitter, 2: they certainly do not (and nothing else emits) */
 			if (have_light) {
@@ -1155,6 +1171,30 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			q_head += (unsigned int) count;
 			wave_fence();
 		};
+#ifndef RT_PUSH_APART
+		/* all three kinds in one go when the ring has room for them (it has, unless most taps of most lanes are traced): one
+		 * prefix sum over the lanes' tap counts instead of three ballots, one fence instead of three (C1 -2.1 %, strip -4.6 %, C2 +0.4 %:
+		 * profiles/r03/ab_push_together.txt) */
+		const unsigned int mine = (unsigned int) __popc((unsigned int) tapmask);
+		const unsigned long long c0 = __ballot((mine & 1u) != 0u), c1 = __ballot((mine & 2u) != 0u);
+		const unsigned int all = (unsigned int) __popcll(c0) + 2u * (unsigned int) __popcll(c1);
+		if (q_tail - q_head + all <= (unsigned int) WF_QUEUE) {
+			unsigned int slot = q_tail + (unsigned int) lanes_below(c0) + 2u * (unsigned int) lanes_below(c1);
+#pragma unroll
+			for (int t = 0; t < 3; t++)
+				if ((tapmask >> t) & 1) {
+					const unsigned int e = slot & (WF_QUEUE - 1);
+					const V3 qd = t == 0 ? tap_j0 : (t == 1 ? tap_j1 : tap_j2);
+					W.q[0][e] = hp.x; W.q[1][e] = hp.y; W.q[2][e] = hp.z;
+					W.q[3][e] = qd.x; W.q[4][e] = qd.y; W.q[5][e] = qd.z;
+					W.qmeta[e] = (unsigned short) (lane | ((t + 2) << 8) | (int) (phase << 12));
+					slot++;
+				}
+			q_tail += all;
+			wave_fence();
+			while (q_tail - q_head >= 64u) trace_taps(64);
+		} else
+#endif
 #pragma unroll 1
 		for (int kind = 2; kind < 5; kind++) {
 			switch (kind) {
@@ -1255,7 +1295,12 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 
 		STAMP(3);
 		/* ---- 6. add the finished samples in sample order (main.c:394) ---------------------------------------- */
-		if (!direct) add_finished_samples();
+		/* Every second round when a pixel has many samples: a stream's eight lanes add up to eight slots per pass and a round finishes
+		 * three or four samples per stream (C1), so one pass has room for two rounds' worth, and the pass costs the same 140
+		 * instructions whether it finds one slot or eight.  C1 -0.5 %, C2 -3.4 %, strips -0.3 % (`RT_SUM_EVERY`, profiles/r03/ab_sum_every.txt;
+		 * every third round: the window fills and lanes wait for slots, +1.5 ... +7 %).  Pixels of few samples complete too fast for
+		 * that -- a pass resolves at most one pixel per stream. */
+		if (!direct && (++sum_tick >= sum_every)) { sum_tick = 0u; add_finished_samples(); }
 		STAMP(4);
 	}
 	STAMP_FLUSH;

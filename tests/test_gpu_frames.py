@@ -152,7 +152,8 @@ def test_multi_single_device_is_the_plain_frame_queue(sky, scene_paths):
 
 @pytest.mark.parametrize("multi", [False, True])
 def test_cancel_reaches_a_frame_in_flight(sky, scene_paths, multi):
-    """rt_cancel() while a submitted frame renders: its wait reports the cut, the frame after it is whole."""
+    """rt_cancel() while a submitted frame renders: its wait reports the cut, the frame after it is whole.  (Compiled kernel:
+    the one that leaves no room on the GPU for anything a request might need to run there.)"""
     W, H, spp, nb = 1920, 1080, 1024, 8        # ~100 ms of GPU work
     if multi:
         q = rt.MultiRenderer([0])
@@ -161,13 +162,14 @@ def test_cancel_reaches_a_frame_in_flight(sky, scene_paths, multi):
     else:
         q = ctx = rt.Renderer(0)
     q.set_scene(scene_paths[0]); q.set_skybox(sky); q.set_camera()
+    q.compile_scene()
     a, b = rt.HostFrame(W, H), rt.HostFrame(320, 180)
     q.frame_submit(rt.Renderer.params(W, H, spp, nb, seed=1), 0, a)
     time.sleep(0.02)
     ctx.cancel()
     t0 = time.time()
     assert q.frame_wait(0) is False            # RT_CANCELLED
-    assert time.time() - t0 < 0.08
+    assert time.time() - t0 < 0.02
     q.frame_submit(rt.Renderer.params(320, 180, 4, 4, seed=2), 1, b)
     assert q.frame_wait(1) is True
     want = _reference_frames(scene_paths[0], sky, 320, 180, 4, 4, [2])[2]
