@@ -376,22 +376,32 @@ def main():
         want = check.render(W, H, spp, nb, seed=last_seed)          # generic kernel, one GPU, blocking
         check.close()
         same = bool((got.view(np.uint32) == want.view(np.uint32)).all())
-        verified = {"last_frame_seed": last_seed, "equals_blocking_rt_render": same, "frame_mean": round(float(got.mean()), 6)}
+        verified = {"last_frame_seed": last_seed, "equals_blocking_rt_render": same, "frame_mean": round(float(got.mean()), 6),
+                    "last_launch_cancelled": bool(gpu.was_cancelled())}
         if not same:                  # where: enough to tell a stale strip from a stray pixel
             bad = (got.view(np.uint32) != want.view(np.uint32)).any(axis=2)
             rows_bad = np.flatnonzero(bad.any(axis=1))
             verified["mismatch"] = {"pixels": int(bad.sum()), "rows": int(rows_bad.size), "first_rows": [int(r) for r in rows_bad[:12]],
-                                    "pixels_in_first_row": int(bad[rows_bad[0]].sum()) if rows_bad.size else 0}
+                                    "last_rows": [int(r) for r in rows_bad[-4:]],
+                                    "pixels_in_first_row": int(bad[rows_bad[0]].sum()) if rows_bad.size else 0,
+                                    # per strip (row block b belongs to strip b % world): rows that differ, and the first of them
+                                    "rows_per_strip": [int(sum(1 for r in rows_bad if (r // ROW_BLOCK) % world == s)) for s in range(world)],
+                                    "first_row_per_strip": [int(min([r for r in rows_bad if (r // ROW_BLOCK) % world == s], default=-1)) for s in range(world)]}
+            sys.stderr.write("VERIFICATION FAILED: " + json.dumps(verified["mismatch"]) + "\n")
         try:
             from rtlibs import Oracle
             o = Oracle(); o.load_scene(scene_path); o.set_skybox(sky); o.set_camera()
-            rows = [H // 3, (2 * H) // 3 + 1]
+            rows = [H // 3, (2 * H) // 3 + 1, H - 3]       # (the last rows are the last pixels a launch gets to: a launch cut short or read early shows there)
             ref_rows = o.render_counter_rows(W, H, spp, nb, rows, seed=last_seed)
             verified["oracle_rows"] = rows
             verified["equals_oracle_rows"] = bool(all((got[r].view(np.uint32) == v.view(np.uint32)).all() for r, v in ref_rows.items()))
+            if not same:              # which of the two GPU frames is the one that is off
+                verified["blocking_render_equals_oracle_rows"] = bool(all((want[r].view(np.uint32) == v.view(np.uint32)).all() for r, v in ref_rows.items()))
         except Exception as e:       # the oracle is a checker that may be absent; the GPU-vs-GPU check above stands
             verified["oracle_error"] = repr(e)
         verified["ok"] = same and verified.get("equals_oracle_rows", True)
+    if world > 1:
+        dist.barrier()                # the other ranks keep their contexts until rank 0 has looked: nobody tears a process down beside the check
 
     # ---- the host hand-off by itself: the frame's bytes from HBM to pinned host memory, nothing else on the GPU (torch is the
     # plumbing here; the loop's own copies are hipMemcpyAsync on the library's copy stream).  The only device crossing of the
