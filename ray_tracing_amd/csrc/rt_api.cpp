@@ -417,6 +417,7 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 				uint32_t bits_;
 				memcpy(&bits_, &shade[i].emission[k], 4);
 				if (i != light && (bits_ & 0x7fffffffu) != 0u) only = false;
+				if (i == light && (bits_ & 0x7f800000u) == 0x7f800000u) only = false;     /* (an infinite or NaN emission: n x e is not the n-fold sum for n = 0) */
 			}
 		ctx->only_light_emits = only;
 	}
@@ -498,7 +499,7 @@ int rt_compile_scene(rt_context *ctx)
 	if (!ctx->scene_fast_ok) return fail(RT_ERR_ARGUMENT, "rt_compile_scene: scene has a box with negative size or out-of-range coordinates");
 	HIP_TRY(hipSetDevice(ctx->device));
 	std::string message;
-	const int rc = rt_jit_build(ctx->h_geom.data(), n, ctx->light_index, ctx->light_pos, ctx->tuning.jit_waves_per_simd, ctx->jit_flags.c_str(),
+	const int rc = rt_jit_build(ctx->h_geom.data(), n, ctx->light_index, ctx->light_pos, ctx->only_light_emits ? 1 : 0, ctx->tuning.jit_waves_per_simd, ctx->jit_flags.c_str(),
 	                            &ctx->spec_module, &ctx->spec_fn, message, &ctx->spec_code);
 	if (rc != RT_OK) { ctx->spec_module = nullptr; ctx->spec_fn = nullptr; return fail(rc, "rt_compile_scene: %s", message.c_str()); }
 	return RT_OK;

@@ -830,10 +830,12 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	const int gshift = (lane & 48) + (lane & 1);            /* position of the stream's first lane */
 	const unsigned long long gmask = 0x5555ull << gshift;
 #ifdef RT_SPEC_HEADER
+	constexpr bool only_light = FAST && SPEC_ONLY_LIGHT_EMITS != 0 && SPEC_LIGHT >= 0;
 	const bool have_light = SPEC_LIGHT >= 0;               /* the compiled scene's emitter: literals, no scalar registers */
 	const V3 light_pos = mk3(SPEC_LIGHT_POS[0], SPEC_LIGHT_POS[1], SPEC_LIGHT_POS[2]);
 	const int light_obj = SPEC_LIGHT;
 #else
+	const bool only_light = FAST && L.only_light_emits != 0 && L.light_index >= 0;
 	const V3 light_pos = ld3(L.light_pos);
 	const bool have_light = L.light_index >= 0;
 	const int light_obj = L.light_index;
@@ -1244,6 +1246,20 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			if (ptaps) {
 				V3 lit = mk3(0, 0, 0);
 				int taps = 0;
+				if (only_light) {
+					/* The emitter is the only object whose emission is not all (signed) zeros, so main.c:200-204 adds its emission once
+					 * per tap that reaches it and a zero otherwise -- which changes nothing: the sum starts as +0 and is never -0.
+					 * n equal terms e: e, 2e (exact), RN(2e + e) = RN(3e): the product n x e, and "+ 0" makes a -0 product the +0 the
+					 * sum would be.  No emission is looked up per tap, nothing branches per tap. */
+					const int t0 = W.tap[due][0][lane], t1 = W.tap[due][1][lane], t2 = W.tap[due][2][lane];
+					taps = __popc((unsigned int) ptaps);
+					int n_hit = ((ptaps & 1) && t0 == light_obj ? 1 : 0) + ((ptaps & 2) && t1 == light_obj ? 1 : 0) + ((ptaps & 4) && t2 == light_obj ? 1 : 0);
+					if (rec2 & REC_TAPS_LIT) n_hit = taps;
+					if (rec2 & REC_TAPS_DARK) n_hit = 0;
+					const float4 e = sc.shade[4 * light_obj + 3];
+					const float nf = (float) n_hit;
+					lit = mk3(e.x * nf + 0.0f, e.y * nf + 0.0f, e.z * nf + 0.0f);
+				} else
 #pragma unroll
 				for (int k = 0; k < 3; k++)
 					if ((ptaps >> k) & 1) {

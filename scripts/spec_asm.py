@@ -30,6 +30,8 @@ def header(scene_path):
             g = rec[4:28].view(np.float32)
             lpos = [g[0], g[1], g[2]] if T[i] == 1 else [f(f(g[k] * f(1)) + f(g[3 + k] * f(0.5))) for k in range(3)]
     h0 = "#define SPEC_LIGHT %d\nstatic constexpr float SPEC_LIGHT_POS[3] = {%s};\n" % (light, ", ".join(float(v).hex() + "f" for v in lpos))
+    only = all(not (buf[68 * i + 28 + 24: 68 * i + 28 + 28].view(np.float32)[0] != 0 and any(buf[68 * i + 28: 68 * i + 28 + 12].view(np.float32) != 0)) for i in range(n) if i != light)
+    h0 += "#define SPEC_ONLY_LIGHT_EMITS %d\n" % (1 if only and light >= 0 else 0)      # (rt_set_scene decides this from the packed emission; close enough for reading ISA)
     h = h0 + "#define SPEC_N %d\nstatic constexpr int SPEC_T[SPEC_N] = {%s};\nstatic constexpr float SPEC_G[SPEC_N][6] = {\n" % (n, ", ".join(map(str, T)))
     h += ",\n".join("\t{" + ", ".join(float(v).hex() + "f" for v in g) + "}" for g in G) + "\n};\n"
     return h
