@@ -141,3 +141,39 @@ def test_ray_origins_on_slab_planes_stay_exact(gpu, oracle):
         gpu.compile_scene()
         assert (bits(gpu.render(80, 60, 3, 6, seed=8)) == bits(c)).all()
     gpu.set_camera(); oracle.set_camera()
+
+
+def test_compiled_scenes_are_kept_and_shared(scene_paths):
+    """rt_jit.cpp keeps every compiled scene for the life of the process (a module is never unloaded: DESIGN.md section 10) and
+    hands it to any context that asks for the same scene, options and device: the second compilation costs nothing, contexts
+    that share a module render the same bits, and a context that moves to another scene and back gets both kernels right --
+    also after the context that compiled first is gone, and after a frame loop has run the kernel on both streams."""
+    import time
+    from ray_tracing_amd.frames import FrameLoop
+    sky = rt.load_skybox()
+    a = rt.Renderer(0)
+    a.set_skybox(sky); a.set_scene(scene_paths[1]); a.set_camera()
+    want1 = a.render(160, 90, 5, 6, seed=9)                     # generic kernel
+    a.compile_scene()
+    assert (bits(a.render(160, 90, 5, 6, seed=9)) == bits(want1)).all()
+    b = rt.Renderer(0)
+    b.set_skybox(sky); b.set_scene(scene_paths[1]); b.set_camera()
+    t0 = time.perf_counter(); b.compile_scene(); shared = time.perf_counter() - t0
+    assert shared < 0.05, shared                                # (a compilation takes 0.4 s)
+    assert (bits(b.render(160, 90, 5, 6, seed=9)) == bits(want1)).all()
+    loop = FrameLoop(a, 640, 360, 16, 6); loop.run(range(6)); loop.close()     # both streams, frames in flight
+    a.close()                                                   # the module stays: b still runs it
+    assert (bits(b.render(160, 90, 5, 6, seed=9)) == bits(want1)).all()
+    b.set_scene(scene_paths[2]); assert not b.scene_is_compiled()
+    want2 = b.render(160, 90, 5, 6, seed=9)
+    b.compile_scene()
+    assert (bits(b.render(160, 90, 5, 6, seed=9)) == bits(want2)).all()
+    b.set_scene(scene_paths[1])
+    t0 = time.perf_counter(); b.compile_scene(); back = time.perf_counter() - t0
+    assert back < 0.05, back
+    assert (bits(b.render(160, 90, 5, 6, seed=9)) == bits(want1)).all()
+    m = rt.MultiRenderer([0])                                   # what used to fault after an unload: other code is loaded now (RCCL's)
+    m.set_tuning(force_collective=1)
+    m.set_scene(scene_paths[1]); m.set_skybox(sky); m.set_camera()
+    assert (bits(m.render(160, 90, 5, 6, seed=9)) == bits(want1)).all()
+    m.close(); b.close()
