@@ -236,19 +236,36 @@ def _rows_match_oracle(frame, o, W, H, spp, nb, seed, rows, what):
     return len(want)
 
 
-def _strips_reassemble(gpu, W, H, spp, nb, seed, world, rb, kernel=rt.KERNEL_AUTO):
+def _strips_reassemble(gpu, W, H, spp, nb, seed, world, rb, kernel=rt.KERNEL_AUTO, rotated=False):
+    """rotated: the hand-out both hosts use -- position r of the gathered buffer holds strip rt_strip_of_rank(r, world), and
+    rt_deinterleave_rotated_device(first = 1) puts the rows back."""
     import torch
     rows = rt.strip_rows(H, rb, world)
     strips = torch.zeros((world, rows, W, 3), dtype=torch.float32, device="cuda:0")
     torch.cuda.synchronize()
     for rank in range(world):
-        gpu.render_device(gpu.params(W, H, spp, nb, seed=seed, row_block=rb, rank=rank, world=world, kernel=kernel), strips[rank].data_ptr())
+        strip = rt.lib().rt_strip_of_rank(rank, world) if rotated else rank
+        gpu.render_device(gpu.params(W, H, spp, nb, seed=seed, row_block=rb, rank=strip, world=world, kernel=kernel), strips[rank].data_ptr())
     gpu.synchronize()
     frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda:0")
     torch.cuda.synchronize()
-    gpu.deinterleave_device(strips.data_ptr(), frame.data_ptr(), W, H, rb, world)
+    gpu.deinterleave_device(strips.data_ptr(), frame.data_ptr(), W, H, rb, world, first=1 if rotated and world > 1 else 0)
     gpu.synchronize()
     return frame.cpu().numpy()
+
+
+@pytest.mark.parametrize("world,H,rb", [(2, 77, 8), (3, 50, 4), (8, 1080, 8), (5, 33, 16)])
+def test_rotated_hand_out_of_the_strips(gpu, real_sky, scene_paths, world, H, rb):
+    """rt_strip_of_rank() / rt_deinterleave_rotated_device(): rank r renders strip r - 1, the root the last one (never longer
+    than another); the reassembled frame is the frame, and the un-rotated hand-out gives the same."""
+    W, spp, nb = 96, 3, 4
+    gpu.set_skybox(real_sky); gpu.set_scene(scene_paths[0]); gpu.set_camera()
+    want = gpu.render(W, H, spp, nb, seed=12)
+    blocks = -(-H // rb)
+    held = [len(range(rt.lib().rt_strip_of_rank(r, world), blocks, world)) for r in range(world)]
+    assert sorted(rt.lib().rt_strip_of_rank(r, world) for r in range(world)) == list(range(world)) and held[0] == min(held)
+    compare(_strips_reassemble(gpu, W, H, spp, nb, 12, world, rb, rotated=True), want, f"rotated hand-out, world {world}")
+    compare(_strips_reassemble(gpu, W, H, spp, nb, 12, world, rb), want, f"plain hand-out, world {world}")
 
 
 def test_c0_exact_config(gpu, real_sky, scene_paths):
