@@ -460,7 +460,7 @@ class Renderer(_FrameQueue):
         _check(lib().rt_synchronize(self._ctx), "rt_synchronize")
 
     def cancel(self):
-        """rt_cancel(): ask the launch in flight to stop (callable from any thread)."""
+        """rt_cancel(): ask every launch enqueued so far -- running or queued -- to stop (one store; callable from any thread)."""
         _check(lib().rt_cancel(self._ctx), "rt_cancel")
 
     def was_cancelled(self):
