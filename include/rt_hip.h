@@ -209,7 +209,8 @@ RT_API int rt_was_cancelled(rt_context *ctx);
  * rt_multi_create() makes one context per listed device and, for n > 1, the RCCL communicators of the group
  * (librccl.so is loaded on first use; a single-device handle never touches it).  The setters broadcast to
  * every device.  rt_multi_render() renders the frame with the interleaved row-block partition of
- * rt_render_device() -- device i takes the row blocks b with b % n == i, all devices at once -- gathers the
+ * rt_render_device() -- device i takes strip rt_strip_of_rank(i, n), i.e. the row blocks b with b % n == (i + n - 1) % n: the
+ * first device, which also gathers and de-interleaves, has the last strip, never the longest; all devices at once -- gathers the
  * strips on the first device with ONE ncclGather over xGMI, de-interleaves them there and returns the frame
  * in host memory exactly as rt_render() does; params->rank / world are ignored.  Frames are bit-identical
  * to rt_render()'s for every n. */
