@@ -5,8 +5,9 @@
  * The reference fans its work out inside the host binary: start_workers() creates one pthread per image
  * column and every worker adds its passes into the shared accumulation buffer (main.c:695-718, 324-414),
  * while the main thread presents what has been accumulated so far (main.c:450-482).
- * Here the fan-out is over GPUs: device i gets the row blocks b with b % n == i (the same interleaved partition
- * rt_render_device() implements for one rank), every device renders its strip concurrently, ONE grouped
+ * Here the fan-out is over GPUs: strip s is the row blocks b with b % n == s (the interleaved partition
+ * rt_render_device() implements for one rank) and device i renders strip rt_strip_of_rank(i, n) -- device 0, which also
+ * gathers, de-interleaves and copies out, the last one, which is never the longest; every device renders its strip concurrently, ONE grouped
  * ncclGather over xGMI brings the strips to device 0, a de-interleave kernel there puts the rows in frame order
  * and the frame is copied to the caller's host buffer -- what update_frame() hands to move_frame_to_the_gpu()
  * (main.c:467-479).  Frames are SUBMITTED and WAITED for (rt_multi_frame_submit / rt_multi_frame_wait), so that
