@@ -104,7 +104,15 @@ RT_API int rt_set_scene(rt_context *ctx, const Scene *scene);
  * 1..64 objects; returns an error -- and leaves the generic kernels in use -- if hiprtc is unavailable. */
 RT_API int rt_compile_scene(rt_context *ctx);
 RT_API int rt_scene_is_compiled(rt_context *ctx);
-/* development aid: instrumentation counters of a compiled kernel built with jit_flags "-DRT_STATS" (scripts/stats_c1.py) */
+/* Compiled scenes are cached per process -- key: device, scene geometry and emitter, options -- and shared by the contexts
+ * that compile the same scene.  The cache holds at most 32 entries, least recently used out first; an evicted entry's module
+ * stays loaded (contexts that still use it are unaffected) but is never looked up again.  *cached = entries in the cache,
+ * *parked = modules evicted so far.  rt_compiled_scene_cache_cap(cap >= 1) changes the cap (testing aid; returns the old one). */
+RT_API void rt_compiled_scene_counts(int *cached, int *parked);
+RT_API int  rt_compiled_scene_cache_cap(int cap);
+/* development aid: instrumentation counters of a compiled kernel built with jit_flags "-DRT_STATS" (scripts/stats_c1.py).
+ * They are variables of the compiled MODULE, i.e. per (device, scene, options), not per context: contexts that share a
+ * compiled scene read and reset the same counters (the same holds for rt_spec_symbol_read). */
 RT_API int rt_spec_stats_read(rt_context *ctx, unsigned long long out[64], int reset);
 /* development aid: copy the named device variable of the compiled kernel's module (e.g. "rt_wave_log" of a build with
  * "-DRT_STATS -DRT_STATS_LIFETIMES_ONLY", scripts/tail_probe.py) to dst, at most `bytes` bytes; *copied = bytes copied.  The
@@ -195,10 +203,13 @@ RT_API void rt_host_free(void *p);
 /* Giving up what has been asked for, as the reference's workers do when the camera moves mid-pass (main.c:316-317, where
  * the generation counter invalidates whatever every worker is doing): rt_cancel() asks EVERY launch enqueued on this
  * context so far -- the one that is running and those still queued behind it (the second of two frames in flight) -- to
- * stop: its waves hand out no more samples, finish the paths in flight and leave, within a millisecond or two of the call
- * (a wave looks for the request every 32 rounds) or of their start.  The request is one store into host memory that the
- * kernels read: the call returns at once, enqueues nothing, and may come from ANY host thread while another one is inside
- * rt_render*() for the same context.  rt_render() then returns RT_CANCELLED and its frame is incomplete; after
+ * stop: its waves hand out no more samples, finish the paths in flight and leave.  A wave looks for the request when it
+ * FETCHES PIXELS (eight waves of a launch read the host word and relay it through a word in device memory that every other
+ * wave reads at its fetches), so the latency grows with the samples per pixel: about 1 ms at 256 spp, 2.4-3.4 ms at 1024
+ * (profiles/r03/cancel_probe.txt); a queued launch stops at its first fetch.  The request is one atomic max on a word of
+ * host memory that the kernels read: the call returns at once, enqueues nothing, and may come from ANY host thread while
+ * another one is inside rt_render*() for the same context -- a launch is covered from the moment the render call has
+ * announced it, which is before its first kernel is enqueued.  rt_render() then returns RT_CANCELLED and its frame is incomplete; after
  * rt_render_device(), rt_was_cancelled() (which waits for the launch) tells; rt_frame_wait() reports it for a submitted
  * frame.  Launches enqueued after the call are not affected.  rt_progressive_invalidate() does this by itself for a pass
  * in flight, and that pass is not accumulated. */
@@ -254,6 +265,7 @@ RT_API int rt_progressive_pass(rt_context *ctx, float *weight_out);
 /* Development / test aid: how many of this context's launches ran rt_primary_pass (camera rays) -- an interactive pass that
  * differs from the pass before last in its sample number only keeps that pass's camera rays instead. */
 RT_API long long rt_primary_passes_run(rt_context *ctx);
+/* (RT_ERR_STATE when nothing has been published yet -- every pass so far was cut short --: frame_out is then untouched) */
 RT_API int rt_progressive_resolve(rt_context *ctx, Vector3 *frame_out);
 RT_API int rt_progressive_invalidate(rt_context *ctx);
 RT_API int rt_progressive_state(rt_context *ctx, int *next_scale, float *count, uint32_t *generation, int *passes);

@@ -64,7 +64,7 @@ class MouseState(C.Structure):
 # every symbol include/rt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
-    "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_spec_stats_read", "rt_spec_symbol_read", "rt_render", "rt_render_device", "rt_stream", "rt_reserve", "rt_strip_rows", "rt_deinterleave_device", "rt_deinterleave_rotated_device", "rt_strip_of_rank",
+    "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_compiled_scene_counts", "rt_compiled_scene_cache_cap", "rt_spec_stats_read", "rt_spec_symbol_read", "rt_render", "rt_render_device", "rt_stream", "rt_reserve", "rt_strip_rows", "rt_deinterleave_device", "rt_deinterleave_rotated_device", "rt_strip_of_rank",
     "rt_frame_submit", "rt_frame_wait", "rt_frame_poll", "rt_host_alloc", "rt_host_free",
     "rt_multi_frame_submit", "rt_multi_frame_wait", "rt_multi_frame_poll", "rt_profile_collect_span",
     "rt_progressive_begin_rank", "rt_progressive_resolve_device", "rt_multi_progressive_begin", "rt_multi_progressive_pass",

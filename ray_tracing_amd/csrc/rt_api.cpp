@@ -208,8 +208,7 @@ static int mark_launch(rt_context *ctx, hipStream_t stream)
 	HIP_TRY(hipEventRecord(sl.done, stream));
 	sl.stream = stream; sl.used = true;
 	ctx->cur = (int) (ctx->launches & 1u);
-	ctx->launches++;
-	ctx->enqueued.store(ctx->launches, std::memory_order_release);
+	ctx->launches++;               /* (== ctx->enqueued, published by prepare_launch() before the launch's first kernel) */
 	return RT_OK;
 }
 
@@ -654,8 +653,15 @@ static int prepare_launch(rt_context *ctx, rt_launch &L, unsigned which)
 	L.control = sl.d_counter + 128 * 32;
 	L.stop = ctx->d_stop;
 	L.launch_id = ctx->launches + 1u;              /* mark_launch() counts it */
+	/* rt_cancel() on another thread must cover this launch from the moment its first kernel can be on the GPU: the number is
+	 * published BEFORE anything of the launch is enqueued (a request that arrives in between stops a launch that has not
+	 * started yet, at its first pixel fetch).  A launch that then fails to enqueue takes the number back (unpublish_launch). */
+	ctx->enqueued.store(L.launch_id, std::memory_order_release);
 	return RT_OK;
 }
+
+/* the launch prepare_launch() announced was not enqueued after all */
+static void unpublish_launch(rt_context *ctx) { ctx->enqueued.store(ctx->launches, std::memory_order_release); }
 
 /* The launch scratch (pixel lists) and rt_render()'s device frame for frames up to width x height, allocated now
  * instead of inside the first render call of that size. */
@@ -669,7 +675,7 @@ int rt_reserve(rt_context *ctx, int width, int height)
 	rt_launch L;
 	memset(&L, 0, sizeof(L));
 	L.width = width; L.local_rows = rt_strip_rows(height, 8, 1);
-	for (unsigned which = 0; which < 2; which++) { const int rc = prepare_launch(ctx, L, which); if (rc != RT_OK) return rc; }
+	for (unsigned which = 0; which < 2; which++) { const int rc = prepare_launch(ctx, L, which); unpublish_launch(ctx); if (rc != RT_OK) return rc; }
 	const size_t need = (size_t) L.local_rows * width * 3 * sizeof(float);
 	if (need > ctx->frame_bytes) {
 		(void) hipFree(ctx->d_frame); ctx->d_frame = nullptr; ctx->frame_bytes = 0;
@@ -715,14 +721,16 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	L.lit_cells = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_cells : nullptr;
 	L.lit_grids = ctx->d_lit_grids;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
-	{ const int rc = prepare_launch(ctx, L, ctx->launches); if (rc != RT_OK) return rc; }
-	{ const int rc = order_behind_previous(ctx, stream); if (rc != RT_OK) return rc; }
-	if (ctx->tuning.poison_frame)
-		HIP_TRY(hipMemsetAsync(d_strip, 0xff, (size_t) rt_strip_rows(p->height, p->row_block, p->world) * p->width * 3 * sizeof(float), stream));
+	{ const int rc = prepare_launch(ctx, L, ctx->launches); if (rc != RT_OK) { unpublish_launch(ctx); return rc; } }
+	{ const int rc = order_behind_previous(ctx, stream); if (rc != RT_OK) { unpublish_launch(ctx); return rc; } }
+	if (ctx->tuning.poison_frame) {
+		const hipError_t pe = hipMemsetAsync(d_strip, 0xff, (size_t) rt_strip_rows(p->height, p->row_block, p->world) * p->width * 3 * sizeof(float), stream);
+		if (pe != hipSuccess) { unpublish_launch(ctx); return fail(RT_ERR_DEVICE, "hipMemsetAsync(poison): %s", hipGetErrorString(pe)); }
+	}
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (ctx->profiling) {
 		e0 = take_event(ctx); e1 = take_event(ctx);
-		if (!e0 || !e1) { give_event(ctx, e0); give_event(ctx, e1); return fail(RT_ERR_DEVICE, "rt_render_device: hipEventCreate failed"); }
+		if (!e0 || !e1) { give_event(ctx, e0); give_event(ctx, e1); unpublish_launch(ctx); return fail(RT_ERR_DEVICE, "rt_render_device: hipEventCreate failed"); }
 	}
 	ctx->slot[ctx->launches & 1u].lists_key = 0;
 	ctx->primary_passes++;
@@ -732,7 +740,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 		if (le == hipSuccess) ctx->events.emplace_back(e0, e1);
 		else { give_event(ctx, e0); give_event(ctx, e1); }                 /* a failed launch keeps no events */
 	}
-	if (le != hipSuccess) return fail(RT_ERR_DEVICE, "trace launch: %s", hipGetErrorString(le));
+	if (le != hipSuccess) { unpublish_launch(ctx); return fail(RT_ERR_DEVICE, "trace launch: %s", hipGetErrorString(le)); }
 	return mark_launch(ctx, stream);
 }
 
@@ -853,7 +861,11 @@ int rt_cancel(rt_context *ctx)
 	 * find room on a GPU whose every wave slot the persistent kernel holds.  (Rounds 1-2 sent a copy down a stream of its own:
 	 * the runtime does small copies with a kernel, and beside the compiled trace kernel -- 4 x 128 registers per SIMD -- that
 	 * kernel only got to run when the launch it was meant to stop had finished.) */
-	__atomic_store_n(&ctx->h_words[RT_STOP_WORD], ctx->enqueued.load(std::memory_order_acquire), __ATOMIC_RELEASE);
+	/* fetch-max, not a store: of two concurrent calls the one that read the smaller number must not move the word backwards */
+	const unsigned int upto = ctx->enqueued.load(std::memory_order_acquire);
+	unsigned int seen = __atomic_load_n(&ctx->h_words[RT_STOP_WORD], __ATOMIC_RELAXED);
+	while ((int) (upto - seen) > 0 &&
+	       !__atomic_compare_exchange_n(&ctx->h_words[RT_STOP_WORD], &seen, upto, true, __ATOMIC_RELEASE, __ATOMIC_RELAXED)) { }
 	return RT_OK;
 }
 
@@ -990,10 +1002,14 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	L.lit_cells = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_cells : nullptr;
 	L.lit_grids = ctx->d_lit_grids;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
-	{ const int rc = prepare_launch(ctx, L, ctx->launches); if (rc != RT_OK) return rc; }
-	{ const int rc = order_behind_previous(ctx, ctx->stream); if (rc != RT_OK) return rc; }
-	if (ctx->tuning.poison_frame) HIP_TRY(hipMemsetAsync(g.d_low, 0xff, g.low_bytes, ctx->stream));
+	{ const int rc = prepare_launch(ctx, L, ctx->launches); if (rc != RT_OK) { unpublish_launch(ctx); return rc; } }
+	{ const int rc = order_behind_previous(ctx, ctx->stream); if (rc != RT_OK) { unpublish_launch(ctx); return rc; } }
+	if (ctx->tuning.poison_frame) {
+		const hipError_t pe = hipMemsetAsync(g.d_low, 0xff, g.low_bytes, ctx->stream);
+		if (pe != hipSuccess) { unpublish_launch(ctx); return fail(RT_ERR_DEVICE, "hipMemsetAsync(poison): %s", hipGetErrorString(pe)); }
+	}
 	if (L.local_rows <= 0) {
+		unpublish_launch(ctx);              /* nothing is launched for a rank without rows at this scale */
 		/* a rank without rows at this scale -- its few frame rows lie below the last whole low-resolution row -- renders
 		 * nothing and adds nothing, but the pass counts (main.c:396): those rows are divided by the same count as all others */
 		HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), reinterpret_cast<unsigned int*>(g.d_count + 1), g.d_count,
@@ -1021,7 +1037,10 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	rt_context::launch_slot &sl = ctx->slot[ctx->launches & 1u];
 	const bool reuse = !ctx->tuning.poison_frame && sl.lists_key == key;
 	sl.lists_key = 0;
-	HIP_TRY(rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, sl.d_counter, nullptr, sl.started, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream, reuse));
+	{
+		const hipError_t le = rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, sl.d_counter, nullptr, sl.started, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream, reuse);
+		if (le != hipSuccess) { unpublish_launch(ctx); return fail(RT_ERR_DEVICE, "trace launch: %s", hipGetErrorString(le)); }
+	}
 	if (!reuse) ctx->primary_passes++;
 	sl.lists_key = ctx->tuning.poison_frame ? 0 : key;
 	/* the low-resolution frame now holds THIS launch's sky pixels: lists of the other set that belong to anything else
@@ -1049,14 +1068,16 @@ int rt_progressive_resolve(rt_context *ctx, Vector3 *frame_out)
 	auto &g = ctx->prog;
 	if (g.passes == 0) return fail(RT_ERR_STATE, "rt_progressive_resolve: nothing accumulated yet");
 	HIP_TRY(hipSetDevice(ctx->device));
-	/* frame = accum * (1 / count) with the count the device holds (main.c:467-477) */
+	/* the count the device holds first (update_frame() waits for a column's count before it divides by it, main.c:461-464): when
+	 * every pass so far was cut short there is nothing to divide, and frame_out is left as it is */
+	float count = 0.0f;
+	{ const int rc = rt_progressive_count(ctx, &count); if (rc != RT_OK) return rc; }
+	if ((double) count < 0.0001)
+		return fail(RT_ERR_STATE, "rt_progressive_resolve: nothing accumulated yet (every pass so far was cancelled)");
+	/* frame = accum * (1 / count) (main.c:467-477) */
 	HIP_TRY(rt_launch_resolve(g.d_accum, g.d_out, (size_t) g.width * g.rows * 3, g.d_count, ctx->stream));
 	HIP_TRY(hipMemcpyAsync(frame_out, g.d_out, g.accum_bytes, hipMemcpyDeviceToHost, ctx->stream));     /* one rank of several: its rows */
-	float *h_count = reinterpret_cast<float*>(&ctx->h_words[8]);
-	HIP_TRY(hipMemcpyAsync(h_count, g.d_count, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
-	if ((double) *h_count < 0.0001)                                              /* update_frame() waits for this, main.c:462 */
-		return fail(RT_ERR_STATE, "rt_progressive_resolve: nothing accumulated yet (every pass so far was cancelled)");
 	return RT_OK;
 }
 

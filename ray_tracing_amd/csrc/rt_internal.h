@@ -14,9 +14,9 @@ void      *rt_context_stream(rt_context *ctx);
 /* copies the control word of the context's most recent launch (non-zero: cut short by rt_cancel) to pinned *h_dst on `stream`,
  * which the caller has ordered behind that launch (not the launch's own stream); *behind (optional) = an event behind the copy */
 int        rt_context_read_control(rt_context *ctx, unsigned int *h_dst, hipStream_t stream, hipEvent_t *behind);
-void      *rt_context_launch_done(rt_context *ctx);
+void      *rt_context_launch_done(rt_context *ctx);                   /* hipEvent_t recorded behind the context's most recent launch, on that launch's stream */
 #define RT_PROGRESSIVE_ROW_BLOCK 16      /* == the header's: a multiple of every scale of the ladder */
-int        rt_progressive_count(rt_context *ctx, float *count);      /* hipEvent_t recorded behind the context's most recent launch */
+int        rt_progressive_count(rt_context *ctx, float *count);      /* the ladder's sum of published weights, read from the device (waits for the passes enqueued so far) */
 
 size_t     rt_counter_bytes();
 size_t     rt_scene_lds_bytes(int num_objects);

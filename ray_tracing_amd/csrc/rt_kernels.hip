@@ -1087,6 +1087,18 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			if (bounce == 0) rng = path_seed(L.seed, (uint32_t) rng, (uint32_t) L.sample_base + (uint32_t) (rng >> 32));
 			const bool taps_lit = lit_next != 0u;      /* ... or a hit point of a later bounce in such a cell of the scene's table (section 4);
 			                                            * 1: they reach the emitter, 2: they certainly do not (and nothing else emits) */
+#ifdef RT_STATS
+			{	/* what kind of shading event this is (scripts/stats_c1.py): a sample's first or a later one, on a box or a sphere, taps known or not */
+				const bool on_box = __float_as_int(sc.geom[2 * hobj + 1].z) == RT_GEOM_CUBE;
+				if (bounce == 0) STAT(9);            /* (sites 25-28 are the section stamps' words) */
+				if (bounce == 0 && taps_lit) STAT(10);
+				if (on_box) STAT(11);
+				if (bounce == 0 && on_box) STAT(18);
+				if (bounce == 0 && on_box && taps_lit) STAT(19);
+				if (taps_lit) STAT(29);
+				if (bounce == 1) STAT(30);
+			}
+#endif
 			if (have_light) {
 				/* main.c:191-195: three rand_dir draws, a tap is skipped when it points into the surface.  Only the sign of
 				 * dot(rand_dir, normal) is needed here, and random_vector() has it before normalize() does (rt_math.hip.h:

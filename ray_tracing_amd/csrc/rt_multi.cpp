@@ -466,6 +466,13 @@ int rt_multi_progressive_resolve(rt_multi *m, Vector3 *frame_out)
 	{ const int rc = init_communicators(m); if (rc != RT_OK) return rc; }
 	{ const int rc = prepare(m, W, H, rb, slot); if (rc != RT_OK) return rc; }
 	rt_multi::frame_slot &f = m->fq[slot];
+	{	/* the count first (update_frame() waits for it, main.c:461-464): with nothing published there is nothing to divide by,
+		 * and frame_out is left as it is */
+		float count = 0;
+		const int crc = rt_progressive_count(m->ctx[0], &count);
+		if (crc != RT_OK) return crc;
+		if ((double) count < 0.0001) return rt_fail(RT_ERR_STATE, "rt_multi_progressive_resolve: nothing accumulated yet (every pass so far was cancelled)");
+	}
 	/* what one rank sends: its rows, padded like a strip -- one rank alone holds exactly the frame */
 	const size_t strip_floats = (size_t) (n == 1 ? H : rt_strip_rows(H, rb, n)) * W * 3, frame_floats = (size_t) H * W * 3;
 	std::vector<void *> d_rows((size_t) n, nullptr);
@@ -492,11 +499,6 @@ int rt_multi_progressive_resolve(rt_multi *m, Vector3 *frame_out)
 		const int src = rt_synchronize(m->ctx[(size_t) i]);
 		if (src != RT_OK) return src;
 	}
-	float count = 0;
-	rc = rt_progressive_count(m->ctx[0], &count);
-	if (rc != RT_OK) return rc;
-	if ((double) count < 0.0001)                        /* update_frame() waits for this, main.c:462 */
-		return rt_fail(RT_ERR_STATE, "rt_multi_progressive_resolve: nothing accumulated yet");
 	return RT_OK;
 }
 
