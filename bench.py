@@ -75,6 +75,9 @@ def parse_args(argv=None):
                          "de-interleave, three strip buffers) so that loop's cost shows beside the plain N = 1 line")
     ap.add_argument("--torch-loop", action="store_true",
                     help="N = 1: run the torch-side frame loop (multi_gpu.TiledFrame) instead of the C ABI's frame queue")
+    ap.add_argument("--leave-early", action="store_true",
+                    help="testing aid (scripts/repro_verify_race.py): ranks other than 0 do not wait for rank 0's verification before they "
+                         "tear their contexts down -- the bench's behaviour when its verification failed intermittently in round 3")
     ap.add_argument("--depth", type=int, default=0, help="frames in flight in the C ABI's frame queue (default 2; 3 with --force-collective)")
     return ap.parse_args(argv)
 
@@ -400,7 +403,7 @@ def main():
         except Exception as e:       # the oracle is a checker that may be absent; the GPU-vs-GPU check above stands
             verified["oracle_error"] = repr(e)
         verified["ok"] = same and verified.get("equals_oracle_rows", True)
-    if world > 1:
+    if world > 1 and not args.leave_early:
         # a mismatch is looked at once more before anybody leaves: the same seed through the same N-rank loop, nothing overlapped --
         # a frame that is right the second time was a race in the pipeline, one that is wrong again is a wrong kernel
         again = torch.tensor([1 if (rank == 0 and not verified["ok"]) else 0], dtype=torch.int32, device=dev)

@@ -88,6 +88,9 @@ typedef struct {
 	                             * launch fails to write cannot pass for correct because an earlier frame left it there */
 	int    trace_known_taps;    /* testing aid: trace every soft-shadow tap, also those of camera-ray hit points from which
 	                             * every tap provably reaches the emitter first (csrc/rt_lit.h; normally answered untraced) */
+	int    first_bounce_probe;  /* EXPERIMENT (round 4): launches of a compiled scene with 2..64 spp run rt_first_bounce_spec
+	                             * -- one wave per pixel, first bounce only, pixels of known tap class only -- instead of the trace
+	                             * kernel.  Frames are complete only at max_bounces == 1 and only on those pixels: a measurement aid */
 } rt_tuning;
 RT_API void rt_default_tuning(rt_tuning *t);
 
@@ -101,9 +104,15 @@ RT_API int rt_set_scene(rt_context *ctx, const Scene *scene);
 /* Optional: compile a trace kernel specialised for the scene that is set (in-process, hiprtc; about
  * a second).  Frames are bit-identical with and without it; it only removes work (shared slab planes are
  * divided once, no geometry loads).  The compiled kernel is dropped by the next rt_set_scene().  Scenes of
- * 1..64 objects; returns an error -- and leaves the generic kernels in use -- if hiprtc is unavailable. */
+ * 1..64 objects; returns an error -- and leaves the generic kernels in use -- if hiprtc is unavailable.
+ * The kernels of the three scene files the reference ships are compiled when the library is BUILT and embedded in it: for
+ * those (recognised by their packed contents, not by a file name) the call is a module load -- no hiprtc, a few milliseconds,
+ * and the same code object in every host process.  rt_compiled_scene_info(): where the kernel in use came from, e.g.
+ * "embedded, compiled with the library by hipcc 7.2..." or "hiprtc 7.2 at run time" ("" when no scene is compiled; the string
+ * is the context's, valid until the scene changes). */
 RT_API int rt_compile_scene(rt_context *ctx);
 RT_API int rt_scene_is_compiled(rt_context *ctx);
+RT_API const char *rt_compiled_scene_info(rt_context *ctx);
 /* Compiled scenes are cached per process -- key: device, scene geometry and emitter, options -- and shared by the contexts
  * that compile the same scene.  The cache holds at most 32 entries, least recently used out first; an evicted entry's module
  * stays loaded (contexts that still use it are unaffected) but is never looked up again.  *cached = entries in the cache,

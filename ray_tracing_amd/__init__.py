@@ -50,7 +50,7 @@ class RenderParams(C.Structure):
 class Tuning(C.Structure):
     _fields_ = [("dequeue_shards", C.c_int),
                 ("workgroups_per_cu", C.c_int), ("jit_waves_per_simd", C.c_int), ("jit_flags", C.c_char_p),
-                ("force_collective", C.c_int), ("poison_frame", C.c_int), ("trace_known_taps", C.c_int)]
+                ("force_collective", C.c_int), ("poison_frame", C.c_int), ("trace_known_taps", C.c_int), ("first_bounce_probe", C.c_int)]
 
 
 STREAM_LEGACY = C.c_void_p(-1).value      # RT_STREAM_LEGACY: the device's legacy null stream
@@ -64,7 +64,7 @@ class MouseState(C.Structure):
 # every symbol include/rt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
-    "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_compiled_scene_counts", "rt_compiled_scene_cache_cap", "rt_spec_stats_read", "rt_spec_symbol_read", "rt_render", "rt_render_device", "rt_stream", "rt_reserve", "rt_strip_rows", "rt_deinterleave_device", "rt_deinterleave_rotated_device", "rt_strip_of_rank",
+    "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_compiled_scene_info", "rt_compiled_scene_counts", "rt_compiled_scene_cache_cap", "rt_spec_stats_read", "rt_spec_symbol_read", "rt_render", "rt_render_device", "rt_stream", "rt_reserve", "rt_strip_rows", "rt_deinterleave_device", "rt_deinterleave_rotated_device", "rt_strip_of_rank",
     "rt_frame_submit", "rt_frame_wait", "rt_frame_poll", "rt_host_alloc", "rt_host_free",
     "rt_multi_frame_submit", "rt_multi_frame_wait", "rt_multi_frame_poll", "rt_profile_collect_span",
     "rt_progressive_begin_rank", "rt_progressive_resolve_device", "rt_multi_progressive_begin", "rt_multi_progressive_pass",
@@ -108,6 +108,9 @@ def lib():
     L.rt_default_tuning.argtypes = [C.POINTER(Tuning)]
     L.rt_compile_scene.argtypes = [C.c_void_p]
     L.rt_scene_is_compiled.argtypes = [C.c_void_p]
+    if hasattr(L, "rt_compiled_scene_info"):
+        L.rt_compiled_scene_info.argtypes = [C.c_void_p]
+        L.rt_compiled_scene_info.restype = C.c_char_p
     L.rt_default_params.argtypes = [C.POINTER(RenderParams), C.c_int, C.c_int, C.c_int, C.c_int]
     L.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p]
     L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p]
@@ -338,6 +341,10 @@ class Renderer(_FrameQueue):
     def scene_is_compiled(self):
         return bool(lib().rt_scene_is_compiled(self._ctx))
 
+    def compiled_scene_info(self):
+        """Where the compiled kernel came from: 'embedded, compiled with the library by ...' or 'hiprtc x.y at run time'."""
+        return lib().rt_compiled_scene_info(self._ctx).decode()
+
     def set_skybox(self, faces):
         """faces: uint8 (6, h, w, chan) in CubeFace order."""
         faces = np.ascontiguousarray(faces, dtype=np.uint8)
@@ -360,7 +367,7 @@ class Renderer(_FrameQueue):
         _check(lib().rt_set_camera(self._ctx, C.byref(cam)), "rt_set_camera")
 
     def set_tuning(self, dequeue_shards=0, workgroups_per_cu=0,
-                   jit_waves_per_simd=0, jit_flags=None, poison_frame=None, trace_known_taps=None):
+                   jit_waves_per_simd=0, jit_flags=None, poison_frame=None, trace_known_taps=None, first_bounce_probe=0):
         """rt_set_tuning(): scheduling knobs (0 / None = automatic).  They never change a frame."""
         t = Tuning()
         lib().rt_default_tuning(C.byref(t))
@@ -373,6 +380,7 @@ class Renderer(_FrameQueue):
         if trace_known_taps is not None:
             self._trace_known = bool(trace_known_taps)
         t.trace_known_taps = 1 if getattr(self, "_trace_known", False) else 0
+        t.first_bounce_probe = first_bounce_probe
         _check(lib().rt_set_tuning(self._ctx, C.byref(t)), "rt_set_tuning")
 
     @staticmethod

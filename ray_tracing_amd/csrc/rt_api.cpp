@@ -26,6 +26,7 @@
 
 #include "../../include/rt_hip.h"
 #include "rt_internal.h"
+#include "rt_pack.h"
 #define RT_LIT_FN static inline
 #include "rt_lit.h"
 
@@ -71,7 +72,8 @@ struct rt_context {
 	bool         have_scene = false;
 	std::vector<rt_geom> h_geom;         /* host copy of the packed geometry (rt_compile_scene) */
 	hipModule_t  spec_module = nullptr;  /* scene-specialised kernel, valid until the scene changes */
-	std::vector<char> spec_code;         /* its code object as hiprtc produced it (rt_spec_symbol_read("") hands it out) */
+	std::vector<char> spec_code;         /* its code object (rt_spec_symbol_read("") hands it out) */
+	std::string  spec_compiler;          /* where it came from (rt_compiled_scene_info) */
 	hipFunction_t spec_fn = nullptr;
 	bool         scene_fast_ok = false;  /* every cube has 0 <= size, plane coordinates +0 or 2^-76 <= |x| <= 2^29, sphere data |x| <= 2^29 */
 	int          light_index = -1;
@@ -358,81 +360,20 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 	HIP_TRY(hipSetDevice(ctx->device));
 	{ const int rc = wait_for_launches(ctx); if (rc != RT_OK) return rc; }   /* frames still in flight read the old scene / compiled kernel */
 
-	std::vector<rt_geom>  geom((size_t) n > 0 ? n : 1);
-	std::vector<rt_shade> shade((size_t) n > 0 ? n : 1);
-	memset(geom.data(), 0, geom.size() * sizeof(rt_geom));
-	memset(shade.data(), 0, shade.size() * sizeof(rt_shade));
-	int light = -1;
-	bool fast_ok = true;
-	auto bounded = [](float x) { return x >= -0x1p+29f && x <= 0x1p+29f; };   /* false for NaN */
-	/* a slab plane coordinate the tuned slab test accepts: +0, or 2^-76 <= |x| <= 2^29 (then `plane - origin`
-	 * is exactly +0 or at least 2^-100 in magnitude unless the origin itself is tiny; see prepare_ray) */
-	auto plane_ok = [](float x) { return (x == 0.0f && !std::signbit(x)) || (std::fabs(x) >= 0x1p-76f && std::fabs(x) <= 0x1p+29f); };
-	for (int i = 0; i < n; i++) {
-		const Object &o = scene->objects[i];
-		const Material &m = o.material;
-		rt_geom &g = geom[i];
-		if (o.type == OBJECT_CUBE) {
-			g.type = RT_GEOM_CUBE;
-			g.a[0] = o.cube.origin.x; g.a[1] = o.cube.origin.y; g.a[2] = o.cube.origin.z;
-			g.b0 = o.cube.origin.x * 1.0f + o.cube.size.x * 1.0f;
-			g.b1 = o.cube.origin.y * 1.0f + o.cube.size.y * 1.0f;
-			g.b2 = o.cube.origin.z * 1.0f + o.cube.size.z * 1.0f;
-			/* the tuned slab test assumes lo <= hi (the loader enforces size >= 0, scene.c:593) */
-			fast_ok = fast_ok && g.a[0] <= g.b0 && g.a[1] <= g.b1 && g.a[2] <= g.b2 &&
-			          plane_ok(g.a[0]) && plane_ok(g.a[1]) && plane_ok(g.a[2]) && plane_ok(g.b0) && plane_ok(g.b1) && plane_ok(g.b2);
-		} else if (o.type == OBJECT_SPHERE) {
-			g.type = RT_GEOM_SPHERE;
-			g.a[0] = o.sphere.center.x; g.a[1] = o.sphere.center.y; g.a[2] = o.sphere.center.z;
-			g.b0 = o.sphere.radius * o.sphere.radius;
-			fast_ok = fast_ok && bounded(g.a[0]) && bounded(g.a[1]) && bounded(g.a[2]) && bounded(g.b0);
-		} else {
-			g.type = -1;   /* intersect_object() returns false for unknown types (scene.c:153) */
-		}
-
-		rt_shade &s = shade[i];
-		const float f0d = (float) (0.16 * (double) m.reflectance * (double) m.reflectance);
-		const float om  = 1 - m.metallic;
-		const float alb[3] = { m.albedo.x, m.albedo.y, m.albedo.z };
-		const float ecol[3] = { m.emission_color.x, m.emission_color.y, m.emission_color.z };
-		for (int k = 0; k < 3; k++) {
-			s.f0[k]           = f0d * om + alb[k] * m.metallic;
-			s.one_minus_f0[k] = 1.0f * 1.0f + s.f0[k] * -1.0f;
-			s.tint[k]         = alb[k] * om;
-			s.emission[k]     = ecol[k] * m.emission_power;
-		}
-		s.roughness = m.roughness;
-		s.is_metal  = ((double) m.metallic > 0.001) ? 1 : 0;
-		if (light < 0 && m.emission_power > 0) light = i;
-	}
+	/* every ray-independent term folded with the reference's roundings: rt_pack.cpp (host only; also behind the build-time
+	 * tool that generates the shipped scenes' headers) */
+	std::vector<rt_geom>  geom;
+	std::vector<rt_shade> shade;
+	rt_packed_scene_info info;
+	rt_pack_scene(scene, geom, shade, &info);
+	const int light = info.light_index;
+	const bool fast_ok = info.fast_ok;
 	ctx->light_index = light;
 	ctx->scene_fast_ok = fast_ok;
-	{
-		/* emission = emission_color * emission_power, bit pattern by bit pattern: +-0 adds nothing to a tap sum, anything else
-		 * (negative, NaN) does and makes the object one whose index a tap must report */
-		bool only = light >= 0;
-		for (int i = 0; i < n && only; i++)
-			for (int k = 0; k < 3; k++) {
-				uint32_t bits_;
-				memcpy(&bits_, &shade[i].emission[k], 4);
-				if (i != light && (bits_ & 0x7fffffffu) != 0u) only = false;
-				if (i == light && (bits_ & 0x7f800000u) == 0x7f800000u) only = false;     /* (an infinite or NaN emission: n x e is not the n-fold sum for n = 0) */
-			}
-		ctx->only_light_emits = only;
-	}
+	ctx->only_light_emits = info.only_light_emits;
+	memcpy(ctx->light_pos, info.light_pos, sizeof(ctx->light_pos));
 	ctx->h_geom.assign(geom.begin(), geom.begin() + n);
 	ctx->spec_module = nullptr; ctx->spec_fn = nullptr;      /* (not unloaded: rt_jit.cpp keeps compiled scenes for the life of the process) */
-	if (light >= 0) {
-		const Object &o = scene->objects[light];
-		if (o.type == OBJECT_SPHERE) {
-			ctx->light_pos[0] = o.sphere.center.x; ctx->light_pos[1] = o.sphere.center.y; ctx->light_pos[2] = o.sphere.center.z;
-		} else {
-			ctx->light_pos[0] = o.cube.origin.x * 1.0f + o.cube.size.x * 0.5f;
-			ctx->light_pos[1] = o.cube.origin.y * 1.0f + o.cube.size.y * 0.5f;
-			ctx->light_pos[2] = o.cube.origin.z * 1.0f + o.cube.size.z * 0.5f;
-		}
-	}
-
 	if (n > ctx->capacity || !ctx->d_geom) {
 		(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
 		ctx->d_geom = nullptr; ctx->d_shade = nullptr; ctx->capacity = 0;
@@ -499,12 +440,14 @@ int rt_compile_scene(rt_context *ctx)
 	HIP_TRY(hipSetDevice(ctx->device));
 	std::string message;
 	const int rc = rt_jit_build(ctx->h_geom.data(), n, ctx->light_index, ctx->light_pos, ctx->only_light_emits ? 1 : 0, ctx->tuning.jit_waves_per_simd, ctx->jit_flags.c_str(),
-	                            &ctx->spec_module, &ctx->spec_fn, message, &ctx->spec_code);
+	                            &ctx->spec_module, &ctx->spec_fn, message, &ctx->spec_code, &ctx->spec_compiler);
 	if (rc != RT_OK) { ctx->spec_module = nullptr; ctx->spec_fn = nullptr; return fail(rc, "rt_compile_scene: %s", message.c_str()); }
 	return RT_OK;
 }
 
 int rt_scene_is_compiled(rt_context *ctx) { return ctx && ctx->spec_fn ? 1 : 0; }
+
+const char *rt_compiled_scene_info(rt_context *ctx) { return ctx && ctx->spec_fn ? ctx->spec_compiler.c_str() : ""; }
 
 /* Development aid (scripts/stats_c1.py): the instrumentation counters of a scene-specialised kernel that was
  * compiled with rt_tuning.jit_flags = "-DRT_STATS" (the kernel then carries its own `rt_stats` array). */
@@ -734,7 +677,8 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	}
 	ctx->slot[ctx->launches & 1u].lists_key = 0;
 	ctx->primary_passes++;
-	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->slot[ctx->launches & 1u].d_counter, e0, ctx->slot[ctx->launches & 1u].started, ctx->num_cus, workgroups_per_cu_for(ctx, stream), stream);
+	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->slot[ctx->launches & 1u].d_counter, e0, ctx->slot[ctx->launches & 1u].started, ctx->num_cus, workgroups_per_cu_for(ctx, stream), stream,
+	                                false, ctx->tuning.first_bounce_probe && ctx->spec_fn ? rt_jit_first_bounce(ctx->spec_module) : nullptr);
 	if (le == hipSuccess && ctx->profiling) le = hipEventRecord(e1, stream);
 	if (ctx->profiling) {
 		if (le == hipSuccess) ctx->events.emplace_back(e0, e1);

@@ -20,7 +20,9 @@
  *                        rt_multi_frame_wait: the copy of a frame to the host runs beside the render of the next, as the
  *                        reference's workers keep rendering while its main thread presents (main.c:354-408 vs 450-482) --
  *                        and print the rate; the last frame goes to the presenter hook
- *   --compile            specialise the trace kernel for the scene first (rt_compile_scene; same pixels)
+ *   --compile            specialise the trace kernel for the scene first (rt_compile_scene; same pixels); the shipped scenes'
+ *                        kernels are embedded in the library, any other scene is compiled by hiprtc
+ *   --warmup <n>         with --frames: untimed frames before the timed ones (default 3, as bench.py)
  *   --force-collective   testing aid for 1-GPU boxes: one device runs the N-GPU path all the same (RCCL gather on a one-rank
  *                        communicator, de-interleave, three strip buffers)
  */
@@ -53,7 +55,8 @@ static double now_s(void)
 int main(int argc, char **argv)
 {
 	const char *scene_file = NULL, *sky_dir = "assets/skybox";
-	int width = 1280, height = 960, spp = 16, bounces = 10, device = 0, gpus = 0, frames = 0, compile = 0, force_collective = 0;
+	int width = 1280, height = 960, spp = 16, bounces = 10, device = 0, gpus = 0, frames = 0, compile = 0, force_collective = 0, warmup = 3;
+	double compile_s = 0;
 	unsigned long long seed = 0;
 
 	for (int i = 1; i < argc; i++) {
@@ -73,6 +76,7 @@ int main(int argc, char **argv)
 		else if (!strcmp(a, "--gpus"))       { NEED_VALUE(); gpus = atoi(v); }
 		else if (!strcmp(a, "--out"))        { NEED_VALUE(); out_file = v; }
 		else if (!strcmp(a, "--frames"))     { NEED_VALUE(); frames = atoi(v); }
+		else if (!strcmp(a, "--warmup"))     { NEED_VALUE(); warmup = atoi(v); }
 		else if (!strcmp(a, "--compile"))    { compile = 1; }
 		else if (!strcmp(a, "--force-collective")) { force_collective = 1; }
 		else fprintf(stderr, "Warning: Ignoring option %s\n", a);
@@ -122,8 +126,15 @@ int main(int argc, char **argv)
 		t.force_collective = 1;
 		rt_multi_set_tuning(group, &t);
 	}
-	if (compile && rt_multi_compile_scene(group) != RT_OK)
-		fprintf(stderr, "Warning: %s (continuing with the generic kernel)\n", rt_last_error());
+	if (compile) {
+		const double tc = now_s();
+		if (rt_multi_compile_scene(group) != RT_OK)
+			fprintf(stderr, "Warning: %s (continuing with the generic kernel)\n", rt_last_error());
+		else {
+			compile_s = now_s() - tc;
+			fprintf(stderr, "Scene kernel: %s (%.3f s)\n", rt_compiled_scene_info(rt_multi_context(group, 0)), compile_s);
+		}
+	}
 
 	rt_render_params p;
 	rt_default_params(&p, width, height, spp, bounces);
@@ -138,10 +149,11 @@ int main(int argc, char **argv)
 				fprintf(stderr, "Error: %s\n", rt_last_error());
 				return -1;
 			}
-		if (rt_multi_frame_submit(group, &p, 0, buf[0]) != RT_OK || rt_multi_frame_wait(group, 0) < 0) {    /* warm-up: allocations, first launches */
-			fprintf(stderr, "Error: %s\n", rt_last_error());
-			return -1;
-		}
+		for (int k = 0; k < (warmup > 1 ? warmup : 1); k++)     /* warm-up: allocations, first launches on both streams */
+			if (rt_multi_frame_submit(group, &p, k & 1, buf[k & 1]) != RT_OK || rt_multi_frame_wait(group, k & 1) < 0) {
+				fprintf(stderr, "Error: %s\n", rt_last_error());
+				return -1;
+			}
 		rt_profile_enable(rt_multi_context(group, 0), 1);      /* the library's own per-launch events on the first device */
 		double t0 = now_s();
 		int rc = rt_multi_frame_submit(group, &p, 0, buf[0]);
@@ -167,8 +179,10 @@ int main(int argc, char **argv)
 		        "kernels of the first device: %.3f ms per launch, %.3f ms of span per launch\n",
 		        frames, width, height, spp, bounces, rt_multi_size(group), dt / frames * 1e3, (double) width * height * spp * frames / dt / 1e6,
 		        kernel_ms / launches, span_ms / launches);
-		printf("{\"frames\": %d, \"ms_per_frame\": %.4f, \"msamples_per_s\": %.2f, \"gpus\": %d, \"kernel_ms_per_launch\": %.4f, \"span_ms_per_launch\": %.4f}\n",
-		       frames, dt / frames * 1e3, (double) width * height * spp * frames / dt / 1e6, rt_multi_size(group), kernel_ms / launches, span_ms / launches);
+		printf("{\"frames\": %d, \"ms_per_frame\": %.4f, \"msamples_per_s\": %.2f, \"gpus\": %d, \"kernel_ms_per_launch\": %.4f, \"span_ms_per_launch\": %.4f, "
+		       "\"scene_kernel\": \"%s\", \"compile_s\": %.4f}\n",
+		       frames, dt / frames * 1e3, (double) width * height * spp * frames / dt / 1e6, rt_multi_size(group), kernel_ms / launches, span_ms / launches,
+		       rt_compiled_scene_info(rt_multi_context(group, 0)), compile_s);
 		rt_move_frame_to_the_gpu(width, height, buf[(frames - 1) & 1]);   /* where update_frame() hands off, main.c:479 */
 		rt_host_free(buf[0]); rt_host_free(buf[1]);
 		rt_free_cubemap(&skybox);

@@ -259,7 +259,8 @@ def test_bench_self_launch_four_ranks_sharing_the_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--share-gpu", "--steps", "3", "--warmup", "1",
-                        "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+                        "--no-extras", "--no-cpu-baseline"] + (["--leave-early"] if os.environ.get("RT_TEST_LEAVE_EARLY") else []),   # (scripts/repro_verify_race.py)
+                       capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-1500:])
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 4 and line["verified"] is True and line["verification"]["equals_blocking_rt_render"] is True
