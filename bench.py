@@ -73,6 +73,12 @@ def parse_args(argv=None):
     ap.add_argument("--force-collective", action="store_true",
                     help="testing aid for 1-GPU boxes: one rank runs the N > 1 frame loop (RCCL gather on a one-rank group, "
                          "de-interleave, three strip buffers) so that loop's cost shows beside the plain N = 1 line")
+    ap.add_argument("--native-multi", action="store_true",
+                    help="N GPUs from ONE process through the C ABI's device group (rt_multi_frame_submit / rt_multi_frame_wait: "
+                         "ncclCommInitAll + one grouped ncclGather per frame) instead of one process per GPU under torch.distributed")
+    ap.add_argument("--one-device", action="store_true",
+                    help="testing aid for 1-GPU boxes, with --native-multi: the N contexts of the group all live on GPU 0 and the gather "
+                         "is the N device copies it amounts to there (rt_multi_create_on_one_device); not a performance configuration")
     ap.add_argument("--torch-loop", action="store_true",
                     help="N = 1: run the torch-side frame loop (multi_gpu.TiledFrame) instead of the C ABI's frame queue")
     ap.add_argument("--leave-early", action="store_true",
@@ -215,7 +221,7 @@ def traffic_from_profiles(config, compiled):
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.native_multi:
         sys.exit(self_launch(args, argv))
     if args.launch_check:
         sys.exit(launch_check(args))
@@ -230,7 +236,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    args.gpus = world
+    ngpus = args.gpus if args.native_multi else world      # GPUs the frame is split over (one process per GPU, or one process for all)
+    args.gpus = ngpus
     # The contract is ONE line on stdout: the JSON.  RCCL prints a version banner and gloo its connection messages to the
     # process's stdout (file descriptor 1, from C): everything written to descriptor 1 from here on goes to stderr, and the
     # JSON line is written to the original descriptor at the end.
@@ -263,13 +270,14 @@ def main():
     gpu.set_camera()
     gpu.reserve(W, H)
     # scene "compilation" (hiprtc, ~1 s, outside the timed region): same frames, fewer instructions
-    compiled, jit_s = False, None
+    compiled, jit_s, scene_kernel_info = False, None, None
     if args.kernel == rt.KERNEL_AUTO and not args.no_jit:
         try:
             t = time.perf_counter()
             gpu.compile_scene()
             jit_s = time.perf_counter() - t
             compiled = True
+            scene_kernel_info = gpu.compiled_scene_info()       # "embedded, compiled with the library by ..." / "hiprtc x.y at run time"
         except rt.RtError as e:
             print(f"[bench] scene not specialised, using the generic kernel: {e}", file=sys.stderr)
 
@@ -283,22 +291,32 @@ def main():
     # --force-collective the N-GPU path of rt_multi_frame_* over a one-rank RCCL communicator), torch.distributed's
     # collective around rt_render_device when every GPU has its own process (N > 1) -----------------------------------
     native = world == 1 and not args.torch_loop
-    multi_path = world > 1 or args.force_collective
+    multi_path = ngpus > 1 or args.force_collective
+    collective = None
     if native:
         from ray_tracing_amd.frames import FrameLoop
         queue = gpu
-        if args.force_collective:
-            queue = rt.MultiRenderer([local_rank])
-            queue.set_tuning(force_collective=1)
+        if args.force_collective or args.native_multi:
+            if args.native_multi and args.one_device:
+                queue = rt.MultiRenderer([local_rank], on_one_device=ngpus)
+            else:
+                queue = rt.MultiRenderer(list(range(ngpus)) if args.native_multi else [local_rank])
+            queue.set_tuning(force_collective=1 if args.force_collective else 0)
             queue.set_scene(scene_path); queue.set_skybox(sky); queue.set_camera()
             if compiled:
                 queue.compile_scene()
             prof = queue.context(0)
+            # what the communicator itself reports -- not what this script asked for
+            info = queue.collective_info()
+            collective = {"host": "rt_multi (one process, ncclCommInitAll)", "ranks_seen": info["ranks"], "devices_seen": info["devices"],
+                          "rccl_version": info["version"], "contexts": queue.size()}
+            if args.one_device:
+                collective["note"] = "testing aid: all contexts on one GPU, the gather is device copies (no communicator: ranks_seen 0)"
         else:
             prof = gpu
-        depth = args.depth or (3 if args.force_collective else 2)
+        depth = args.depth or (3 if multi_path else 2)
         loop = FrameLoop(queue, W, H, spp, nb, depth=depth, row_block=ROW_BLOCK, kernel=args.kernel)
-        primitive = "ncclGather (native, one process)" if args.force_collective else None
+        primitive = ("device copies on one GPU (testing aid)" if args.one_device else "ncclGather (native, one process)") if multi_path else None
 
         def run_steps(first_seed, n):
             t0 = time.perf_counter()
@@ -317,6 +335,14 @@ def main():
         prof = gpu
         depth = 3 if tiled.multi else 2
         primitive = tiled.primitive
+        if tiled.multi:
+            # what the process group itself reports: its size, and the device every rank really is on
+            mine = [rank, torch.cuda.current_device(), socket.gethostname()]
+            seen = [None] * dist.get_world_size()
+            dist.all_gather_object(seen, mine)
+            collective = {"host": "torch.distributed (one process per GPU)", "backend": str(dist.get_backend()), "ranks_seen": dist.get_world_size(),
+                          "devices_seen": [d for _, d, _ in sorted(seen)],
+                          "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if str(dist.get_backend()) == "nccl" else None}
 
         def run_steps(first_seed, n):
             t0 = time.perf_counter()
@@ -375,8 +401,10 @@ def main():
     if rank == 0:
         got = np.array(last_frame(), copy=True)
         check = rt.Renderer(local_rank)
+        check.set_tuning(poison_frame=True)           # a pixel the check render leaves unwritten is a NaN, not whatever the fresh buffer held
         check.set_scene(scene_path); check.set_skybox(sky); check.set_camera()
         want = check.render(W, H, spp, nb, seed=last_seed)          # generic kernel, one GPU, blocking
+        check_counts = check.last_launch_counts()
         check.close()
         same = bool((got.view(np.uint32) == want.view(np.uint32)).all())
         verified = {"last_frame_seed": last_seed, "equals_blocking_rt_render": same, "frame_mean": round(float(got.mean()), 6),
@@ -384,12 +412,18 @@ def main():
         if not same:                  # where: enough to tell a stale strip from a stray pixel
             bad = (got.view(np.uint32) != want.view(np.uint32)).any(axis=2)
             rows_bad = np.flatnonzero(bad.any(axis=1))
+            # Which frame is off?  Round 3's intermittent failure differed only in pixels whose value does not depend on the seed (sky,
+            # and the emitter's disc, where every sample clamps to 1): a stale frame cannot differ there, only memory a launch did not
+            # write -- and every buffer of the timed loop had been filled by earlier frames, the check render's were fresh.
+            verified["mismatch_diagnosis"] = {"nan_pixels_in_timed_frame": int(np.isnan(got).any(axis=2).sum()),
+                                              "nan_pixels_in_check_render": int(np.isnan(want).any(axis=2).sum()),
+                                              "check_render_launch": check_counts, "timed_loop_last_launch": gpu.last_launch_counts()}
             verified["mismatch"] = {"pixels": int(bad.sum()), "rows": int(rows_bad.size), "first_rows": [int(r) for r in rows_bad[:12]],
                                     "last_rows": [int(r) for r in rows_bad[-4:]],
                                     "pixels_in_first_row": int(bad[rows_bad[0]].sum()) if rows_bad.size else 0,
                                     # per strip (row block b belongs to strip b % world): rows that differ, and the first of them
-                                    "rows_per_strip": [int(sum(1 for r in rows_bad if (r // ROW_BLOCK) % world == s)) for s in range(world)],
-                                    "first_row_per_strip": [int(min([r for r in rows_bad if (r // ROW_BLOCK) % world == s], default=-1)) for s in range(world)]}
+                                    "rows_per_strip": [int(sum(1 for r in rows_bad if (r // ROW_BLOCK) % ngpus == s)) for s in range(ngpus)],
+                                    "first_row_per_strip": [int(min([r for r in rows_bad if (r // ROW_BLOCK) % ngpus == s], default=-1)) for s in range(ngpus)]}
             sys.stderr.write("VERIFICATION FAILED: " + json.dumps(verified["mismatch"]) + "\n")
         try:
             from rtlibs import Oracle
@@ -453,6 +487,25 @@ def main():
         latency = runs[len(runs) // 2]
 
     samples_per_step = W * H * spp
+    # ---- the same loop with the frame LEFT ON THE DEVICE (rt_frame_submit_device): what a presenter that takes the frame from
+    # device memory gets -- the reference's own hand-off goes host -> GPU (glTexImage2D, gpu_and_windowing.c:371-376)
+    device_resident = None
+    if native and not multi_path and not args.no_extras:
+        n_dev = max(args.steps, 10)
+        p_of = lambda k: rt.Renderer.params(W, H, spp, nb, seed=seed + k, row_block=ROW_BLOCK, kernel=args.kernel)   # noqa: E731
+        for k in range(2):
+            gpu.frame_submit_device(p_of(k), k); gpu.frame_wait(k)
+        fence()
+        t1 = time.perf_counter()
+        gpu.frame_submit_device(p_of(0), 0)
+        for k in range(n_dev):
+            if k + 1 < n_dev:
+                gpu.frame_submit_device(p_of(k + 1), (k + 1) & 1)
+            gpu.frame_wait(k & 1)
+        dt_dev = (time.perf_counter() - t1) / n_dev
+        device_resident = {"ms_per_step": round(dt_dev * 1e3, 4), "value": round(samples_per_step / dt_dev / 1e6, 2), "unit": "Msamples/s", "steps": n_dev,
+                           "region": "K frames through rt_frame_submit_device / rt_frame_wait, two in flight: the frame stays in HBM, only the "
+                                     "launch's control word goes to the host"}
     if rank == 0:
         value = samples_per_step * args.steps / elapsed / 1e6
         metric = "Msamples/s (rays/s) at 1920x1080x64spp scene_0; 1/2/4/8 GPU"
@@ -460,7 +513,7 @@ def main():
             metric = f"Msamples/s at {W}x{H}x{spp}spp {w['scene'][:-4]} ({args.config})"
         out = {
             "metric": metric,
-            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": ngpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "verified": bool(verified and verified["ok"]), "verification": verified,
@@ -469,15 +522,17 @@ def main():
                        "timed_region": "K frames, each: strip render -> "
                                        + ("one RCCL gather to rank 0 -> de-interleave -> " if multi_path else "")
                                        + f"resolved frame copied to pinned host memory; {depth} frames in flight; step k renders seed k",
-                       "frame_loop": "C ABI frame queue (rt_frame_submit / rt_frame_wait)" if native and not args.force_collective
-                                     else "C ABI frame queue of the device group (rt_multi_frame_submit / rt_multi_frame_wait)" if native
+                       "frame_loop": "C ABI frame queue (rt_frame_submit / rt_frame_wait)" if native and not multi_path
+                                     else "C ABI frame queue of the device group (rt_multi_frame_submit / rt_multi_frame_wait), one host process" if native
                                      else "multi_gpu.TiledFrame: rt_render_device + torch.distributed collective, one process per GPU",
-                       "partition": f"interleaved blocks of {ROW_BLOCK} rows over {world} " + ("rank(s) SHARING ONE GPU (testing aid)" if args.share_gpu else "GPU(s)")
+                       "partition": f"interleaved blocks of {ROW_BLOCK} rows over {ngpus} " + ("rank(s) SHARING ONE GPU (testing aid)" if (args.share_gpu or args.one_device) else "GPU(s)")
                                     + (f"; collective: {primitive}" if multi_path else "")
-                                    + (" (one-rank group: testing aid)" if args.force_collective and world == 1 else ""),
+                                    + (" (one-rank group: testing aid)" if args.force_collective and ngpus == 1 else ""),
                        "kernel": {0: "wavefront" + ("+scene-specialised (hiprtc)" if compiled else ""), 1: "simple",
                                   2: "wavefront, plain IEEE ops"}.get(args.kernel, str(args.kernel))},
         }
+        if collective is not None:
+            out["collective"] = collective
         if step_ms:
             med = step_ms[len(step_ms) // 2]
             out["ms_per_step_median"] = round(med, 4)
@@ -489,8 +544,16 @@ def main():
                                     "region": "first launch -> gathered, resolved frame resident in host memory, nothing overlapped"}
         if jit_s is not None:
             out["jit_compile_s"] = round(jit_s, 3)
+            out["config"]["scene_kernel"] = gpu.compiled_scene_info() if gpu.scene_is_compiled() else scene_kernel_info
         if host_copy is not None:
             out["host_copy"] = host_copy
+            if step_ms and abs(step_ms[len(step_ms) // 2] - host_copy["ms"]) <= 0.1 * host_copy["ms"]:
+                # the median step IS the copy of the frame to the host: the line's rate is the link's, not a kernel's
+                out["step_bound"] = "pcie"
+                out["step_bound_note"] = (f"median step {step_ms[len(step_ms) // 2]:.3f} ms = the {host_copy['bytes'] / 1e6:.1f} MB frame at "
+                                          f"{host_copy['GBps']} GB/s, {host_copy['frac_of_link']} of a PCIe 5.0 x16 link; see device_resident for the step without it")
+        if device_resident is not None:
+            out["device_resident"] = device_resident
         # ---- roofline of the dominant kernel (rank 0's launches; every rank runs the same kernel on 1/N of the rows)
         from rtlibs import Oracle
         try:
@@ -503,7 +566,7 @@ def main():
         if work and launches:
             avg_ms = kernel_ms / launches
             span_launches = launches
-            samples_per_launch = samples_per_step / world
+            samples_per_launch = samples_per_step / ngpus
             flops = work["flops"] * samples_per_launch
             # algorithmic bytes: 3 B per skybox fetch + 12 B per pixel written once per launch
             bytes_ = 3.0 * work["sky_fetches"] * samples_per_launch + 12.0 * (samples_per_launch / spp)
@@ -537,10 +600,25 @@ def main():
                         "launches overlap on two streams and the shared time is in both) and (span from the first launch to the end "
                         "of the last trace kernel / launches; contains idle time when launches wait for host copies)",
             })
-            tr = traffic_from_profiles(args.config, compiled) if world == 1 else None
+            tr = traffic_from_profiles(args.config, compiled) if ngpus == 1 else None
             if tr:
                 out["roofline"]["traffic"] = round(tr["fetch_bytes"] + tr["write_bytes"])
                 out["roofline"]["traffic_note"] = tr.get("source", "")
+            if gather_bound:
+                # A memory-bound line says what was MOVED: `achieved` = the bytes the PMC passes counted between L2 and the fabric
+                # per launch over the measured kernel time.  The algorithmic bytes (one texel per sample) are not moved -- a sky
+                # pixel's spp samples are one fetch (bit-exact: the reference has no sub-pixel jitter, main.c:293-296) -- and go to
+                # a side key.
+                out["roofline"]["algorithmic"] = {"GBps": hbm["achieved"], "frac_of_peak": hbm["frac"], "bytes_per_sample": hbm["bytes_per_sample"],
+                                                  "note": f"3 B per sky fetch + 12 B per pixel, as if every sample fetched its texel; the kernels fetch once per "
+                                                          f"sky pixel and add the value {spp} times in sample order ({spp}x reuse), so these bytes are not traffic"}
+                if tr:
+                    moved = float(tr["fetch_bytes"] + tr["write_bytes"])
+                    out["roofline"].update({"achieved": round(moved / (avg_ms * 1e-3) / 1e9, 3), "frac": round(moved / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                                            "achieved_from": "traffic / avg_kernel_ms (PMC bytes of the committed passes, this run's kernel time)"})
+                else:
+                    out["roofline"].update({"achieved": None, "frac": None, "achieved_from": "no PMC pass committed for this config (profiles/pmc_latest.json)"})
+                out["roofline"].pop("bytes_per_sample", None)
                 if tr.get("valu_instructions"):
                     # The same launch against the ISSUE ceiling of the SIMDs, which is what binds it: VALU instructions per launch
                     # (committed rocprofv3 PMC pass of this build) x 2 clk per wave64 instruction -- the guide's rate for the
@@ -555,7 +633,7 @@ def main():
                         "valu_busy_pct": tr.get("valu_busy_pct"), "valu_lane_utilisation_pct": tr.get("valu_lane_utilisation_pct"),
                         "note": "instructions x 2 clk / (1024 SIMDs x 2.4 GHz x avg_kernel_ms); VALUBusy / VALUUtilization from the same PMC passes"}
         # ---- the generic kernel (no hiprtc): same frames, same events
-        if native and not args.force_collective and compiled and not args.no_extras:
+        if native and not multi_path and compiled and not args.no_extras:
             gpu.set_scene(scene_path)                 # drops the compiled kernel
             one_frame(seed)
             gpu.profile(True)
@@ -564,7 +642,7 @@ def main():
             gpu.profile(False)
             if g_n:
                 out.setdefault("roofline", {})["generic_kernel_ms"] = round(min(g_ms, g_span) / g_n, 4)
-        if world == 1 and not args.no_cpu_baseline:
+        if ngpus == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(rt, w, sky)
                 out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

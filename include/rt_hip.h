@@ -205,6 +205,16 @@ RT_API int rt_synchronize(rt_context *ctx);
 RT_API int rt_frame_submit(rt_context *ctx, const rt_render_params *params, int slot, Vector3 *frame_out);
 RT_API int rt_frame_wait(rt_context *ctx, int slot);
 RT_API int rt_frame_poll(rt_context *ctx, int slot);
+/* The same queue for a consumer that is ON THE GPU.  The reference's only device crossing is host -> GPU: update_frame() hands
+ * the finished frame to glTexImage2D (main.c:479, gpu_and_windowing.c:371-376) -- a presenter that takes the frame from device
+ * memory (GL / Vulkan interop, a tone-mapping or encoding kernel) needs no copy at all.  rt_frame_submit_device() renders
+ * into the slot's device buffer and returns it: *d_frame = height * width Vector3 in frame order on the context's device,
+ * *hip_event (optional) = a hipEvent_t recorded behind the render on its stream -- the consumer orders its own stream behind it
+ * (hipStreamWaitEvent) or waits on it; nothing is copied to the host but the launch's 4-byte control word.  Both stay valid
+ * until the slot is submitted again; rt_frame_wait() / rt_frame_poll() release the slot as usual (and report RT_CANCELLED):
+ * wait for the slot before submitting into it again, i.e. when the consumer is done with the buffer.  C3 (3840 x 2160): the
+ * delivered-to-host step is the 99.5 MB copy (1.77 ms at 56 GB/s); the device-resident step is the kernels' 0.63 ms. */
+RT_API int rt_frame_submit_device(rt_context *ctx, const rt_render_params *params, int slot, void **d_frame, void **hip_event);
 /* page-locked host memory for frame_out (hipHostMalloc): any thread, no context needed */
 RT_API int  rt_host_alloc(void **out, size_t bytes);
 RT_API void rt_host_free(void *p);
@@ -224,6 +234,10 @@ RT_API void rt_host_free(void *p);
  * in flight, and that pass is not accumulated. */
 RT_API int rt_cancel(rt_context *ctx);
 RT_API int rt_was_cancelled(rt_context *ctx);
+/* Diagnostic aid (bench.py's verification logs it when frames differ): what the context's most recent launch left in its
+ * counters -- object pixels listed by the camera-ray pass, how many of them the trace kernel's waves fetched (all of them unless
+ * the launch was cut short), and the launch's four control words ([1] != 0: a wave gave up after rt_cancel).  Waits for it. */
+RT_API int rt_last_launch_counts(rt_context *ctx, unsigned long long *pixels_listed, unsigned long long *pixels_fetched, unsigned int control[4]);
 
 /* ---- several GPUs of one node, one host process: replaces start_workers()'s fan-out (main.c:695-718) ----
  * rt_multi_create() makes one context per listed device and, for n > 1, the RCCL communicators of the group
@@ -255,6 +269,19 @@ RT_API int  rt_multi_render(rt_multi *m, const rt_render_params *params, Vector3
 RT_API int  rt_multi_frame_submit(rt_multi *m, const rt_render_params *params, int slot, Vector3 *frame_out);
 RT_API int  rt_multi_frame_wait(rt_multi *m, int slot);
 RT_API int  rt_multi_frame_poll(rt_multi *m, int slot);
+/* rt_frame_submit_device() for the group: the assembled frame stays on the FIRST device (*d_frame: height * width Vector3 in
+ * frame order; *hip_event: a hipEvent_t of that device recorded behind the de-interleave); nothing but the launches' control
+ * words goes to the host. */
+RT_API int  rt_multi_frame_submit_device(rt_multi *m, const rt_render_params *params, int slot, void **d_frame, void **hip_event);
+/* What the group's RCCL communicator itself says (not what the host asked for): *ranks = ncclCommCount, devices[i] =
+ * ncclCommCuDevice of rank i's communicator (room for 64), *version = ncclGetVersion (e.g. 22707).  A group that has no
+ * communicator -- one device without rt_tuning.force_collective -- reports *ranks = 0. */
+RT_API int  rt_multi_collective_info(rt_multi *m, int *ranks, int devices[64], int *version);
+/* TESTING AID for 1-GPU boxes: a group of n contexts that all live on ONE device.  Everything the n-device path does runs --
+ * n strips from n contexts on their own streams, three strip buffers each, the rotated hand-out, the de-interleave, the
+ * frame queue, the ladder -- except RCCL, which refuses two ranks on one device: the gather is the n device-to-device copies
+ * it amounts to there.  Frames are bit-identical to rt_render()'s.  Not a performance configuration. */
+RT_API int  rt_multi_create_on_one_device(rt_multi **out, int device_id, int n);
 
 /* ---- progressive accumulation: the reference's interactive protocol ----------------------------
  * worker() renders passes of 1 sample per (low-resolution) pixel, starting at 1/init_scale resolution

@@ -65,11 +65,12 @@ class MouseState(C.Structure):
 EXPORTS = [
     "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
     "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_compiled_scene_info", "rt_compiled_scene_counts", "rt_compiled_scene_cache_cap", "rt_spec_stats_read", "rt_spec_symbol_read", "rt_render", "rt_render_device", "rt_stream", "rt_reserve", "rt_strip_rows", "rt_deinterleave_device", "rt_deinterleave_rotated_device", "rt_strip_of_rank",
-    "rt_frame_submit", "rt_frame_wait", "rt_frame_poll", "rt_host_alloc", "rt_host_free",
+    "rt_frame_submit", "rt_frame_submit_device", "rt_frame_wait", "rt_frame_poll", "rt_host_alloc", "rt_host_free",
+    "rt_multi_frame_submit_device", "rt_multi_collective_info", "rt_multi_create_on_one_device",
     "rt_multi_frame_submit", "rt_multi_frame_wait", "rt_multi_frame_poll", "rt_profile_collect_span",
     "rt_progressive_begin_rank", "rt_progressive_resolve_device", "rt_multi_progressive_begin", "rt_multi_progressive_pass",
     "rt_multi_progressive_resolve", "rt_multi_progressive_invalidate", "rt_multi_progressive_state",
-    "rt_synchronize", "rt_cancel", "rt_was_cancelled", "rt_primary_passes_run", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
+    "rt_synchronize", "rt_cancel", "rt_was_cancelled", "rt_last_launch_counts", "rt_primary_passes_run", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
     "rt_progressive_invalidate", "rt_progressive_state", "rt_selftest", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
     "rt_parse_scene_string", "rt_load_cubemap", "rt_free_cubemap", "rt_decode_jpeg_file",
     "rt_camera_default", "rt_camera_basis_for", "rt_mouse_state_default", "rt_move_camera",
@@ -142,6 +143,11 @@ def lib():
         L.rt_multi_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p]
     if hasattr(L, "rt_frame_submit"):
         L.rt_frame_submit.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_int, C.c_void_p]
+        if hasattr(L, "rt_frame_submit_device"):
+            L.rt_frame_submit_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+            L.rt_multi_frame_submit_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+            L.rt_multi_collective_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+            L.rt_multi_create_on_one_device.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
         L.rt_frame_wait.argtypes = [C.c_void_p, C.c_int]
         L.rt_frame_poll.argtypes = [C.c_void_p, C.c_int]
         L.rt_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
@@ -282,6 +288,13 @@ class _FrameQueue:
         """host: a HostFrame (or any writable float32 array of the frame's size; page-locked memory lets the copy overlap)."""
         ptr = host.ptr if isinstance(host, HostFrame) else host.ctypes.data
         _check(getattr(lib(), self._prefix + "frame_submit")(self._handle(), C.byref(params), slot, C.c_void_p(ptr)), self._prefix + "frame_submit")
+
+    def frame_submit_device(self, params, slot):
+        """The frame stays in device memory: returns (device pointer of height x width x 3 floats, hipEvent_t handle recorded behind
+        it); frame_wait(slot) releases the slot."""
+        d, e = C.c_void_p(), C.c_void_p()
+        _check(getattr(lib(), self._prefix + "frame_submit_device")(self._handle(), C.byref(params), slot, C.byref(d), C.byref(e)), self._prefix + "frame_submit_device")
+        return d.value, e.value
 
     def frame_wait(self, slot):
         """Blocks until the slot's frame is in host memory; True if it is complete, False if rt_cancel() cut it short."""
@@ -477,6 +490,15 @@ class Renderer(_FrameQueue):
             _check(rc, "rt_was_cancelled")
         return rc == 1
 
+    def last_launch_counts(self):
+        """(object pixels listed, object pixels fetched by the trace kernel, the launch's control words) of the most recent launch."""
+        a, b = C.c_ulonglong(), C.c_ulonglong()
+        w = (C.c_uint * 4)()
+        f = lib().rt_last_launch_counts
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)]
+        _check(f(self._ctx, C.byref(a), C.byref(b), w), "rt_last_launch_counts")
+        return {"pixels_listed": a.value, "pixels_fetched": b.value, "control": list(w)}
+
     def profile(self, on=True):
         _check(lib().rt_profile_enable(self._ctx, 1 if on else 0), "rt_profile_enable")
 
@@ -506,11 +528,22 @@ class MultiRenderer(_FrameQueue):
         r.device, r._keep, r._borrowed = i, {}, True
         return r
 
-    def __init__(self, devices):
+    def __init__(self, devices, on_one_device=None):
+        """devices: the GPUs of the group.  on_one_device=n (testing aid): n contexts on devices[0], the gather done by copies."""
         devices = list(devices)
         self._m = C.c_void_p()
+        if on_one_device:
+            _check(lib().rt_multi_create_on_one_device(C.byref(self._m), devices[0], on_one_device), "rt_multi_create_on_one_device")
+            return
         ids = (C.c_int * len(devices))(*devices)
         _check(lib().rt_multi_create(C.byref(self._m), ids, len(devices)), "rt_multi_create")
+
+    def collective_info(self):
+        """What the group's RCCL communicator reports: dict(ranks=ncclCommCount, devices=[ncclCommCuDevice ...], version=ncclGetVersion)."""
+        ranks, ver = C.c_int(), C.c_int()
+        devs = (C.c_int * 64)()
+        _check(lib().rt_multi_collective_info(self._m, C.byref(ranks), devs, C.byref(ver)), "rt_multi_collective_info")
+        return {"ranks": ranks.value, "devices": [devs[i] for i in range(ranks.value)], "version": ver.value}
 
     def close(self):
         if self._m:

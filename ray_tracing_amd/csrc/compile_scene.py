@@ -34,6 +34,13 @@ else:
     R.hiprtcGetCodeSize(prog, C.byref(n))
     code = C.create_string_buffer(n.value); R.hiprtcGetCode(prog, code)
     open(out, "wb").write(code.raw)
-    major, minor = C.c_int(), C.c_int()
-    R.hiprtcVersion(C.byref(major), C.byref(minor))
-    print(f"hiprtc {major.value}.{minor.value} ({os.path.realpath(tool)})")
+    # which ROCm it belongs to: PyTorch's bundle says so in torch/version.py (read as text: importing torch takes seconds)
+    rocm = ""
+    vpy = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(tool))), "version.py")
+    if os.path.exists(vpy):
+        for line in open(vpy):
+            if line.startswith("hip"):
+                rocm = " of ROCm " + line.split("=", 1)[1].strip().strip("'\"") + " (PyTorch's bundle)"
+    elif "rocm" in os.path.realpath(tool):
+        rocm = " of " + [c for c in os.path.realpath(tool).split(os.sep) if c.startswith("rocm")][0]
+    print(f"hiprtc{rocm}, {os.path.basename(os.path.realpath(tool))}")

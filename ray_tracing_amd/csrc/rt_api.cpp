@@ -131,6 +131,7 @@ struct rt_context {
 		float     *d_buf = nullptr;
 		size_t     bytes = 0;
 		hipEvent_t copied = nullptr;     /* behind the copy of the frame (and of the launch's control word) to the host */
+		hipEvent_t rendered = nullptr;   /* behind the render, on its stream: what rt_frame_submit_device() hands to the caller */
 		bool       busy = false;         /* submitted and not waited for yet */
 	} fq[RT_FRAME_SLOTS];
 	unsigned long long frames_submitted = 0;   /* frame n renders on the context's stream n & 1 */
@@ -268,7 +269,7 @@ int rt_set_tuning(rt_context *ctx, const rt_tuning *t)
 {
 	if (!ctx || !t) return fail(RT_ERR_ARGUMENT, "rt_set_tuning: NULL argument");
 	if ((t->dequeue_shards != 0 && t->dequeue_shards != 1 && t->dequeue_shards != 64) ||
-	    t->workgroups_per_cu < 0 || t->workgroups_per_cu > 4 || t->jit_waves_per_simd < 0 || t->jit_waves_per_simd > 8)
+	    t->workgroups_per_cu < 0 || t->workgroups_per_cu > 8 || t->jit_waves_per_simd < 0 || t->jit_waves_per_simd > 8)
 		return fail(RT_ERR_ARGUMENT, "rt_set_tuning: value out of range");
 	ctx->tuning = *t;
 	ctx->jit_flags = t->jit_flags ? t->jit_flags : "";
@@ -340,7 +341,7 @@ void rt_destroy(rt_context *ctx)
 		(void) hipFree(sl.d_counter); (void) hipFree(sl.d_pix);
 	}
 	if (ctx->copy_stream) { (void) hipStreamSynchronize(ctx->copy_stream); (void) hipStreamDestroy(ctx->copy_stream); }
-	for (auto &f : ctx->fq) { if (f.copied) (void) hipEventDestroy(f.copied); (void) hipFree(f.d_buf); }
+	for (auto &f : ctx->fq) { if (f.copied) (void) hipEventDestroy(f.copied); if (f.rendered) (void) hipEventDestroy(f.rendered); (void) hipFree(f.d_buf); }
 	if (ctx->stream2) { (void) hipStreamSynchronize(ctx->stream2); (void) hipStreamDestroy(ctx->stream2); }
 	if (ctx->h_words) (void) hipHostFree(ctx->h_words);
 	/* (the compiled scene's module belongs to the process-wide cache of rt_jit.cpp: never unloaded) */
@@ -726,11 +727,12 @@ static int frame_copy_stream(rt_context *ctx)
 	return RT_OK;
 }
 
-int rt_frame_submit(rt_context *ctx, const rt_render_params *p, int slot, Vector3 *frame_out)
+/* frame_out != NULL: the frame is copied to the caller's host memory; NULL (rt_frame_submit_device): it stays in the slot's
+ * device buffer and the caller gets that buffer and an event recorded behind the render */
+static int frame_submit(rt_context *ctx, const rt_render_params *p, int slot, Vector3 *frame_out, void **d_frame, void **hip_event)
 {
 	int rc = check_params(ctx, p);
 	if (rc != RT_OK) return rc;
-	if (!frame_out) return fail(RT_ERR_ARGUMENT, "rt_frame_submit: frame_out is NULL");
 	if (slot < 0 || slot >= RT_FRAME_SLOTS) return fail(RT_ERR_ARGUMENT, "rt_frame_submit: slot %d not in [0,%d)", slot, RT_FRAME_SLOTS);
 	if (p->world != 1) return fail(RT_ERR_ARGUMENT, "rt_frame_submit: world must be 1 (rt_multi_frame_submit renders on several GPUs)");
 	rt_context::frame_slot &f = ctx->fq[slot];
@@ -739,6 +741,7 @@ int rt_frame_submit(rt_context *ctx, const rt_render_params *p, int slot, Vector
 	rc = frame_copy_stream(ctx);
 	if (rc != RT_OK) return rc;
 	if (!f.copied) HIP_TRY(hipEventCreateWithFlags(&f.copied, hipEventDisableTiming));
+	if (!f.rendered) HIP_TRY(hipEventCreateWithFlags(&f.rendered, hipEventDisableTiming));
 	const size_t need = (size_t) rt_strip_rows(p->height, p->row_block, 1) * p->width * 3 * sizeof(float);
 	if (need > f.bytes) {
 		(void) hipFree(f.d_buf); f.d_buf = nullptr; f.bytes = 0;       /* (the slot is idle: its last copy was waited for) */
@@ -750,16 +753,32 @@ int rt_frame_submit(rt_context *ctx, const rt_render_params *p, int slot, Vector
 	rc = rt_render_device(ctx, p, f.d_buf, stream);
 	if (rc != RT_OK) return rc;
 	ctx->frames_submitted++;
+	HIP_TRY(hipEventRecord(f.rendered, stream));
 	/* the copy waits for the render (an event recorded behind it on `stream`); the launch's control word (rt_cancel) follows
 	 * the frame on the copy stream, and nothing waits for either but the slot -- and the scratch set's launch after next,
 	 * which clears that word */
-	HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->slot[ctx->cur].done, 0));
-	HIP_TRY(hipMemcpyAsync(frame_out, f.d_buf, (size_t) p->height * p->width * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->copy_stream));
+	HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, f.rendered, 0));
+	if (frame_out)
+		HIP_TRY(hipMemcpyAsync(frame_out, f.d_buf, (size_t) p->height * p->width * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->copy_stream));
 	rc = rt_context_read_control(ctx, &ctx->h_words[1 + slot], ctx->copy_stream, nullptr);
 	if (rc != RT_OK) return rc;
 	HIP_TRY(hipEventRecord(f.copied, ctx->copy_stream));
 	f.busy = true;
+	if (d_frame) *d_frame = f.d_buf;
+	if (hip_event) *hip_event = (void *) f.rendered;
 	return RT_OK;
+}
+
+int rt_frame_submit(rt_context *ctx, const rt_render_params *p, int slot, Vector3 *frame_out)
+{
+	if (!frame_out) return fail(RT_ERR_ARGUMENT, "rt_frame_submit: frame_out is NULL");
+	return frame_submit(ctx, p, slot, frame_out, nullptr, nullptr);
+}
+
+int rt_frame_submit_device(rt_context *ctx, const rt_render_params *p, int slot, void **d_frame, void **hip_event)
+{
+	if (!d_frame) return fail(RT_ERR_ARGUMENT, "rt_frame_submit_device: d_frame is NULL");
+	return frame_submit(ctx, p, slot, nullptr, d_frame, hip_event);
 }
 
 int rt_frame_wait(rt_context *ctx, int slot)
@@ -823,6 +842,27 @@ int rt_was_cancelled(rt_context *ctx)
 	unsigned int w = 0;
 	HIP_TRY(hipMemcpy(&w, ctx->slot[ctx->cur].d_counter + 128 * 32 + 1, sizeof(w), hipMemcpyDeviceToHost));
 	return w ? RT_CANCELLED : RT_OK;
+}
+
+/* Diagnostic aid: what the context's most recent launch left in its counters -- how many object pixels rt_primary_pass listed,
+ * how many of them the trace kernel's waves fetched (all of them, unless the launch was cut short), and its control words
+ * ([1]: a wave gave up because of rt_cancel, [2]: the relayed request).  Waits for the launch. */
+int rt_last_launch_counts(rt_context *ctx, unsigned long long *pixels_listed, unsigned long long *pixels_fetched, unsigned int control[4])
+{
+	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_last_launch_counts: NULL context");
+	HIP_TRY(hipSetDevice(ctx->device));
+	{ const int rc = wait_for_launches(ctx); if (rc != RT_OK) return rc; }
+	std::vector<unsigned int> words(rt_counter_bytes() / sizeof(unsigned int));
+	HIP_TRY(hipMemcpy(words.data(), ctx->slot[ctx->cur].d_counter, rt_counter_bytes(), hipMemcpyDeviceToHost));
+	unsigned long long listed = 0, fetched = 0;
+	for (int s = 0; s < 64; s++) {
+		const unsigned int fill = words[(size_t) (64 + s) * 32], taken = words[(size_t) s * 32];
+		listed += fill; fetched += taken < fill ? taken : fill;
+	}
+	if (pixels_listed) *pixels_listed = listed;
+	if (pixels_fetched) *pixels_fetched = fetched;
+	if (control) for (int k = 0; k < 4; k++) control[k] = words[(size_t) 128 * 32 + k];
+	return RT_OK;
 }
 
 int rt_deinterleave_rotated_device(rt_context *ctx, const void *d_strips, void *d_frame,

@@ -1376,7 +1376,10 @@ rt_trace_spec(const rt_launch L, unsigned int *block_counter)
  * ============================================================================================= */
 struct FirstLDS { float col[3][8 * 65]; };      /* 8 pixels x 64 samples (+1: rows on different banks) per channel */
 
-extern "C" __global__ void __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD)
+#ifndef RT_FIRST_WAVES_PER_SIMD
+#define RT_FIRST_WAVES_PER_SIMD 6      /* 80 registers are enough for one pixel's first bounce; 6 x 4 x 6.2 KB of colours fit the CU */
+#endif
+extern "C" __global__ void __launch_bounds__(RT_BLOCK, RT_FIRST_WAVES_PER_SIMD)
 rt_first_bounce_spec(const rt_launch L, unsigned int *block_counter)
 {
 	extern __shared__ float4 lds[];
@@ -1408,13 +1411,20 @@ rt_first_bounce_spec(const rt_launch L, unsigned int *block_counter)
 		wave_fence();
 	};
 
-	for (;;) {
-		/* ---- the next pixel of the lists rt_primary_pass filled (same lists and counters as the general kernel) ---- */
-		unsigned int k = 0;
-		if (lane == 0) k = atomicAdd(block_counter + shard * 32u, 1u);
-		k = (unsigned int) __builtin_amdgcn_readfirstlane((int) k);
-		const unsigned int filled = (unsigned int) __builtin_amdgcn_readfirstlane((int) fill_counts[shard * 32u]);
-		if (k >= filled) {
+	/* ---- pixel supply (the lists and counters of the general kernel), two steps ahead of the arithmetic: the dequeue of the
+	 * pixel after next is sent off (lane 0's atomic; nobody waits for it) before the record of the next pixel is asked for
+	 * with the number the previous dequeue has brought by now, and that record is in flight while the current pixel is worked
+	 * on.  A wave alone would spend two memory round trips (2-3 us) per pixel of 0.6 us arithmetic. */
+	unsigned int asked_shard = shard, asked = 0u;      /* the dequeue in flight: lane 0 of `asked` holds the list position */
+	auto ask = [&]() { asked_shard = shard; if (lane == 0) asked = atomicAdd(block_counter + shard * 32u, 1u); };
+	/* the position the dequeue in flight returned, or -- that list has run out -- a pixel of another list, fetched on the spot;
+	 * false: the launch has no pixels left */
+	auto claim = [&](size_t &record) -> bool {
+		unsigned int k = (unsigned int) __builtin_amdgcn_readfirstlane((int) asked);
+		unsigned int from = asked_shard;
+		for (;;) {
+			const unsigned int filled = (unsigned int) __builtin_amdgcn_readfirstlane((int) fill_counts[from * 32u]);
+			if (k < filled) { record = (size_t) from * (size_t) C->pix_shard_cap + k; return true; }
 			unsigned int left = 0;
 			if (lane < C->num_shards) {
 				const unsigned int taken = __hip_atomic_load(block_counter + (unsigned int) lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1422,15 +1432,32 @@ rt_first_bounce_spec(const rt_launch L, unsigned int *block_counter)
 				left = have > taken ? have - taken : 0u;
 			}
 			const unsigned long long some = __ballot(left != 0u);
-			if (some == 0ull) break;
+			if (some == 0ull) return false;
 			const int pick = (int) ((blockIdx.x * (RT_BLOCK / 64) + (unsigned int) wave) % (unsigned int) __popcll(some));
-			shard = (unsigned int) __builtin_ctzll(__ballot(left != 0u && lanes_below(some) == pick));
-			continue;
+			shard = from = (unsigned int) __builtin_ctzll(__ballot(left != 0u && lanes_below(some) == pick));
+			unsigned int kk = 0;
+			if (lane == 0) kk = atomicAdd(block_counter + from * 32u, 1u);
+			k = (unsigned int) __builtin_amdgcn_readfirstlane((int) kk);
 		}
-		const PixelRec px = load_pixel(C, (size_t) shard * (size_t) C->pix_shard_cap + k);      /* every lane the same record */
+	};
+	size_t record = 0;
+	ask();
+	bool have = claim(record);
+	PixelRec px = load_pixel(C, have ? record : 0);
+	if (have) ask();
+	while (have) {
+		/* the record after this one: its loads are in flight during this pixel's arithmetic */
+		size_t record_next = 0;
+		const bool have_next = claim(record_next);
+		const PixelRec px_next = load_pixel(C, have_next ? record_next : record);
+		if (have_next) ask();
+		const PixelRec cur = px;
+		px = px_next; have = have_next; record = record_next;
+		{
+		const PixelRec &px = cur;
 		const int hobj = __builtin_amdgcn_readfirstlane(px.obj & (RT_PIX_TAPS_LIT - 1));
 		const int cls = __builtin_amdgcn_readfirstlane((int) (((uint32_t) px.obj >> 16) & 3u));
-		if (cls == 0) continue;                     /* taps to be traced: the general kernel's pixel */
+		if (cls != 0) {                             /* (0: taps to be traced -- the general kernel's pixel) */
 		const V3 hp = px.a, hn = px.n, hdir = px.dir;
 
 		/* ---- the first bounce of every sample of the pixel (main.c:180-261 with i == 0) ---- */
@@ -1519,6 +1546,8 @@ rt_first_bounce_spec(const rt_launch L, unsigned int *block_counter)
 		batch++;
 		wave_fence();
 		if (batch == 8) flush();
+		}
+		}
 	}
 	if (batch) flush();
 }
@@ -1916,7 +1945,14 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 		rt_launch Lc = Lq;
 		unsigned int *counter = block_counter;
 		void *args[] = { &Lc, &counter };
-		return hipModuleLaunchKernel(first_bounce_fn, (unsigned int) grid, 1, 1, RT_BLOCK, 1, 1, (unsigned int) rt_first_bounce_lds_bytes(L.num_objects), stream, args, nullptr);
+		const size_t flds = rt_first_bounce_lds_bytes(L.num_objects);
+		int fper = (int) ((160u * 1024u) / flds);
+		if (fper > 6) fper = 6;
+		if (workgroups_per_cu >= 1 && workgroups_per_cu < fper) fper = workgroups_per_cu;
+		long long fgrid = (long long) num_cus * fper;
+		if (fgrid > blocks * 16) fgrid = blocks * 16;          /* (a wave per pixel: never more waves than pixels) */
+		if (fgrid < 1) fgrid = 1;
+		return hipModuleLaunchKernel(first_bounce_fn, (unsigned int) fgrid, 1, 1, RT_BLOCK, 1, 1, (unsigned int) flds, stream, args, nullptr);
 	}
 	if (variant == 0 /* RT_KERNEL_AUTO */ && scene_fast_ok && spec_fn) {
 		/* same kernel, trace loop specialised for this scene by rt_compile_scene() */

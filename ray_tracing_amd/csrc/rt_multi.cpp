@@ -53,6 +53,10 @@ struct Rccl {
 	ncclResult_t (*group_start)() = nullptr;
 	ncclResult_t (*group_end)() = nullptr;
 	const char  *(*error_string)(ncclResult_t) = nullptr;
+	ncclResult_t (*comm_count)(const ncclComm_t comm, int *count) = nullptr;       /* optional: rt_multi_collective_info() */
+	ncclResult_t (*comm_device)(const ncclComm_t comm, int *device) = nullptr;
+	ncclResult_t (*comm_rank)(const ncclComm_t comm, int *rank) = nullptr;
+	ncclResult_t (*get_version)(int *version) = nullptr;
 	bool ok = false;
 };
 
@@ -69,6 +73,7 @@ Rccl &rccl()
 #define SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name))
 	SYM(comm_init_all, "ncclCommInitAll"); SYM(comm_destroy, "ncclCommDestroy"); SYM(gather, "ncclGather");
 	SYM(group_start, "ncclGroupStart");    SYM(group_end, "ncclGroupEnd");       SYM(error_string, "ncclGetErrorString");
+	SYM(comm_count, "ncclCommCount");      SYM(comm_device, "ncclCommCuDevice"); SYM(comm_rank, "ncclCommUserRank"); SYM(get_version, "ncclGetVersion");
 #undef SYM
 	r.ok = r.comm_init_all && r.comm_destroy && r.gather && r.group_start && r.group_end && r.error_string;
 	return r;
@@ -81,6 +86,7 @@ constexpr int STRIP_BUFFERS = 3;
 struct rt_multi {
 	int n = 0;
 	bool force_collective = false;              /* rt_tuning.force_collective: gather + de-interleave even with one device */
+	bool one_device = false;                    /* rt_multi_create_on_one_device(): n contexts on ONE device, the gather is n device copies (testing aid) */
 	std::vector<int>          devices;
 	std::vector<rt_context *> ctx;
 	std::vector<ncclComm_t>   comms;            /* made on first use of the collective */
@@ -211,18 +217,19 @@ static int prepare(rt_multi *m, int W, int H, int rb, int slot)
 
 extern "C" {
 
-int rt_multi_create(rt_multi **out, const int *device_ids, int n)
+static int multi_create(rt_multi **out, const int *device_ids, int n, bool one_device)
 {
 	if (!out) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_create: out is NULL");
 	*out = nullptr;
 	if (!device_ids || n < 1 || n > 64) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_create: need 1..64 device ids");
-	for (int i = 0; i < n; i++)
+	for (int i = 0; i < n && !one_device; i++)
 		for (int k = 0; k < i; k++)
 			if (device_ids[i] == device_ids[k])
 				return rt_fail(RT_ERR_ARGUMENT, "rt_multi_create: device %d listed twice", device_ids[i]);
 	rt_multi *m = new (std::nothrow) rt_multi();
 	if (!m) return rt_fail(RT_ERR_MEMORY, "rt_multi_create: out of host memory");
 	m->n = n;
+	m->one_device = one_device;
 	m->devices.assign(device_ids, device_ids + n);
 	m->ctx.assign((size_t) n, nullptr);
 	m->dev.resize((size_t) n);
@@ -230,12 +237,26 @@ int rt_multi_create(rt_multi **out, const int *device_ids, int n)
 		const int rc = rt_create(&m->ctx[(size_t) i], device_ids[i]);
 		if (rc != RT_OK) { rt_multi_destroy(m); return rc; }          /* rt_last_error() holds rt_create's text */
 	}
-	if (n > 1) {
+	if (n > 1 && !one_device) {
 		const int rc = init_communicators(m);
 		if (rc != RT_OK) { rt_multi_destroy(m); return rc; }
 	}
 	*out = m;
 	return RT_OK;
+}
+
+int rt_multi_create(rt_multi **out, const int *device_ids, int n) { return multi_create(out, device_ids, n, false); }
+
+/* TESTING AID for boxes with one GPU: a group of n contexts that all live on `device_id`.  Everything the n-device path does
+ * runs -- n strips rendered by n contexts on their own streams, three strip buffers each, the rotated hand-out, the
+ * de-interleave, the frame queue, the ladder -- except RCCL, which refuses two ranks on one device: the gather is the n
+ * device-to-device copies it amounts to there.  Frames are bit-identical to rt_render()'s; not a performance configuration. */
+int rt_multi_create_on_one_device(rt_multi **out, int device_id, int n)
+{
+	if (n < 1 || n > 64) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_create_on_one_device: need 1..64 contexts");
+	int ids[64];
+	for (int i = 0; i < n; i++) ids[i] = device_id;
+	return multi_create(out, ids, n, true);
 }
 
 void rt_multi_destroy(rt_multi *m)
@@ -289,23 +310,50 @@ int rt_multi_set_tuning(rt_multi *m, const rt_tuning *tuning)
 }
 int rt_multi_compile_scene(rt_multi *m)                       { FOR_ALL(rt_compile_scene(ctx)); }
 
-int rt_multi_frame_submit(rt_multi *m, const rt_render_params *params, int slot, Vector3 *frame_out)
+/* the strips of frame buffer j to device 0: ONE grouped ncclGather, each rank's part on its own collective stream -- or, for a
+ * group whose contexts share one device (testing aid), the copies that gather amounts to there */
+static int gather_strips(rt_multi *m, int j, size_t strip_floats)
 {
-	if (!m || !params || !frame_out) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_frame_submit: NULL argument");
+	const int n = m->n;
+	if (m->one_device) {
+		/* on the ROOT's collective stream, where the collective's receives run too: behind the root's own earlier work on the
+		 * destination (the de-interleave that read d_strips[j] three frames back) and behind every context's render */
+		for (int i = 0; i < n; i++) {
+			hipError_t e = i == 0 ? hipSuccess : hipStreamWaitEvent(m->dev[0].gather_stream, (hipEvent_t) rt_context_launch_done(m->ctx[(size_t) i]), 0);
+			if (e == hipSuccess)
+				e = hipMemcpyAsync(m->d_strips[j] + (size_t) i * strip_floats, m->dev[(size_t) i].d_strip[j], strip_floats * sizeof(float),
+				                   hipMemcpyDeviceToDevice, m->dev[0].gather_stream);
+			if (e != hipSuccess) return rt_fail(RT_ERR_DEVICE, "rt_multi (one device): %s", hipGetErrorString(e));
+		}
+		return RT_OK;
+	}
+	Rccl &r = rccl();
+	ncclResult_t nrc = r.group_start();
+	for (int i = 0; i < n && nrc == ncclSuccess_; i++)
+		nrc = r.gather(m->dev[(size_t) i].d_strip[j], i == 0 ? m->d_strips[j] : nullptr, strip_floats, ncclFloat_, 0,
+		               m->comms[(size_t) i], m->dev[(size_t) i].gather_stream);
+	{ const ncclResult_t end = r.group_end(); if (nrc == ncclSuccess_) nrc = end; }
+	if (nrc != ncclSuccess_) return rt_fail(RT_ERR_DEVICE, "ncclGather: %s", r.error_string(nrc));
+	return RT_OK;
+}
+
+static int multi_frame_submit(rt_multi *m, const rt_render_params *params, int slot, Vector3 *frame_out, void **d_frame, void **hip_event)
+{
+	if (!m || !params) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_frame_submit: NULL argument");
 	if (slot < 0 || slot >= RT_FRAME_SLOTS) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_frame_submit: slot %d not in [0,%d)", slot, RT_FRAME_SLOTS);
 	rt_multi::frame_slot &f = m->fq[slot];
 	if (f.busy) return rt_fail(RT_ERR_STATE, "rt_multi_frame_submit: slot %d holds a frame that has not been waited for", slot);
 	if (m->n == 1 && !m->force_collective) {    /* one device: the strip is the frame */
 		rt_render_params p = *params;
 		p.rank = 0; p.world = 1;
-		const int rc = rt_frame_submit(m->ctx[0], &p, slot, frame_out);
+		const int rc = frame_out ? rt_frame_submit(m->ctx[0], &p, slot, frame_out) : rt_frame_submit_device(m->ctx[0], &p, slot, d_frame, hip_event);
 		if (rc == RT_OK) { f.busy = true; f.plain = true; }
 		return rc;
 	}
 	if (params->width < 2 || params->height < 2 || params->row_block < 1)
 		return rt_fail(RT_ERR_ARGUMENT, "rt_multi_frame_submit: bad frame %dx%d / row_block %d", params->width, params->height, params->row_block);
 	const int n = m->n, W = params->width, H = params->height, rb = params->row_block;
-	{ const int rc = init_communicators(m); if (rc != RT_OK) return rc; }
+	if (!m->one_device) { const int rc = init_communicators(m); if (rc != RT_OK) return rc; }
 	{ const int rc = prepare(m, W, H, rb, slot); if (rc != RT_OK) return rc; }
 	const size_t strip_floats = (size_t) rt_strip_rows(H, rb, n) * W * 3, frame_floats = (size_t) H * W * 3;
 	const int j = (int) (m->frames % STRIP_BUFFERS), which = (int) (m->frames & 1ull);
@@ -335,19 +383,12 @@ int rt_multi_frame_submit(rt_multi *m, const rt_render_params *params, int slot,
 		if (e != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: device %d: %s", m->devices[(size_t) i], hipGetErrorString(e));
 	}
 	/* ONE gather of the finished strips to device 0, each rank's part on its own collective stream */
-	Rccl &r = rccl();
-	if (rc == RT_OK) {
-		ncclResult_t nrc = r.group_start();
-		for (int i = 0; i < n && nrc == ncclSuccess_; i++)
-			nrc = r.gather(m->dev[(size_t) i].d_strip[j], i == 0 ? m->d_strips[j] : nullptr, strip_floats, ncclFloat_, 0,
-			               m->comms[(size_t) i], m->dev[(size_t) i].gather_stream);
-		{ const ncclResult_t end = r.group_end(); if (nrc == ncclSuccess_) nrc = end; }
-		if (nrc != ncclSuccess_) rc = rt_fail(RT_ERR_DEVICE, "ncclGather: %s", r.error_string(nrc));
-	}
+	if (rc == RT_OK) rc = gather_strips(m, j, strip_floats);
 	for (int i = 0; i < n && rc == RT_OK; i++) {
 		rt_multi::per_device &d = m->dev[(size_t) i];
 		hipError_t e = hipSetDevice(m->devices[(size_t) i]);
-		if (e == hipSuccess) e = hipEventRecord(d.gathered[j], d.gather_stream);
+		/* (contexts sharing one device: all the copies ran on the root's stream) */
+		if (e == hipSuccess) e = hipEventRecord(d.gathered[j], m->one_device ? m->dev[0].gather_stream : d.gather_stream);
 		if (e != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: device %d: %s", m->devices[(size_t) i], hipGetErrorString(e));
 		else d.gathered_set[j] = true;
 	}
@@ -359,8 +400,8 @@ int rt_multi_frame_submit(rt_multi *m, const rt_render_params *params, int slot,
 			rc = rt_deinterleave_rotated_device(m->ctx[0], m->d_strips[j], f.d_frame, W, H, rb, n, n > 1 ? 1 : 0, m->dev[0].gather_stream);
 		if (rc == RT_OK && e == hipSuccess) e = hipEventRecord(f.assembled, m->dev[0].gather_stream);
 		if (rc == RT_OK && e == hipSuccess) e = hipStreamWaitEvent(m->copy_stream, f.assembled, 0);
-		if (rc == RT_OK && e == hipSuccess) e = hipMemcpyAsync(frame_out, f.d_frame, frame_floats * sizeof(float), hipMemcpyDeviceToHost, m->copy_stream);
-		if (rc == RT_OK && e == hipSuccess) e = hipEventRecord(f.copied, m->copy_stream);
+		if (rc == RT_OK && e == hipSuccess && frame_out) e = hipMemcpyAsync(frame_out, f.d_frame, frame_floats * sizeof(float), hipMemcpyDeviceToHost, m->copy_stream);
+		if (rc == RT_OK && e == hipSuccess) e = hipEventRecord(f.copied, m->copy_stream);      /* (device-resident frame: behind the de-interleave only) */
 		if (rc == RT_OK && e != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: %s", hipGetErrorString(e));
 	}
 	if (rc != RT_OK) {
@@ -371,6 +412,45 @@ int rt_multi_frame_submit(rt_multi *m, const rt_render_params *params, int slot,
 	}
 	m->frames++;
 	f.busy = true; f.plain = false;
+	if (d_frame) *d_frame = f.d_frame;
+	if (hip_event) *hip_event = (void *) f.assembled;
+	return RT_OK;
+}
+
+int rt_multi_frame_submit(rt_multi *m, const rt_render_params *params, int slot, Vector3 *frame_out)
+{
+	if (!frame_out) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_frame_submit: frame_out is NULL");
+	return multi_frame_submit(m, params, slot, frame_out, nullptr, nullptr);
+}
+
+/* the frame stays on the first device: *d_frame = height * width Vector3 in frame order, *hip_event = behind the de-interleave */
+int rt_multi_frame_submit_device(rt_multi *m, const rt_render_params *params, int slot, void **d_frame, void **hip_event)
+{
+	if (!d_frame) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_frame_submit_device: d_frame is NULL");
+	return multi_frame_submit(m, params, slot, nullptr, d_frame, hip_event);
+}
+
+/* What the group's communicator itself reports (bench.py puts it into its line): ranks = ncclCommCount of the first
+ * communicator, devices[i] = ncclCommCuDevice of communicator i, *version = ncclGetVersion.  A group without a communicator
+ * (one device without force_collective, or contexts sharing one device) reports ranks = 0. */
+int rt_multi_collective_info(rt_multi *m, int *ranks, int devices[64], int *version)
+{
+	if (!m) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_collective_info: NULL handle");
+	if (ranks) *ranks = 0;
+	if (version) *version = 0;
+	if (m->one_device || (m->n == 1 && !m->force_collective)) return RT_OK;
+	{ const int rc = init_communicators(m); if (rc != RT_OK) return rc; }
+	Rccl &r = rccl();
+	if (!r.comm_count || !r.comm_device || !r.get_version) return rt_fail(RT_ERR_DEVICE, "rt_multi_collective_info: this RCCL lacks ncclCommCount / ncclCommCuDevice");
+	int count = 0, v = 0;
+	if (r.comm_count(m->comms[0], &count) != ncclSuccess_ || r.get_version(&v) != ncclSuccess_) return rt_fail(RT_ERR_DEVICE, "ncclCommCount failed");
+	for (int i = 0; i < m->n && devices; i++) {
+		int dev = -1;
+		if (r.comm_device(m->comms[(size_t) i], &dev) != ncclSuccess_) return rt_fail(RT_ERR_DEVICE, "ncclCommCuDevice failed");
+		devices[i] = dev;
+	}
+	if (ranks) *ranks = count;
+	if (version) *version = v;
 	return RT_OK;
 }
 
@@ -463,7 +543,7 @@ int rt_multi_progressive_resolve(rt_multi *m, Vector3 *frame_out)
 	for (int s = 0; s < RT_FRAME_SLOTS; s++)
 		if (m->fq[s].busy) return rt_fail(RT_ERR_STATE, "rt_multi_progressive_resolve: slot %d holds a frame that has not been waited for", s);
 	const int slot = 0;
-	{ const int rc = init_communicators(m); if (rc != RT_OK) return rc; }
+	if (!m->one_device) { const int rc = init_communicators(m); if (rc != RT_OK) return rc; }
 	{ const int rc = prepare(m, W, H, rb, slot); if (rc != RT_OK) return rc; }
 	rt_multi::frame_slot &f = m->fq[slot];
 	{	/* the count first (update_frame() waits for it, main.c:461-464): with nothing published there is nothing to divide by,
@@ -479,8 +559,17 @@ int rt_multi_progressive_resolve(rt_multi *m, Vector3 *frame_out)
 	int rc = RT_OK;
 	for (int i = 0; i < n && rc == RT_OK; i++)          /* frame = accum * (1 / count) (main.c:467-477), every device its own rows */
 		rc = rt_progressive_resolve_device(m->ctx[(size_t) i], &d_rows[(size_t) i]);
+	if (rc == RT_OK && m->one_device) {                 /* (testing aid: the copies the gather amounts to on one device, then the root waits for them) */
+		for (int i = 0; i < n && rc == RT_OK; i++) {
+			hipStream_t cs = (hipStream_t) rt_context_stream(m->ctx[(size_t) i]);
+			hipError_t e = hipMemcpyAsync(m->d_strips[0] + (size_t) i * strip_floats, d_rows[(size_t) i], strip_floats * sizeof(float), hipMemcpyDeviceToDevice, cs);
+			if (e == hipSuccess) e = hipEventRecord(m->dev[(size_t) i].gathered[0], cs);
+			if (e == hipSuccess && i > 0) e = hipStreamWaitEvent((hipStream_t) rt_context_stream(m->ctx[0]), m->dev[(size_t) i].gathered[0], 0);
+			if (e != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_multi_progressive_resolve: %s", hipGetErrorString(e));
+		}
+	}
 	Rccl &r = rccl();
-	if (rc == RT_OK) {                                  /* ONE gather per displayed frame, behind the resolves on the contexts' streams */
+	if (rc == RT_OK && !m->one_device) {                /* ONE gather per displayed frame, behind the resolves on the contexts' streams */
 		ncclResult_t nrc = r.group_start();
 		for (int i = 0; i < n && nrc == ncclSuccess_; i++)
 			nrc = r.gather(d_rows[(size_t) i], i == 0 ? m->d_strips[0] : nullptr, strip_floats, ncclFloat_, 0,

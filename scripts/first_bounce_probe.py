@@ -16,13 +16,15 @@ import ray_tracing_amd as rt
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 15
 W, H, spp = 1920, 1080, 64
 sky = rt.load_skybox()
-def make(first):
+def make(first, waves=0):
     g = rt.Renderer(0)
     g.set_skybox(sky); g.set_scene(f"{rt.DATA_DIR}/scene_0.txt"); g.set_camera()
-    g.set_tuning(jit_flags="-DRT_PROBE_KNOWN_ONLY", poison_frame=True, first_bounce_probe=1 if first else 0)
+    g.set_tuning(jit_flags="-DRT_PROBE_KNOWN_ONLY" + (f" -DRT_FIRST_WAVES_PER_SIMD={waves}" if waves else ""), poison_frame=True,
+                 first_bounce_probe=1 if first else 0, workgroups_per_cu=waves if first else 0)
     g.compile_scene(); g.profile(True)
     return g
-A, B = make(False), make(True)
+waves = int(sys.argv[2]) if len(sys.argv) > 2 else 6         # resident waves per SIMD of the first-bounce kernel (6: 80 registers, 5: 96, 4: 128)
+A, B = make(False), make(True, waves)
 P = rt.Renderer(0); P.set_skybox(sky); P.set_scene(f"{rt.DATA_DIR}/scene_0.txt"); P.set_camera(); P.compile_scene(); P.profile(True)   # the product kernel, all pixels
 out = {}
 for nb in (1, 4):
@@ -42,7 +44,7 @@ for nb in (1, 4):
     known = int((~np.isnan(frames["A"]).any(axis=2)).sum())
     # where both have rendered something they must agree with the product kernel's frame too
     ok_p = bool((frames["A"].view(np.uint32) == frames["P"].view(np.uint32))[~np.isnan(frames["A"])].all()) if nb == 1 else None
-    print(f"max_bounces {nb}: general kernel, known-class pixels only {a:.3f} ms | first-bounce kernel {b:.3f} ms | product kernel, all pixels {p_:.3f} ms | "
+    print(f"[first-bounce kernel at {waves} waves per SIMD] max_bounces {nb}: general kernel, known-class pixels only {a:.3f} ms | first-bounce kernel {b:.3f} ms | product kernel, all pixels {p_:.3f} ms | "
           f"A == B bit for bit: {same}; pixels rendered by A: {known}; A == product frame on them: {ok_p}", flush=True)
     out[nb] = (a, b, p_, same)
 print(f"saving at one event per sample: {out[1][0] - out[1][1]:.3f} ms = {(out[1][0] - out[1][1]) / out[4][2] * 100:.1f} % of the product's C1 kernel time ({out[4][2]:.3f} ms); "

@@ -228,3 +228,92 @@ def test_cli_frame_loop(tmp_path, scene_paths):
         img = np.frombuffer(raw[len(head):], np.uint8).reshape(H, W, 3)
         want = _reference_frames(scene_paths[0], rt.load_skybox(), W, H, spp, nb, [seed + K - 1])[seed + K - 1]
         assert (img == (want * np.float32(255)).astype(np.uint8)[::-1]).all(), extra
+
+
+def _read_device_frame(ptr, event, W, H):
+    """What an on-GPU consumer does: order itself behind the event, then read the device frame (here: copy it out)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipEventSynchronize(C.c_void_p(event)) == 0
+    out = np.empty((H, W, 3), np.float32)
+    assert hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(out.nbytes), 2) == 0      # hipMemcpyDeviceToHost
+    return out
+
+
+@pytest.mark.parametrize("group", [False, True])
+def test_device_resident_frames(sky, scene_paths, group):
+    """rt_frame_submit_device / rt_multi_frame_submit_device: the frame stays in device memory, the caller gets the buffer and
+    an event behind it (the reference's presenter re-uploads the frame at once, gpu_and_windowing.c:371-376: a consumer on the
+    GPU needs no copy).  Every frame, read back by the test itself, is the frame rt_frame_submit delivers; slots rotate."""
+    W, H, spp, nb = 320, 181, 8, 4
+    seeds = [21, 22, 23, 24, 25, 26, 27]
+    want = _reference_frames(scene_paths[0], sky, W, H, spp, nb, seeds)
+    if group:
+        q = rt.MultiRenderer([0]); q.set_tuning(force_collective=1)
+    else:
+        q = rt.Renderer(0)
+    q.set_scene(scene_paths[0]); q.set_skybox(sky); q.set_camera()
+    slots, pending = 3, {}
+    for k, s in enumerate(seeds):
+        j = k % slots
+        if k >= slots:                 # the consumer of the frame three back is done with the buffer: release the slot
+            ptr, ev, seed_ = pending.pop(j)
+            got = _read_device_frame(ptr, ev, W, H)
+            assert q.frame_wait(j)
+            assert (bits(got) == bits(want[seed_])).all(), (k, seed_)
+        ptr, ev = q.frame_submit_device(rt.Renderer.params(W, H, spp, nb, seed=s), j)
+        assert ptr and ev
+        pending[j] = (ptr, ev, s)
+    for j, (ptr, ev, seed_) in sorted(pending.items()):
+        got = _read_device_frame(ptr, ev, W, H)
+        assert q.frame_wait(j)
+        assert (bits(got) == bits(want[seed_])).all(), seed_
+    q.close()
+
+
+@pytest.mark.parametrize("n", [2, 5, 8])
+def test_group_of_contexts_on_one_device(sky, scene_paths, n):
+    """rt_multi_create_on_one_device: the n-device code of rt_multi -- n contexts, n strips per frame on their own streams, three
+    strip buffers each, the rotated hand-out, the de-interleave, frames in flight, the ladder -- on the ONE GPU of the box (the
+    gather is the n device copies it amounts to there: RCCL refuses two ranks on one device).  Bit-identical to rt_render()."""
+    from ray_tracing_amd.frames import FrameLoop
+    W, H, spp, nb = 320, 181, 8, 4
+    seeds = list(range(30, 41))
+    want = _reference_frames(scene_paths[0], sky, W, H, spp, nb, seeds)
+    m = rt.MultiRenderer([0], on_one_device=n)
+    assert m.size() == n and m.collective_info()["ranks"] == 0
+    m.set_tuning(poison_frame=1)
+    m.set_scene(scene_paths[0]); m.set_skybox(sky); m.set_camera()
+    assert (bits(m.render(W, H, spp, nb, seed=30)) == bits(want[30])).all()
+    m.compile_scene()
+    for depth in (2, 3, 4):
+        loop = FrameLoop(m, W, H, spp, nb, depth=depth)
+        got = []
+        loop.run(seeds, on_frame=lambda k, a: got.append(a.copy()))
+        for k, s in enumerate(seeds):
+            assert (bits(got[k]) == bits(want[s])).all(), (n, depth, k)
+        loop.close()
+    g = rt.Renderer(0)
+    g.set_scene(scene_paths[0]); g.set_skybox(sky); g.set_camera()
+    m.progressive_begin(W, H, init_scale=8, max_bounces=4, seed=1)
+    g.progressive_begin(W, H, init_scale=8, max_bounces=4, seed=1)
+    for _ in range(6):
+        m.progressive_pass(); g.progressive_pass()
+    assert (bits(m.progressive_resolve()) == bits(g.progressive_resolve())).all()
+    g.close(); m.close()
+
+
+def test_group_on_one_device_at_the_benchmark_size(sky, scene_paths):
+    """C1 through eight contexts on the one GPU (strips of 136 rows, the last one a row block short), frames in flight."""
+    from ray_tracing_amd.frames import FrameLoop
+    W, H, spp, nb = 1920, 1080, 64, 4
+    seeds = [3, 4, 5, 6, 7]
+    want = _reference_frames(scene_paths[0], sky, W, H, spp, nb, seeds)
+    m = rt.MultiRenderer([0], on_one_device=8)
+    m.set_scene(scene_paths[0]); m.set_skybox(sky); m.set_camera(); m.compile_scene()
+    loop = FrameLoop(m, W, H, spp, nb, depth=3)
+    got = []
+    loop.run(seeds, on_frame=lambda k, a: got.append(a.copy()))
+    for k, s in enumerate(seeds):
+        assert (bits(got[k]) == bits(want[s])).all(), k
+    loop.close(); m.close()

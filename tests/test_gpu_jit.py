@@ -177,3 +177,88 @@ def test_compiled_scenes_are_kept_and_shared(scene_paths):
     m.set_scene(scene_paths[1]); m.set_skybox(sky); m.set_camera()
     assert (bits(m.render(160, 90, 5, 6, seed=9)) == bits(want1)).all()
     m.close(); b.close()
+
+
+@pytest.mark.parametrize("scene_i,bounces", [(0, 4), (1, 8), (2, 8)])
+def test_embedded_kernel_equals_hiprtc_equals_generic(oracle, scene_paths, scene_i, bounces):
+    """The kernels of the shipped scenes are compiled when the library is built and embedded in it (csrc/Makefile): the one a
+    default rt_compile_scene() loads, the one hiprtc makes at run time (any extra option bypasses the embedded table) and the
+    generic kernel render the same bits -- and the oracle's."""
+    import time
+    sky = rt.load_skybox()
+    W, H, spp, seed = 256, 144, 8, 12
+    frames, info = {}, {}
+    for name, flags in (("generic", None), ("embedded", ""), ("hiprtc", "-DRT_FORCE_HIPRTC")):
+        g = rt.Renderer(0)
+        g.set_tuning(poison_frame=True, jit_flags=flags or None)
+        g.set_skybox(sky); g.set_scene(scene_paths[scene_i]); g.set_camera()
+        if flags is not None:
+            t0 = time.perf_counter()
+            g.compile_scene()
+            info[name] = (g.compiled_scene_info(), time.perf_counter() - t0)
+        frames[name] = g.render(W, H, spp, bounces, seed=seed)
+        g.close()
+    assert info["embedded"][0].startswith("embedded"), info
+    assert info["hiprtc"][0].startswith("hiprtc"), info
+    assert info["embedded"][1] < 0.1, info                 # a module load, not a compilation
+    oracle.set_skybox(sky); oracle.load_scene(scene_paths[scene_i]); oracle.set_camera()
+    want = oracle.render_counter(W, H, spp, bounces, seed=seed)
+    for name in ("generic", "embedded", "hiprtc"):
+        assert (bits(frames[name]) == bits(want)).all(), name
+
+
+def test_an_edited_shipped_scene_is_not_mistaken_for_the_embedded_one(oracle, scene_paths):
+    """The embedded table is keyed by the packed scene, not by a file name: one coordinate changed -> hiprtc compiles it."""
+    from rtlibs import scene_objects
+    sky = rt.load_skybox()
+    rc, buf = rt.parse_scene_file(scene_paths[0])
+    assert rc == 0
+    objs, n = scene_objects(buf)
+    objs[6]["geom"][1] = np.float32(1.25)                  # the first sphere, lifted a little
+    g = rt.Renderer(0)
+    g.set_tuning(poison_frame=True)
+    g.set_skybox(sky); g.set_scene(buf); g.set_camera()
+    g.compile_scene()
+    assert g.compiled_scene_info().startswith("hiprtc")
+    got = g.render(192, 108, 4, 4, seed=2)
+    g.close()
+    oracle.set_skybox(sky); oracle.set_scene(buf); oracle.set_camera()
+    assert (bits(got) == bits(oracle.render_counter(192, 108, 4, 4, seed=2))).all()
+
+
+def test_compiled_scene_cache_is_bounded():
+    """A host that edits its scene and recompiles makes a new cache key per edit: the cache keeps at most its cap, evicted
+    modules are parked (still loaded: the contexts that use them go on), nothing is unloaded."""
+    import ctypes as C
+    L = rt.lib()
+    L.rt_compiled_scene_counts.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.rt_compiled_scene_cache_cap.argtypes = [C.c_int]
+
+    def counts():
+        a, b = C.c_int(), C.c_int()
+        L.rt_compiled_scene_counts(C.byref(a), C.byref(b))
+        return a.value, b.value
+    old_cap = L.rt_compiled_scene_cache_cap(4)
+    try:
+        sky = synthetic_skybox(16, seed=1)
+        g = rt.Renderer(0)
+        g.set_tuning(poison_frame=True)
+        g.set_skybox(sky); g.set_camera()
+        cached0, parked0 = counts()
+        first = None
+        for k in range(7):
+            g.set_scene(make_scene([dict(type="sphere", center=(0, 0, 0), radius=1.0 + 0.125 * k, albedo=(.5, .5, .5)),
+                                    dict(type="cube", origin=(-4, -2, -4), size=(8, .5, 8), albedo=(.8, .2, .2))]))
+            g.compile_scene()
+            if first is None:
+                first = g.render(96, 54, 2, 3, seed=1)
+        cached, parked = counts()
+        assert cached <= 4 and parked >= parked0 + 3, (cached0, parked0, cached, parked)     # seven new keys into a cache of four
+        # the first scene's module was evicted; compiling it again works (a new module) and renders the same bits
+        g.set_scene(make_scene([dict(type="sphere", center=(0, 0, 0), radius=1.0, albedo=(.5, .5, .5)),
+                                dict(type="cube", origin=(-4, -2, -4), size=(8, .5, 8), albedo=(.8, .2, .2))]))
+        g.compile_scene()
+        assert (bits(g.render(96, 54, 2, 3, seed=1)) == bits(first)).all()
+        g.close()
+    finally:
+        L.rt_compiled_scene_cache_cap(old_cap)

@@ -290,3 +290,46 @@ def test_native_multi_gpu_frames_in_flight_two_devices(gpu):
         m.progressive_pass(); gpu.progressive_pass()
     assert (bits(m.progressive_resolve()) == bits(gpu.progressive_resolve())).all()
     m.close()
+
+
+def _bench_line(args):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args + ["--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-1500:])
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def test_bench_native_multi_eight_contexts_on_the_one_gpu():
+    """`bench.py --gpus 8 --native-multi --one-device`: the ONE-process host of the N-GPU path (rt_multi_frame_submit /
+    rt_multi_frame_wait) with eight contexts, strips of 136 rows and the frame queue three deep, on the one GPU of the box;
+    its built-in check compares the last frame with a blocking render and oracle rows."""
+    line = _bench_line(["--gpus", "8", "--native-multi", "--one-device", "--steps", "4", "--warmup", "2"])
+    assert line["n_gpus"] == 8 and line["verified"] is True
+    assert line["collective"]["contexts"] == 8 and line["collective"]["ranks_seen"] == 0      # no communicator on one device
+    assert "one host process" in line["config"]["frame_loop"]
+
+
+def test_bench_native_multi_one_rank_communicator():
+    """`bench.py --gpus 1 --native-multi --force-collective`: the same host over RCCL itself; the line carries what the
+    communicator reports (ncclCommCount, ncclCommCuDevice, ncclGetVersion), not what the script asked for."""
+    line = _bench_line(["--gpus", "1", "--native-multi", "--force-collective", "--steps", "4", "--warmup", "2"])
+    assert line["verified"] is True
+    c = line["collective"]
+    assert c["ranks_seen"] == 1 and c["devices_seen"] == [0] and c["rccl_version"] > 20000
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (ncclGather between them)")
+def test_bench_native_multi_two_devices():
+    line = _bench_line(["--gpus", "2", "--native-multi", "--steps", "4", "--warmup", "2"])
+    assert line["n_gpus"] == 2 and line["verified"] is True
+    assert line["collective"]["ranks_seen"] == 2 and sorted(line["collective"]["devices_seen"]) == [0, 1]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL gather between ranks)")
+def test_bench_two_ranks_over_rccl():
+    line = _bench_line(["--gpus", "2", "--steps", "4", "--warmup", "2"])
+    assert line["n_gpus"] == 2 and line["verified"] is True
+    assert line["collective"]["ranks_seen"] == 2 and sorted(line["collective"]["devices_seen"]) == [0, 1] and line["collective"]["backend"] == "nccl"
