@@ -45,6 +45,12 @@ WORKLOADS = {
     "C2": dict(name="C2", scene="scene_1.txt", width=1920, height=1080, spp=256, max_bounces=8, seed=0),
     "C3": dict(name="C3", scene="scene_2.txt", width=3840, height=2160, spp=64, max_bounces=8, seed=0),
     "C4": dict(name="C4", scene="scene_0.txt", width=3840, height=2160, spp=1024, max_bounces=8, seed=0),
+    # not BASELINE configs: synthetic scenes of many objects (tests/rtlibs.py large_scene): 64 is the largest a
+    # scene-specialised kernel takes, above that the generic kernel runs with the cluster cull of csrc/rt_cull.h
+    # (--every-object: without it, every ray tests every object as the reference does)
+    "L64": dict(name="L64", scene="synthetic:64", width=1920, height=1080, spp=16, max_bounces=5, seed=0),
+    "L256": dict(name="L256", scene="synthetic:256", width=1920, height=1080, spp=16, max_bounces=5, seed=0),
+    "L1024": dict(name="L1024", scene="synthetic:1024", width=1920, height=1080, spp=16, max_bounces=5, seed=0),
 }
 ROW_BLOCK = 8
 
@@ -73,6 +79,7 @@ def parse_args(argv=None):
     ap.add_argument("--force-collective", action="store_true",
                     help="testing aid for 1-GPU boxes: one rank runs the N > 1 frame loop (RCCL gather on a one-rank group, "
                          "de-interleave, three strip buffers) so that loop's cost shows beside the plain N = 1 line")
+    ap.add_argument("--every-object", action="store_true", help="L* workloads: no cluster cull (rt_tuning.test_every_object)")
     ap.add_argument("--native-multi", action="store_true",
                     help="N GPUs from ONE process through the C ABI's device group (rt_multi_frame_submit / rt_multi_frame_wait: "
                          "ncclCommInitAll + one grouped ncclGather per frame) instead of one process per GPU under torch.distributed")
@@ -262,12 +269,25 @@ def main():
 
     w = WORKLOADS[args.config]
     W, H, spp, nb, seed = w["width"], w["height"], w["spp"], w["max_bounces"], w["seed"]
-    scene_path = os.path.join(rt.DATA_DIR, w["scene"])
+    synthetic = w["scene"].startswith("synthetic:")
+    if synthetic:
+        from rtlibs import LARGE_SCENE_CAMERA, large_scene
+        scene_path = large_scene(int(w["scene"].split(":")[1]), seed=17)       # a raw Scene buffer: everything below takes either
+        camera = LARGE_SCENE_CAMERA
+        args.no_cpu_baseline = True       # (the reference harness loads scene FILES; the headline's baseline is C1's)
+    else:
+        scene_path = os.path.join(rt.DATA_DIR, w["scene"])
+        camera = {}
     sky = rt.load_skybox()
+
+    def into(o):                          # the workload's inputs into a Renderer / MultiRenderer / Oracle
+        (o.set_scene if (synthetic or not hasattr(o, "load_scene")) else o.load_scene)(scene_path)
+        o.set_skybox(sky); o.set_camera(**camera)
+        return o
     gpu = rt.Renderer(local_rank)
-    gpu.set_scene(scene_path)
-    gpu.set_skybox(sky)
-    gpu.set_camera()
+    if args.every_object:
+        gpu.set_tuning(test_every_object=True)
+    into(gpu)
     gpu.reserve(W, H)
     # scene "compilation" (hiprtc, ~1 s, outside the timed region): same frames, fewer instructions
     compiled, jit_s, scene_kernel_info = False, None, None
@@ -302,7 +322,7 @@ def main():
             else:
                 queue = rt.MultiRenderer(list(range(ngpus)) if args.native_multi else [local_rank])
             queue.set_tuning(force_collective=1 if args.force_collective else 0)
-            queue.set_scene(scene_path); queue.set_skybox(sky); queue.set_camera()
+            into(queue)
             if compiled:
                 queue.compile_scene()
             prof = queue.context(0)
@@ -402,7 +422,7 @@ def main():
         got = np.array(last_frame(), copy=True)
         check = rt.Renderer(local_rank)
         check.set_tuning(poison_frame=True)           # a pixel the check render leaves unwritten is a NaN, not whatever the fresh buffer held
-        check.set_scene(scene_path); check.set_skybox(sky); check.set_camera()
+        into(check)
         want = check.render(W, H, spp, nb, seed=last_seed)          # generic kernel, one GPU, blocking
         check_counts = check.last_launch_counts()
         check.close()
@@ -427,7 +447,7 @@ def main():
             sys.stderr.write("VERIFICATION FAILED: " + json.dumps(verified["mismatch"]) + "\n")
         try:
             from rtlibs import Oracle
-            o = Oracle(); o.load_scene(scene_path); o.set_skybox(sky); o.set_camera()
+            o = into(Oracle())
             rows = [H // 3, (2 * H) // 3 + 1, H - 3]       # (the last rows are the last pixels a launch gets to: a launch cut short or read early shows there)
             ref_rows = o.render_counter_rows(W, H, spp, nb, rows, seed=last_seed)
             verified["oracle_rows"] = rows
@@ -510,7 +530,7 @@ def main():
         value = samples_per_step * args.steps / elapsed / 1e6
         metric = "Msamples/s (rays/s) at 1920x1080x64spp scene_0; 1/2/4/8 GPU"
         if args.config != "C1":
-            metric = f"Msamples/s at {W}x{H}x{spp}spp {w['scene'][:-4]} ({args.config})"
+            metric = f"Msamples/s at {W}x{H}x{spp}spp {w['scene'].replace('.txt', '')} ({args.config})"
         out = {
             "metric": metric,
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": ngpus, "steps": args.steps,
@@ -557,9 +577,9 @@ def main():
         # ---- roofline of the dominant kernel (rank 0's launches; every rank runs the same kernel on 1/N of the rows)
         from rtlibs import Oracle
         try:
-            oc = Oracle(counters=True)
-            oc.load_scene(scene_path); oc.set_skybox(sky); oc.set_camera()
-            work = algorithmic_work(oc, W, H, nb, seed)
+            oc = into(Oracle(counters=True))
+            # (a frame of 1024 objects costs the CPU 1024 tests per ray: the per-sample figures of the L* workloads come from a quarter-size frame)
+            work = algorithmic_work(oc, W // 4 if synthetic else W, H // 4 if synthetic else H, nb, seed)
         except Exception as e:   # the oracle is a checker; the bench line must still print
             work = None
             out["roofline_error"] = repr(e)

@@ -88,6 +88,8 @@ typedef struct {
 	                             * launch fails to write cannot pass for correct because an earlier frame left it there */
 	int    trace_known_taps;    /* testing aid: trace every soft-shadow tap, also those of camera-ray hit points from which
 	                             * every tap provably reaches the emitter first (csrc/rt_lit.h; normally answered untraced) */
+	int    test_every_object;   /* testing / measurement aid: scenes of more than 64 objects are rendered without the cluster cull
+	                             * (csrc/rt_cull.h) -- every ray tests every object, as the reference does; same frames, slower */
 	int    first_bounce_probe;  /* EXPERIMENT (round 4): launches of a compiled scene with 2..64 spp run rt_first_bounce_spec
 	                             * -- one wave per pixel, first bounce only, pixels of known tap class only -- instead of the trace
 	                             * kernel.  Frames are complete only at max_bounces == 1 and only on those pixels: a measurement aid */
@@ -124,7 +126,7 @@ RT_API int  rt_compiled_scene_cache_cap(int cap);
  * compiled scene read and reset the same counters (the same holds for rt_spec_symbol_read). */
 RT_API int rt_spec_stats_read(rt_context *ctx, unsigned long long out[64], int reset);
 /* development aid: copy the named device variable of the compiled kernel's module (e.g. "rt_wave_log" of a build with
- * "-DRT_STATS -DRT_STATS_LIFETIMES_ONLY", scripts/tail_probe.py) to dst, at most `bytes` bytes; *copied = bytes copied.  The
+ * "-DRT_STATS -DRT_STATS_LIFETIMES_ONLY", scripts/probes/tail_probe.py) to dst, at most `bytes` bytes; *copied = bytes copied.  The
  * empty name "" stands for the compiled kernel's code object itself (*copied = its full size), for disassembly. */
 RT_API int rt_spec_symbol_read(rt_context *ctx, const char *name, void *dst, size_t bytes, size_t *copied);
 /* chan must be 3 or 4 (what stb_image returns for the shipped JPEGs is 3); all faces w x h */

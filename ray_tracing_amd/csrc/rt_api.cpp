@@ -27,6 +27,7 @@
 #include "../../include/rt_hip.h"
 #include "rt_internal.h"
 #include "rt_pack.h"
+#include "rt_cull.h"
 #define RT_LIT_FN static inline
 #include "rt_lit.h"
 
@@ -88,6 +89,10 @@ struct rt_context {
 	bool         have_lit = false;
 	long long    primary_passes = 0;     /* launches that ran rt_primary_pass (rt_primary_passes_run) */
 	uint64_t     input_version = 1;      /* bumped by rt_set_scene / rt_set_skybox: part of launch_slot::lists_key */
+	/* large scenes (rt_cull.h): clusters of close objects with conservative boxes; num_clusters = 0: every ray tests every object */
+	rt_cluster  *d_clusters = nullptr;
+	int          clusters_capacity = 0;
+	rt_cull_info cull = { 0, 0.0f, 0.0f };
 
 	uint32_t    *d_sky = nullptr;
 	size_t       sky_bytes = 0;
@@ -189,7 +194,7 @@ static int order_behind_previous(rt_context *ctx, hipStream_t stream)
  * launch enqueued while the previous one, on the context's OTHER stream, has not even started takes half the chip's
  * workgroup slots (2 of 4 per CU).  In a run of such launches two are resident side by side, half a launch apart, and the
  * compute units a launch's last waves leave idle belong to waves of the next one that are already there, not to workgroups
- * that have yet to start (C1: strips of 8 ranks -4.6 %, of 4 -4.4 %, of 2 -3 %, whole frames the same; scripts/wg_probe.py).
+ * that have yet to start (C1: strips of 8 ranks -4.6 %, of 4 -4.4 %, of 2 -3 %, whole frames the same; scripts/probes/wg_probe.py).
  * It only pays when the host keeps two launches resident at all times, i.e. enqueues more than a launch ahead -- the N-GPU
  * loops do (three frames in flight) -- and costs when it does not: a loop with two frames in flight submits frame k+2 when
  * frame k has been delivered, and until then frame k+1 would have half a chip to itself (C1 whole frames +2.7 %).  That is
@@ -346,7 +351,7 @@ void rt_destroy(rt_context *ctx)
 	if (ctx->h_words) (void) hipHostFree(ctx->h_words);
 	/* (the compiled scene's module belongs to the process-wide cache of rt_jit.cpp: never unloaded) */
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
-	(void) hipFree(ctx->d_lit_cells); (void) hipFree(ctx->d_lit_grids);
+	(void) hipFree(ctx->d_lit_cells); (void) hipFree(ctx->d_lit_grids); (void) hipFree(ctx->d_clusters);
 	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame);
 	(void) hipFree(ctx->prog.d_accum); (void) hipFree(ctx->prog.d_low); (void) hipFree(ctx->prog.d_out); (void) hipFree(ctx->prog.d_count);
 	(void) hipStreamDestroy(ctx->stream);
@@ -373,6 +378,17 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 	ctx->scene_fast_ok = fast_ok;
 	ctx->only_light_emits = info.only_light_emits;
 	memcpy(ctx->light_pos, info.light_pos, sizeof(ctx->light_pos));
+	/* scenes of more than 64 objects: clusters for the culled trace (also sets the half extents in the spheres' records) */
+	std::vector<rt_cluster> clusters;
+	ctx->cull = fast_ok ? rt_cull_build(geom, n, clusters) : rt_cull_info{ 0, 0.0f, 0.0f };
+	if (ctx->cull.num_clusters > 0) {
+		if (ctx->cull.num_clusters > ctx->clusters_capacity) {
+			(void) hipFree(ctx->d_clusters); ctx->d_clusters = nullptr; ctx->clusters_capacity = 0;
+			HIP_TRY(hipMalloc((void**) &ctx->d_clusters, (size_t) RT_MAX_CLUSTERS * sizeof(rt_cluster)));
+			ctx->clusters_capacity = RT_MAX_CLUSTERS;
+		}
+		HIP_TRY(hipMemcpy(ctx->d_clusters, clusters.data(), clusters.size() * sizeof(rt_cluster), hipMemcpyHostToDevice));
+	}
 	ctx->h_geom.assign(geom.begin(), geom.begin() + n);
 	ctx->spec_module = nullptr; ctx->spec_fn = nullptr;      /* (not unloaded: rt_jit.cpp keeps compiled scenes for the life of the process) */
 	if (n > ctx->capacity || !ctx->d_geom) {
@@ -472,7 +488,7 @@ int rt_spec_symbol_read(rt_context *ctx, const char *name, void *dst, size_t byt
 {
 	if (!ctx || !name || !dst) return fail(RT_ERR_ARGUMENT, "rt_spec_symbol_read: NULL argument");
 	if (!ctx->spec_module) return fail(RT_ERR_STATE, "rt_spec_symbol_read: no compiled scene");
-	if (name[0] == '\0') {                 /* the empty name: the compiled kernel's code object itself (scripts/runtime_probe.py) */
+	if (name[0] == '\0') {                 /* the empty name: the compiled kernel's code object itself (scripts/probes/runtime_probe.py) */
 		const size_t n = ctx->spec_code.size() < bytes ? ctx->spec_code.size() : bytes;
 		memcpy(dst, ctx->spec_code.data(), n);
 		if (copied) *copied = ctx->spec_code.size();
@@ -665,6 +681,9 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	L.lit_cells = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_cells : nullptr;
 	L.lit_grids = ctx->d_lit_grids;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
+	if (ctx->cull.num_clusters > 0 && !ctx->tuning.test_every_object) {
+		L.clusters = ctx->d_clusters; L.num_clusters = ctx->cull.num_clusters; L.cull_margin = ctx->cull.margin; L.cull_origin_max = ctx->cull.origin_max;
+	}
 	{ const int rc = prepare_launch(ctx, L, ctx->launches); if (rc != RT_OK) { unpublish_launch(ctx); return rc; } }
 	{ const int rc = order_behind_previous(ctx, stream); if (rc != RT_OK) { unpublish_launch(ctx); return rc; } }
 	if (ctx->tuning.poison_frame) {
@@ -986,6 +1005,9 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	L.lit_cells = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_cells : nullptr;
 	L.lit_grids = ctx->d_lit_grids;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
+	if (ctx->cull.num_clusters > 0 && !ctx->tuning.test_every_object) {
+		L.clusters = ctx->d_clusters; L.num_clusters = ctx->cull.num_clusters; L.cull_margin = ctx->cull.margin; L.cull_origin_max = ctx->cull.origin_max;
+	}
 	{ const int rc = prepare_launch(ctx, L, ctx->launches); if (rc != RT_OK) { unpublish_launch(ctx); return rc; } }
 	{ const int rc = order_behind_previous(ctx, ctx->stream); if (rc != RT_OK) { unpublish_launch(ctx); return rc; } }
 	if (ctx->tuning.poison_frame) {

@@ -1,0 +1,119 @@
+/*
+ * rt_cull.h -- object culling for scenes of many objects ("where a BVH or wave-cooperative culling would start
+ * to pay").  Host side: clusters of spatially close objects with conservative bounding boxes, built by rt_set_scene().
+ *
+ * The reference tests every object for every ray (scene.c:163-173) and keeps the nearest hit, the lowest index among equal
+ * distances (strict `<`, scene.c:168).  The kernels keep that answer bit for bit and skip the tests that cannot produce it:
+ * an object -- or a whole cluster -- is skipped only when its CONSERVATIVE box is missed by the ray, or lies entirely behind
+ * it, in a slab test whose margins exceed every rounding error of the reference's own tests:
+ *
+ *   - a box is tested as [lo - m, hi + m] with m = RT_CULL_MARGIN.  The reference's quotients (plane - o) / d are correctly
+ *     rounded (relative error 2^-24); the cull's products (plane' - o) * RN(1/d) are within 2^-21 of theirs in relative terms.
+ *     With every coordinate of the scene within S and ray origins within 2 S of the origin, |plane - o| <= 3 S <= 192 and the
+ *     inflation moves an entry / exit parameter by m / |d| against an error of at most 192 * 2^-21 / |d| = 9.2e-5 / |d|:
+ *     a margin of 21, on every axis, for every |d| (the ray directions the cull accepts are those of the shared-reciprocal
+ *     division: 2^-30 <= |d| <= 2^20 on every axis).  "Entirely behind" is exit' < 0 on the inflated box: then the true exit
+ *     is negative and the reference rejects the hit itself (t >= 0, scene.c:168).
+ *   - a sphere is tested as the box centre +- h with h = sqrt(r^2 + E) + m.  The reference reports a sphere hit when its FLOAT
+ *     discriminant b*b - 4*a*c is positive (scene.c:93-101), which a ray can reach although it passes outside the sphere:
+ *     summing the roundings of oc, the two dot products, the squares and the final difference bounds the error of the
+ *     discriminant by 108 * 2^-24 * |oc|^2, i.e. r^2 - dist^2 > -1.6e-6 |oc|^2 for every hit the reference reports.  With
+ *     |oc| <= 3 sqrt(3) S: E = 2 * 1.6e-6 * 27 S^2 (twice the bound).
+ * Scenes with coordinates beyond RT_CULL_MAX_COORD get no clusters (every object is tested, as before), and a wave one of whose
+ * rays starts farther out than 2 S -- a camera far outside the scene -- tests every object as well.
+ *
+ * Clusters: objects sorted along a Morton curve of their centres, RT_CLUSTER_SIZE consecutive ones per cluster (members keep
+ * their object indices: ties between equal distances go to the lowest INDEX whatever the order of the tests).
+ */
+#ifndef RT_CULL_H
+#define RT_CULL_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "rt_device.h"
+
+#define RT_CULL_MARGIN     0.001953125f     /* 2^-9 */
+#define RT_CULL_MAX_COORD  64.0f
+#define RT_CULL_MIN_OBJECTS 65              /* scenes of up to 64 objects can be compiled (rt_compile_scene) and are not culled */
+
+struct rt_cull_info { int num_clusters; float margin; float origin_max; };
+
+/* the conservative box of object i as the kernels form it from the packed record (geom.b1 of a sphere = its h) */
+static inline void rt_cull_object_box(const rt_geom &g, float m, float lo[3], float hi[3])
+{
+	if (g.type == RT_GEOM_CUBE) {
+		lo[0] = g.a[0] - m; lo[1] = g.a[1] - m; lo[2] = g.a[2] - m;
+		hi[0] = g.b0 + m;   hi[1] = g.b1 + m;   hi[2] = g.b2 + m;
+	} else {
+		for (int k = 0; k < 3; k++) { lo[k] = g.a[k] - g.b1; hi[k] = g.a[k] + g.b1; }
+	}
+}
+
+static inline uint32_t rt_cull_spread(uint32_t v) { v &= 1023u; v = (v | (v << 16)) & 0x030000ffu; v = (v | (v << 8)) & 0x0300f00fu; v = (v | (v << 4)) & 0x030c30c3u; return (v | (v << 2)) & 0x09249249u; }
+
+/* Fills `clusters` (and the spheres' geom.b1) when the scene qualifies; returns num_clusters = 0 otherwise. */
+static inline rt_cull_info rt_cull_build(std::vector<rt_geom> &geom, int n, std::vector<rt_cluster> &clusters)
+{
+	rt_cull_info info = { 0, RT_CULL_MARGIN, 0.0f };
+	clusters.clear();
+	if (n < RT_CULL_MIN_OBJECTS || n > RT_CLUSTER_SIZE * RT_MAX_CLUSTERS) return info;
+	float S = 0.0f;
+	for (int i = 0; i < n; i++) {
+		const rt_geom &g = geom[(size_t) i];
+		if (g.type == RT_GEOM_CUBE) {
+			const float v[6] = { g.a[0], g.a[1], g.a[2], g.b0, g.b1, g.b2 };
+			for (float x : v) { if (!(fabsf(x) <= RT_CULL_MAX_COORD)) return info; S = std::max(S, fabsf(x)); }
+		} else if (g.type == RT_GEOM_SPHERE) {
+			const float r = sqrtf(g.b0);
+			for (int k = 0; k < 3; k++) { const float x = fabsf(g.a[k]) + r; if (!(x <= RT_CULL_MAX_COORD)) return info; S = std::max(S, x); }
+		} else return info;          /* an object of unknown type is never hit (scene.c:153); keep such scenes on the plain path */
+	}
+	if (!(S > 0.0f)) return info;
+	const float E = 2.0f * 1.6e-6f * 27.0f * S * S;
+	for (int i = 0; i < n; i++) {
+		rt_geom &g = geom[(size_t) i];
+		if (g.type == RT_GEOM_SPHERE) g.b1 = sqrtf(g.b0 + E) * 1.0001f + RT_CULL_MARGIN;      /* h: see above (b1 of a sphere is otherwise unused) */
+	}
+	/* Morton order of the centres on a 1024^3 grid over [-S, S]^3 */
+	std::vector<std::pair<uint32_t, int>> order((size_t) n);
+	for (int i = 0; i < n; i++) {
+		float lo[3], hi[3];
+		rt_cull_object_box(geom[(size_t) i], RT_CULL_MARGIN, lo, hi);
+		uint32_t code = 0;
+		for (int k = 0; k < 3; k++) {
+			const float c = 0.5f * (lo[k] + hi[k]);
+			int q = (int) ((c + S) / (2.0f * S) * 1023.0f);
+			q = q < 0 ? 0 : (q > 1023 ? 1023 : q);
+			code |= rt_cull_spread((uint32_t) q) << k;
+		}
+		order[(size_t) i] = { code, i };
+	}
+	std::sort(order.begin(), order.end());
+	const int C = (n + RT_CLUSTER_SIZE - 1) / RT_CLUSTER_SIZE;
+	clusters.assign((size_t) C, rt_cluster());
+	for (int c = 0; c < C; c++) {
+		rt_cluster &K = clusters[(size_t) c];
+		memset(&K, 0, sizeof(K));
+		float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
+		int members[RT_CLUSTER_SIZE], cnt = 0;
+		for (int j = 0; j < RT_CLUSTER_SIZE && c * RT_CLUSTER_SIZE + j < n; j++) members[cnt++] = order[(size_t) (c * RT_CLUSTER_SIZE + j)].second;
+		std::sort(members, members + cnt);          /* (index order inside a cluster: not needed for the answer, tidy for reading) */
+		for (int j = 0; j < RT_CLUSTER_SIZE; j++) K.member[j] = 0xffff;
+		for (int j = 0; j < cnt; j++) {
+			float blo[3], bhi[3];
+			rt_cull_object_box(geom[(size_t) members[j]], RT_CULL_MARGIN, blo, bhi);
+			for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], blo[k]); hi[k] = std::max(hi[k], bhi[k]); }
+			K.member[j] = (unsigned short) members[j];
+		}
+		K.lo[0] = lo[0]; K.lo[1] = lo[1]; K.lo[2] = lo[2]; K.hi0 = hi[0]; K.hi1 = hi[1]; K.hi2 = hi[2];
+		K.count = cnt;
+	}
+	info.num_clusters = C;
+	info.origin_max = 2.0f * S;
+	return info;
+}
+
+#endif

@@ -44,6 +44,19 @@ typedef struct {
 	float pad1;
 } rt_shade;
 
+/* Large scenes (more objects than a scene-specialised kernel takes): objects grouped into clusters of up to RT_CLUSTER_SIZE
+ * spatially close ones, so that a ray first asks RT_CLUSTER_SIZE times fewer boxes "could anything in here be hit at all"
+ * (rt_kernels.hip nearest_hit_culled, rt_cull.h).  48 B: a conservative bounding box of the members' own conservative boxes,
+ * and the members' object indices (0xffff: none). */
+#define RT_CLUSTER_SIZE 8
+#define RT_MAX_CLUSTERS 128
+typedef struct {
+	float          lo[3], hi0;
+	float          hi1, hi2;
+	int            count, pad;
+	unsigned short member[RT_CLUSTER_SIZE];
+} rt_cluster;
+
 typedef struct {
 	/* camera.c:99-118, frame constants */
 	float pos[3], llc[3], horiz[3], vert[3];
@@ -97,6 +110,11 @@ typedef struct {
 	unsigned int launch_id;
 	const rt_geom  *geom;      /* num_objects records (global; staged to LDS)  */
 	const rt_shade *shade;
+	/* object culling for large scenes (rt_cull.h): num_clusters = 0 -> every ray tests every object, as the reference does */
+	const rt_cluster *clusters;
+	int   num_clusters;
+	float cull_margin;         /* every box is tested as if it were this much larger on every side ...                         */
+	float cull_origin_max;     /* ... which covers the rounding of the tests for rays that start within this of the origin      */
 } rt_launch;
 
 #endif

@@ -47,7 +47,7 @@ extern "C" { __device__ unsigned long long rt_stats[64]; }
 #ifdef RT_STATS_LIFETIMES_ONLY
 /* The per-site atomics slow a launch down a hundredfold and the section stamps by a third; what a look at the end of a
  * launch needs is the real pace: every wave writes four words of its own -- start, the time it found the pixel lists
- * empty, the rounds it ran after that, its end (s_memrealtime, 10 ns) -- and nothing else (scripts/tail_probe.py). */
+ * empty, the rounds it ran after that, its end (s_memrealtime, 10 ns) -- and nothing else (scripts/probes/tail_probe.py). */
 extern "C" { __device__ unsigned long long rt_wave_log[4 * 8192]; }
 #define STAT(site) do {} while (0)
 #define STAMP(k) do {} while (0)
@@ -85,6 +85,18 @@ struct SceneLDS {
 	const float4 *geom;    /* 2 x float4 per object */
 	const float4 *shade;   /* 4 x float4 per object */
 };
+
+/* Large scenes (the culled kernels): only the geometry goes to LDS -- 32 B an object, read per lane by the members' tests --;
+ * the shading records, 64 B an object and touched once per bounce, are read from memory (L2), so that a scene of 1024 objects
+ * leaves room for two workgroups per CU instead of one (one wave per SIMD is latency-bound: 22 vs 12 ms on C1). */
+RT_DEV SceneLDS stage_geometry(const rt_launch &L, float4 *lds, int n)
+{
+	const float4 *g = reinterpret_cast<const float4*>(L.geom);
+	for (int i = threadIdx.x; i < 2 * n; i += RT_BLOCK) lds[i] = g[i];
+	__syncthreads();
+	SceneLDS sc; sc.geom = lds; sc.shade = reinterpret_cast<const float4*>(L.shade);
+	return sc;
+}
 
 RT_DEV SceneLDS stage_scene(const rt_launch &L, float4 *lds, int n)
 {
@@ -335,6 +347,107 @@ RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d, bool want_nor
 			best.n = unit3_fast(sub3(madd3(o, d, best_t), mk3(g0.x, g0.y, g0.z)));   /* scene.c:146-147 */
 	}
 	return best;
+}
+
+/* ---- large scenes: the same nearest hit, most objects never tested (rt_cull.h has the margins and their proof) -------------
+ * Objects are grouped into clusters of up to RT_CLUSTER_SIZE spatially close ones (rt_set_scene).  A ray first tests the
+ * clusters' conservative boxes -- all lanes the same cluster, box read once for the wave -- and remembers the ones it may
+ * touch in a bit mask; then every lane walks ITS clusters, tests the members' conservative boxes (a slab test on the box
+ * inflated by the margin, products by the ray's refined reciprocals) and runs the reference's exact test only on the members
+ * that pass.  The exact tests are the very functions of the linear scan, so every distance is the same number; the scan's
+ * "lowest index among equal distances" (strict `<` in index order, scene.c:168) is kept explicitly, because the clusters
+ * are visited out of index order. */
+struct ClusterLDS { const float4 *rec; int count; float margin, origin_max; };      /* 3 x float4 per cluster (rt_cluster) */
+
+RT_DEV bool slab_may_touch(V3 o, V3 inv, V3 lo, V3 hi)
+{
+	const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
+	const float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
+	const float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+	const float enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+	const float leave = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+	return enter <= leave && leave >= 0.0f;
+}
+
+RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, V3 o, V3 d, bool want_normal = true)
+{
+	const RayPrep rp = prepare_ray<true>(o, d);
+	const float omax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z));
+	/* the margins are proved for directions inside the window of the shared-reciprocal division and origins within twice the
+	 * scene's extent; a wave with any other ray tests every object */
+	if (!wave_all(rp.inv_ok && omax <= cl.origin_max)) return nearest_hit_fast(sc, n, o, d, want_normal);
+	STAT(9);
+	/* 1. which clusters may this ray touch?  (wave-uniform loop: one box per step, read once for all lanes) */
+	uint32_t mask[RT_MAX_CLUSTERS / 32];
+#pragma unroll
+	for (int w = 0; w < RT_MAX_CLUSTERS / 32; w++) {
+		uint32_t bits = 0u;
+		const int first = 32 * w, last = cl.count < first + 32 ? cl.count : first + 32;
+		for (int c = first; c < last; c++) {
+			const float4 k0 = cl.rec[3 * c], k1 = cl.rec[3 * c + 1];
+			if (slab_may_touch(o, rp.inv, mk3(k0.x, k0.y, k0.z), mk3(k0.w, k1.x, k1.y))) bits |= 1u << (c - first);
+		}
+		mask[w] = bits;
+	}
+	/* 2. every lane its own clusters: members' conservative boxes first, exact tests on what is left */
+	float best_t = 3.402823466e+38f;
+	int best_obj = -1, best_axis = 0;
+#pragma unroll
+	for (int w = 0; w < RT_MAX_CLUSTERS / 32; w++) {
+		uint32_t todo = mask[w];
+		while (__ballot(todo != 0u) != 0ull) {
+			if (todo != 0u) {
+				const int c = 32 * w + (int) __builtin_ctz(todo);
+				todo &= todo - 1u;
+				const unsigned short *member = reinterpret_cast<const unsigned short*>(cl.rec + 3 * c + 2);
+				uint32_t cand = 0u;
+#pragma unroll
+				for (int j = 0; j < RT_CLUSTER_SIZE; j++) {
+					const uint32_t idx = member[j];
+					if (idx != 0xffffu) {
+						const float4 g0 = sc.geom[2 * idx], g1 = sc.geom[2 * idx + 1];
+						const bool box = __float_as_int(g1.z) == RT_GEOM_CUBE;
+						const float e = box ? cl.margin : g1.x;                       /* a sphere's record carries its half extent (rt_cull.h) */
+						const V3 lo = mk3(g0.x - e, g0.y - e, g0.z - e);
+						const V3 hi = mk3((box ? g0.w : g0.x) + e, (box ? g1.x : g0.y) + e, (box ? g1.y : g0.z) + e);
+						if (slab_may_touch(o, rp.inv, lo, hi)) cand |= 1u << j;
+					}
+				}
+				while (cand != 0u) {
+					const int idx = (int) member[__builtin_ctz(cand)];
+					cand &= cand - 1u;
+					const float4 g0 = sc.geom[2 * idx], g1 = sc.geom[2 * idx + 1];
+					float t = 0.0f; int axis = 0; bool hit = false;
+					if (__float_as_int(g1.z) == RT_GEOM_CUBE)
+						hit = box_entry_fast(o, d, rp, true, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), t, axis);
+					else
+						hit = ball_entry_fast(o, d, rp, mk3(g0.x, g0.y, g0.z), g0.w, t);
+					if (hit && t >= 0 && (t < best_t || (t == best_t && idx < best_obj))) { best_t = t; best_obj = idx; best_axis = axis; }
+				}
+			}
+		}
+	}
+	Hit best; best.t = best_t; best.obj = best_obj; best.n = mk3(0, 0, 0);
+	if (best_obj >= 0 && want_normal) {
+		const float4 g0 = sc.geom[2 * best_obj], g1 = sc.geom[2 * best_obj + 1];
+		if (__float_as_int(g1.z) == RT_GEOM_CUBE) {
+			const float dc = best_axis == 0 ? d.x : (best_axis == 1 ? d.y : d.z);
+			const float s = dc > 0 ? -1.0f : 1.0f;                               /* scene.c:71-73 */
+			best.n = mk3(best_axis == 0 ? s : 0.0f, best_axis == 1 ? s : 0.0f, best_axis == 2 ? s : 0.0f);
+		} else
+			best.n = unit3_fast(sub3(madd3(o, d, best_t), mk3(g0.x, g0.y, g0.z)));   /* scene.c:146-147 */
+	}
+	return best;
+}
+
+/* the clusters behind the scene records in LDS (the caller has staged the scene: lds[0 .. 6 n)) */
+RT_DEV ClusterLDS stage_clusters(const rt_launch &L, float4 *dst)
+{
+	const float4 *src = reinterpret_cast<const float4*>(L.clusters);
+	for (int i = threadIdx.x; i < 3 * L.num_clusters; i += RT_BLOCK) dst[i] = src[i];
+	__syncthreads();
+	ClusterLDS cl; cl.rec = dst; cl.count = L.num_clusters; cl.margin = L.cull_margin; cl.origin_max = L.cull_origin_max;
+	return cl;
 }
 
 /* ---- scene-specialised trace (rt_compile_scene, rt_jit.cpp) ----------------------------------------
@@ -597,13 +710,15 @@ rt_trace_simple(const rt_launch L)
  * L.num_shards pixel lists, from which the trace kernel's waves deal pixels to their lanes.
  * ============================================================================================= */
 #define RT_PIX_WORDS 12
-template <bool FAST>
+template <bool FAST, bool CULL = false>
 __global__ void __launch_bounds__(RT_BLOCK)
 rt_primary_pass(const rt_launch L, int blocks_per_group)
 {
 	extern __shared__ float4 lds[];
 	const int n = L.num_objects;
-	const SceneLDS sc = stage_scene(L, lds, n);
+	const SceneLDS sc = CULL ? stage_geometry(L, lds, n) : stage_scene(L, lds, n);
+	ClusterLDS cl; cl.rec = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
+	if (CULL) cl = stage_clusters(L, lds + 2 * n);
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int tiles_x = (L.width + 7) >> 3, tiles_y = (L.local_rows + 7) >> 3;
 	const unsigned int total = (unsigned int) (tiles_x * tiles_y);
@@ -629,7 +744,7 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 			v = 1.0f - v;
 			pd = primary_dir(L, u, v);
 			const V3 dn = FAST ? unit3_fast(pd) : unit3(pd);                           /* scene.c:158 */
-			const Hit hit = FAST ? nearest_hit_fast(sc, n, cam, dn) : nearest_hit(sc, n, cam, dn);
+			const Hit hit = CULL ? nearest_hit_culled(sc, n, cl, cam, dn) : (FAST ? nearest_hit_fast(sc, n, cam, dn) : nearest_hit(sc, n, cam, dn));
 			obj = hit.obj;
 			if (obj >= 0) {
 				a = madd3(cam, dn, hit.t);                                               /* scene.c:186 */
@@ -789,7 +904,7 @@ RT_DEV PixelRec load_pixel(rt_launch_cold C, size_t c)
 	return p;
 }
 
-template <bool FAST>
+template <bool FAST, bool CULL = false>
 RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 {
 	extern __shared__ float4 lds[];
@@ -798,7 +913,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 #else
 	const int n = L.num_objects;
 #endif
-	const SceneLDS sc = stage_scene(L, lds, n);
+	const SceneLDS sc = CULL ? stage_geometry(L, lds, n) : stage_scene(L, lds, n);
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	/* the grids of the "taps certainly lit" table (rt_lit.h), when the launcher found room for them: 3 x float4 per object */
 	if (L.lit_grids_in_lds) {
@@ -811,7 +926,10 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	const rt_lit_grid *lit_grids_lds = reinterpret_cast<const rt_lit_grid*>(lds + 6 * n);
 	const rt_lit_grid *lit_grids_mem = reinterpret_cast<const rt_lit_grid*>(L.lit_grids);
 	const bool grids_in_lds = L.lit_grids_in_lds != 0;
-	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (L.lit_grids_in_lds ? 9 : 6) * n)[wave];
+	/* large scenes: the clusters of rt_cull.h behind the scene records (such scenes have no lit-taps table: it needs <= 64 objects) */
+	ClusterLDS cl; cl.rec = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
+	if (CULL) cl = stage_clusters(L, lds + 2 * n);
+	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (CULL ? 2 * n + 3 * L.num_clusters : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
 
 	const float inv_spp = 1.0f / (float) L.spp;
 	const unsigned int spp = (unsigned int) L.spp;
@@ -1093,7 +1211,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 #ifdef RT_STATS
 			{	/* what kind of shading event this is (scripts/stats_c1.py): a sample's first or a later one, on a box or a sphere, taps known or not */
 				const bool on_box = __float_as_int(sc.geom[2 * hobj + 1].z) == RT_GEOM_CUBE;
-				if (bounce == 0) STAT(9);            /* (sites 25-28 are the section stamps' words) */
+				if (bounce == 0) STAT(0);            /* (sites 25-28 are the section stamps' words) */
 				if (bounce == 0 && taps_lit) STAT(10);
 				if (on_box) STAT(11);
 				if (bounce == 0 && on_box) STAT(18);
@@ -1182,7 +1300,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				V3 o, d; int meta;
 				tap_ray((q_head + (unsigned int) lane) & (WF_QUEUE - 1), o, d, meta);
 				const V3 dn = unit3_sel<FAST>(d);                                         /* scene.c:158 */
-				const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, n, o, dn, false) : nearest_hit(sc, n, o, dn);
+				const Hit hit = CULL ? nearest_hit_culled(sc, n, cl, o, dn, false) : (FAST ? NEAREST_HIT_TUNED(sc, n, o, dn, false) : nearest_hit(sc, n, o, dn));
 				tap_answer(meta, hit.obj);
 			}
 			q_head += (unsigned int) count;
@@ -1228,7 +1346,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			if (emit_main) {
 				STAT(13);
 				const V3 dn = unit3_sel<FAST>(ray_d);                                     /* scene.c:158 */
-				const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, n, ray_o, dn, true) : nearest_hit(sc, n, ray_o, dn);
+				const Hit hit = CULL ? nearest_hit_culled(sc, n, cl, ray_o, dn, true) : (FAST ? NEAREST_HIT_TUNED(sc, n, ray_o, dn, true) : nearest_hit(sc, n, ray_o, dn));
 				hobj = hit.obj; hn = hit.n;
 				hp = hit.obj >= 0 ? madd3(ray_o, dn, hit.t)                               /* scene.c:186 */
 				                  : dn;                 /* left the scene: the sky is looked up in that direction (main.c:170) */
@@ -1338,11 +1456,12 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 }
 
 #ifndef RT_SPEC_ONLY
-template <bool FAST>
-__global__ void __launch_bounds__(RT_BLOCK, 4)
+/* (a large scene's records leave room for one or two workgroups per CU anyway: the culled variant may use 256 registers) */
+template <bool FAST, bool CULL = false>
+__global__ void __launch_bounds__(RT_BLOCK, CULL ? 2 : 4)
 rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 {
-	wavefront_body<FAST>(L, block_counter);
+	wavefront_body<FAST, CULL>(L, block_counter);
 }
 #endif
 
@@ -1856,6 +1975,7 @@ size_t rt_counter_bytes() { return RT_COUNTER_BYTES; }
 size_t rt_scene_lds_bytes(int num_objects) { return (size_t) num_objects * (sizeof(rt_geom) + sizeof(rt_shade)); }
 
 size_t rt_wavefront_lds_bytes(int num_objects) { return rt_scene_lds_bytes(num_objects) + (RT_BLOCK / 64) * sizeof(WaveLDS); }
+static_assert(sizeof(rt_cluster) == 48, "the kernels read a cluster as three float4");
 /* rt_first_bounce_spec (experiment): per wave 3 x 8 x 65 floats of colours */
 size_t rt_first_bounce_lds_bytes(int num_objects) { return rt_scene_lds_bytes(num_objects) + (RT_BLOCK / 64) * (size_t) (3 * 8 * 65 * sizeof(float)); }
 
@@ -1901,7 +2021,9 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 		return e != hipSuccess ? e : hipEventRecord(primary_done, stream);
 	}
 	/* persistent waves: as many workgroups as fit on the chip at once, capped by the work */
-	size_t lds = rt_wavefront_lds_bytes(L.num_objects);
+	const bool cull = L.num_clusters > 0 && L.clusters != nullptr && scene_fast_ok && variant == 0;
+	size_t lds = cull ? (size_t) L.num_objects * sizeof(rt_geom) + (size_t) L.num_clusters * sizeof(rt_cluster) + (RT_BLOCK / 64) * sizeof(WaveLDS)
+	                  : rt_wavefront_lds_bytes(L.num_objects);
 	int per_cu = (int) ((160u * 1024u) / lds);
 	if (per_cu < 1) per_cu = 1;
 	if (per_cu > 4) per_cu = 4;
@@ -1912,6 +2034,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 		const size_t with = lds + (size_t) L.num_objects * 48;
 		if (with <= 160u * 1024u && (int) ((160u * 1024u) / with) >= per_cu) { Lq.lit_grids_in_lds = 1; lds = with; }
 	}
+	if (cull && per_cu > 3) per_cu = 3;                                                        /* (the culled variant's 136 registers: three waves per SIMD) */
 	if (workgroups_per_cu >= 1 && workgroups_per_cu < per_cu) per_cu = workgroups_per_cu;     /* rt_tuning */
 	const long long blocks = (long long) ((L.width + 7) / 8) * ((L.local_rows + 7) / 8);
 	long long grid = (long long) num_cus * per_cu;
@@ -1931,9 +2054,11 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	} else {
 		unsigned int groups; int per_group;
 		rt_primary_geometry(L.width, L.local_rows, num_cus, &groups, &per_group);
-		const size_t plds = rt_scene_lds_bytes(L.num_objects);
+		const size_t plds = cull ? (size_t) L.num_objects * sizeof(rt_geom) + (size_t) L.num_clusters * sizeof(rt_cluster) : rt_scene_lds_bytes(L.num_objects);
 		if (variant == 2 || !scene_fast_ok)
 			hipLaunchKernelGGL(rt_primary_pass<false>, dim3(groups), dim3(RT_BLOCK), plds, stream, L, per_group);
+		else if (cull)
+			hipLaunchKernelGGL((rt_primary_pass<true, true>), dim3(groups), dim3(RT_BLOCK), plds, stream, L, per_group);
 		else
 			hipLaunchKernelGGL(rt_primary_pass<true>, dim3(groups), dim3(RT_BLOCK), plds, stream, L, per_group);
 		e = hipGetLastError();
@@ -1963,6 +2088,8 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	}
 	if (variant == 2 /* RT_KERNEL_WAVEFRONT: same schedule, plain IEEE operations */ || !scene_fast_ok)
 		hipLaunchKernelGGL(rt_trace_wavefront<false>, dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, Lq, block_counter);
+	else if (cull)
+		hipLaunchKernelGGL((rt_trace_wavefront<true, true>), dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, Lq, block_counter);
 	else
 		hipLaunchKernelGGL(rt_trace_wavefront<true>, dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, Lq, block_counter);
 	return hipGetLastError();

@@ -2,7 +2,7 @@
 pixel, 20 ms into the frame -- and what a whole frame takes before and after (a request must leave nothing behind).
 usage: cancel_probe.py [librt_hip.so of another build]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ray_tracing_amd as rt
 if len(sys.argv) > 1: rt.LIB_PATH = os.path.abspath(sys.argv[1])
 sky = rt.load_skybox()

@@ -1,7 +1,7 @@
 """Development aid: the C1 frame on subsets of the compute units (hipExtStreamCreateWithCUMask), to see whether two
 CUs that share an instruction cache slow each other down.  usage: cu_mask_probe.py [C1|C2]"""
 import ctypes as C, os, sys, time, statistics
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import ray_tracing_amd as rt
 hip = C.CDLL("libamdhip64.so")

@@ -2,7 +2,7 @@
 (multi_gpu.TiledFrame) in ONE process on ONE device: ms per step, per-launch kernel time, span per launch.
 usage: frame_loop_probe.py [lib.so ...]   (default: the tree's library)"""
 import os, sys, time, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import numpy as np

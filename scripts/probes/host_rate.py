@@ -1,7 +1,7 @@
 """Development aid: can the host keep a 1 ms frame loop fed?  A strip-sized frame (the 135 rows one of eight ranks
 renders of a 1080p frame, here as a frame of its own) through TiledFrame: GPU time per step vs host time per step()."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import ray_tracing_amd as rt
 from ray_tracing_amd.multi_gpu import TiledFrame

@@ -1,7 +1,7 @@
 """Development aid: C1 kernel time with different extra hiprtc options for the scene-specialised kernel (rt_tuning.jit_flags),
 interleaved in one process.  usage: jit_flags_probe.py "<flags A>" "<flags B>" ..."""
 import os, sys, statistics
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 if os.environ.get("NOTORCH"): sys.modules["torch"] = None     # the system's HIP runtime and compiler instead of torch's bundled ones
 import ray_tracing_amd as rt
 flags = [""] + sys.argv[1:]

@@ -1,7 +1,7 @@
 """Development aid: compile the scene-specialised trace kernel with a given libhiprtc.so (no GPU needed) exactly as
 rt_compile_scene does, and write the code object -- to compare compilers.  usage: jit_offline.py <libhiprtc.so> scene.txt out.co [flags...]"""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scripts"))
 from spec_asm import header
 lib, scene, out = sys.argv[1], sys.argv[2], sys.argv[3]

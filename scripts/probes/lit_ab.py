@@ -1,7 +1,7 @@
 """Development aid: frames with the "taps certainly lit" flags honoured and ignored (rt_tuning.trace_known_taps): must be
 bit-identical; prints both kernel times.  usage: lit_ab.py [C1|C2|C1strip8|...]"""
 import os, sys, time, statistics
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import ray_tracing_amd as rt
 CFG = {"C1": (0, 1920, 1080, 64, 4, 1, 0), "C2": (1, 1920, 1080, 256, 8, 1, 0), "C3": (2, 3840, 2160, 64, 8, 1, 0),

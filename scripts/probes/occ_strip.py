@@ -1,6 +1,6 @@
 """Development aid: time of the strip one of 8 ranks renders of C1, at 2..4 resident workgroups per CU."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import ray_tracing_amd as rt
 g = rt.Renderer(0)

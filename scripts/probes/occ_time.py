@@ -1,6 +1,6 @@
 """Development aid: C1 / C2 kernel time at 1..4 resident workgroups per CU (= waves per SIMD)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ray_tracing_amd as rt
 g = rt.Renderer(0)
 g.set_skybox(rt.load_skybox()); g.profile(True)

@@ -2,7 +2,7 @@
 the context's two streams (rt_stream: the tail of one launch then runs under the start of the next).
 usage: overlap_probe.py [world ...]     (C1; the strip of rank 3 of `world`)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import ray_tracing_amd as rt
 g = rt.Renderer(0)

@@ -1,7 +1,7 @@
 """Development aid: time of the reference's interactive protocol (rt_progressive_pass: 1 sample per pixel per pass,
 scale ladder from 1/8 resolution) at 1920x1080, scene_0, 10 bounces.  usage: prog_time.py [lib.so]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ray_tracing_amd as rt
 if len(sys.argv) > 1: rt.LIB_PATH = os.path.abspath(sys.argv[1])
 g = rt.Renderer(0)

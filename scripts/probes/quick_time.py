@@ -1,6 +1,6 @@
 """Quick GPU timing of the configs in BASELINE.json (development aid; bench.py is the contract)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import ray_tracing_amd as rt
 if os.environ.get('RT_LIB'): rt.LIB_PATH = os.path.join(os.path.dirname(rt.LIB_PATH), os.environ['RT_LIB'])

@@ -7,7 +7,7 @@ strips is missing.  Prints ms per step for: strips alone, + gather stand-in and 
 Also prints the time of one of the OTHER ranks' strips alone (strip 0: a longest one), which bounds the step from below.
 usage: rank0_probe.py [C1|C4] [world] [strip=<s>]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import ray_tracing_amd as rt
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C1"

@@ -1,7 +1,7 @@
 """Development aid: the C ABI's frame queue on C1 in a Python process WITHOUT torch (librt_hip.so then binds to the system's
 HIP runtime, as rt_cli does) or with it (torch's bundled runtime is loaded first).  usage: runtime_probe.py [notorch] [generic]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 if len(sys.argv) > 1 and sys.argv[1] == "notorch":
     sys.modules["torch"] = None          # `import torch` raises ImportError

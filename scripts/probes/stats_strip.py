@@ -1,6 +1,6 @@
 """Per-site lane utilisation of the trace kernel on the strip one of eight ranks renders of C1 (needs `make -C ray_tracing_amd/csrc stats`)."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import ray_tracing_amd as rt
 rt.LIB_PATH = os.path.join(os.path.dirname(rt.LIB_PATH), "librt_hip_stats.so")

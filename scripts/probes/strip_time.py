@@ -1,7 +1,7 @@
 """Kernel time of one rank's strip for world = 1, 2, 4, 8 on a single GPU (what each GPU of an N-GPU
 run executes), with the automatic schedule."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import ray_tracing_amd as rt
 g = rt.Renderer(0)

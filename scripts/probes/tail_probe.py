@@ -3,7 +3,7 @@ every wave logs its start, the time it found the pixel lists empty, the rounds i
 (rt_kernels.hip, STAMP_FLUSH).  The time between the mean and the last exit is what a perfectly balanced end would save.
 usage: [SPP=n] tail_probe.py [world ...]     (C1, strip of rank 3 of `world`; world 1 = the whole frame)"""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import ray_tracing_amd as rt

@@ -4,7 +4,7 @@ device only -- and against the step time of the C ABI's frame queue (frames to p
 C1 / C2 / C3.  Fewer workgroups per launch leave room for the next launch to be resident beside this one's tail.
 usage: wg_probe.py"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import ray_tracing_amd as rt
 from ray_tracing_amd.frames import FrameLoop

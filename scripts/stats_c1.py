@@ -22,7 +22,7 @@ read()
 names = {1: "box test", 2: "box slow path", 3: "sphere test", 4: "sphere discr>0 (fp64 roots)", 5: "sphere 2nd root", 6: "sphere slow path",
          7: "round (setup site)", 8: "setup body", 12: "trace batch", 13: "trace batch active",
          14: "sky lookup", 15: "specular branch", 16: "consume site", 17: "consume body", 22: "sample hand-out", 23: "in-order sum pass", 24: "lanes left without a sample", 20: "supply attempt", 21: "pixel fetch event",
-         9: "shading event, bounce 0", 10: "  bounce 0, taps known", 11: "shading event on a box", 18: "  bounce 0 on a box", 19: "  bounce 0, box, taps known",
+         0: "shading event, bounce 0", 9: "culled trace (large scenes)", 10: "  bounce 0, taps known", 11: "shading event on a box", 18: "  bounce 0 on a box", 19: "  bounce 0, box, taps known",
          29: "shading event, taps known", 30: "shading event, bounce 1"}
 samples = W * H * spp
 for k in sorted(names):

@@ -94,6 +94,28 @@ def make_scene(objects):
     return buf
 
 
+def large_scene(n, seed, extent=10.0, floor=True, light=True):
+    """n objects: small spheres and boxes scattered over [-extent, extent]^3, optionally a floor slab and a sphere emitter
+    (the generator of test_max_objects, parametrised; also bench.py's L* workloads)."""
+    rng = np.random.default_rng(seed)
+    objs = []
+    for k in range(n):
+        if floor and k == 0:
+            objs.append(dict(type="cube", origin=(-extent, -extent - 0.5, -extent), size=(2 * extent, 0.5, 2 * extent), albedo=(.6, .6, .6), roughness=1.0))
+        elif light and k == n // 2:
+            objs.append(dict(type="sphere", center=(0.0, extent * 0.8, 0.0), radius=1.0, albedo=(1, 1, 1), emission_power=4.0))
+        elif k % 2:
+            objs.append(dict(type="sphere", center=rng.uniform(-extent, extent, 3), radius=rng.uniform(0.1, 0.6), albedo=rng.uniform(0, 1, 3),
+                             roughness=rng.uniform(0, 1), metallic=float(k % 7 == 0)))
+        else:
+            objs.append(dict(type="cube", origin=rng.uniform(-extent, extent - 1, 3), size=rng.uniform(0.1, 1, 3), albedo=rng.uniform(0, 1, 3),
+                             metallic=float(k % 8 == 0), roughness=rng.uniform(0, 1), reflectance=rng.uniform(0, 1)))
+    return make_scene(objs)
+
+
+LARGE_SCENE_CAMERA = dict(pos=(14, 9, 14), front=(-1, -0.5, -1), up=(0, 1, 0), fov=1.0)      # outside large_scene(), looking in
+
+
 def synthetic_skybox(size=64, seed=7):
     """Deterministic 6 x size x size x 3 u8 skybox (distinct per face, varying per texel)."""
     rng = np.random.default_rng(seed)

@@ -1,0 +1,101 @@
+"""Scenes of more than 64 objects: the cluster cull of csrc/rt_cull.h must not change a bit.  The culled
+kernels against the same kernels with every object tested (rt_tuning.test_every_object) and against the oracle, on random
+scenes that mix small and large objects, cameras inside and outside the scene, and the largest scene the reference takes."""
+import os
+
+import numpy as np
+import pytest
+
+import ray_tracing_amd as rt
+from rtlibs import LARGE_SCENE_CAMERA, bits, large_scene, synthetic_skybox
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    r = rt.Renderer(0)
+    r.set_tuning(poison_frame=True)
+    yield r
+    r.close()
+
+
+CAMERAS = [LARGE_SCENE_CAMERA,                                                        # outside, looking in
+           dict(pos=(0.3, 0.2, -0.4), front=(0.2, -0.1, 1), up=(0, 1, 0), fov=1.2),    # in the middle of the objects
+           dict(pos=(-9, 9, 2), front=(1, -1, 0), up=(0, 1, 0), fov=0.8)]              # axis-aligned components in the view direction
+
+
+@pytest.mark.parametrize("n", [65, 100, 256, 777, 1024])
+def test_culled_equals_every_object_equals_oracle(gpu, oracle, n):
+    sky = synthetic_skybox(32, seed=n)
+    scene = large_scene(n, seed=n)
+    gpu.set_skybox(sky); gpu.set_scene(scene)
+    oracle.set_skybox(sky); oracle.set_scene(scene)
+    W, H, spp, nb = 96, 54, 3, 5
+    for cam in CAMERAS:
+        gpu.set_camera(**cam); oracle.set_camera(**cam)
+        gpu.set_tuning(test_every_object=False)
+        culled = gpu.render(W, H, spp, nb, seed=n)
+        gpu.set_tuning(test_every_object=True)
+        plain = gpu.render(W, H, spp, nb, seed=n)
+        gpu.set_tuning(test_every_object=False)
+        assert (bits(culled) == bits(plain)).all(), (n, cam)
+        want = oracle.render_counter(W, H, spp, nb, seed=n, threads=min(os.cpu_count() or 1, 32))
+        assert (bits(culled) == bits(want)).all(), (n, cam)
+    gpu.set_camera(); oracle.set_camera()
+
+
+def test_cull_fuzz_against_every_object(gpu):
+    """Random large scenes at random scales and cameras: the culled frame is the every-object frame (GPU against GPU: cheap enough
+    for many cases; the oracle pins a subset above)."""
+    rng = np.random.default_rng(2024)
+    sky = synthetic_skybox(16, seed=5)
+    gpu.set_skybox(sky)
+    for case in range(24):
+        n = int(rng.integers(65, 400))
+        extent = float(rng.choice([0.5, 3.0, 10.0, 30.0]))
+        gpu.set_scene(large_scene(n, seed=1000 + case, extent=extent, floor=bool(case & 1), light=bool(case & 2)))
+        pos = rng.uniform(-1.5 * extent, 1.5 * extent, 3)
+        front = -pos + rng.uniform(-0.3 * extent, 0.3 * extent, 3)
+        gpu.set_camera(pos=tuple(pos), front=tuple(front), up=(0, 1, 0), fov=float(rng.uniform(0.5, 1.4)))
+        W, H, spp, nb = 128, 72, 2, 6
+        gpu.set_tuning(test_every_object=False)
+        culled = gpu.render(W, H, spp, nb, seed=case)
+        gpu.set_tuning(test_every_object=True)
+        plain = gpu.render(W, H, spp, nb, seed=case)
+        gpu.set_tuning(test_every_object=False)
+        assert (bits(culled) == bits(plain)).all(), (case, n, extent)
+    gpu.set_camera()
+
+
+def test_camera_far_outside_tests_every_object(gpu, oracle):
+    """A camera farther out than twice the scene's extent: its waves take the plain loop (the margins are proved for origins
+    within that); the frame is the oracle's either way."""
+    sky = synthetic_skybox(16, seed=9)
+    scene = large_scene(128, seed=4, extent=2.0)
+    cam = dict(pos=(40, 25, 40), front=(-1, -0.6, -1), up=(0, 1, 0), fov=0.15)
+    for r in (gpu, oracle):
+        r.set_skybox(sky); r.set_scene(scene); r.set_camera(**cam)
+    got = gpu.render(96, 54, 2, 4, seed=3)
+    assert (bits(got) == bits(oracle.render_counter(96, 54, 2, 4, seed=3))).all()
+    gpu.set_camera(); oracle.set_camera()
+
+
+def test_largest_scene_at_full_hd_rows_against_the_oracle(gpu, oracle):
+    """1024 objects at 1920x1080: the culled frame equals the every-object frame, and rows of it the oracle's."""
+    sky = synthetic_skybox(32, seed=3)
+    scene = large_scene(1024, seed=17)
+    cam = CAMERAS[0]
+    for r in (gpu, oracle):
+        r.set_skybox(sky); r.set_scene(scene); r.set_camera(**cam)
+    W, H, spp, nb = 1920, 1080, 2, 5
+    culled = gpu.render(W, H, spp, nb, seed=1)
+    gpu.set_tuning(test_every_object=True)
+    plain = gpu.render(W, H, spp, nb, seed=1)
+    gpu.set_tuning(test_every_object=False)
+    assert (bits(culled) == bits(plain)).all()
+    rows = [0, 137, 540, 811, 1079]
+    want = oracle.render_counter_rows(W, H, spp, nb, rows, seed=1, threads=min(os.cpu_count() or 1, 64))
+    for r_, v in want.items():
+        assert (bits(culled[r_]) == bits(v)).all(), r_
+    gpu.set_camera(); oracle.set_camera()
