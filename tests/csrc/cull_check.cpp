@@ -1,0 +1,133 @@
+/* CPU check of csrc/rt_cull.h (tests/test_cull_margins.py): the cluster structure, and the soundness of the conservative tests --
+ * for random scenes and rays, many of them aimed at box edges, box corners and sphere tangents, WHENEVER the reference's own
+ * float test of an object reports a hit with t >= 0 (scene.c:17-77 slab test with correctly rounded quotients, scene.c:79-134 float
+ * discriminant; the acceptance of scene.c:168), the cull's test of that object's conservative box and of its cluster's box --
+ * products by the correctly rounded reciprocal of the direction, as nearest_hit_culled forms them -- must pass.
+ * usage: cull_check <scenes> <rays per scene>   -> prints "<pairs tested> <reference hits> <violations> <structure errors> <scenes refused>" */
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+#include "../../ray_tracing_amd/csrc/rt_cull.h"
+
+struct V { float x, y, z; };
+
+static bool ref_box(V o, V d, const rt_geom &g, float &t)          /* scene.c:17-77 */
+{
+	const float lo[3] = { g.a[0], g.a[1], g.a[2] }, hi[3] = { g.b0, g.b1, g.b2 };
+	const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+	float n[3], f[3];
+	for (int k = 0; k < 3; k++) {
+		const float a = (lo[k] - oo[k]) / dd[k], b = (hi[k] - oo[k]) / dd[k];
+		n[k] = dd[k] >= 0 ? a : b; f[k] = dd[k] >= 0 ? b : a;
+	}
+	if (n[0] > f[1] || n[1] > f[0]) return false;
+	float tn = n[0], tf = f[0];
+	if (n[1] > tn) tn = n[1];
+	if (f[1] < tf) tf = f[1];
+	if (tn > f[2] || n[2] > tf) return false;
+	if (n[2] > tn) tn = n[2];
+	t = tn;
+	return true;
+}
+
+static bool ref_sphere(V o, V d, const rt_geom &g, float &t)       /* scene.c:79-134 */
+{
+	const V oc = { g.a[0] - o.x, g.a[1] - o.y, g.a[2] - o.z };
+	const float a = d.x * d.x + d.y * d.y + d.z * d.z;
+	const float b = -2.0f * (oc.x * d.x + oc.y * d.y + oc.z * d.z);
+	const float c = (oc.x * oc.x + oc.y * oc.y + oc.z * oc.z) - g.b0;
+	const float discr = b * b - 4.0f * a * c;
+	if (!(discr > 0)) return false;
+	const double root = sqrt((double) discr);
+	float r0 = (float) (((double) -b + root) / (double) (2.0f * a)), r1 = (float) (((double) -b - root) / (double) (2.0f * a));
+	if (r0 > r1) { const float s = r0; r0 = r1; r1 = s; }
+	if (r0 < 0) { r0 = r1; if (r0 < 0) return false; }
+	t = r0;
+	return true;
+}
+
+static bool may_touch(V o, V inv, const float lo[3], const float hi[3])     /* slab_may_touch of rt_kernels.hip */
+{
+	const float ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
+	const float ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
+	const float az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
+	const float enter = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+	const float leave = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+	return enter <= leave && leave >= 0.0f;
+}
+
+int main(int argc, char **argv)
+{
+	const int scenes = argc > 1 ? atoi(argv[1]) : 20, rays = argc > 2 ? atoi(argv[2]) : 20000;
+	std::mt19937_64 rng(12345);
+	auto uni = [&](float a, float b) { return a + (b - a) * (float) ((rng() >> 11) * (1.0 / 9007199254740992.0)); };
+	unsigned long long pairs = 0, hits = 0, bad = 0, structure_bad = 0, refused = 0;
+	for (int sc = 0; sc < scenes; sc++) {
+		const int n = 65 + (int) (rng() % 960);
+		const float extent = (const float[]) { 0.5f, 3.0f, 10.0f, 30.0f, 60.0f }[rng() % 5];
+		std::vector<rt_geom> geom((size_t) n);
+		for (int i = 0; i < n; i++) {
+			rt_geom &g = geom[(size_t) i];
+			memset(&g, 0, sizeof(g));
+			const float s = extent * (i % 17 == 0 ? 0.5f : 0.03f);           /* a few large objects among many small ones */
+			if (i & 1) { g.type = RT_GEOM_SPHERE; for (int k = 0; k < 3; k++) g.a[k] = uni(-extent * 0.9f, extent * 0.9f); const float r = uni(0.02f, 1.0f) * s; g.b0 = r * r; }
+			else { g.type = RT_GEOM_CUBE; for (int k = 0; k < 3; k++) g.a[k] = uni(-extent * 0.9f, extent * 0.8f);
+			       g.b0 = g.a[0] * 1.0f + uni(0.01f, 1.0f) * s * 1.0f; g.b1 = g.a[1] * 1.0f + uni(0.01f, 1.0f) * s * 1.0f; g.b2 = g.a[2] * 1.0f + uni(0.01f, 1.0f) * s * 1.0f; }
+		}
+		std::vector<rt_cluster> cl;
+		const rt_cull_info info = rt_cull_build(geom, n, cl);
+		if (info.num_clusters <= 0) { refused++; continue; }      /* coordinates beyond RT_CULL_MAX_COORD: such scenes are not culled */
+		std::vector<int> owner((size_t) n, -1);
+		for (int c = 0; c < info.num_clusters; c++)
+			for (int j = 0; j < RT_CLUSTER_SIZE; j++) {
+				const int i = cl[(size_t) c].member[j];
+				if (i == 0xffff) continue;
+				if (i >= n || owner[(size_t) i] >= 0) structure_bad++; else owner[(size_t) i] = c;
+				float lo[3], hi[3];
+				rt_cull_object_box(geom[(size_t) i], info.margin, lo, hi);
+				const float clo[3] = { cl[(size_t) c].lo[0], cl[(size_t) c].lo[1], cl[(size_t) c].lo[2] }, chi[3] = { cl[(size_t) c].hi0, cl[(size_t) c].hi1, cl[(size_t) c].hi2 };
+				for (int k = 0; k < 3; k++) if (lo[k] < clo[k] || hi[k] > chi[k]) structure_bad++;
+			}
+		for (int i = 0; i < n; i++) if (owner[(size_t) i] < 0) structure_bad++;
+		for (int r = 0; r < rays; r++) {
+			/* origin within the bound the kernel checks; direction: random, or aimed at a feature of a random object (edge, corner,
+			 * tangent), optionally nearly axis-aligned */
+			V o = { uni(-1, 1) * info.origin_max, uni(-1, 1) * info.origin_max, uni(-1, 1) * info.origin_max };
+			if (r % 3 == 0) { const rt_geom &g = geom[rng() % (size_t) n]; o = { g.a[0] + uni(-0.01f, 0.01f), g.a[1] + uni(-0.01f, 0.01f), g.a[2] + uni(-2, 2) }; }
+			V d = { uni(-1, 1), uni(-1, 1), uni(-1, 1) };
+			if (r % 2 == 0) {
+				const rt_geom &g = geom[rng() % (size_t) n];
+				V p;
+				if (g.type == RT_GEOM_CUBE) p = { (rng() & 1) ? g.a[0] : g.b0, (rng() & 1) ? g.a[1] : g.b1, (rng() & 2) ? uni(g.a[2], g.b2) : ((rng() & 1) ? g.a[2] : g.b2) };
+				else { const float rr = sqrtf(g.b0); V u = { uni(-1, 1), uni(-1, 1), uni(-1, 1) }; const float l = sqrtf(u.x * u.x + u.y * u.y + u.z * u.z) + 1e-9f;
+				       p = { g.a[0] + u.x / l * rr, g.a[1] + u.y / l * rr, g.a[2] + u.z / l * rr };
+				       /* tangent: move the target perpendicular to the line of sight is approximated by a tiny random offset */ }
+				const float e = (r % 4 == 0) ? 0.0f : uni(-1, 1) * 1e-4f * (1.0f + fabsf(p.x) + fabsf(p.y) + fabsf(p.z));
+				d = { p.x + e - o.x, p.y - e - o.y, p.z + e - o.z };
+			}
+			if (r % 7 == 0) d.y *= 1e-6f;
+			const float len = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+			if (!(len > 1e-12f)) continue;
+			d = { d.x / len, d.y / len, d.z / len };
+			const float w[3] = { fabsf(d.x), fabsf(d.y), fabsf(d.z) };
+			if (!(w[0] >= 0x1p-30f && w[1] >= 0x1p-30f && w[2] >= 0x1p-30f)) continue;       /* (outside the window the kernel tests every object) */
+			const V inv = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };                               /* rcp_refined == RN(1/d) inside the window */
+			for (int i = 0; i < n; i++) {
+				float t = 0;
+				const bool hit = geom[(size_t) i].type == RT_GEOM_CUBE ? ref_box(o, d, geom[(size_t) i], t) : ref_sphere(o, d, geom[(size_t) i], t);
+				pairs++;
+				if (!(hit && t >= 0)) continue;
+				hits++;
+				float lo[3], hi[3];
+				rt_cull_object_box(geom[(size_t) i], info.margin, lo, hi);
+				const rt_cluster &K = cl[(size_t) owner[(size_t) i]];
+				const float clo[3] = { K.lo[0], K.lo[1], K.lo[2] }, chi[3] = { K.hi0, K.hi1, K.hi2 };
+				if (!may_touch(o, inv, lo, hi) || !may_touch(o, inv, clo, chi)) bad++;
+			}
+		}
+	}
+	printf("%llu %llu %llu %llu %llu\n", pairs, hits, bad, structure_bad, refused);
+	return bad || structure_bad ? 1 : 0;
+}

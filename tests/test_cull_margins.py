@@ -1,0 +1,17 @@
+"""csrc/rt_cull.h on the CPU: every object sits in exactly one cluster whose box contains its conservative box, and -- over random
+scenes at five scales and rays aimed at edges, corners and tangents -- no hit the reference's float tests report is ever missed
+by the conservative tests that decide whether an object is tested at all (tests/csrc/cull_check.cpp).  The check has teeth: with
+the margin and the discriminant allowance set to zero the same run reports 9 607 missed hits of 939 289; with the derived values, none."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_no_reference_hit_is_culled(tmp_path):
+    exe = tmp_path / "cull_check"
+    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-o", str(exe), os.path.join(HERE, "csrc", "cull_check.cpp"), "-lm"], check=True)
+    out = subprocess.run([str(exe), "40", "20000"], capture_output=True, text=True, timeout=600)
+    pairs, hits, bad, structure_bad, refused = (int(x) for x in out.stdout.split())
+    assert pairs > 2e8 and hits > 5e5 and refused < 20, out.stdout
+    assert bad == 0 and structure_bad == 0 and out.returncode == 0, out.stdout
