@@ -8,12 +8,13 @@
  * it, in a slab test whose margins exceed every rounding error of the reference's own tests:
  *
  *   - a box is tested as [lo - m, hi + m] with m = RT_CULL_MARGIN.  The reference's quotients (plane - o) / d are correctly
- *     rounded (relative error 2^-24); the cull's products (plane' - o) * RN(1/d) are within 2^-21 of theirs in relative terms.
- *     With every coordinate of the scene within S and ray origins within 2 S of the origin, |plane - o| <= 3 S <= 192 and the
- *     inflation moves an entry / exit parameter by m / |d| against an error of at most 192 * 2^-21 / |d| = 9.2e-5 / |d|:
- *     a margin of 21, on every axis, for every |d| (the ray directions the cull accepts are those of the shared-reciprocal
- *     division: 2^-30 <= |d| <= 2^20 on every axis).  "Entirely behind" is exit' < 0 on the inflated box: then the true exit
- *     is negative and the reference rejects the hit itself (t >= 0, scene.c:168).
+ *     rounded (relative error 2^-24).  The cull forms plane' * r - o * r with r = RN(1/d), one fused multiply-add per plane:
+ *     its error is at most 2^-23 |t| + 2^-24 |o| / |d|.  With every coordinate of the scene within S <= 64 and ray origins
+ *     within 2 S of the origin, |t| <= 3 S / |d|, so the error stays below 4.8e-7 S / |d| <= 3.1e-5 / |d|, while the inflation
+ *     moves an entry / exit parameter by m / |d| = 1.95e-3 / |d|: a margin of 63, on every axis, for every |d| (the ray
+ *     directions the cull accepts are those of the shared-reciprocal division: 2^-30 <= |d| <= 2^20 on every axis).
+ *     "Entirely behind" is exit' < 0 on the inflated box: then the true exit is negative and the reference rejects the hit
+ *     itself (t >= 0, scene.c:168).
  *   - a sphere is tested as the box centre +- h with h = sqrt(r^2 + E) + m.  The reference reports a sphere hit when its FLOAT
  *     discriminant b*b - 4*a*c is positive (scene.c:93-101), which a ray can reach although it passes outside the sphere:
  *     summing the roundings of oc, the two dot products, the squares and the final difference bounds the error of the

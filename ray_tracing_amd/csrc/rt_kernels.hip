@@ -43,7 +43,7 @@ struct Hit { float t; V3 n; int obj; };
 /* Development instrumentation (make stats): per-site counts of executions and of active lanes,
  * accumulated in a device array.  Compiled out of the product build. */
 #ifdef RT_STATS
-extern "C" { __device__ unsigned long long rt_stats[64]; }
+extern "C" { __device__ unsigned long long rt_stats[128]; }     /* sites 0..31: words 0..63 (50..57: the section stamps); 32..63: the culled trace */
 #ifdef RT_STATS_LIFETIMES_ONLY
 /* The per-site atomics slow a launch down a hundredfold and the section stamps by a third; what a look at the end of a
  * launch needs is the real pace: every wave writes four words of its own -- start, the time it found the pixel lists
@@ -78,6 +78,9 @@ extern "C" { __device__ unsigned long long rt_wave_log[4 * 8192]; }
 #define STAMP_DRY do {} while (0)
 #define STAMP_ROUND do {} while (0)
 #endif
+
+/* LDS written by some lanes of a wave is read by others of the same wave */
+RT_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 /* ---- LDS-resident scene ------------------------------------------------------------------- */
 
@@ -359,85 +362,159 @@ RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d, bool want_nor
  * are visited out of index order. */
 struct ClusterLDS { const float4 *rec; int count; float margin, origin_max; };      /* 3 x float4 per cluster (rt_cluster) */
 
-RT_DEV bool slab_may_touch(V3 o, V3 inv, V3 lo, V3 hi)
+/* the conservative slab test: parameters plane * (1/d) - o * (1/d), one fused multiply-add each (oi = o * inv is formed once per
+ * ray).  This is the cull's own arithmetic, not the reference's: its error -- 2^-23 |t| + 2^-24 |o| / |d| <= 3.1e-5 / |d| with
+ * coordinates within 64 and origins within 128 -- is what the margin of rt_cull.h (1.95e-3 / |d|) has to cover, 63 times over */
+RT_DEV bool slab_may_touch(V3 oi, V3 inv, V3 lo, V3 hi)
 {
-	const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
-	const float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
-	const float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+	const float ax = __builtin_fmaf(lo.x, inv.x, -oi.x), bx = __builtin_fmaf(hi.x, inv.x, -oi.x);
+	const float ay = __builtin_fmaf(lo.y, inv.y, -oi.y), by = __builtin_fmaf(hi.y, inv.y, -oi.y);
+	const float az = __builtin_fmaf(lo.z, inv.z, -oi.z), bz = __builtin_fmaf(hi.z, inv.z, -oi.z);
 	const float enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
 	const float leave = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
 	return enter <= leave && leave >= 0.0f;
 }
 
-RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, V3 o, V3 d, bool want_normal = true)
+/* the value lane `src` holds (every lane of the wave must be active: ds_bpermute reads registers of executing lanes) */
+RT_DEV float from_lane(float v, int src) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v))); }
+RT_DEV uint32_t from_lane(uint32_t v, int src) { return (uint32_t) __builtin_amdgcn_ds_bpermute(src << 2, (int) v); }
+
+/* ALL 64 lanes must call this (on: the lane has a ray); best = 64 words of 8 bytes of LDS of the calling wave.
+ *
+ * Step 2 is shared out evenly: a ray touches 11 clusters on average but the busiest of 64 rays 31 (1024 random objects,
+ * profiles/r04/stats_large_1024.txt) -- walking its own clusters, a wave took 31 steps at a quarter of its lanes.  Instead the
+ * (ray, cluster) pairs of the whole wave are numbered by a prefix sum over the lanes' counts and dealt 64 at a time: lane i
+ * takes pair 64 k + i, finds the lane whose ray it is by a binary search over the prefix sums, picks that lane's r-th cluster
+ * out of its mask, fetches the ray with ds_bpermute (no LDS memory: registers of another lane), tests the members' conservative
+ * boxes and then runs the exact tests on what is left; a hit goes to its ray with one 64-bit LDS minimum on the packed
+ * (distance, object index, -0 flag, entry axis) -- distances are >= 0, so their bit patterns order like the numbers, and among
+ * equal distances the lower index wins, as in the reference's scan (scene.c:168). */
+RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, unsigned long long *best, bool on, V3 o, V3 d, bool want_normal = true)
 {
+	const int lane = threadIdx.x & 63;
 	const RayPrep rp = prepare_ray<true>(o, d);
 	const float omax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z));
 	/* the margins are proved for directions inside the window of the shared-reciprocal division and origins within twice the
 	 * scene's extent; a wave with any other ray tests every object */
-	if (!wave_all(rp.inv_ok && omax <= cl.origin_max)) return nearest_hit_fast(sc, n, o, d, want_normal);
-	STAT(9);
+	if (!wave_all(!on || (rp.inv_ok && omax <= cl.origin_max))) {
+		Hit h; h.t = 0.0f; h.obj = -1; h.n = mk3(0, 0, 0);
+		if (on) h = nearest_hit_fast(sc, n, o, d, want_normal);
+		return h;
+	}
+	if (on) STAT(9);
 	/* 1. which clusters may this ray touch?  (wave-uniform loop: one box per step, read once for all lanes) */
 	uint32_t mask[RT_MAX_CLUSTERS / 32];
+	const V3 oi = mk3(o.x * rp.inv.x, o.y * rp.inv.y, o.z * rp.inv.z);
 #pragma unroll
 	for (int w = 0; w < RT_MAX_CLUSTERS / 32; w++) {
 		uint32_t bits = 0u;
 		const int first = 32 * w, last = cl.count < first + 32 ? cl.count : first + 32;
 		for (int c = first; c < last; c++) {
+			STAT(32);
 			const float4 k0 = cl.rec[3 * c], k1 = cl.rec[3 * c + 1];
-			if (slab_may_touch(o, rp.inv, mk3(k0.x, k0.y, k0.z), mk3(k0.w, k1.x, k1.y))) bits |= 1u << (c - first);
+			if (slab_may_touch(oi, rp.inv, mk3(k0.x, k0.y, k0.z), mk3(k0.w, k1.x, k1.y))) bits |= 1u << (c - first);
 		}
-		mask[w] = bits;
+		mask[w] = on ? bits : 0u;
 	}
-	/* 2. every lane its own clusters: members' conservative boxes first, exact tests on what is left */
-	float best_t = 3.402823466e+38f;
-	int best_obj = -1, best_axis = 0;
+	static_assert(RT_MAX_CLUSTERS == 128, "the pair numbering below reads a lane's clusters as four 32-bit words");
+	/* 2. the wave's (ray, cluster) pairs, numbered: inclusive prefix sum of the lanes' counts */
+	const uint32_t count = (uint32_t) (__popc(mask[0]) + __popc(mask[1]) + __popc(mask[2]) + __popc(mask[3]));
+	uint32_t upto = count;
 #pragma unroll
-	for (int w = 0; w < RT_MAX_CLUSTERS / 32; w++) {
-		uint32_t todo = mask[w];
-		while (__ballot(todo != 0u) != 0ull) {
-			if (todo != 0u) {
-				const int c = 32 * w + (int) __builtin_ctz(todo);
-				todo &= todo - 1u;
-				const unsigned short *member = reinterpret_cast<const unsigned short*>(cl.rec + 3 * c + 2);
-				uint32_t cand = 0u;
+	for (int step = 1; step < 64; step <<= 1) {
+		const uint32_t below = from_lane(upto, lane >= step ? lane - step : lane);
+		if (lane >= step) upto += below;
+	}
+	const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) upto, 63);
+	best[lane] = ~0ull;
+	wave_fence();
+	for (uint32_t base = 0; base < total; base += 64u) {
+		STAT(33);
+		const uint32_t q = base + (uint32_t) lane;
+		const bool mine = q < total;
+		/* whose ray: the first lane whose inclusive prefix exceeds q */
+		int src = 0;
 #pragma unroll
-				for (int j = 0; j < RT_CLUSTER_SIZE; j++) {
-					const uint32_t idx = member[j];
-					if (idx != 0xffffu) {
-						const float4 g0 = sc.geom[2 * idx], g1 = sc.geom[2 * idx + 1];
-						const bool box = __float_as_int(g1.z) == RT_GEOM_CUBE;
-						const float e = box ? cl.margin : g1.x;                       /* a sphere's record carries its half extent (rt_cull.h) */
-						const V3 lo = mk3(g0.x - e, g0.y - e, g0.z - e);
-						const V3 hi = mk3((box ? g0.w : g0.x) + e, (box ? g1.x : g0.y) + e, (box ? g1.y : g0.z) + e);
-						if (slab_may_touch(o, rp.inv, lo, hi)) cand |= 1u << j;
-					}
-				}
-				while (cand != 0u) {
-					const int idx = (int) member[__builtin_ctz(cand)];
-					cand &= cand - 1u;
+		for (int bit = 32; bit >= 1; bit >>= 1) {
+			const uint32_t v = from_lane(upto, src + bit - 1);
+			if (v <= q) src += bit;
+		}
+		src = src > 63 ? 63 : src;
+		uint32_t r = q - (from_lane(upto, src) - from_lane(count, src));        /* its r-th cluster */
+		const uint32_t m0 = from_lane(mask[0], src), m1 = from_lane(mask[1], src), m2 = from_lane(mask[2], src), m3 = from_lane(mask[3], src);
+		const V3 so = mk3(from_lane(o.x, src), from_lane(o.y, src), from_lane(o.z, src));
+		const V3 sd = mk3(from_lane(d.x, src), from_lane(d.y, src), from_lane(d.z, src));
+		RayPrep sp;
+		sp.inv = mk3(from_lane(rp.inv.x, src), from_lane(rp.inv.y, src), from_lane(rp.inv.z, src));
+		sp.dd = from_lane(rp.dd, src);
+		const V3 soi = mk3(from_lane(oi.x, src), from_lane(oi.y, src), from_lane(oi.z, src));
+		if (mine) {
+			sp.inv_ok = true;
+			sp.den = (double) (2.0f * sp.dd); sp.den_ok = near_one(sp.dd); sp.rden = rcp_twice_near_one(sp.dd);     /* as prepare_ray() forms them */
+			int word = 0;
+			uint32_t mm = m0;
+			const uint32_t c0 = (uint32_t) __popc(m0), c1 = (uint32_t) __popc(m1), c2 = (uint32_t) __popc(m2);
+			if (r >= c0) { r -= c0; word = 1; mm = m1; if (r >= c1) { r -= c1; word = 2; mm = m2; if (r >= c2) { r -= c2; word = 3; mm = m3; } } }
+			int pos = 0;
+			uint32_t t_;
+			t_ = (uint32_t) __popc(mm & 0xffffu); if (r >= t_) { pos += 16; r -= t_; mm >>= 16; }
+			t_ = (uint32_t) __popc(mm & 0xffu);   if (r >= t_) { pos += 8;  r -= t_; mm >>= 8; }
+			t_ = (uint32_t) __popc(mm & 0xfu);    if (r >= t_) { pos += 4;  r -= t_; mm >>= 4; }
+			t_ = (uint32_t) __popc(mm & 0x3u);    if (r >= t_) { pos += 2;  r -= t_; mm >>= 2; }
+			t_ = mm & 1u;                         if (r >= t_) { pos += 1; }
+			const int c = 32 * word + pos;
+			const unsigned short *member = reinterpret_cast<const unsigned short*>(cl.rec + 3 * c + 2);
+			uint32_t cand = 0u;
+#pragma unroll
+			for (int j = 0; j < RT_CLUSTER_SIZE; j++) {
+				const uint32_t idx = member[j];
+				if (idx != 0xffffu) {
+					STAT(34);
 					const float4 g0 = sc.geom[2 * idx], g1 = sc.geom[2 * idx + 1];
-					float t = 0.0f; int axis = 0; bool hit = false;
-					if (__float_as_int(g1.z) == RT_GEOM_CUBE)
-						hit = box_entry_fast(o, d, rp, true, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), t, axis);
-					else
-						hit = ball_entry_fast(o, d, rp, mk3(g0.x, g0.y, g0.z), g0.w, t);
-					if (hit && t >= 0 && (t < best_t || (t == best_t && idx < best_obj))) { best_t = t; best_obj = idx; best_axis = axis; }
+					const bool box = __float_as_int(g1.z) == RT_GEOM_CUBE;
+					const float e = box ? cl.margin : g1.x;                       /* a sphere's record carries its half extent (rt_cull.h) */
+					const V3 lo = mk3(g0.x - e, g0.y - e, g0.z - e);
+					const V3 hi = mk3((box ? g0.w : g0.x) + e, (box ? g1.x : g0.y) + e, (box ? g1.y : g0.z) + e);
+					if (slab_may_touch(soi, sp.inv, lo, hi)) cand |= 1u << j;
+				}
+			}
+			while (cand != 0u) {
+				STAT(35);
+				const uint32_t idx = member[__builtin_ctz(cand)];
+				cand &= cand - 1u;
+				const float4 g0 = sc.geom[2 * idx], g1 = sc.geom[2 * idx + 1];
+				float t = 0.0f; int axis = 0; bool hit = false;
+				if (__float_as_int(g1.z) == RT_GEOM_CUBE)
+					hit = box_entry_fast(so, sd, sp, true, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), t, axis);
+				else
+					hit = ball_entry_fast(so, sd, sp, mk3(g0.x, g0.y, g0.z), g0.w, t);
+				if (hit && t >= 0) {
+					const uint32_t tb = __float_as_uint(t);                          /* t >= 0: +0 ... +inf, or -0 (0x80000000), which orders as 0 */
+					const unsigned long long key = ((unsigned long long) (tb & 0x7fffffffu) << 32) | ((unsigned long long) idx << 3) | (unsigned long long) ((tb >> 31) << 2) | (unsigned long long) axis;
+					__hip_atomic_fetch_min(best + src, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 				}
 			}
 		}
 	}
-	Hit best; best.t = best_t; best.obj = best_obj; best.n = mk3(0, 0, 0);
-	if (best_obj >= 0 && want_normal) {
-		const float4 g0 = sc.geom[2 * best_obj], g1 = sc.geom[2 * best_obj + 1];
-		if (__float_as_int(g1.z) == RT_GEOM_CUBE) {
-			const float dc = best_axis == 0 ? d.x : (best_axis == 1 ? d.y : d.z);
-			const float s = dc > 0 ? -1.0f : 1.0f;                               /* scene.c:71-73 */
-			best.n = mk3(best_axis == 0 ? s : 0.0f, best_axis == 1 ? s : 0.0f, best_axis == 2 ? s : 0.0f);
-		} else
-			best.n = unit3_fast(sub3(madd3(o, d, best_t), mk3(g0.x, g0.y, g0.z)));   /* scene.c:146-147 */
+	wave_fence();
+	const unsigned long long won = best[lane];
+	Hit hit; hit.t = 3.402823466e+38f; hit.obj = -1; hit.n = mk3(0, 0, 0);
+	if (on && won != ~0ull) {
+		const int best_axis = (int) (won & 3ull), best_obj = (int) ((won >> 3) & 0xffffull);
+		hit.t = __uint_as_float((uint32_t) (won >> 32) | ((uint32_t) ((won >> 2) & 1ull) << 31));
+		hit.obj = best_obj;
+		if (want_normal) {
+			const float4 g0 = sc.geom[2 * best_obj], g1 = sc.geom[2 * best_obj + 1];
+			if (__float_as_int(g1.z) == RT_GEOM_CUBE) {
+				const float dc = best_axis == 0 ? d.x : (best_axis == 1 ? d.y : d.z);
+				const float s = dc > 0 ? -1.0f : 1.0f;                               /* scene.c:71-73 */
+				hit.n = mk3(best_axis == 0 ? s : 0.0f, best_axis == 1 ? s : 0.0f, best_axis == 2 ? s : 0.0f);
+			} else
+				hit.n = unit3_fast(sub3(madd3(o, d, hit.t), mk3(g0.x, g0.y, g0.z)));   /* scene.c:146-147 */
+		}
 	}
-	return best;
+	wave_fence();                   /* (the next call of this wave clears `best` again) */
+	return hit;
 }
 
 /* the clusters behind the scene records in LDS (the caller has staged the scene: lds[0 .. 6 n)) */
@@ -720,6 +797,7 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 	ClusterLDS cl; cl.rec = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
 	if (CULL) cl = stage_clusters(L, lds + 2 * n);
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	unsigned long long *cull_best = reinterpret_cast<unsigned long long*>(lds + 2 * n + 3 * L.num_clusters) + 64 * wave;     /* (CULL) 64 x 8 B per wave */
 	const int tiles_x = (L.width + 7) >> 3, tiles_y = (L.local_rows + 7) >> 3;
 	const unsigned int total = (unsigned int) (tiles_x * tiles_y);
 	/* the workgroup's share of the blocks: blocks_per_group consecutive ones.  Its object pixels go to list
@@ -737,14 +815,21 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 		const int j = global_row(L, lr);
 		int obj = -2, known = 0;                        /* outside the frame */
 		V3 a = mk3(0, 0, 0), nn = mk3(0, 0, 0), pd = mk3(0, 0, 0);
-		if (i < L.width && lr < L.local_rows && j < L.height) {
+		const bool inside = i < L.width && lr < L.local_rows && j < L.height;
+		Hit culled; culled.t = 0.0f; culled.obj = -1; culled.n = mk3(0, 0, 0);
+		if (CULL) {         /* the culled trace shares its work out over the wave: every lane takes part, with or without a ray of its own */
+			float u = 1.0f - (float) (inside ? i : 0) / (float) L.u_den, v = 1.0f - (float) (inside ? j : 0) / (float) L.v_den;
+			const V3 cd = unit3_fast(primary_dir(L, u, v));
+			culled = nearest_hit_culled(sc, n, cl, cull_best, inside, cam, cd);
+		}
+		if (inside) {
 			float u = (float) i / (float) L.u_den;      /* main.c:293-296 */
 			float v = (float) j / (float) L.v_den;
 			u = 1.0f - u;
 			v = 1.0f - v;
 			pd = primary_dir(L, u, v);
 			const V3 dn = FAST ? unit3_fast(pd) : unit3(pd);                           /* scene.c:158 */
-			const Hit hit = CULL ? nearest_hit_culled(sc, n, cl, cam, dn) : (FAST ? nearest_hit_fast(sc, n, cam, dn) : nearest_hit(sc, n, cam, dn));
+			const Hit hit = CULL ? culled : (FAST ? nearest_hit_fast(sc, n, cam, dn) : nearest_hit(sc, n, cam, dn));
 			obj = hit.obj;
 			if (obj >= 0) {
 				a = madd3(cam, dn, hit.t);                                               /* scene.c:186 */
@@ -873,7 +958,6 @@ RT_DEV rt_launch_cold cold_view()
  * slots cost 58 % on C1, 48 instead of 32 per stream buy 2 % there and 9 % at 1024 samples per pixel.) */
 static_assert(4 * sizeof(WaveLDS) + 96 * 17 <= 160 * 1024 / 4, "WaveLDS grew: scenes of up to 17 objects no longer fit four workgroups per CU");
 
-RT_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 template <bool FAST> RT_DEV V3 unit3_sel(V3 v) { return FAST ? unit3_fast(v) : unit3(v); }
 
@@ -930,6 +1014,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	ClusterLDS cl; cl.rec = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
 	if (CULL) cl = stage_clusters(L, lds + 2 * n);
 	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (CULL ? 2 * n + 3 * L.num_clusters : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
+	unsigned long long *cull_best = reinterpret_cast<unsigned long long*>(reinterpret_cast<WaveLDS*>(lds + 2 * n + 3 * L.num_clusters) + RT_BLOCK / 64) + 64 * wave;   /* (CULL) */
 
 	const float inv_spp = 1.0f / (float) L.spp;
 	const unsigned int spp = (unsigned int) L.spp;
@@ -1295,12 +1380,20 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		auto tap_answer = [&](int meta, int obj) { W.tap[(meta >> 12) & 3][((meta >> 8) & 15) - 2][meta & 255] = (short) obj; };
 		auto trace_taps = [&](int count) {         /* the `count` <= 64 oldest taps */
 			STAT(12);
+			if (CULL) {            /* every lane takes part in the culled trace (its work is shared out over the wave); lanes without a tap pass `on` = false */
+				const bool on = lane < count;
+				V3 o = mk3(0, 0, 0), d = mk3(1, 0, 0); int meta = 0;
+				if (on) tap_ray((q_head + (unsigned int) lane) & (WF_QUEUE - 1), o, d, meta);
+				const V3 dn = unit3_sel<FAST>(d);
+				const Hit hit = nearest_hit_culled(sc, n, cl, cull_best, on, o, dn, false);
+				if (on) tap_answer(meta, hit.obj);
+			} else
 			if (lane < count) {
 				STAT(13);
 				V3 o, d; int meta;
 				tap_ray((q_head + (unsigned int) lane) & (WF_QUEUE - 1), o, d, meta);
 				const V3 dn = unit3_sel<FAST>(d);                                         /* scene.c:158 */
-				const Hit hit = CULL ? nearest_hit_culled(sc, n, cl, o, dn, false) : (FAST ? NEAREST_HIT_TUNED(sc, n, o, dn, false) : nearest_hit(sc, n, o, dn));
+				const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, n, o, dn, false) : nearest_hit(sc, n, o, dn);
 				tap_answer(meta, hit.obj);
 			}
 			q_head += (unsigned int) count;
@@ -1343,10 +1436,13 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		/* ---- 4. the bounce rays: every lane traces its own, straight from its registers -- no queue, no LDS ---------- */
 		if (__ballot(emit_main) != 0ull) {
 			STAT(12);
+			Hit culled; culled.t = 0.0f; culled.obj = -1; culled.n = mk3(0, 0, 0);
+			if (CULL)              /* (all lanes: see trace_taps) */
+				culled = nearest_hit_culled(sc, n, cl, cull_best, emit_main, ray_o, unit3_sel<FAST>(emit_main ? ray_d : mk3(1, 0, 0)), true);
 			if (emit_main) {
 				STAT(13);
 				const V3 dn = unit3_sel<FAST>(ray_d);                                     /* scene.c:158 */
-				const Hit hit = CULL ? nearest_hit_culled(sc, n, cl, ray_o, dn, true) : (FAST ? NEAREST_HIT_TUNED(sc, n, ray_o, dn, true) : nearest_hit(sc, n, ray_o, dn));
+				const Hit hit = CULL ? culled : (FAST ? NEAREST_HIT_TUNED(sc, n, ray_o, dn, true) : nearest_hit(sc, n, ray_o, dn));
 				hobj = hit.obj; hn = hit.n;
 				hp = hit.obj >= 0 ? madd3(ray_o, dn, hit.t)                               /* scene.c:186 */
 				                  : dn;                 /* left the scene: the sky is looked up in that direction (main.c:170) */
@@ -1956,12 +2052,12 @@ hipError_t rt_launch_selftest(int which, uint64_t seed, int blocks, int iters, u
 }
 
 #ifdef RT_STATS
-extern "C" __attribute__((visibility("default"))) int rt_stats_read(unsigned long long out[64], int reset)
+extern "C" __attribute__((visibility("default"))) int rt_stats_read(unsigned long long out[128], int reset)
 {
 	if (hipDeviceSynchronize() != hipSuccess) return -2;
-	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rt_stats), 64 * sizeof(unsigned long long)) != hipSuccess) return -2;
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rt_stats), 128 * sizeof(unsigned long long)) != hipSuccess) return -2;
 	if (reset) {
-		unsigned long long zero[64] = {0};
+		unsigned long long zero[128] = {0};
 		if (hipMemcpyToSymbol(HIP_SYMBOL(rt_stats), zero, sizeof(zero)) != hipSuccess) return -2;
 	}
 	return 0;
@@ -2022,7 +2118,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	}
 	/* persistent waves: as many workgroups as fit on the chip at once, capped by the work */
 	const bool cull = L.num_clusters > 0 && L.clusters != nullptr && scene_fast_ok && variant == 0;
-	size_t lds = cull ? (size_t) L.num_objects * sizeof(rt_geom) + (size_t) L.num_clusters * sizeof(rt_cluster) + (RT_BLOCK / 64) * sizeof(WaveLDS)
+	size_t lds = cull ? (size_t) L.num_objects * sizeof(rt_geom) + (size_t) L.num_clusters * sizeof(rt_cluster) + (RT_BLOCK / 64) * (sizeof(WaveLDS) + 64 * sizeof(unsigned long long))
 	                  : rt_wavefront_lds_bytes(L.num_objects);
 	int per_cu = (int) ((160u * 1024u) / lds);
 	if (per_cu < 1) per_cu = 1;
@@ -2054,7 +2150,8 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	} else {
 		unsigned int groups; int per_group;
 		rt_primary_geometry(L.width, L.local_rows, num_cus, &groups, &per_group);
-		const size_t plds = cull ? (size_t) L.num_objects * sizeof(rt_geom) + (size_t) L.num_clusters * sizeof(rt_cluster) : rt_scene_lds_bytes(L.num_objects);
+		const size_t plds = cull ? (size_t) L.num_objects * sizeof(rt_geom) + (size_t) L.num_clusters * sizeof(rt_cluster) + (RT_BLOCK / 64) * 64 * sizeof(unsigned long long)
+		                         : rt_scene_lds_bytes(L.num_objects);
 		if (variant == 2 || !scene_fast_ok)
 			hipLaunchKernelGGL(rt_primary_pass<false>, dim3(groups), dim3(RT_BLOCK), plds, stream, L, per_group);
 		else if (cull)

@@ -48,11 +48,12 @@ static bool ref_sphere(V o, V d, const rt_geom &g, float &t)       /* scene.c:79
 	return true;
 }
 
-static bool may_touch(V o, V inv, const float lo[3], const float hi[3])     /* slab_may_touch of rt_kernels.hip */
+static bool may_touch(V o, V inv, const float lo[3], const float hi[3])     /* slab_may_touch of rt_kernels.hip: plane * inv - o * inv, fused */
 {
-	const float ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
-	const float ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
-	const float az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
+	const V oi = { o.x * inv.x, o.y * inv.y, o.z * inv.z };
+	const float ax = fmaf(lo[0], inv.x, -oi.x), bx = fmaf(hi[0], inv.x, -oi.x);
+	const float ay = fmaf(lo[1], inv.y, -oi.y), by = fmaf(hi[1], inv.y, -oi.y);
+	const float az = fmaf(lo[2], inv.z, -oi.z), bz = fmaf(hi[2], inv.z, -oi.z);
 	const float enter = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
 	const float leave = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
 	return enter <= leave && leave >= 0.0f;

@@ -32,3 +32,13 @@ def test_single_rank_needs_no_launcher():
                        capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     assert _last_json(p.stdout)["world"] == 1
+
+
+def test_native_multi_does_not_launch_ranks():
+    """`bench.py --gpus N --native-multi` is ONE process that drives the N devices through rt_multi_* (ncclCommInitAll inside the
+    library): no torch.distributed.run child, no rendezvous -- the launch check sees a world of one."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--native-multi", "--launch-check"], capture_output=True, text=True,
+                       timeout=120, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = _last_json(p.stdout)
+    assert line["launch_check"] is True and line["world"] == 1 and line["backend"] is None
