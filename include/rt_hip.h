@@ -137,7 +137,9 @@ RT_API int rt_set_tuning(rt_context *ctx, const rt_tuning *tuning);
 /* ---- the hot path: replaces start_workers()+worker()+update_frame() ------------------------ */
 /* Renders the whole frame (world must be 1) into caller-allocated host memory: width*height
  * Vector3, row-major, frame[j*width+i], row 0 = bottom of the displayed image, values in [0,1] --
- * exactly what update_frame() hands to move_frame_to_the_gpu() (main.c:467-479). */
+ * exactly what update_frame() hands to move_frame_to_the_gpu() (main.c:467-479).  Returns RT_CANCELLED when rt_cancel() cut the
+ * launch short, and -- the blocking call looks at the launch's counters before it returns -- RT_ERR_DEVICE when the launch ended
+ * with object pixels that no wave fetched: an incomplete frame is an error, never a frame with a hole in it. */
 RT_API int rt_render(rt_context *ctx, const rt_render_params *params, Vector3 *frame_out);
 
 /* Same, but the destination is DEVICE memory (rt_strip_rows()*width*12 bytes) and the call only
