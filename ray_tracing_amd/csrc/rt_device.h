@@ -46,10 +46,13 @@ typedef struct {
 
 /* Large scenes (more objects than a scene-specialised kernel takes): objects grouped into clusters of up to RT_CLUSTER_SIZE
  * spatially close ones, so that a ray first asks RT_CLUSTER_SIZE times fewer boxes "could anything in here be hit at all"
- * (rt_kernels.hip nearest_hit_culled, rt_cull.h).  48 B: a conservative bounding box of the members' own conservative boxes,
+ * (rt_kernels.hip nearest_hit_culled, rt_cull.h).  32 + 2 x RT_CLUSTER_SIZE bytes: a conservative bounding box of the members' own conservative boxes,
  * and the members' object indices (0xffff: none). */
+#ifndef RT_CLUSTER_SIZE
 #define RT_CLUSTER_SIZE 8
+#endif
 #define RT_MAX_CLUSTERS 128
+#define RT_CLUSTER_F4 ((32 + 2 * RT_CLUSTER_SIZE) / 16)      /* a cluster as float4 words: 2 of box and count, then the members */
 typedef struct {
 	float          lo[3], hi0;
 	float          hi1, hi2;

@@ -360,7 +360,7 @@ RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d, bool want_nor
  * that pass.  The exact tests are the very functions of the linear scan, so every distance is the same number; the scan's
  * "lowest index among equal distances" (strict `<` in index order, scene.c:168) is kept explicitly, because the clusters
  * are visited out of index order. */
-struct ClusterLDS { const float4 *rec; int count; float margin, origin_max; };      /* 3 x float4 per cluster (rt_cluster) */
+struct ClusterLDS { const float4 *rec; int count; float margin, origin_max; };      /* RT_CLUSTER_F4 x float4 per cluster (rt_cluster) */
 
 /* the conservative slab test: parameters plane * (1/d) - o * (1/d), one fused multiply-add each (oi = o * inv is formed once per
  * ray).  This is the cull's own arithmetic, not the reference's: its error -- 2^-23 |t| + 2^-24 |o| / |d| <= 3.1e-5 / |d| with
@@ -411,7 +411,7 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, u
 		const int first = 32 * w, last = cl.count < first + 32 ? cl.count : first + 32;
 		for (int c = first; c < last; c++) {
 			STAT(32);
-			const float4 k0 = cl.rec[3 * c], k1 = cl.rec[3 * c + 1];
+			const float4 k0 = cl.rec[RT_CLUSTER_F4 * c], k1 = cl.rec[RT_CLUSTER_F4 * c + 1];
 			if (slab_may_touch(oi, rp.inv, mk3(k0.x, k0.y, k0.z), mk3(k0.w, k1.x, k1.y))) bits |= 1u << (c - first);
 		}
 		mask[w] = on ? bits : 0u;
@@ -463,7 +463,7 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, u
 			t_ = (uint32_t) __popc(mm & 0x3u);    if (r >= t_) { pos += 2;  r -= t_; mm >>= 2; }
 			t_ = mm & 1u;                         if (r >= t_) { pos += 1; }
 			const int c = 32 * word + pos;
-			const unsigned short *member = reinterpret_cast<const unsigned short*>(cl.rec + 3 * c + 2);
+			const unsigned short *member = reinterpret_cast<const unsigned short*>(cl.rec + RT_CLUSTER_F4 * c + 2);
 			uint32_t cand = 0u;
 #pragma unroll
 			for (int j = 0; j < RT_CLUSTER_SIZE; j++) {
@@ -521,7 +521,7 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, u
 RT_DEV ClusterLDS stage_clusters(const rt_launch &L, float4 *dst)
 {
 	const float4 *src = reinterpret_cast<const float4*>(L.clusters);
-	for (int i = threadIdx.x; i < 3 * L.num_clusters; i += RT_BLOCK) dst[i] = src[i];
+	for (int i = threadIdx.x; i < RT_CLUSTER_F4 * L.num_clusters; i += RT_BLOCK) dst[i] = src[i];
 	__syncthreads();
 	ClusterLDS cl; cl.rec = dst; cl.count = L.num_clusters; cl.margin = L.cull_margin; cl.origin_max = L.cull_origin_max;
 	return cl;
@@ -797,7 +797,7 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 	ClusterLDS cl; cl.rec = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
 	if (CULL) cl = stage_clusters(L, lds + 2 * n);
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	unsigned long long *cull_best = reinterpret_cast<unsigned long long*>(lds + 2 * n + 3 * L.num_clusters) + 64 * wave;     /* (CULL) 64 x 8 B per wave */
+	unsigned long long *cull_best = reinterpret_cast<unsigned long long*>(lds + 2 * n + RT_CLUSTER_F4 * L.num_clusters) + 64 * wave;     /* (CULL) 64 x 8 B per wave */
 	const int tiles_x = (L.width + 7) >> 3, tiles_y = (L.local_rows + 7) >> 3;
 	const unsigned int total = (unsigned int) (tiles_x * tiles_y);
 	/* the workgroup's share of the blocks: blocks_per_group consecutive ones.  Its object pixels go to list
@@ -1013,8 +1013,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	/* large scenes: the clusters of rt_cull.h behind the scene records (such scenes have no lit-taps table: it needs <= 64 objects) */
 	ClusterLDS cl; cl.rec = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
 	if (CULL) cl = stage_clusters(L, lds + 2 * n);
-	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (CULL ? 2 * n + 3 * L.num_clusters : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
-	unsigned long long *cull_best = reinterpret_cast<unsigned long long*>(reinterpret_cast<WaveLDS*>(lds + 2 * n + 3 * L.num_clusters) + RT_BLOCK / 64) + 64 * wave;   /* (CULL) */
+	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (CULL ? 2 * n + RT_CLUSTER_F4 * L.num_clusters : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
+	unsigned long long *cull_best = reinterpret_cast<unsigned long long*>(reinterpret_cast<WaveLDS*>(lds + 2 * n + RT_CLUSTER_F4 * L.num_clusters) + RT_BLOCK / 64) + 64 * wave;   /* (CULL) */
 
 	const float inv_spp = 1.0f / (float) L.spp;
 	const unsigned int spp = (unsigned int) L.spp;
@@ -2071,7 +2071,7 @@ size_t rt_counter_bytes() { return RT_COUNTER_BYTES; }
 size_t rt_scene_lds_bytes(int num_objects) { return (size_t) num_objects * (sizeof(rt_geom) + sizeof(rt_shade)); }
 
 size_t rt_wavefront_lds_bytes(int num_objects) { return rt_scene_lds_bytes(num_objects) + (RT_BLOCK / 64) * sizeof(WaveLDS); }
-static_assert(sizeof(rt_cluster) == 48, "the kernels read a cluster as three float4");
+static_assert(sizeof(rt_cluster) == 16 * RT_CLUSTER_F4 && RT_CLUSTER_SIZE % 8 == 0 && RT_CLUSTER_SIZE <= 32, "the kernels read a cluster as RT_CLUSTER_F4 float4 words");
 /* rt_first_bounce_spec (experiment): per wave 3 x 8 x 65 floats of colours */
 size_t rt_first_bounce_lds_bytes(int num_objects) { return rt_scene_lds_bytes(num_objects) + (RT_BLOCK / 64) * (size_t) (3 * 8 * 65 * sizeof(float)); }
 
