@@ -92,12 +92,22 @@ struct SceneLDS {
 /* Large scenes (the culled kernels): only the geometry goes to LDS -- 32 B an object, read per lane by the members' tests --;
  * the shading records, 64 B an object and touched once per bounce, are read from memory (L2), so that a scene of 1024 objects
  * leaves room for two workgroups per CU instead of one (one wave per SIMD is latency-bound: 22 vs 12 ms on C1). */
+#ifdef RT_CULL_GEOM_GLOBAL      /* experiment: the members' geometry from memory too -- no LDS for it, three workgroups per CU at 1024 objects */
+#define CULL_GEOM_F4(n) 0
+#else
+#define CULL_GEOM_F4(n) (2 * (n))
+#endif
 RT_DEV SceneLDS stage_geometry(const rt_launch &L, float4 *lds, int n)
 {
 	const float4 *g = reinterpret_cast<const float4*>(L.geom);
-	for (int i = threadIdx.x; i < 2 * n; i += RT_BLOCK) lds[i] = g[i];
+	for (int i = threadIdx.x; i < CULL_GEOM_F4(n); i += RT_BLOCK) lds[i] = g[i];
 	__syncthreads();
-	SceneLDS sc; sc.geom = lds; sc.shade = reinterpret_cast<const float4*>(L.shade);
+	SceneLDS sc; sc.shade = reinterpret_cast<const float4*>(L.shade);
+#ifdef RT_CULL_GEOM_GLOBAL
+	sc.geom = g;
+#else
+	sc.geom = lds;
+#endif
 	return sc;
 }
 
@@ -795,9 +805,9 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 	const int n = L.num_objects;
 	const SceneLDS sc = CULL ? stage_geometry(L, lds, n) : stage_scene(L, lds, n);
 	ClusterLDS cl; cl.rec = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
-	if (CULL) cl = stage_clusters(L, lds + 2 * n);
+	if (CULL) cl = stage_clusters(L, lds + CULL_GEOM_F4(n));
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	unsigned long long *cull_best = reinterpret_cast<unsigned long long*>(lds + 2 * n + RT_CLUSTER_F4 * L.num_clusters) + 64 * wave;     /* (CULL) 64 x 8 B per wave */
+	unsigned long long *cull_best = reinterpret_cast<unsigned long long*>(lds + CULL_GEOM_F4(n) + RT_CLUSTER_F4 * L.num_clusters) + 64 * wave;     /* (CULL) 64 x 8 B per wave */
 	const int tiles_x = (L.width + 7) >> 3, tiles_y = (L.local_rows + 7) >> 3;
 	const unsigned int total = (unsigned int) (tiles_x * tiles_y);
 	/* the workgroup's share of the blocks: blocks_per_group consecutive ones.  Its object pixels go to list
@@ -1012,9 +1022,9 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	const bool grids_in_lds = L.lit_grids_in_lds != 0;
 	/* large scenes: the clusters of rt_cull.h behind the scene records (such scenes have no lit-taps table: it needs <= 64 objects) */
 	ClusterLDS cl; cl.rec = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
-	if (CULL) cl = stage_clusters(L, lds + 2 * n);
-	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (CULL ? 2 * n + RT_CLUSTER_F4 * L.num_clusters : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
-	unsigned long long *cull_best = reinterpret_cast<unsigned long long*>(reinterpret_cast<WaveLDS*>(lds + 2 * n + RT_CLUSTER_F4 * L.num_clusters) + RT_BLOCK / 64) + 64 * wave;   /* (CULL) */
+	if (CULL) cl = stage_clusters(L, lds + CULL_GEOM_F4(n));
+	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (CULL ? CULL_GEOM_F4(n) + RT_CLUSTER_F4 * L.num_clusters : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
+	unsigned long long *cull_best = reinterpret_cast<unsigned long long*>(reinterpret_cast<WaveLDS*>(lds + CULL_GEOM_F4(n) + RT_CLUSTER_F4 * L.num_clusters) + RT_BLOCK / 64) + 64 * wave;   /* (CULL) */
 
 	const float inv_spp = 1.0f / (float) L.spp;
 	const unsigned int spp = (unsigned int) L.spp;
@@ -2118,7 +2128,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	}
 	/* persistent waves: as many workgroups as fit on the chip at once, capped by the work */
 	const bool cull = L.num_clusters > 0 && L.clusters != nullptr && scene_fast_ok && variant == 0;
-	size_t lds = cull ? (size_t) L.num_objects * sizeof(rt_geom) + (size_t) L.num_clusters * sizeof(rt_cluster) + (RT_BLOCK / 64) * (sizeof(WaveLDS) + 64 * sizeof(unsigned long long))
+	size_t lds = cull ? (size_t) CULL_GEOM_F4(L.num_objects) * 16 + (size_t) L.num_clusters * sizeof(rt_cluster) + (RT_BLOCK / 64) * (sizeof(WaveLDS) + 64 * sizeof(unsigned long long))
 	                  : rt_wavefront_lds_bytes(L.num_objects);
 	int per_cu = (int) ((160u * 1024u) / lds);
 	if (per_cu < 1) per_cu = 1;
@@ -2150,7 +2160,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	} else {
 		unsigned int groups; int per_group;
 		rt_primary_geometry(L.width, L.local_rows, num_cus, &groups, &per_group);
-		const size_t plds = cull ? (size_t) L.num_objects * sizeof(rt_geom) + (size_t) L.num_clusters * sizeof(rt_cluster) + (RT_BLOCK / 64) * 64 * sizeof(unsigned long long)
+		const size_t plds = cull ? (size_t) CULL_GEOM_F4(L.num_objects) * 16 + (size_t) L.num_clusters * sizeof(rt_cluster) + (RT_BLOCK / 64) * 64 * sizeof(unsigned long long)
 		                         : rt_scene_lds_bytes(L.num_objects);
 		if (variant == 2 || !scene_fast_ok)
 			hipLaunchKernelGGL(rt_primary_pass<false>, dim3(groups), dim3(RT_BLOCK), plds, stream, L, per_group);
