@@ -13,6 +13,7 @@ through) and logged.  One GPU is enough: ranks share it (gloo moves the strips),
   stress_frame_loop.py rccl1   [frames]    one rank: TiledFrame(force_collective) over a one-rank RCCL group
   stress_frame_loop.py native  [frames]    one rank: rt_multi_frame_* over a one-rank RCCL communicator (depth 2, 3, 4)
   stress_frame_loop.py queue   [frames]    one rank: rt_frame_* (depth 2, 3, 4)
+  stress_frame_loop.py onedev  [frames]    one process: rt_multi_frame_* over EIGHT contexts on the one GPU (depth 2, 3, 4)
 
 Results: one JSON line per mode on stdout and in gpurun_out/stress/<mode>.json.
 """
@@ -309,15 +310,19 @@ def mode_rccl1(frames):
     return {"mode": "rccl1 (TiledFrame over a one-rank RCCL group)", "frames": frames, "mismatching": len(bad), "details": bad[:20]}
 
 
-def _queue_mode(frames, native):
+def _queue_mode(frames, native, contexts=0):
     import numpy as np
     import torch  # noqa: F401
     import ray_tracing_amd as rt
     from ray_tracing_amd.frames import FrameLoop
     ref = references(rt, np)
-    out = {"mode": "native (rt_multi_frame_* over a one-rank RCCL communicator)" if native else "queue (rt_frame_*)", "depths": {}}
+    out = {"mode": f"onedev (rt_multi_frame_* over {contexts} contexts on one GPU)" if contexts else
+                   "native (rt_multi_frame_* over a one-rank RCCL communicator)" if native else "queue (rt_frame_*)", "depths": {}}
     for depth in (2, 3, 4):
-        if native:
+        if contexts:
+            q = rt.MultiRenderer([0], on_one_device=contexts)
+            q.set_scene(os.path.join(rt.DATA_DIR, "scene_0.txt")); q.set_skybox(rt.load_skybox()); q.set_camera(); q.compile_scene()
+        elif native:
             q = rt.MultiRenderer([0]); q.set_tuning(force_collective=1)
             q.set_scene(os.path.join(rt.DATA_DIR, "scene_0.txt")); q.set_skybox(rt.load_skybox()); q.set_camera(); q.compile_scene()
         else:
@@ -357,6 +362,8 @@ if __name__ == "__main__":
         res = _queue_mode(n, True)
     elif mode == "queue":
         res = _queue_mode(n, False)
+    elif mode == "onedev":
+        res = _queue_mode(n, True, contexts=8)
     else:
         raise SystemExit(__doc__)
     line = json.dumps(res)
