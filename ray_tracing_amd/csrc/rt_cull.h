@@ -23,8 +23,8 @@
  * Scenes with coordinates beyond RT_CULL_MAX_COORD get no clusters (every object is tested, as before), and a wave one of whose
  * rays starts farther out than 2 S -- a camera far outside the scene -- tests every object as well.
  *
- * Clusters: objects sorted along a Morton curve of their centres, RT_CLUSTER_SIZE consecutive ones per cluster (members keep
- * their object indices: ties between equal distances go to the lowest INDEX whatever the order of the tests).
+ * Clusters: the leaves of a median-split tree over the objects' centres, RT_CLUSTER_SIZE objects each (members keep their object
+ * indices: ties between equal distances go to the lowest INDEX whatever the order of the tests).
  */
 #ifndef RT_CULL_H
 #define RT_CULL_H
@@ -53,7 +53,6 @@ static inline void rt_cull_object_box(const rt_geom &g, float m, float lo[3], fl
 	}
 }
 
-static inline uint32_t rt_cull_spread(uint32_t v) { v &= 1023u; v = (v | (v << 16)) & 0x030000ffu; v = (v | (v << 8)) & 0x0300f00fu; v = (v | (v << 4)) & 0x030c30c3u; return (v | (v << 2)) & 0x09249249u; }
 
 /* Fills `clusters` (and the spheres' geom.b1) when the scene qualifies; returns num_clusters = 0 otherwise. */
 static inline rt_cull_info rt_cull_build(std::vector<rt_geom> &geom, int n, std::vector<rt_cluster> &clusters)
@@ -78,21 +77,38 @@ static inline rt_cull_info rt_cull_build(std::vector<rt_geom> &geom, int n, std:
 		rt_geom &g = geom[(size_t) i];
 		if (g.type == RT_GEOM_SPHERE) g.b1 = sqrtf(g.b0 + E) * 1.0001f + RT_CULL_MARGIN;      /* h: see above (b1 of a sphere is otherwise unused) */
 	}
-	/* Morton order of the centres on a 1024^3 grid over [-S, S]^3 */
+	/* Clusters = the leaves of a median-split tree over the objects' centres: a range of objects is cut in two at a multiple of
+	 * RT_CLUSTER_SIZE nearest its middle, along the axis on which its centres spread most, until it fits one cluster.  (A Morton
+	 * curve of the centres -- round 4's first version -- gives longer, overlapping boxes: a ray of the 1024-object test scene then
+	 * touches 12.2 clusters instead of 6.6; profiles/r04/stats_large_1024.txt and stats_large_1024_split.txt.) */
 	std::vector<std::pair<uint32_t, int>> order((size_t) n);
-	for (int i = 0; i < n; i++) {
-		float lo[3], hi[3];
-		rt_cull_object_box(geom[(size_t) i], RT_CULL_MARGIN, lo, hi);
-		uint32_t code = 0;
-		for (int k = 0; k < 3; k++) {
-			const float c = 0.5f * (lo[k] + hi[k]);
-			int q = (int) ((c + S) / (2.0f * S) * 1023.0f);
-			q = q < 0 ? 0 : (q > 1023 ? 1023 : q);
-			code |= rt_cull_spread((uint32_t) q) << k;
+	{
+		std::vector<float> centre((size_t) n * 3);
+		for (int i = 0; i < n; i++) {
+			float lo[3], hi[3];
+			rt_cull_object_box(geom[(size_t) i], RT_CULL_MARGIN, lo, hi);
+			for (int k = 0; k < 3; k++) centre[(size_t) i * 3 + k] = 0.5f * (lo[k] + hi[k]);
 		}
-		order[(size_t) i] = { code, i };
+		std::vector<int> ids((size_t) n);
+		for (int i = 0; i < n; i++) ids[(size_t) i] = i;
+		struct Range { int first, last; };
+		std::vector<Range> todo{ { 0, n } };
+		while (!todo.empty()) {
+			const Range r = todo.back(); todo.pop_back();
+			if (r.last - r.first <= RT_CLUSTER_SIZE) continue;
+			float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
+			for (int i = r.first; i < r.last; i++)
+				for (int k = 0; k < 3; k++) { const float c = centre[(size_t) ids[(size_t) i] * 3 + k]; lo[k] = std::min(lo[k], c); hi[k] = std::max(hi[k], c); }
+			int axis = 0;
+			for (int k = 1; k < 3; k++) if (hi[k] - lo[k] > hi[axis] - lo[axis]) axis = k;
+			const int clusters = (r.last - r.first + RT_CLUSTER_SIZE - 1) / RT_CLUSTER_SIZE;
+			const int mid = r.first + (clusters / 2) * RT_CLUSTER_SIZE;          /* whole clusters on the left: only the very last cluster may be short */
+			std::nth_element(ids.begin() + r.first, ids.begin() + mid, ids.begin() + r.last,
+			                 [&](int a, int b) { const float ca = centre[(size_t) a * 3 + axis], cb = centre[(size_t) b * 3 + axis]; return ca < cb || (ca == cb && a < b); });
+			todo.push_back({ r.first, mid }); todo.push_back({ mid, r.last });
+		}
+		for (int i = 0; i < n; i++) order[(size_t) i] = { (uint32_t) i, ids[(size_t) i] };
 	}
-	std::sort(order.begin(), order.end());
 	const int C = (n + RT_CLUSTER_SIZE - 1) / RT_CLUSTER_SIZE;
 	clusters.assign((size_t) C, rt_cluster());
 	for (int c = 0; c < C; c++) {
