@@ -100,7 +100,7 @@ struct SceneLDS {
 RT_DEV SceneLDS stage_geometry(const rt_launch &L, float4 *lds, int n)
 {
 	const float4 *g = reinterpret_cast<const float4*>(L.geom);
-	for (int i = threadIdx.x; i < CULL_GEOM_F4(n); i += RT_BLOCK) lds[i] = g[i];
+	for (int i = threadIdx.x; i < CULL_GEOM_F4(n); i += (int) blockDim.x) lds[i] = g[i];
 	__syncthreads();
 	SceneLDS sc; sc.shade = reinterpret_cast<const float4*>(L.shade);
 #ifdef RT_CULL_GEOM_GLOBAL
@@ -370,7 +370,8 @@ RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d, bool want_nor
  * that pass.  The exact tests are the very functions of the linear scan, so every distance is the same number; the scan's
  * "lowest index among equal distances" (strict `<` in index order, scene.c:168) is kept explicitly, because the clusters
  * are visited out of index order. */
-struct ClusterLDS { const float4 *rec; int count; float margin, origin_max; };      /* RT_CLUSTER_F4 x float4 per cluster (rt_cluster) */
+typedef const __attribute__((address_space(4))) float *rt_const_f;        /* memory read with scalar loads when the address is wave-uniform */
+struct ClusterLDS { const float4 *rec; rt_const_f mem; int count; float margin, origin_max; };      /* RT_CLUSTER_F4 x float4 per cluster (rt_cluster): in LDS, and where they came from */
 
 /* the conservative slab test: parameters plane * (1/d) - o * (1/d), one fused multiply-add each (oi = o * inv is formed once per
  * ray).  This is the cull's own arithmetic, not the reference's: its error -- 2^-23 |t| + 2^-24 |o| / |d| <= 3.1e-5 / |d| with
@@ -421,7 +422,14 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, u
 		const int first = 32 * w, last = cl.count < first + 32 ? cl.count : first + 32;
 		for (int c = first; c < last; c++) {
 			STAT(32);
+#ifdef RT_CULL_BOXES_FROM_LDS
 			const float4 k0 = cl.rec[RT_CLUSTER_F4 * c], k1 = cl.rec[RT_CLUSTER_F4 * c + 1];
+#else		/* the box is the same for all lanes: two scalar loads, planes as scalar operands of the FMAs -- the LDS pipe is what the
+			 * culled trace is short of (the members' boxes, the geometry, the cross-lane fetches and the minimum all go through it) */
+			const rt_const_f km = cl.mem + 4 * RT_CLUSTER_F4 * c;
+			float4 k0, k1;
+			k0.x = km[0]; k0.y = km[1]; k0.z = km[2]; k0.w = km[3]; k1.x = km[4]; k1.y = km[5];
+#endif
 			if (slab_may_touch(oi, rp.inv, mk3(k0.x, k0.y, k0.z), mk3(k0.w, k1.x, k1.y))) bits |= 1u << (c - first);
 		}
 		mask[w] = on ? bits : 0u;
@@ -531,9 +539,9 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, u
 RT_DEV ClusterLDS stage_clusters(const rt_launch &L, float4 *dst)
 {
 	const float4 *src = reinterpret_cast<const float4*>(L.clusters);
-	for (int i = threadIdx.x; i < RT_CLUSTER_F4 * L.num_clusters; i += RT_BLOCK) dst[i] = src[i];
+	for (int i = threadIdx.x; i < RT_CLUSTER_F4 * L.num_clusters; i += (int) blockDim.x) dst[i] = src[i];
 	__syncthreads();
-	ClusterLDS cl; cl.rec = dst; cl.count = L.num_clusters; cl.margin = L.cull_margin; cl.origin_max = L.cull_origin_max;
+	ClusterLDS cl; cl.rec = dst; cl.mem = (rt_const_f) (unsigned long long) L.clusters; cl.count = L.num_clusters; cl.margin = L.cull_margin; cl.origin_max = L.cull_origin_max;
 	return cl;
 }
 
@@ -804,7 +812,7 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 	extern __shared__ float4 lds[];
 	const int n = L.num_objects;
 	const SceneLDS sc = CULL ? stage_geometry(L, lds, n) : stage_scene(L, lds, n);
-	ClusterLDS cl; cl.rec = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
+	ClusterLDS cl; cl.rec = nullptr; cl.mem = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
 	if (CULL) cl = stage_clusters(L, lds + CULL_GEOM_F4(n));
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	unsigned long long *cull_best = reinterpret_cast<unsigned long long*>(lds + CULL_GEOM_F4(n) + RT_CLUSTER_F4 * L.num_clusters) + 64 * wave;     /* (CULL) 64 x 8 B per wave */
@@ -998,7 +1006,7 @@ RT_DEV PixelRec load_pixel(rt_launch_cold C, size_t c)
 	return p;
 }
 
-template <bool FAST, bool CULL = false>
+template <bool FAST, bool CULL = false, int BLOCK = RT_BLOCK>      /* BLOCK: threads per workgroup (the culled variant also comes with RT_BLOCK_WIDE) */
 RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 {
 	extern __shared__ float4 lds[];
@@ -1012,7 +1020,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	/* the grids of the "taps certainly lit" table (rt_lit.h), when the launcher found room for them: 3 x float4 per object */
 	if (L.lit_grids_in_lds) {
 		const float4 *gsrc = reinterpret_cast<const float4*>(L.lit_grids);
-		for (int i = threadIdx.x; i < 3 * n; i += RT_BLOCK) lds[6 * n + i] = gsrc[i];
+		for (int i = threadIdx.x; i < 3 * n; i += BLOCK) lds[6 * n + i] = gsrc[i];
 		__syncthreads();
 	}
 	/* (two pointers, not one chosen at run time: a pointer that may be LDS or memory makes every access a flat load with a
@@ -1021,10 +1029,10 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	const rt_lit_grid *lit_grids_mem = reinterpret_cast<const rt_lit_grid*>(L.lit_grids);
 	const bool grids_in_lds = L.lit_grids_in_lds != 0;
 	/* large scenes: the clusters of rt_cull.h behind the scene records (such scenes have no lit-taps table: it needs <= 64 objects) */
-	ClusterLDS cl; cl.rec = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
+	ClusterLDS cl; cl.rec = nullptr; cl.mem = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
 	if (CULL) cl = stage_clusters(L, lds + CULL_GEOM_F4(n));
 	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (CULL ? CULL_GEOM_F4(n) + RT_CLUSTER_F4 * L.num_clusters : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
-	unsigned long long *cull_best = reinterpret_cast<unsigned long long*>(reinterpret_cast<WaveLDS*>(lds + CULL_GEOM_F4(n) + RT_CLUSTER_F4 * L.num_clusters) + RT_BLOCK / 64) + 64 * wave;   /* (CULL) */
+	unsigned long long *cull_best = reinterpret_cast<unsigned long long*>(reinterpret_cast<WaveLDS*>(lds + CULL_GEOM_F4(n) + RT_CLUSTER_F4 * L.num_clusters) + BLOCK / 64) + 64 * wave;   /* (CULL) */
 
 	const float inv_spp = 1.0f / (float) L.spp;
 	const unsigned int spp = (unsigned int) L.spp;
@@ -1214,7 +1222,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 						const unsigned long long some = __ballot(left != 0u);
 						if (some == 0ull || cancelled) { exhausted = true; STAMP_DRY; }
 						else {      /* the waves spread over the lists that are left (one address takes ~88 atomics per microsecond) */
-							const int pick = (int) ((blockIdx.x * (RT_BLOCK / 64) + (unsigned int) wave) % (unsigned int) __popcll(some));
+							const int pick = (int) ((blockIdx.x * (BLOCK / 64) + (unsigned int) wave) % (unsigned int) __popcll(some));
 							shard = (unsigned int) __builtin_ctzll(__ballot(left != 0u && lanes_below(some) == pick));
 						}
 					}
@@ -1568,6 +1576,16 @@ __global__ void __launch_bounds__(RT_BLOCK, CULL ? 2 : 4)
 rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 {
 	wavefront_body<FAST, CULL>(L, block_counter);
+}
+/* The culled trace is bound by the latency of its LDS reads and cross-lane fetches, i.e. by the waves a SIMD has to switch
+ * between, and the scene's records are per workgroup while a wave's own LDS is 10 KB: one workgroup of twelve waves shares
+ * one copy of 1024 objects' records (36 + 12 x 10 = 156 KB: three waves per SIMD) where two workgroups of four hold two
+ * copies (2 x 77 KB: two waves per SIMD). */
+#define RT_BLOCK_WIDE 768
+__global__ void __launch_bounds__(RT_BLOCK_WIDE, 1)
+rt_trace_wavefront_wide(const rt_launch L, unsigned int *block_counter)
+{
+	wavefront_body<true, true, RT_BLOCK_WIDE>(L, block_counter);
 }
 #endif
 
@@ -2141,10 +2159,16 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 		if (with <= 160u * 1024u && (int) ((160u * 1024u) / with) >= per_cu) { Lq.lit_grids_in_lds = 1; lds = with; }
 	}
 	if (cull && per_cu > 3) per_cu = 3;                                                        /* (the culled variant's 136 registers: three waves per SIMD) */
+	/* a large scene whose records leave room for fewer than three workgroups of four waves: one workgroup of twelve (rt_trace_wavefront_wide) */
+	int block = RT_BLOCK;
+	if (cull && per_cu < 3 && workgroups_per_cu < 1) {
+		const size_t wide = (size_t) CULL_GEOM_F4(L.num_objects) * 16 + (size_t) L.num_clusters * sizeof(rt_cluster) + (RT_BLOCK_WIDE / 64) * (sizeof(WaveLDS) + 64 * sizeof(unsigned long long));
+		if (wide <= 160u * 1024u) { block = RT_BLOCK_WIDE; lds = wide; per_cu = 1; }
+	}
 	if (workgroups_per_cu >= 1 && workgroups_per_cu < per_cu) per_cu = workgroups_per_cu;     /* rt_tuning */
 	const long long blocks = (long long) ((L.width + 7) / 8) * ((L.local_rows + 7) / 8);
 	long long grid = (long long) num_cus * per_cu;
-	const long long useful = (blocks + (RT_BLOCK / 64) - 1) / (RT_BLOCK / 64);
+	const long long useful = (blocks + (block / 64) - 1) / (block / 64);
 	if (grid > useful) grid = useful;
 	if (grid < 1) grid = 1;
 	/* counter block: WF_SHARDS dequeue counters, WF_SHARDS fill counters, one line of control words.  When the lists of the
@@ -2195,6 +2219,8 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	}
 	if (variant == 2 /* RT_KERNEL_WAVEFRONT: same schedule, plain IEEE operations */ || !scene_fast_ok)
 		hipLaunchKernelGGL(rt_trace_wavefront<false>, dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, Lq, block_counter);
+	else if (cull && block == RT_BLOCK_WIDE)
+		hipLaunchKernelGGL(rt_trace_wavefront_wide, dim3((unsigned int) grid), dim3(RT_BLOCK_WIDE), lds, stream, Lq, block_counter);
 	else if (cull)
 		hipLaunchKernelGGL((rt_trace_wavefront<true, true>), dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, Lq, block_counter);
 	else
