@@ -526,6 +526,26 @@ def main():
         device_resident = {"ms_per_step": round(dt_dev * 1e3, 4), "value": round(samples_per_step / dt_dev / 1e6, 2), "unit": "Msamples/s", "steps": n_dev,
                            "region": "K frames through rt_frame_submit_device / rt_frame_wait, two in flight: the frame stays in HBM, only the "
                                      "launch's control word goes to the host"}
+    # ---- the interactive ladder at full resolution (main.c:354-408): passes of one sample per pixel, one launch
+    # each (rt_progressive_pass) and RT_PROGRESSIVE_BATCH to a launch (rt_progressive_passes: same sums, bit for bit)
+    interactive = None
+    if native and not multi_path and not args.no_extras and world == 1:
+        n_pass = 256
+        rates = {}
+        for batched in (False, True):
+            gpu.progressive_begin(W, H, init_scale=1, max_bounces=10, seed=seed)
+            if batched: gpu.progressive_passes(8)
+            else: [gpu.progressive_pass() for _ in range(8)]
+            fence()
+            t1 = time.perf_counter()
+            if batched: gpu.progressive_passes(n_pass)
+            else: [gpu.progressive_pass() for _ in range(n_pass)]
+            fence()
+            rates[batched] = (time.perf_counter() - t1) / n_pass
+        interactive = {"ms_per_pass": round(rates[False] * 1e3, 4), "ms_per_pass_batched": round(rates[True] * 1e3, 4),
+                       "msamples_per_s": round(W * H / rates[False] / 1e6, 1), "msamples_per_s_batched": round(W * H / rates[True] / 1e6, 1),
+                       "region": f"{n_pass} passes of 1 sample per pixel at {W}x{H}, 10 bounces, after the scale ladder: one launch per pass "
+                                 "(rt_progressive_pass) / all in one launch (rt_progressive_passes); host enqueue -> synchronised"}
     if rank == 0:
         value = samples_per_step * args.steps / elapsed / 1e6
         metric = "Msamples/s (rays/s) at 1920x1080x64spp scene_0; 1/2/4/8 GPU"
@@ -574,6 +594,8 @@ def main():
                                           f"{host_copy['GBps']} GB/s, {host_copy['frac_of_link']} of a PCIe 5.0 x16 link; see device_resident for the step without it")
         if device_resident is not None:
             out["device_resident"] = device_resident
+        if interactive is not None:
+            out["interactive"] = interactive
         # ---- roofline of the dominant kernel (rank 0's launches; every rank runs the same kernel on 1/N of the rows)
         from rtlibs import Oracle
         try:

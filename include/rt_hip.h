@@ -302,6 +302,16 @@ RT_API int  rt_multi_create_on_one_device(rt_multi **out, int device_id, int n);
  * with rt_path_seed(seed, (j*s)*w + i*s, p).  init_scale must be 1, 2, 4, 8 or 16 (main.c:611-621). */
 RT_API int rt_progressive_begin(rt_context *ctx, int width, int height, int init_scale, int max_bounces, uint64_t seed);
 RT_API int rt_progressive_pass(rt_context *ctx, float *weight_out);
+/* `count` worker iterations in as few launches as the ladder allows: below full resolution one launch per pass, as above; at
+ * full resolution up to RT_PROGRESSIVE_BATCH passes per launch -- the trace kernel adds a pixel's samples, in pass order, onto
+ * the sums so far, which is what that many publish steps (main.c:394-396) do one after the other.  Sums, count and sample
+ * numbers are those of `count` calls of rt_progressive_pass(): the resolved frame is bit-identical.  A GPU renders a 1080p
+ * pass of one sample per pixel in a quarter of a millisecond, most of it launch, camera rays and half-empty waves; a host
+ * that shows a frame every 16 ms gets three times the samples out of rt_progressive_passes(ctx, n) between two of them.
+ * (A launch cut short by rt_cancel() publishes none of its passes; their sample numbers stay unused.) */
+#define RT_PROGRESSIVE_BATCH 256
+#define RT_PROGRESSIVE_BATCH_MIN 8        /* fewer passes than this are launched one by one (faster: profiles/r04/progressive_rate.txt) */
+RT_API int rt_progressive_passes(rt_context *ctx, int count);
 /* Development / test aid: how many of this context's launches ran rt_primary_pass (camera rays) -- an interactive pass that
  * differs from the pass before last in its sample number only keeps that pass's camera rays instead. */
 RT_API long long rt_primary_passes_run(rt_context *ctx);
@@ -330,6 +340,7 @@ RT_API int rt_progressive_begin_rank(rt_context *ctx, int width, int height, int
 RT_API int rt_progressive_resolve_device(rt_context *ctx, void **d_rows);
 RT_API int rt_multi_progressive_begin(rt_multi *m, int width, int height, int init_scale, int max_bounces, uint64_t seed);
 RT_API int rt_multi_progressive_pass(rt_multi *m, float *weight_out);
+RT_API int rt_multi_progressive_passes(rt_multi *m, int count);       /* rt_progressive_passes() on every device */
 RT_API int rt_multi_progressive_resolve(rt_multi *m, Vector3 *frame_out);
 RT_API int rt_multi_progressive_invalidate(rt_multi *m);
 RT_API int rt_multi_progressive_state(rt_multi *m, int *next_scale, float *count, uint32_t *generation, int *passes);

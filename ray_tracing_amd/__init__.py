@@ -68,7 +68,7 @@ EXPORTS = [
     "rt_frame_submit", "rt_frame_submit_device", "rt_frame_wait", "rt_frame_poll", "rt_host_alloc", "rt_host_free",
     "rt_multi_frame_submit_device", "rt_multi_collective_info", "rt_multi_create_on_one_device",
     "rt_multi_frame_submit", "rt_multi_frame_wait", "rt_multi_frame_poll", "rt_profile_collect_span",
-    "rt_progressive_begin_rank", "rt_progressive_resolve_device", "rt_multi_progressive_begin", "rt_multi_progressive_pass",
+    "rt_progressive_begin_rank", "rt_progressive_resolve_device", "rt_multi_progressive_begin", "rt_multi_progressive_pass", "rt_multi_progressive_passes", "rt_progressive_passes",
     "rt_multi_progressive_resolve", "rt_multi_progressive_invalidate", "rt_multi_progressive_state",
     "rt_synchronize", "rt_cancel", "rt_was_cancelled", "rt_last_launch_counts", "rt_primary_passes_run", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
     "rt_progressive_invalidate", "rt_progressive_state", "rt_selftest", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
@@ -161,11 +161,15 @@ def lib():
         L.rt_progressive_resolve_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.rt_multi_progressive_begin.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
         L.rt_multi_progressive_pass.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        if hasattr(L, "rt_multi_progressive_passes"):
+            L.rt_multi_progressive_passes.argtypes = [C.c_void_p, C.c_int]
         L.rt_multi_progressive_resolve.argtypes = [C.c_void_p, C.c_void_p]
         L.rt_multi_progressive_invalidate.argtypes = [C.c_void_p]
         L.rt_multi_progressive_state.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
     L.rt_progressive_begin.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
     L.rt_progressive_pass.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    if hasattr(L, "rt_progressive_passes"):
+        L.rt_progressive_passes.argtypes = [C.c_void_p, C.c_int]
     L.rt_progressive_resolve.argtypes = [C.c_void_p, C.c_void_p]
     L.rt_progressive_invalidate.argtypes = [C.c_void_p]
     L.rt_progressive_state.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
@@ -462,6 +466,10 @@ class Renderer(_FrameQueue):
         _check(lib().rt_progressive_pass(self._ctx, C.byref(w)), "rt_progressive_pass")
         return w.value
 
+    def progressive_passes(self, count):
+        """`count` passes in as few launches as the ladder allows (rt_progressive_passes): the same frame as `count` progressive_pass() calls."""
+        _check(lib().rt_progressive_passes(self._ctx, int(count)), "rt_progressive_passes")
+
     def progressive_resolve(self):
         out = np.empty(self._prog_shape, dtype=np.float32)
         _check(lib().rt_progressive_resolve(self._ctx, out.ctypes.data_as(C.c_void_p)), "rt_progressive_resolve")
@@ -609,6 +617,9 @@ class MultiRenderer(_FrameQueue):
         w = C.c_float()
         _check(lib().rt_multi_progressive_pass(self._m, C.byref(w)), "rt_multi_progressive_pass")
         return w.value
+
+    def progressive_passes(self, count):
+        _check(lib().rt_multi_progressive_passes(self._m, int(count)), "rt_multi_progressive_passes")
 
     def progressive_resolve(self):
         out = np.empty(self._prog_shape, dtype=np.float32)

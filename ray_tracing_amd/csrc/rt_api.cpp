@@ -977,7 +977,10 @@ int rt_progressive_invalidate(rt_context *ctx)
 	return RT_OK;
 }
 
-int rt_progressive_pass(rt_context *ctx, float *weight_out)
+/* One launch of the ladder: `samples` = 1 is one worker iteration (main.c:354-408) at the ladder's current scale; more than one
+ * (full resolution only) is that many iterations in ONE launch -- the trace kernel adds the pixel's samples, in pass order, onto
+ * the sums so far (rt_launch.sum_onto), which is what `samples` publish steps (main.c:394) would have done one after the other. */
+static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 {
 	if (!ctx || !ctx->prog.active) return fail(RT_ERR_STATE, "rt_progressive_pass: call rt_progressive_begin first");
 	if (!ctx->have_scene) return fail(RT_ERR_STATE, "render: no scene set (rt_set_scene)");
@@ -998,8 +1001,11 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	memcpy(L.light_pos, ctx->light_pos, sizeof(L.light_pos));
 	L.only_light_emits = ctx->only_light_emits ? 1 : 0;
 	L.num_objects = ctx->num_objects;
-	L.width = lcw; L.height = lh; L.local_rows = lh;
-	L.spp = 1; L.max_bounces = g.max_bounces; L.seed = g.seed;
+	const bool batch = samples > 1;             /* (s == 1: the caller's business) */
+	/* (the reference's low-resolution frame has one column more than it shows, main.c:286; a batch renders onto the sums, which
+	 * have the frame's own width, and leaves that column out -- nothing ever reads it) */
+	L.width = batch ? lw : lcw; L.height = lh; L.local_rows = lh;
+	L.spp = samples; L.max_bounces = g.max_bounces; L.seed = g.seed;
 	L.u_den = lw - 1; L.v_den = lh - 1; L.pix_scale = s; L.pix_width = g.width; L.sample_base = g.passes;
 	L.row_block = 8; L.rank = 0; L.world = 1;
 	if (g.world > 1) {
@@ -1011,6 +1017,7 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	}
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.sky_wm1 = (float) (ctx->sky_w - 1); L.sky_hm1 = (float) (ctx->sky_h - 1);
 	L.frame = g.d_low;
+	L.sum_onto = batch ? g.d_accum : nullptr;
 	L.skip_known_taps = ctx->tuning.trace_known_taps ? 0 : 1;   /* the flags are kept with the lists: paid once per camera position */
 	L.lit_cells = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_cells : nullptr;
 	L.lit_grids = ctx->d_lit_grids;
@@ -1028,9 +1035,10 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 		unpublish_launch(ctx);              /* nothing is launched for a rank without rows at this scale */
 		/* a rank without rows at this scale -- its few frame rows lie below the last whole low-resolution row -- renders
 		 * nothing and adds nothing, but the pass counts (main.c:396): those rows are divided by the same count as all others */
-		HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), reinterpret_cast<unsigned int*>(g.d_count + 1), g.d_count,
-		                             RT_PROGRESSIVE_ROW_BLOCK, g.rank, g.world, 0, ctx->stream));
-		g.passes++;
+		for (int k = 0; k < samples; k++)
+			HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), reinterpret_cast<unsigned int*>(g.d_count + 1), g.d_count,
+			                             RT_PROGRESSIVE_ROW_BLOCK, g.rank, g.world, 0, ctx->stream));
+		g.passes += samples;
 		if (g.scale > 1) g.scale >>= 1;
 		if (weight_out) *weight_out = 1.0f / (s * s);
 		return RT_OK;
@@ -1051,14 +1059,14 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 		if (key == 0) key = 1;
 	}
 	rt_context::launch_slot &sl = ctx->slot[ctx->launches & 1u];
-	const bool reuse = !ctx->tuning.poison_frame && sl.lists_key == key;
+	const bool reuse = !ctx->tuning.poison_frame && !batch && sl.lists_key == key;      /* (a batch's sky pixels are sums: never the same twice) */
 	sl.lists_key = 0;
 	{
 		const hipError_t le = rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, sl.d_counter, nullptr, sl.started, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream, reuse);
 		if (le != hipSuccess) { unpublish_launch(ctx); return fail(RT_ERR_DEVICE, "trace launch: %s", hipGetErrorString(le)); }
 	}
 	if (!reuse) ctx->primary_passes++;
-	sl.lists_key = ctx->tuning.poison_frame ? 0 : key;
+	sl.lists_key = ctx->tuning.poison_frame || batch ? 0 : key;
 	/* the low-resolution frame now holds THIS launch's sky pixels: lists of the other set that belong to anything else
 	 * (a pass at another scale before the ladder came back to this one) no longer have theirs */
 	{
@@ -1068,12 +1076,36 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out)
 	const float weight = 1.0f / (s * s);                                         /* main.c:278 */
 	/* accum += pass * weight and accum_counts += weight (main.c:394-396), both on the device and both skipped for a pass
 	 * that rt_cancel() cut short (main.c:382): the count can never include a pass the buffer does not */
+	if (batch)        /* the launch wrote sums-so-far + its samples: they become the sums, and `samples` passes count */
+		HIP_TRY(rt_launch_commit_sums(g.d_accum, g.d_low, (size_t) g.width * L.local_rows * 3, samples, L.control + 1, g.d_count, ctx->stream));
+	else
 	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), L.control + 1, g.d_count,
 	                             RT_PROGRESSIVE_ROW_BLOCK, g.rank, g.world, g.rows, ctx->stream));
 	{ const int rc = mark_launch(ctx, ctx->stream); if (rc != RT_OK) return rc; }
-	g.passes++;
+	g.passes += samples;
 	if (g.scale > 1) g.scale >>= 1;                                              /* main.c:402-403 */
 	if (weight_out) *weight_out = weight;
+	return RT_OK;
+}
+
+int rt_progressive_pass(rt_context *ctx, float *weight_out) { return progressive_launch(ctx, 1, weight_out); }
+
+/* `count` worker iterations.  While the ladder is below full resolution they are what `count` calls of rt_progressive_pass()
+ * are; at full resolution the rest go into launches of up to RT_PROGRESSIVE_BATCH samples per pixel.  Same sums, same count,
+ * same sample numbers: the frame is bit-identical -- a 1080p pass of one sample per pixel is a quarter of a millisecond of
+ * launch, camera rays and half-empty waves, sixty of them in one launch take a third of sixty launches. */
+int rt_progressive_passes(rt_context *ctx, int count)
+{
+	if (!ctx || !ctx->prog.active) return fail(RT_ERR_STATE, "rt_progressive_passes: call rt_progressive_begin first");
+	if (count < 1) return fail(RT_ERR_ARGUMENT, "rt_progressive_passes: count must be at least 1");
+	while (count > 0) {
+		/* (fewer than RT_PROGRESSIVE_BATCH_MIN passes are faster one by one: a batch renders its camera rays again -- single passes
+		 * keep them from the pass before last -- and copies the sums once more; profiles/r04/progressive_rate.txt) */
+		const int n = ctx->prog.scale > 1 || count < RT_PROGRESSIVE_BATCH_MIN ? 1 : (count < RT_PROGRESSIVE_BATCH ? count : RT_PROGRESSIVE_BATCH);
+		const int rc = progressive_launch(ctx, n, nullptr);
+		if (rc != RT_OK) return rc;
+		count -= n;
+	}
 	return RT_OK;
 }
 

@@ -90,6 +90,11 @@ typedef struct {
 	float sky_wm1, sky_hm1;    /* (float)(w - 1), (float)(h - 1): the texel scale of gpu_and_windowing.c:103-104 */
 
 	float *frame;              /* local_rows x width x 3 floats, resolved      */
+	/* several interactive passes at full resolution in one launch (rt_progressive_passes): the sums the frame rows hold so far,
+	 * laid out like `frame`.  A pixel's samples are then added, in order, to sum_onto[...] instead of to zero and the result is
+	 * written to `frame` as it is, not divided by the sample count -- worker()'s publish step (main.c:394) `spp` times over.
+	 * NULL: a frame of its own. */
+	const float *sum_onto;
 	int    skip_known_taps;    /* rt_primary_pass flags the pixels whose bounce-0 taps need no tracing (rt_lit.h); 0: every tap is traced */
 	/* the same answer for hit points of any bounce, from a table built once per scene (rt_lit.h: one entry per cell of a grid
 	 * over every object's bounding box, rt_lit_grid per object); NULL: no table (no sphere emitter, or every tap is traced) */

@@ -40,6 +40,7 @@ hipError_t rt_launch_deinterleave(const float *strips, float *frame, int width, 
 hipError_t rt_launch_accumulate(float *accum, const float *lowres, int width, int height, int scale,
                                 int low_w, int low_h, float k, const unsigned int *cancelled, float *count,
                                 int row_block, int rank, int world, int local_rows, hipStream_t stream);
+hipError_t rt_launch_commit_sums(float *accum, const float *sums, size_t floats, int passes, const unsigned int *cancelled, float *count, hipStream_t stream);
 hipError_t rt_launch_resolve(const float *accum, float *frame, size_t floats, const float *count, hipStream_t stream);
 hipError_t rt_launch_selftest(int which, uint64_t seed, int blocks, int iters, unsigned long long *d_out, hipStream_t stream);
 

@@ -824,7 +824,7 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 	const unsigned int shard = blockIdx.x % (unsigned int) L.num_shards;
 	const size_t plane = (size_t) L.pix_shard_cap * (size_t) L.num_shards;
 	const V3 cam = ld3(L.pos);
-	const float inv_spp = 1.0f / (float) L.spp;
+	const float inv_spp = L.sum_onto ? 1.0f : 1.0f / (float) L.spp;
 	const unsigned int first = blockIdx.x * (unsigned int) blocks_per_group;
 	for (unsigned int k = (unsigned int) wave; k < (unsigned int) blocks_per_group; k += RT_BLOCK / 64) {
 		const unsigned int blk = first + k;
@@ -863,6 +863,7 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 				const V3 sky = sky_lookup<FAST>(L, dn);                                  /* main.c:170 */
 				const V3 c = mk3(clamp01(sky.x), clamp01(sky.y), clamp01(sky.z));
 				V3 acc = mk3(0, 0, 0);
+				if (L.sum_onto) { const float *b = L.sum_onto + ((size_t) lr * L.width + i) * 3; acc = mk3(b[0], b[1], b[2]); }
 				for (int s = 0; s < L.spp; s++) acc = add3(acc, c);
 				const V3 res = scale3(acc, inv_spp);
 				float *dst = L.frame + ((size_t) lr * L.width + i) * 3;
@@ -1034,7 +1035,11 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (CULL ? CULL_GEOM_F4(n) + RT_CLUSTER_F4 * L.num_clusters : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
 	unsigned long long *cull_best = reinterpret_cast<unsigned long long*>(reinterpret_cast<WaveLDS*>(lds + CULL_GEOM_F4(n) + RT_CLUSTER_F4 * L.num_clusters) + BLOCK / 64) + 64 * wave;   /* (CULL) */
 
-	const float inv_spp = 1.0f / (float) L.spp;
+	/* rt_launch.sum_onto (several interactive passes in one launch): a pixel's samples are added to what the frame holds so far.
+	 * That value takes the window slot BEFORE the pixel's first sample, as if it were a sample: 0 + value is the value (it is
+	 * >= +0), and section 6 then adds the samples onto it in order; the sum is written as it is. */
+	const bool onto = L.sum_onto != nullptr;
+	const float inv_spp = onto ? 1.0f : 1.0f / (float) L.spp;
 	const unsigned int spp = (unsigned int) L.spp;
 	/* spp == 1 (progressive passes): a pixel is its one sample, nothing has to be ordered -- every lane takes a
 	 * pixel for itself and writes it when the path retires.  Otherwise the wave runs P pixel streams. */
@@ -1175,6 +1180,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			if (!direct) {
 				nxt = W.s_nxt[sg];
 				need_pixel = leader && gm != 0ull && nxt >= spp;
+				if (onto) need_pixel = need_pixel && W.s_seq[sg] - W.s_drained[sg] < wn - 1u;      /* (the slot for what the frame holds so far) */
 			}
 			const unsigned long long nmask = __ballot(need_pixel);
 			STAMP(0);
@@ -1245,6 +1251,14 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 						W.rec[10][sg] = __uint_as_float(px.index);
 						W.rec[11][sg] = __int_as_float(px.off);
 						W.s_nxt[sg] = 0u;
+						if (onto) {
+							typedef const __attribute__((address_space(1))) float *gfloat;
+							const gfloat held = (gfloat) C->sum_onto + (size_t) px.off * 3;
+							const unsigned int sq = W.s_seq[sg], e = (unsigned int) sg * wn + sq % wn;
+							W.win[1][e] = held[1]; W.win[2][e] = held[2];
+							W.win[0][e] = held[0];
+							W.s_seq[sg] = sq + 1u;
+						}
 #ifdef RT_PROBE_KNOWN_ONLY          /* experiment (scripts/first_bounce_probe.py): only pixels whose tap class is known are rendered, by either kernel */
 						if ((((uint32_t) px.obj >> 16) & 3u) == 0u) W.s_nxt[sg] = spp;
 #endif
@@ -1824,6 +1838,21 @@ rt_accumulate(float *accum, const float *lowres, int width, int height, int scal
 	}
 }
 
+/* the publish step of `passes` full-resolution passes that one launch rendered onto the sums so far (rt_launch.sum_onto):
+ * the new sums take the old ones' place, and the passes count (weight 1 each, main.c:396) -- unless the launch was cut short */
+extern "C" __global__ void __launch_bounds__(RT_BLOCK)
+rt_commit_sums(float *accum, const float *sums, size_t floats, int passes, const unsigned int *cancelled, float *count)
+{
+	if (*cancelled) return;
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		float c = *count;
+		for (int k = 0; k < passes; k++) c = c + 1.0f;
+		*count = c;
+	}
+	for (size_t p = (size_t) blockIdx.x * RT_BLOCK + threadIdx.x; p < floats; p += (size_t) gridDim.x * RT_BLOCK)
+		accum[p] = sums[p];
+}
+
 extern "C" __global__ void __launch_bounds__(RT_BLOCK)
 rt_resolve(const float *accum, float *frame, size_t floats, const float *count)
 {
@@ -2064,6 +2093,12 @@ hipError_t rt_launch_accumulate(float *accum, const float *lowres, int width, in
 {
 	hipLaunchKernelGGL(rt_accumulate, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, lowres, width, height, scale, low_w, low_h, k, cancelled, count,
 	                   row_block, rank, world, local_rows);
+	return hipGetLastError();
+}
+
+hipError_t rt_launch_commit_sums(float *accum, const float *sums, size_t floats, int passes, const unsigned int *cancelled, float *count, hipStream_t stream)
+{
+	hipLaunchKernelGGL(rt_commit_sums, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, sums, floats, passes, cancelled, count);
 	return hipGetLastError();
 }
 

@@ -517,6 +517,16 @@ int rt_multi_progressive_pass(rt_multi *m, float *weight_out)
 	return RT_OK;
 }
 
+int rt_multi_progressive_passes(rt_multi *m, int count)
+{
+	if (!m) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_progressive_passes: NULL handle");
+	for (int i = 0; i < m->n; i++) {       /* every device goes through the same ladder: the same launches on each */
+		const int rc = rt_progressive_passes(m->ctx[(size_t) i], count);
+		if (rc != RT_OK) return rc;
+	}
+	return RT_OK;
+}
+
 int rt_multi_progressive_invalidate(rt_multi *m)
 {
 	if (!m) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_progressive_invalidate: NULL handle");

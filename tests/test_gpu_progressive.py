@@ -265,3 +265,109 @@ def test_group_ladder_over_a_one_rank_rccl_communicator(oracle, scene_paths):
     want, _, _, _ = oracle_progressive(oracle, W, H, 8, 3, 10, 5)
     assert (bits(m.progressive_resolve()) == bits(want)).all()
     oracle.set_camera(); m.close()
+
+
+@pytest.mark.parametrize("compiled", [False, True])
+@pytest.mark.parametrize("W,H,init_scale,calls", [(64, 32, 8, [20]), (96, 50, 4, [1, 12, 1, 9]), (50, 30, 1, [8, 1, 30]), (131, 67, 2, [40])])
+def test_batched_passes_are_the_passes_one_by_one(oracle, scene_paths, compiled, W, H, init_scale, calls):
+    """rt_progressive_passes(): the passes at full resolution go several to a launch (the kernel adds a pixel's samples, in
+    pass order, onto the sums so far); sums, count, ladder state and the resolved frame are those of one call of
+    rt_progressive_pass() per pass -- and the oracle's ladder."""
+    sky = synthetic_skybox(32, seed=7)
+    g = rt.Renderer(0)
+    g.set_skybox(sky); oracle.set_skybox(sky); oracle.set_camera()
+    for si in (0, 1):
+        g.set_scene(scene_paths[si]); oracle.load_scene(scene_paths[si])
+        if compiled:
+            g.compile_scene()
+        g.progressive_begin(W, H, init_scale=init_scale, max_bounces=10, seed=5)
+        done = 0
+        for n in calls:
+            g.progressive_passes(n)
+            done += n
+            if n == calls[0] or done == sum(calls):       # a frame is shown between the calls too
+                want, _, count, next_scale = oracle_progressive(oracle, W, H, init_scale, done, 10, 5)
+                st = g.progressive_state()
+                assert st["passes"] == done and st["next_scale"] == next_scale and np.float32(st["count"]) == np.float32(count)
+                assert (bits(g.progressive_resolve()) == bits(want)).all(), (si, W, H, init_scale, done)
+    g.close()
+
+
+def test_batched_passes_at_a_frame_size_with_many_samples(oracle, scene_paths):
+    """A batch as a presenter would ask for it: 640x360, the ladder from 1/8 and then 150 passes at full resolution in one call
+    (one launch of 147 samples per pixel after the three low-resolution ones) against rt_render()-style single passes."""
+    sky = synthetic_skybox(64, seed=3)
+    a, b = rt.Renderer(0), rt.Renderer(0)
+    for g in (a, b):
+        g.set_skybox(sky); g.set_scene(scene_paths[0]); g.compile_scene()
+        g.progressive_begin(640, 360, init_scale=8, max_bounces=6, seed=77)
+    a.progressive_passes(150)
+    for _ in range(150):
+        b.progressive_pass()
+    assert a.progressive_state() == b.progressive_state()
+    assert (bits(a.progressive_resolve()) == bits(b.progressive_resolve())).all()
+    a.progressive_passes(300)                    # more than RT_PROGRESSIVE_BATCH: two launches
+    for _ in range(300):
+        b.progressive_pass()
+    assert a.progressive_state() == b.progressive_state()
+    assert (bits(a.progressive_resolve()) == bits(b.progressive_resolve())).all()
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_batched_passes_on_ranks_and_on_a_group(oracle, scene_paths, world):
+    """The same on the ranks of a host with one process per GPU (rt_progressive_begin_rank) and on a device group
+    (rt_multi_progressive_passes, here `world` contexts on the one GPU of the box)."""
+    from ray_tracing_amd.multi_gpu import frame_index
+    sky = synthetic_skybox(32, seed=7)
+    oracle.set_skybox(sky); oracle.set_camera(); oracle.load_scene(scene_paths[0])
+    W, H, init_scale, passes = 96, 70, 4, 30
+    want, _, count, next_scale = oracle_progressive(oracle, W, H, init_scale, passes, 10, 5)
+    ranks = []
+    for r in range(world):
+        g = rt.Renderer(0)
+        g.set_skybox(sky); g.set_scene(scene_paths[0])
+        g.progressive_begin(W, H, init_scale=init_scale, max_bounces=10, seed=5, rank=r, world=world)
+        ranks.append(g)
+    for g in ranks:
+        g.progressive_passes(12)         # two at 1/4 and 1/2, ten at full resolution in one launch
+    for g in ranks:
+        g.progressive_passes(passes - 12)
+    rows = np.concatenate([g.progressive_resolve() for g in ranks])
+    st = ranks[0].progressive_state()
+    assert st["passes"] == passes and st["next_scale"] == next_scale and np.float32(st["count"]) == np.float32(count)
+    assert (bits(rows[frame_index(H, 16, world)]) == bits(want)).all()
+    for g in ranks:
+        g.close()
+    m = rt.MultiRenderer([0], on_one_device=world)
+    m.set_scene(scene_paths[0]); m.set_skybox(sky); m.set_camera()
+    m.progressive_begin(W, H, init_scale=init_scale, max_bounces=10, seed=5)
+    m.progressive_passes(passes)
+    assert (bits(m.progressive_resolve()) == bits(want)).all()
+    m.close()
+
+
+def test_cancelled_batch_publishes_none_of_its_passes(oracle, scene_paths):
+    """A batch that rt_cancel() cuts short is not published (main.c:382) -- none of its passes: sums and count stay those of the
+    passes before it, and the ladder goes on with the next call."""
+    import torch
+    sky = synthetic_skybox(32, seed=7)
+    W, H, nb, seed = 640, 360, 10, 3
+    g = rt.Renderer(0)
+    g.set_scene(scene_paths[0]); g.set_skybox(sky); g.set_camera()
+    g.progressive_begin(W, H, init_scale=1, max_bounces=nb, seed=seed)
+    g.progressive_passes(10)
+    g.synchronize()
+    before = g.progressive_resolve()
+    # (the deterministic cancel point of test_gpu_frames.py: the batch is still queued behind ~90 ms of other work when the request is made)
+    scratch = torch.empty((1080, 1920, 3), dtype=torch.float32, device="cuda:0")
+    g.render_device(g.params(1920, 1080, 1024, 8, seed=9), scratch.data_ptr())
+    g.progressive_passes(20)
+    g.cancel()
+    assert g.was_cancelled()
+    st = g.progressive_state()
+    assert st["passes"] == 30 and st["count"] == 10.0
+    assert (bits(g.progressive_resolve()) == bits(before)).all()
+    g.progressive_passes(9)
+    assert g.progressive_state()["count"] == 19.0
+    g.close()
