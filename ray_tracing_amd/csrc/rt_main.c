@@ -6,7 +6,12 @@
  *
  *   --scene <file>       required, as in the reference
  *   --threads <n>        accepted for command-line compatibility; the GPU replaces the worker threads
- *   --init-scale <n>     accepted; the final image always accumulates full-resolution passes
+ *   --init-scale <n>     with --interactive: the scale the ladder starts at after an invalidation (reference: 8, main.c:611-621);
+ *                        otherwise accepted and ignored (the image accumulates full-resolution passes)
+ *   --interactive <n>    the reference's interactive protocol instead of one frame (main.c:354-408, 450-482): the scale ladder
+ *                        from --init-scale, n passes in all, a frame resolved (update_frame()) every --present-every passes
+ *                        (default 16: the passes between two frames go to the GPU in one call, rt_multi_progressive_passes);
+ *                        the last resolved frame goes to --out
  *   --width/--height     frame size         (reference: window size, 1280x960, main.c:512)
  *   --spp <n>            passes accumulated (reference: until the camera moves)
  *   --bounces <n>        path length limit  (reference: 10, main.c:156)
@@ -56,6 +61,7 @@ int main(int argc, char **argv)
 {
 	const char *scene_file = NULL, *sky_dir = "assets/skybox";
 	int width = 1280, height = 960, spp = 16, bounces = 10, device = 0, gpus = 0, frames = 0, compile = 0, force_collective = 0, warmup = 3;
+	int init_scale = 8, interactive = 0, present_every = 16;
 	double compile_s = 0;
 	unsigned long long seed = 0;
 
@@ -65,7 +71,9 @@ int main(int argc, char **argv)
 #define NEED_VALUE() do { if (!v) { fprintf(stderr, "Error: Missing value after %s\n", a); return -1; } i++; } while (0)
 		if      (!strcmp(a, "--scene"))      { NEED_VALUE(); scene_file = v; }
 		else if (!strcmp(a, "--threads"))    { NEED_VALUE(); }
-		else if (!strcmp(a, "--init-scale")) { NEED_VALUE(); }
+		else if (!strcmp(a, "--init-scale")) { NEED_VALUE(); init_scale = atoi(v); }
+		else if (!strcmp(a, "--interactive")) { NEED_VALUE(); interactive = atoi(v); }
+		else if (!strcmp(a, "--present-every")) { NEED_VALUE(); present_every = atoi(v); }
 		else if (!strcmp(a, "--width"))      { NEED_VALUE(); width = atoi(v); }
 		else if (!strcmp(a, "--height"))     { NEED_VALUE(); height = atoi(v); }
 		else if (!strcmp(a, "--spp"))        { NEED_VALUE(); spp = atoi(v); }
@@ -192,6 +200,38 @@ int main(int argc, char **argv)
 
 	Vector3 *frame = malloc(sizeof(Vector3) * (size_t) width * height);
 	if (!frame) { printf("OUT OF MEMORY\n"); return -1; }
+
+	if (interactive > 0) {
+		/* worker() + update_frame() with the GPU in the workers' place: the ladder runs on the device(s), the host asks for the
+		 * passes between two displayed frames in one call and resolves a frame after each (main.c:354-408, 450-482) */
+		if (present_every < 1) present_every = 1;
+		if (rt_multi_progressive_begin(group, width, height, init_scale, bounces, seed) != RT_OK) {
+			fprintf(stderr, "Error: %s\n", rt_last_error());
+			return -1;
+		}
+		double t0 = now_s();
+		int done = 0, shown = 0;
+		while (done < interactive) {
+			const int n = interactive - done < present_every ? interactive - done : present_every;
+			if (rt_multi_progressive_passes(group, n) != RT_OK || rt_multi_progressive_resolve(group, frame) != RT_OK) {
+				fprintf(stderr, "Error: %s\n", rt_last_error());
+				return -1;
+			}
+			done += n; shown++;
+		}
+		double dt = now_s() - t0;
+		int next_scale = 0, passes = 0; float count = 0; uint32_t generation = 0;
+		rt_multi_progressive_state(group, &next_scale, &count, &generation, &passes);
+		fprintf(stderr, "Interactive: %d passes from scale 1/%d at %dx%d, %d bounces on %d GPU(s), %d frames resolved: %.3f s, %.3f ms per pass\n",
+		        passes, init_scale, width, height, bounces, rt_multi_size(group), shown, dt, dt / interactive * 1e3);
+		printf("{\"passes\": %d, \"frames_resolved\": %d, \"ms_per_pass\": %.4f, \"weight_sum\": %.6f, \"next_scale\": %d, \"gpus\": %d}\n",
+		       passes, shown, dt / interactive * 1e3, (double) count, next_scale, rt_multi_size(group));
+		rt_move_frame_to_the_gpu(width, height, frame);
+		free(frame);
+		rt_free_cubemap(&skybox);
+		rt_multi_destroy(group);
+		return 0;
+	}
 
 	double t0 = now_s();
 	if (rt_multi_render(group, &p, frame) != RT_OK) {

@@ -42,3 +42,27 @@ def test_cli_reports_errors_like_the_reference(tmp_path):
     bad.write_text("sphere radius x")
     p = subprocess.run([CLI, "--scene", str(bad)], capture_output=True, text=True, timeout=60)
     assert p.returncode != 0 and "Couldn't parse scene" in p.stderr and "Missing number after property name (line 1)" in p.stderr
+
+
+@pytest.mark.parametrize("extra", [[], ["--gpus", "1", "--force-collective"], ["--compile"]])
+def test_cli_interactive_ladder(tmp_path, scene_paths, oracle, extra):
+    """rt_cli --interactive: the reference's interactive protocol from the plain-C host -- the scale ladder from --init-scale, the
+    passes between two displayed frames in one call (rt_multi_progressive_passes), a resolve after each; the last frame shown is
+    the oracle's ladder after as many passes (main.c:354-408, 450-482)."""
+    import json
+    from rtlibs import oracle_progressive
+    out = tmp_path / "frame.ppm"
+    W, H, nb, seed, init_scale, passes = 96, 54, 10, 7, 8, 40
+    cmd = [CLI, "--scene", scene_paths[0], "--skybox", os.path.join(rt.DATA_DIR, "skybox"), "--width", str(W), "--height", str(H), "--bounces", str(nb),
+           "--seed", str(seed), "--init-scale", str(init_scale), "--interactive", str(passes), "--present-every", "12", "--out", str(out)] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    oracle.set_skybox(rt.load_skybox()); oracle.load_scene(scene_paths[0]); oracle.set_camera()
+    want, _, count, next_scale = oracle_progressive(oracle, W, H, init_scale, passes, nb, seed)
+    assert line["passes"] == passes and line["frames_resolved"] == 4 and line["next_scale"] == next_scale
+    assert np.float32(line["weight_sum"]) == np.float32(count)
+    raw = out.read_bytes()
+    head = f"P6\n{W} {H}\n255\n".encode()
+    img = np.frombuffer(raw[len(head):], np.uint8).reshape(H, W, 3)
+    assert (img == (want * np.float32(255)).astype(np.uint8)[::-1]).all(), extra
