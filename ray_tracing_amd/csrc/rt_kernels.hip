@@ -2018,6 +2018,17 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 			}
 			const V3 v = mk3(dr[0] * 2.0f - 1.0f, dr[1] * 2.0f - 1.0f, dr[2] * 2.0f - 1.0f);
 			const V3 want = unit3(v), got = unit3_of_draws(v);
+			/* the draw itself: the conversion of rng_draw() against the plain one, on words with any number of leading zeros, on
+			 * rounding boundaries (a run of ones / a one and zeros below the 24th bit) and on 0, 1 and 2^64 - 1; and the fused
+			 * draw * 2 - 1 of rng_vector() against the two operations */
+			const uint64_t word = r3 >> (r1 & 63);
+			const uint64_t cases[6] = { r0, word, word | (word >> 25), (word >> 40 << 40) | (1ull << 39) >> (r2 & 1), (r2 & 3) == 0 ? 0ull : 1ull, ~0ull >> (r0 & 63) };
+			bool draw_ok = true;
+			for (int c = 0; c < 6; c++)
+				draw_ok = draw_ok && __float_as_uint(unit_float_of_bits(cases[c])) == __float_as_uint((float) cases[c] * 0x1p-64f);
+			for (int c = 0; c < 3; c++)
+				draw_ok = draw_ok && __float_as_uint(__builtin_fmaf(dr[c], 2.0f, -1.0f)) == __float_as_uint(dr[c] * 2.0f - 1.0f);
+			if (!draw_ok) { bad++; out[6] = (uint32_t) word; out[7] = (uint32_t) (word >> 32); }
 			if (__float_as_uint(want.x) != __float_as_uint(got.x) || __float_as_uint(want.y) != __float_as_uint(got.y) ||
 			    __float_as_uint(want.z) != __float_as_uint(got.z)) {
 				bad++;

@@ -195,11 +195,31 @@ RT_DEV uint64_t fold_mul(uint64_t a)
 #endif
 }
 
+/* (float) bits * 2^-64  [== (float) bits / (float) UINT64_MAX (utils.c:74): the divisor is 2^64] */
+RT_DEV float unit_float_of_bits(uint64_t bits)
+{
+#if defined(__gfx950__) || defined(__gfx942__) || defined(__gfx90a__)
+	/* As the compiler converts a 64-bit integer -- normalise, keep the top 32 bits with everything below them OR-ed into the
+	 * last one, round those to 24 with v_cvt_f32_u32, scale with v_ldexp_f32 -- except that the 2^-64 goes into that same ldexp
+	 * instead of a multiply behind it (both scalings are exact: a non-zero result is at least 2^-64).  One instruction less per
+	 * draw, fourteen draws per bounce: C1 -1.1 %, C3 -2.7 % (profiles/r04/ab_draw_ldexp.txt); rt_selftest(7) compares the two.
+	 * (Written as instructions: from C the compiler turns both minima into a compare and a select.) */
+	const uint32_t hi = (uint32_t) (bits >> 32);
+	uint32_t lead, sticky;
+	asm("v_ffbh_u32 %0, %1\n\tv_min_u32 %0, 32, %0" : "=&v"(lead) : "v"(hi));      /* leading zeros of the high word; 32 when it is zero */
+	const uint64_t norm = bits << lead;
+	asm("v_min_u32 %0, 1, %1" : "=v"(sticky) : "v"((uint32_t) norm));
+	const uint32_t top = (uint32_t) (norm >> 32) | sticky;
+	return __builtin_ldexpf((float) top, -32 - (int) lead);
+#else
+	return (float) bits * 0x1p-64f;
+#endif
+}
+
 RT_DEV float rng_draw(uint64_t &state)
 {
 	state += 0x60bee2bee120fc15ull;
-	uint64_t bits = fold_mul<0x1b03738712fad5c9ull>(fold_mul<0xa3b195354a39b70dull>(state));
-	return (float) bits * 0x1p-64f;       /* == (float)bits / (float)UINT64_MAX, the divisor is 2^64 */
+	return unit_float_of_bits(fold_mul<0x1b03738712fad5c9ull>(fold_mul<0xa3b195354a39b70dull>(state)));
 }
 
 /* `counter` mode path seed -- must match oracle/rt_oracle.c orc_path_seed() */
@@ -229,9 +249,11 @@ RT_DEV V3 unit3_of_draws(V3 v)
 /* vector.c:99-111: x, y, z drawn in that order; rng_vector is random_vector(), before normalize() */
 RT_DEV V3 rng_vector(uint64_t &state)
 {
-	float x = rng_draw(state) * 2.0f - 1.0f;
-	float y = rng_draw(state) * 2.0f - 1.0f;
-	float z = rng_draw(state) * 2.0f - 1.0f;
+	/* draw * 2 - 1 (vector.c:101-103) as one fused multiply-add: doubling is exact, so the one rounding of fma(d, 2, -1) is the
+	 * rounding of the subtraction -- the same bits, one instruction instead of two, twelve times per bounce */
+	float x = __builtin_fmaf(rng_draw(state), 2.0f, -1.0f);
+	float y = __builtin_fmaf(rng_draw(state), 2.0f, -1.0f);
+	float z = __builtin_fmaf(rng_draw(state), 2.0f, -1.0f);
 	return mk3(x, y, z);
 }
 template <bool FAST = false>
