@@ -88,7 +88,7 @@ typedef struct {
 	                             * launch fails to write cannot pass for correct because an earlier frame left it there */
 	int    trace_known_taps;    /* testing aid: trace every soft-shadow tap, also those of camera-ray hit points from which
 	                             * every tap provably reaches the emitter first (csrc/rt_lit.h; normally answered untraced) */
-	int    test_every_object;   /* testing / measurement aid: scenes of more than 64 objects are rendered without the cluster cull
+	int    test_every_object;   /* testing / measurement aid: scenes of 32 objects and more are rendered without the cluster cull
 	                             * (csrc/rt_cull.h) -- every ray tests every object, as the reference does; same frames, slower */
 	int    first_bounce_probe;  /* EXPERIMENT (round 4): launches of a compiled scene with 2..64 spp run rt_first_bounce_spec
 	                             * -- one wave per pixel, first bounce only, pixels of known tap class only -- instead of the trace

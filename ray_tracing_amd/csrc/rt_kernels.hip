@@ -2191,7 +2191,9 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 		return e != hipSuccess ? e : hipEventRecord(primary_done, stream);
 	}
 	/* persistent waves: as many workgroups as fit on the chip at once, capped by the work */
-	const bool cull = L.num_clusters > 0 && L.clusters != nullptr && scene_fast_ok && variant == 0;
+	/* (a scene the host has had compiled keeps its compiled kernel: clusters are built from RT_CULL_MIN_OBJECTS objects, scenes
+	 * of up to 64 can be compiled) */
+	const bool cull = L.num_clusters > 0 && L.clusters != nullptr && scene_fast_ok && variant == 0 && !spec_fn;
 	size_t lds = cull ? (size_t) CULL_GEOM_F4(L.num_objects) * 16 + (size_t) L.num_clusters * sizeof(rt_cluster) + (RT_BLOCK / 64) * (sizeof(WaveLDS) + 64 * sizeof(unsigned long long))
 	                  : rt_wavefront_lds_bytes(L.num_objects);
 	int per_cu = (int) ((160u * 1024u) / lds);
@@ -2200,7 +2202,9 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	/* the grids of the lit-taps table go into LDS as well if that costs no workgroup per CU (else they are read from memory) */
 	rt_launch Lq = L;
 	Lq.lit_grids_in_lds = 0;
-	if (L.lit_cells != nullptr) {
+	/* (the culled kernel's LDS layout has no place for the lit-taps grids: a culled scene that has the table -- 40 to 64 objects --
+	 * reads them from memory) */
+	if (Lq.lit_cells != nullptr && !cull) {
 		const size_t with = lds + (size_t) L.num_objects * 48;
 		if (with <= 160u * 1024u && (int) ((160u * 1024u) / with) >= per_cu) { Lq.lit_grids_in_lds = 1; lds = with; }
 	}

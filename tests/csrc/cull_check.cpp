@@ -66,7 +66,7 @@ int main(int argc, char **argv)
 	auto uni = [&](float a, float b) { return a + (b - a) * (float) ((rng() >> 11) * (1.0 / 9007199254740992.0)); };
 	unsigned long long pairs = 0, hits = 0, bad = 0, structure_bad = 0, refused = 0;
 	for (int sc = 0; sc < scenes; sc++) {
-		const int n = 65 + (int) (rng() % 960);
+		const int n = 32 + (int) (rng() % 993);
 		const float extent = (const float[]) { 0.5f, 3.0f, 10.0f, 30.0f, 60.0f }[rng() % 5];
 		std::vector<rt_geom> geom((size_t) n);
 		for (int i = 0; i < n; i++) {

@@ -15,7 +15,8 @@ gpu, orc = rt.Renderer(0), Oracle()
 gpu.set_tuning(poison_frame=True)
 bad = 0
 for case in range(cases):
-    n = int(rng.integers(65, 300)) if rng.random() < 0.15 else int(rng.integers(1, 14))      # (65 and up: the cluster cull of rt_cull.h)
+    pick = rng.random()
+    n = int(rng.integers(65, 300)) if pick < 0.15 else (int(rng.integers(15, 65)) if pick < 0.25 else int(rng.integers(1, 14)))      # (32 and up, not compiled: the cluster cull of rt_cull.h)
     objs = []
     for k in range(n):
         mat = dict(albedo=rng.uniform(0, 1, 3), roughness=float(rng.choice([0, 0.3, 1.0])), reflectance=float(rng.uniform(0, 1)),

@@ -25,7 +25,7 @@ CAMERAS = [LARGE_SCENE_CAMERA,                                                  
            dict(pos=(-9, 9, 2), front=(1, -1, 0), up=(0, 1, 0), fov=0.8)]              # axis-aligned components in the view direction
 
 
-@pytest.mark.parametrize("n", [65, 100, 256, 777, 1024])
+@pytest.mark.parametrize("n", [32, 47, 64, 65, 100, 256, 777, 1024])
 def test_culled_equals_every_object_equals_oracle(gpu, oracle, n):
     sky = synthetic_skybox(32, seed=n)
     scene = large_scene(n, seed=n)
@@ -52,7 +52,7 @@ def test_cull_fuzz_against_every_object(gpu):
     sky = synthetic_skybox(16, seed=5)
     gpu.set_skybox(sky)
     for case in range(24):
-        n = int(rng.integers(65, 400))
+        n = int(rng.integers(32, 400))
         extent = float(rng.choice([0.5, 3.0, 10.0, 30.0]))
         gpu.set_scene(large_scene(n, seed=1000 + case, extent=extent, floor=bool(case & 1), light=bool(case & 2)))
         pos = rng.uniform(-1.5 * extent, 1.5 * extent, 3)
@@ -98,4 +98,23 @@ def test_largest_scene_at_full_hd_rows_against_the_oracle(gpu, oracle):
     want = oracle.render_counter_rows(W, H, spp, nb, rows, seed=1, threads=min(os.cpu_count() or 1, 64))
     for r_, v in want.items():
         assert (bits(culled[r_]) == bits(v)).all(), r_
+    gpu.set_camera(); oracle.set_camera()
+
+
+def test_a_compiled_scene_keeps_its_compiled_kernel(gpu, oracle):
+    """32 ... 64 objects: rt_set_scene builds clusters and the generic path is the culled one; a scene the host has compiled
+    (rt_compile_scene, up to 64 objects) renders with its compiled kernel -- the same frame either way, and the oracle's."""
+    n = 48
+    sky = synthetic_skybox(32, seed=n)
+    scene = large_scene(n, seed=n)
+    gpu.set_skybox(sky); gpu.set_scene(scene); gpu.set_camera(**LARGE_SCENE_CAMERA)
+    oracle.set_skybox(sky); oracle.set_scene(scene); oracle.set_camera(**LARGE_SCENE_CAMERA)
+    W, H, spp, nb = 96, 54, 3, 5
+    culled = gpu.render(W, H, spp, nb, seed=n)
+    gpu.compile_scene()
+    assert gpu.scene_is_compiled()
+    compiled = gpu.render(W, H, spp, nb, seed=n)
+    want = oracle.render_counter(W, H, spp, nb, seed=n, threads=min(os.cpu_count() or 1, 32))
+    assert (bits(culled) == bits(want)).all() and (bits(compiled) == bits(want)).all()
+    gpu.set_scene(scene)                      # drops the compiled kernel
     gpu.set_camera(); oracle.set_camera()
