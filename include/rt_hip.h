@@ -90,9 +90,6 @@ typedef struct {
 	                             * every tap provably reaches the emitter first (csrc/rt_lit.h; normally answered untraced) */
 	int    test_every_object;   /* testing / measurement aid: scenes of 32 objects and more are rendered without the cluster cull
 	                             * (csrc/rt_cull.h) -- every ray tests every object, as the reference does; same frames, slower */
-	int    first_bounce_probe;  /* EXPERIMENT (round 4): launches of a compiled scene with 2..64 spp run rt_first_bounce_spec
-	                             * -- one wave per pixel, first bounce only, pixels of known tap class only -- instead of the trace
-	                             * kernel.  Frames are complete only at max_bounces == 1 and only on those pixels: a measurement aid */
 } rt_tuning;
 RT_API void rt_default_tuning(rt_tuning *t);
 

@@ -50,7 +50,7 @@ class RenderParams(C.Structure):
 class Tuning(C.Structure):
     _fields_ = [("dequeue_shards", C.c_int),
                 ("workgroups_per_cu", C.c_int), ("jit_waves_per_simd", C.c_int), ("jit_flags", C.c_char_p),
-                ("force_collective", C.c_int), ("poison_frame", C.c_int), ("trace_known_taps", C.c_int), ("test_every_object", C.c_int), ("first_bounce_probe", C.c_int)]
+                ("force_collective", C.c_int), ("poison_frame", C.c_int), ("trace_known_taps", C.c_int), ("test_every_object", C.c_int)]
 
 
 STREAM_LEGACY = C.c_void_p(-1).value      # RT_STREAM_LEGACY: the device's legacy null stream
@@ -384,7 +384,7 @@ class Renderer(_FrameQueue):
         _check(lib().rt_set_camera(self._ctx, C.byref(cam)), "rt_set_camera")
 
     def set_tuning(self, dequeue_shards=0, workgroups_per_cu=0,
-                   jit_waves_per_simd=0, jit_flags=None, poison_frame=None, trace_known_taps=None, first_bounce_probe=0, test_every_object=None):
+                   jit_waves_per_simd=0, jit_flags=None, poison_frame=None, trace_known_taps=None, test_every_object=None):
         """rt_set_tuning(): scheduling knobs (0 / None = automatic).  They never change a frame."""
         t = Tuning()
         lib().rt_default_tuning(C.byref(t))
@@ -397,7 +397,6 @@ class Renderer(_FrameQueue):
         if trace_known_taps is not None:
             self._trace_known = bool(trace_known_taps)
         t.trace_known_taps = 1 if getattr(self, "_trace_known", False) else 0
-        t.first_bounce_probe = first_bounce_probe
         if test_every_object is not None:
             self._every_object = bool(test_every_object)
         t.test_every_object = 1 if getattr(self, "_every_object", False) else 0

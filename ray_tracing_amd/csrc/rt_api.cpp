@@ -697,8 +697,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	}
 	ctx->slot[ctx->launches & 1u].lists_key = 0;
 	ctx->primary_passes++;
-	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->slot[ctx->launches & 1u].d_counter, e0, ctx->slot[ctx->launches & 1u].started, ctx->num_cus, workgroups_per_cu_for(ctx, stream), stream,
-	                                false, ctx->tuning.first_bounce_probe && ctx->spec_fn ? rt_jit_first_bounce(ctx->spec_module) : nullptr);
+	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->slot[ctx->launches & 1u].d_counter, e0, ctx->slot[ctx->launches & 1u].started, ctx->num_cus, workgroups_per_cu_for(ctx, stream), stream);
 	if (le == hipSuccess && ctx->profiling) le = hipEventRecord(e1, stream);
 	if (ctx->profiling) {
 		if (le == hipSuccess) ctx->events.emplace_back(e0, e1);

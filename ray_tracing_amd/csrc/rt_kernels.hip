@@ -1259,9 +1259,6 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 							W.win[0][e] = held[0];
 							W.s_seq[sg] = sq + 1u;
 						}
-#ifdef RT_PROBE_KNOWN_ONLY          /* experiment (scripts/first_bounce_probe.py): only pixels whose tap class is known are rendered, by either kernel */
-						if ((((uint32_t) px.obj >> 16) & 3u) == 0u) W.s_nxt[sg] = spp;
-#endif
 					}
 				}
 				wave_fence();
@@ -1612,203 +1609,6 @@ rt_trace_spec(const rt_launch L, unsigned int *block_counter)
 }
 #endif
 
-#ifdef RT_SPEC_HEADER
-/* =============================================================================================
- * rt_first_bounce_spec -- EXPERIMENT of round 4 (DESIGN.md "A first-bounce pass"): one wave = the samples of ONE pixel.
- *
- * 58 % of C1's shading events are a sample's first, at the camera ray's hit point, which all samples of the pixel share:
- * object, normal, material, tap class (rt_lit.h) are wave-uniform here.  What that buys, per event:
- *   - no hand-out: lane s IS sample s, its window slot is row `s` of the wave's colour buffer;
- *   - on a box the side of a tap (main.c:194) is the sign of ONE component of random_vector() -- the component along the
- *     face's normal -- and the generator is a counter (utils.c:62: x += constant), so when the taps' answer is known
- *     (class lit / dark) the other two draws of each tap are never computed: 7 draws instead of 13;
- *   - no tap is queued, no per-lane record travels from a front to a back;
- *   - the in-order sum (main.c:394) runs for eight pixels at once, one lane per pixel walking its 64 colours in LDS.
- * This kernel finishes a sample whose path ends with its first bounce (bounce limit 1, or -- with the bounce ray traced --
- * a ray that leaves the scene); a sample that goes on would have to be handed to the general loop, which this probe
- * does NOT do (its colour is left out: frames are complete only at max_bounces == 1).  It exists to measure what the
- * specialisation is worth before the hand-over is built; rt_tuning.first_bounce_probe selects it.
- * Pixels of unknown tap class (their taps must be traced) are not handled: they are skipped (RT_PROBE_KNOWN_ONLY leaves
- * them out of the general kernel's frame as well, so the two frames can be compared).
- * ============================================================================================= */
-struct FirstLDS { float col[3][8 * 65]; };      /* 8 pixels x 64 samples (+1: rows on different banks) per channel */
-
-#ifndef RT_FIRST_WAVES_PER_SIMD
-#define RT_FIRST_WAVES_PER_SIMD 6      /* 80 registers are enough for one pixel's first bounce; 6 x 4 x 6.2 KB of colours fit the CU */
-#endif
-extern "C" __global__ void __launch_bounds__(RT_BLOCK, RT_FIRST_WAVES_PER_SIMD)
-rt_first_bounce_spec(const rt_launch L, unsigned int *block_counter)
-{
-	extern __shared__ float4 lds[];
-	constexpr int n = SPEC_N;
-	const SceneLDS sc = stage_scene(L, lds, n);
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	FirstLDS &F = reinterpret_cast<FirstLDS*>(lds + 6 * n)[wave];
-	const rt_launch_cold C = cold_view();
-	typedef const __attribute__((address_space(1))) unsigned int *guint;
-	const guint fill_counts = (guint) C->pix_count;
-	const int light_obj = SPEC_LIGHT;
-	const float inv_spp = 1.0f / (float) L.spp;
-	const bool active = lane < L.spp;               /* the host launches this kernel for spp <= 64 only */
-	const float nan_f = __uint_as_float(0x7fc00000u);
-
-	unsigned int shard = blockIdx.x % (unsigned int) L.num_shards;
-	int batch = 0, my_off = 0;
-	/* the in-order sum of the pixels waiting in F.col (main.c:394,476): lane p adds pixel p's colours one after the other */
-	auto flush = [&]() {
-		if (lane < batch) {
-			V3 sum = mk3(0, 0, 0);
-			for (int k = 0; k < L.spp; k++)
-				sum = add3(sum, mk3(F.col[0][lane * 65 + k], F.col[1][lane * 65 + k], F.col[2][lane * 65 + k]));
-			const V3 res = scale3(sum, inv_spp);
-			float *dst = L.frame + (size_t) my_off * 3;
-			dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
-		}
-		batch = 0;
-		wave_fence();
-	};
-
-	/* ---- pixel supply (the lists and counters of the general kernel), two steps ahead of the arithmetic: the dequeue of the
-	 * pixel after next is sent off (lane 0's atomic; nobody waits for it) before the record of the next pixel is asked for
-	 * with the number the previous dequeue has brought by now, and that record is in flight while the current pixel is worked
-	 * on.  A wave alone would spend two memory round trips (2-3 us) per pixel of 0.6 us arithmetic. */
-	unsigned int asked_shard = shard, asked = 0u;      /* the dequeue in flight: lane 0 of `asked` holds the list position */
-	auto ask = [&]() { asked_shard = shard; if (lane == 0) asked = atomicAdd(block_counter + shard * 32u, 1u); };
-	/* the position the dequeue in flight returned, or -- that list has run out -- a pixel of another list, fetched on the spot;
-	 * false: the launch has no pixels left */
-	auto claim = [&](size_t &record) -> bool {
-		unsigned int k = (unsigned int) __builtin_amdgcn_readfirstlane((int) asked);
-		unsigned int from = asked_shard;
-		for (;;) {
-			const unsigned int filled = (unsigned int) __builtin_amdgcn_readfirstlane((int) fill_counts[from * 32u]);
-			if (k < filled) { record = (size_t) from * (size_t) C->pix_shard_cap + k; return true; }
-			unsigned int left = 0;
-			if (lane < C->num_shards) {
-				const unsigned int taken = __hip_atomic_load(block_counter + (unsigned int) lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				const unsigned int have = fill_counts[(unsigned int) lane * 32u];
-				left = have > taken ? have - taken : 0u;
-			}
-			const unsigned long long some = __ballot(left != 0u);
-			if (some == 0ull) return false;
-			const int pick = (int) ((blockIdx.x * (RT_BLOCK / 64) + (unsigned int) wave) % (unsigned int) __popcll(some));
-			shard = from = (unsigned int) __builtin_ctzll(__ballot(left != 0u && lanes_below(some) == pick));
-			unsigned int kk = 0;
-			if (lane == 0) kk = atomicAdd(block_counter + from * 32u, 1u);
-			k = (unsigned int) __builtin_amdgcn_readfirstlane((int) kk);
-		}
-	};
-	size_t record = 0;
-	ask();
-	bool have = claim(record);
-	PixelRec px = load_pixel(C, have ? record : 0);
-	if (have) ask();
-	while (have) {
-		/* the record after this one: its loads are in flight during this pixel's arithmetic */
-		size_t record_next = 0;
-		const bool have_next = claim(record_next);
-		const PixelRec px_next = load_pixel(C, have_next ? record_next : record);
-		if (have_next) ask();
-		const PixelRec cur = px;
-		px = px_next; have = have_next; record = record_next;
-		{
-		const PixelRec &px = cur;
-		const int hobj = __builtin_amdgcn_readfirstlane(px.obj & (RT_PIX_TAPS_LIT - 1));
-		const int cls = __builtin_amdgcn_readfirstlane((int) (((uint32_t) px.obj >> 16) & 3u));
-		if (cls != 0) {                             /* (0: taps to be traced -- the general kernel's pixel) */
-		const V3 hp = px.a, hn = px.n, hdir = px.dir;
-
-		/* ---- the first bounce of every sample of the pixel (main.c:180-261 with i == 0) ---- */
-		uint64_t rng = path_seed(L.seed, px.index, (uint32_t) L.sample_base + (uint32_t) lane);
-		int tapmask = 0;
-		const bool on_box = __builtin_amdgcn_readfirstlane(__float_as_int(sc.geom[2 * hobj + 1].z)) == RT_GEOM_CUBE;
-		if (light_obj >= 0) {
-			if (on_box) {
-				/* main.c:193-195 on a face with normal s * e_a: dot(normalize(v), n) = s * v_a / |v| plus signed zeros -- positive
-				 * exactly when s * v_a is (a component of random_vector() is 0 or at least 2^-24 in magnitude and |v| <= sqrt(3):
-				 * the quotient neither vanishes nor changes sign; a vector too short to be normalised is used as it is).  Draw
-				 * number 3 t + a of the bounce is that component of tap t: the state is a counter, the other six draws are
-				 * stepped over (utils.c:62). */
-				const int a = __builtin_amdgcn_readfirstlane(hn.x != 0.0f ? 0 : (hn.y != 0.0f ? 1 : 2));
-				const float sgn = a == 0 ? hn.x : (a == 1 ? hn.y : hn.z);
-				constexpr uint64_t inc = 0x60bee2bee120fc15ull;
-				uint64_t s0 = rng + (uint64_t) a * inc, s1 = s0 + 3ull * inc, s2 = s0 + 6ull * inc;
-				const float v0 = rng_draw(s0) * 2.0f - 1.0f, v1 = rng_draw(s1) * 2.0f - 1.0f, v2 = rng_draw(s2) * 2.0f - 1.0f;
-				tapmask = (v0 * sgn > 0 ? 1 : 0) | (v1 * sgn > 0 ? 2 : 0) | (v2 * sgn > 0 ? 4 : 0);
-				rng += 9ull * inc;
-			} else {
-				const V3 tap_j0 = rng_vector(rng), tap_j1 = rng_vector(rng), tap_j2 = rng_vector(rng);
-				const float side0 = dot3(tap_j0, hn), side1 = dot3(tap_j1, hn), side2 = dot3(tap_j2, hn);
-				if (wave_all(side_is_certain(side0) && side_is_certain(side1) && side_is_certain(side2)))
-					tapmask = (side0 > 0 ? 1 : 0) | (side1 > 0 ? 2 : 0) | (side2 > 0 ? 4 : 0);
-				else
-					tapmask = (dot3(unit3_of_vector<true>(tap_j0), hn) > 0 ? 1 : 0) | (dot3(unit3_of_vector<true>(tap_j1), hn) > 0 ? 2 : 0) |
-					          (dot3(unit3_of_vector<true>(tap_j2), hn) > 0 ? 4 : 0);
-			}
-		}
-		const float4 m0 = sc.shade[4 * hobj], m1 = sc.shade[4 * hobj + 1], m2 = sc.shade[4 * hobj + 2], m3 = sc.shade[4 * hobj + 3];
-		const V3 f0 = mk3(m0.x, m0.y, m0.z), omf0 = mk3(m1.x, m1.y, m1.z);
-		const float n_dot_v = clamp01(dot3(hn, neg3(hdir)));
-		const double xg = 1.0 - (double) n_dot_v;
-		const double xg2 = xg * xg;
-		const float grazing = (float) (xg2 * xg2 * xg);                       /* main.c:128, tests/test_pow5.py */
-		const V3 fresnel = madd3(f0, omf0, grazing);
-
-		V3 scatter = rng_direction<true>(rng);
-		if (dot3(scatter, hn) < 0) scatter = neg3(scatter);
-		bool specular = __float_as_int(m1.w) != 0;
-		if (!specular)
-			specular = rng_draw(rng) <= third_of(fresnel.x + fresnel.y + fresnel.z);
-		V3 out_dir;
-		if (specular) {
-			const V3 nneg = neg3(hn);
-			const float f = -2.0f * dot3(nneg, hdir);
-			out_dir = unit3_fast(lin2(scatter, madd3(hdir, nneg, f), m0.w, 1.0f));
-		} else
-			out_dir = scatter;
-
-		/* the radiance arithmetic of the bounce (main.c:232,248,257-261): contrib is (1,1,1), result (0,0,0) */
-		V3 carry = mk3(1, 1, 1), rad = mk3(0, 0, 0);
-		rad = add3(rad, had3(mk3(m3.x, m3.y, m3.z), carry));
-		if (!specular) carry = had3(carry, mk3(m2.x, m2.y, m2.z));
-		if (tapmask != 0 && cls == 1) {
-			/* every accepted tap reaches the emitter (rt_lit.h): n equal terms e add up to e, 2e, RN(3e) = the product n x e,
-			 * "+ 0" turns a -0 product into the sum's +0 (wavefront_body, section 5); class 2: they add nothing */
-			const int taps = __popc((unsigned int) tapmask);
-			const float4 e = sc.shade[4 * light_obj + 3];
-			const float nf = (float) taps;
-			V3 lit = mk3(e.x * nf + 0.0f, e.y * nf + 0.0f, e.z * nf + 0.0f);
-			lit = scale3(lit, taps == 1 ? 1.0f : (taps == 2 ? 0.5f : __uint_as_float(0x3eaaaaabu)));
-			if (!(tiny_f_fast(lit.x) && tiny_f_fast(lit.y) && tiny_f_fast(lit.z))) {
-				const float w = 0.05f;
-				rad = madd3(rad, had3(lit, carry), w);
-				carry = scale3(carry, 1.0f - w);
-			}
-		}
-		V3 col = mk3(nan_f, nan_f, nan_f);
-		if (1 < L.max_bounces) {
-			/* the bounce ray (main.c:250,161): a path that leaves the scene ends here with the sky (main.c:163-172) */
-			const V3 ray_o = madd3(hp, out_dir, 0.001f);
-			const V3 dn = unit3_fast(out_dir);
-			const Hit hit = nearest_hit_spec(sc, n, ray_o, dn, true);
-			if (hit.obj < 0) {
-				rad = add3(rad, had3(sky_colour<true>(sky_texel<true>(L, dn)), carry));
-				col = mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z));
-			}
-			/* (a path that goes on is the general loop's: not handed over by this probe) */
-		} else
-			col = mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z));       /* bounce limit (main.c:158), main.c:267-269 */
-
-		if (active) { F.col[0][batch * 65 + lane] = col.x; F.col[1][batch * 65 + lane] = col.y; F.col[2][batch * 65 + lane] = col.z; }
-		if (lane == batch) my_off = px.off;
-		batch++;
-		wave_fence();
-		if (batch == 8) flush();
-		}
-		}
-	}
-	if (batch) flush();
-}
-#endif /* RT_SPEC_HEADER */
 
 #ifndef RT_SPEC_ONLY
 /* ---- progressive accumulation: worker()'s publish step (main.c:387-396) and update_frame()'s
@@ -2146,8 +1946,6 @@ size_t rt_scene_lds_bytes(int num_objects) { return (size_t) num_objects * (size
 
 size_t rt_wavefront_lds_bytes(int num_objects) { return rt_scene_lds_bytes(num_objects) + (RT_BLOCK / 64) * sizeof(WaveLDS); }
 static_assert(sizeof(rt_cluster) == 16 * RT_CLUSTER_F4 && RT_CLUSTER_SIZE % 8 == 0 && RT_CLUSTER_SIZE <= 32, "the kernels read a cluster as RT_CLUSTER_F4 float4 words");
-/* rt_first_bounce_spec (experiment): per wave 3 x 8 x 65 floats of colours */
-size_t rt_first_bounce_lds_bytes(int num_objects) { return rt_scene_lds_bytes(num_objects) + (RT_BLOCK / 64) * (size_t) (3 * 8 * 65 * sizeof(float)); }
 
 /* rt_primary_pass: a few workgroups per CU, each with a run of consecutive 8x8 pixel blocks (at least one per wave) */
 void rt_primary_geometry(int width, int local_rows, int num_cus, unsigned int *groups_out, int *per_group_out)
@@ -2172,7 +1970,7 @@ size_t rt_pixel_list_capacity(int width, int local_rows, int num_cus, int num_sh
 
 hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, hipFunction_t spec_fn,
                            unsigned int *block_counter, hipEvent_t cleared, hipEvent_t primary_done, int num_cus, int workgroups_per_cu, hipStream_t stream,
-                           bool reuse_pixel_lists, hipFunction_t first_bounce_fn)
+                           bool reuse_pixel_lists)
 {
 	if (L.local_rows <= 0 || L.width <= 0) {
 		hipError_t e = cleared ? hipEventRecord(cleared, stream) : hipSuccess;
@@ -2245,20 +2043,6 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 		e = hipGetLastError();
 		if (e == hipSuccess) e = hipEventRecord(primary_done, stream);       /* the next launch of the context may start (rt_api.cpp) */
 		if (e != hipSuccess) return e;
-	}
-	if (variant == 0 && scene_fast_ok && first_bounce_fn && L.spp <= 64 && L.spp > 1) {
-		/* experiment (rt_tuning.first_bounce_probe): the first-bounce kernel alone, on the pixels whose tap class is known */
-		rt_launch Lc = Lq;
-		unsigned int *counter = block_counter;
-		void *args[] = { &Lc, &counter };
-		const size_t flds = rt_first_bounce_lds_bytes(L.num_objects);
-		int fper = (int) ((160u * 1024u) / flds);
-		if (fper > 6) fper = 6;
-		if (workgroups_per_cu >= 1 && workgroups_per_cu < fper) fper = workgroups_per_cu;
-		long long fgrid = (long long) num_cus * fper;
-		if (fgrid > blocks * 16) fgrid = blocks * 16;          /* (a wave per pixel: never more waves than pixels) */
-		if (fgrid < 1) fgrid = 1;
-		return hipModuleLaunchKernel(first_bounce_fn, (unsigned int) fgrid, 1, 1, RT_BLOCK, 1, 1, (unsigned int) flds, stream, args, nullptr);
 	}
 	if (variant == 0 /* RT_KERNEL_AUTO */ && scene_fast_ok && spec_fn) {
 		/* same kernel, trace loop specialised for this scene by rt_compile_scene() */

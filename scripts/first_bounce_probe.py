@@ -6,7 +6,10 @@ C1's frame at max_bounces = 1 (every sample is exactly one shading event, no bou
 interleaved on one device, HIP events over primary pass + kernel; the two frames must be identical.  Then both at the real
 bounce limit (4): B then also traces the bounce ray and finishes the samples that leave the scene -- its frame is
 incomplete (survivors are not handed over), only its time means something: T_B(4) - T_B(1) is the cost of the bounce-ray
-batch at 100 % lanes.  usage: first_bounce_probe.py [rounds]"""
+batch at 100 % lanes.  usage: first_bounce_probe.py [rounds]
+
+The kernel and its tuning switch are no longer in the library (the experiment was killed at its kill line): apply
+scripts/patches/first_bounce_pass.diff to a scratch copy of the tree (`git apply`), build with -DRT_PROBE_KNOWN_ONLY, run this."""
 import os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
