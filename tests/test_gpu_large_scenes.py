@@ -118,3 +118,27 @@ def test_a_compiled_scene_keeps_its_compiled_kernel(gpu, oracle):
     assert (bits(culled) == bits(want)).all() and (bits(compiled) == bits(want)).all()
     gpu.set_scene(scene)                      # drops the compiled kernel
     gpu.set_camera(); oracle.set_camera()
+
+
+@pytest.mark.parametrize("n", [40, 100, 600])
+def test_interactive_ladder_on_a_large_scene(gpu, oracle, n):
+    """The culled kernels under the interactive protocol: passes of one sample per pixel (every lane takes a pixel for itself),
+    the low-resolution steps, and several full-resolution passes in one launch (rt_progressive_passes) -- 40 objects (with the
+    lit-taps table), 100, and 600 (one workgroup of twelve waves per CU) -- against the oracle's ladder."""
+    from rtlibs import oracle_progressive
+    sky = synthetic_skybox(32, seed=n)
+    scene = large_scene(n, seed=n)
+    gpu.set_skybox(sky); gpu.set_scene(scene); gpu.set_camera(**LARGE_SCENE_CAMERA)
+    oracle.set_skybox(sky); oracle.set_scene(scene); oracle.set_camera(**LARGE_SCENE_CAMERA)
+    W, H, init_scale, nb, seed = 80, 48, 4, 6, 11
+    gpu.progressive_begin(W, H, init_scale=init_scale, max_bounces=nb, seed=seed)
+    for _ in range(4):
+        gpu.progressive_pass()
+    want, _, _, _ = oracle_progressive(oracle, W, H, init_scale, 4, nb, seed)
+    assert (bits(gpu.progressive_resolve()) == bits(want)).all(), n
+    gpu.progressive_passes(12)
+    want, _, count, _ = oracle_progressive(oracle, W, H, init_scale, 16, nb, seed)
+    st = gpu.progressive_state()
+    assert st["passes"] == 16 and np.float32(st["count"]) == np.float32(count)
+    assert (bits(gpu.progressive_resolve()) == bits(want)).all(), n
+    gpu.set_camera(); oracle.set_camera()
