@@ -20,8 +20,10 @@
  *     summing the roundings of oc, the two dot products, the squares and the final difference bounds the error of the
  *     discriminant by 108 * 2^-24 * |oc|^2, i.e. r^2 - dist^2 > -1.6e-6 |oc|^2 for every hit the reference reports.  With
  *     |oc| <= 3 sqrt(3) S: E = 2 * 1.6e-6 * 27 S^2 (twice the bound).
- * Scenes with coordinates beyond RT_CULL_MAX_COORD get no clusters (every object is tested, as before), and a wave one of whose
- * rays starts farther out than 2 S -- a camera far outside the scene -- tests every object as well.
+ *   Both bounds are proportional to S: a scene that reaches beyond 64 gets the margin m = 2^-9 * P / 64, P the power of two at
+ *   or above its S -- the same factor of 63 (and the spheres' E is already in terms of S).  Scenes beyond RT_CULL_MAX_COORD
+ *   (2^20: squares stay far from the top of the float range) get no clusters: every object is tested, as before.
+ * A wave one of whose rays starts farther out than 2 S -- a camera far outside the scene -- tests every object as well.
  *
  * Clusters: the leaves of a median-split tree over the objects' centres, RT_CLUSTER_SIZE objects each (members keep their object
  * indices: ties between equal distances go to the lowest INDEX whatever the order of the tests).
@@ -37,7 +39,8 @@
 #include "rt_device.h"
 
 #define RT_CULL_MARGIN     0.001953125f     /* 2^-9 */
-#define RT_CULL_MAX_COORD  64.0f
+#define RT_CULL_UNIT_EXTENT 64.0f           /* scenes within this get the margin as it stands; larger ones a proportionally larger one */
+#define RT_CULL_MAX_COORD  1048576.0f
 #define RT_CULL_MIN_OBJECTS 32              /* below this the every-object loop is faster (profiles/r04/cull_vs_compiled_probe.txt: 24 objects +5 %, 32 -6 %, 64 -22 %);
                                              * a scene of up to 64 objects that the host has compiled (rt_compile_scene) keeps its compiled kernel */
 
@@ -73,10 +76,13 @@ static inline rt_cull_info rt_cull_build(std::vector<rt_geom> &geom, int n, std:
 		} else return info;          /* an object of unknown type is never hit (scene.c:153); keep such scenes on the plain path */
 	}
 	if (!(S > 0.0f)) return info;
+	float margin = RT_CULL_MARGIN;
+	for (float p = RT_CULL_UNIT_EXTENT; p < S; p *= 2.0f) margin *= 2.0f;      /* (exact: powers of two) */
+	info.margin = margin;
 	const float E = 2.0f * 1.6e-6f * 27.0f * S * S;
 	for (int i = 0; i < n; i++) {
 		rt_geom &g = geom[(size_t) i];
-		if (g.type == RT_GEOM_SPHERE) g.b1 = sqrtf(g.b0 + E) * 1.0001f + RT_CULL_MARGIN;      /* h: see above (b1 of a sphere is otherwise unused) */
+		if (g.type == RT_GEOM_SPHERE) g.b1 = sqrtf(g.b0 + E) * 1.0001f + margin;      /* h: see above (b1 of a sphere is otherwise unused) */
 	}
 	/* Clusters = the leaves of a median-split tree over the objects' centres: a range of objects is cut in two at a multiple of
 	 * RT_CLUSTER_SIZE nearest its middle, along the axis on which its centres spread most, until it fits one cluster.  (A Morton
@@ -87,7 +93,7 @@ static inline rt_cull_info rt_cull_build(std::vector<rt_geom> &geom, int n, std:
 		std::vector<float> centre((size_t) n * 3);
 		for (int i = 0; i < n; i++) {
 			float lo[3], hi[3];
-			rt_cull_object_box(geom[(size_t) i], RT_CULL_MARGIN, lo, hi);
+			rt_cull_object_box(geom[(size_t) i], margin, lo, hi);
 			for (int k = 0; k < 3; k++) centre[(size_t) i * 3 + k] = 0.5f * (lo[k] + hi[k]);
 		}
 		std::vector<int> ids((size_t) n);
@@ -122,7 +128,7 @@ static inline rt_cull_info rt_cull_build(std::vector<rt_geom> &geom, int n, std:
 		for (int j = 0; j < RT_CLUSTER_SIZE; j++) K.member[j] = 0xffff;
 		for (int j = 0; j < cnt; j++) {
 			float blo[3], bhi[3];
-			rt_cull_object_box(geom[(size_t) members[j]], RT_CULL_MARGIN, blo, bhi);
+			rt_cull_object_box(geom[(size_t) members[j]], margin, blo, bhi);
 			for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], blo[k]); hi[k] = std::max(hi[k], bhi[k]); }
 			K.member[j] = (unsigned short) members[j];
 		}

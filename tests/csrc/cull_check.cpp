@@ -67,7 +67,7 @@ int main(int argc, char **argv)
 	unsigned long long pairs = 0, hits = 0, bad = 0, structure_bad = 0, refused = 0;
 	for (int sc = 0; sc < scenes; sc++) {
 		const int n = 32 + (int) (rng() % 993);
-		const float extent = (const float[]) { 0.5f, 3.0f, 10.0f, 30.0f, 60.0f }[rng() % 5];
+		const float extent = (const float[]) { 0.5f, 3.0f, 10.0f, 30.0f, 60.0f, 250.0f, 3000.0f, 100000.0f }[rng() % 8];      /* (beyond 64: the margin grows with the scene) */
 		std::vector<rt_geom> geom((size_t) n);
 		for (int i = 0; i < n; i++) {
 			rt_geom &g = geom[(size_t) i];
@@ -79,7 +79,7 @@ int main(int argc, char **argv)
 		}
 		std::vector<rt_cluster> cl;
 		const rt_cull_info info = rt_cull_build(geom, n, cl);
-		if (info.num_clusters <= 0) { refused++; continue; }      /* coordinates beyond RT_CULL_MAX_COORD: such scenes are not culled */
+		if (info.num_clusters <= 0) { refused++; continue; }      /* (coordinates beyond RT_CULL_MAX_COORD: none here) */
 		std::vector<int> owner((size_t) n, -1);
 		for (int c = 0; c < info.num_clusters; c++)
 			for (int j = 0; j < RT_CLUSTER_SIZE; j++) {

@@ -1,5 +1,5 @@
 """csrc/rt_cull.h on the CPU: every object sits in exactly one cluster whose box contains its conservative box, and -- over random
-scenes at five scales and rays aimed at edges, corners and tangents -- no hit the reference's float tests report is ever missed
+scenes at eight scales (0.5 ... 100 000) and rays aimed at edges, corners and tangents -- no hit the reference's float tests report is ever missed
 by the conservative tests that decide whether an object is tested at all (tests/csrc/cull_check.cpp).  The check has teeth: with
 the margin and the discriminant allowance set to zero the same run reports 9 607 missed hits of 939 289; with the derived values, none."""
 import os

@@ -53,7 +53,7 @@ def test_cull_fuzz_against_every_object(gpu):
     gpu.set_skybox(sky)
     for case in range(24):
         n = int(rng.integers(32, 400))
-        extent = float(rng.choice([0.5, 3.0, 10.0, 30.0]))
+        extent = float(rng.choice([0.5, 3.0, 10.0, 30.0, 300.0, 5000.0]))      # (beyond 64 the cull's margin grows with the scene)
         gpu.set_scene(large_scene(n, seed=1000 + case, extent=extent, floor=bool(case & 1), light=bool(case & 2)))
         pos = rng.uniform(-1.5 * extent, 1.5 * extent, 3)
         front = -pos + rng.uniform(-0.3 * extent, 0.3 * extent, 3)
@@ -141,4 +141,25 @@ def test_interactive_ladder_on_a_large_scene(gpu, oracle, n):
     st = gpu.progressive_state()
     assert st["passes"] == 16 and np.float32(st["count"]) == np.float32(count)
     assert (bits(gpu.progressive_resolve()) == bits(want)).all(), n
+    gpu.set_camera(); oracle.set_camera()
+
+
+@pytest.mark.parametrize("extent", [500.0, 20000.0])
+def test_scenes_with_large_coordinates_are_culled_too(gpu, oracle, extent):
+    """Coordinates beyond 64: the conservative margins are proportional to the scene's extent (rt_cull.h), the frame is the
+    every-object frame and the oracle's."""
+    n = 200
+    sky = synthetic_skybox(32, seed=n)
+    scene = large_scene(n, seed=n, extent=extent)
+    cam = dict(pos=(1.4 * extent, 0.9 * extent, 1.4 * extent), front=(-1, -0.5, -1), up=(0, 1, 0), fov=1.0)
+    gpu.set_skybox(sky); gpu.set_scene(scene); gpu.set_camera(**cam)
+    oracle.set_skybox(sky); oracle.set_scene(scene); oracle.set_camera(**cam)
+    W, H, spp, nb = 96, 54, 3, 5
+    gpu.set_tuning(test_every_object=False)
+    culled = gpu.render(W, H, spp, nb, seed=n)
+    gpu.set_tuning(test_every_object=True)
+    plain = gpu.render(W, H, spp, nb, seed=n)
+    gpu.set_tuning(test_every_object=False)
+    want = oracle.render_counter(W, H, spp, nb, seed=n, threads=min(os.cpu_count() or 1, 32))
+    assert (bits(culled) == bits(plain)).all() and (bits(culled) == bits(want)).all(), extent
     gpu.set_camera(); oracle.set_camera()
