@@ -80,6 +80,10 @@ extern "C" { __device__ unsigned long long rt_wave_log[4 * 8192]; }
 #endif
 
 /* LDS written by some lanes of a wave is read by others of the same wave */
+RT_DEV int lanes_below(unsigned long long m)      /* number of set bits of m below this lane */
+{
+	return (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u));
+}
 RT_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 /* ---- LDS-resident scene ------------------------------------------------------------------- */
@@ -371,7 +375,11 @@ RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d, bool want_nor
  * "lowest index among equal distances" (strict `<` in index order, scene.c:168) is kept explicitly, because the clusters
  * are visited out of index order. */
 typedef const __attribute__((address_space(4))) float *rt_const_f;        /* memory read with scalar loads when the address is wave-uniform */
-struct ClusterLDS { const float4 *rec; rt_const_f mem; int count; float margin, origin_max; };      /* RT_CLUSTER_F4 x float4 per cluster (rt_cluster): in LDS, and where they came from */
+#define RT_CLUSTER_MEMBER_F4 (RT_CLUSTER_F4 - 2)      /* a cluster's member list as float4 words: what the culled trace keeps in LDS (the boxes are read with scalar loads) */
+struct ClusterLDS { const float4 *members; rt_const_f mem; int count; float margin, origin_max; };      /* members: RT_CLUSTER_MEMBER_F4 x float4 per cluster, in LDS; mem: the rt_cluster records in memory */
+/* a wave's scratch for the culled trace: the rays' best hits, and the queue of (ray, object) candidates waiting for their exact test */
+#define CULL_QUEUE 128
+struct CullWave { unsigned long long best[64]; unsigned short queue[CULL_QUEUE]; };
 
 /* the conservative slab test: parameters plane * (1/d) - o * (1/d), one fused multiply-add each (oi = o * inv is formed once per
  * ray).  This is the cull's own arithmetic, not the reference's: its error -- 2^-23 |t| + 2^-24 |o| / |d| <= 3.1e-5 / |d| with
@@ -397,12 +405,13 @@ RT_DEV uint32_t from_lane(uint32_t v, int src) { return (uint32_t) __builtin_amd
  * (ray, cluster) pairs of the whole wave are numbered by a prefix sum over the lanes' counts and dealt 64 at a time: lane i
  * takes pair 64 k + i, finds the lane whose ray it is by a binary search over the prefix sums, picks that lane's r-th cluster
  * out of its mask, fetches the ray with ds_bpermute (no LDS memory: registers of another lane), tests the members' conservative
- * boxes and then runs the exact tests on what is left; a hit goes to its ray with one 64-bit LDS minimum on the packed
+ * boxes and queues what is left for the exact tests, which run on full batches (step 3); a hit goes to its ray with one 64-bit LDS minimum on the packed
  * (distance, object index, -0 flag, entry axis) -- distances are >= 0, so their bit patterns order like the numbers, and among
  * equal distances the lower index wins, as in the reference's scan (scene.c:168). */
-RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, unsigned long long *best, bool on, V3 o, V3 d, bool want_normal = true)
+RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, CullWave *cw, bool on, V3 o, V3 d, bool want_normal = true)
 {
 	const int lane = threadIdx.x & 63;
+	unsigned long long *best = cw->best;
 	const RayPrep rp = prepare_ray<true>(o, d);
 	const float omax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z));
 	/* the margins are proved for directions inside the window of the shared-reciprocal division and origins within twice the
@@ -422,14 +431,11 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, u
 		const int first = 32 * w, last = cl.count < first + 32 ? cl.count : first + 32;
 		for (int c = first; c < last; c++) {
 			STAT(32);
-#ifdef RT_CULL_BOXES_FROM_LDS
-			const float4 k0 = cl.rec[RT_CLUSTER_F4 * c], k1 = cl.rec[RT_CLUSTER_F4 * c + 1];
-#else		/* the box is the same for all lanes: two scalar loads, planes as scalar operands of the FMAs -- the LDS pipe is what the
+			/* the box is the same for all lanes: two scalar loads, planes as scalar operands of the FMAs -- the LDS pipe is what the
 			 * culled trace is short of (the members' boxes, the geometry, the cross-lane fetches and the minimum all go through it) */
 			const rt_const_f km = cl.mem + 4 * RT_CLUSTER_F4 * c;
 			float4 k0, k1;
 			k0.x = km[0]; k0.y = km[1]; k0.z = km[2]; k0.w = km[3]; k1.x = km[4]; k1.y = km[5];
-#endif
 			if (slab_may_touch(oi, rp.inv, mk3(k0.x, k0.y, k0.z), mk3(k0.w, k1.x, k1.y))) bits |= 1u << (c - first);
 		}
 		mask[w] = on ? bits : 0u;
@@ -446,6 +452,39 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, u
 	const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) upto, 63);
 	best[lane] = ~0ull;
 	wave_fence();
+	/* 3 (declared first). the exact tests -- the reference's own, on full batches: a (ray, cluster) pair leaves 0.4 members on
+	 * average and one lane in five with any, so the members that pass their conservative box go into a queue of (ray, object) and
+	 * are tested 64 at a time by whichever lane gets them (the ray fetched from its lane's registers again) */
+	uint32_t cq_head = 0u, cq_tail = 0u;
+	auto test_queued = [&](uint32_t batch) {               /* the `batch` <= 64 oldest candidates */
+		STAT(35);
+		const bool mine = (uint32_t) lane < batch;
+		const uint32_t e = mine ? (uint32_t) cw->queue[(cq_head + (uint32_t) lane) & (CULL_QUEUE - 1)] : (uint32_t) lane;
+		const int src = (int) (e & 63u);
+		const uint32_t idx = e >> 6;
+		const V3 so = mk3(from_lane(o.x, src), from_lane(o.y, src), from_lane(o.z, src));
+		const V3 sd = mk3(from_lane(d.x, src), from_lane(d.y, src), from_lane(d.z, src));
+		RayPrep sp;
+		sp.inv = mk3(from_lane(rp.inv.x, src), from_lane(rp.inv.y, src), from_lane(rp.inv.z, src));
+		sp.dd = from_lane(rp.dd, src);
+		if (mine) {
+			sp.inv_ok = true;
+			sp.den = (double) (2.0f * sp.dd); sp.den_ok = near_one(sp.dd); sp.rden = rcp_twice_near_one(sp.dd);     /* as prepare_ray() forms them */
+			const float4 g0 = sc.geom[2 * idx], g1 = sc.geom[2 * idx + 1];
+			float t = 0.0f; int axis = 0; bool hit = false;
+			if (__float_as_int(g1.z) == RT_GEOM_CUBE)
+				hit = box_entry_fast(so, sd, sp, true, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), t, axis);
+			else
+				hit = ball_entry_fast(so, sd, sp, mk3(g0.x, g0.y, g0.z), g0.w, t);
+			if (hit && t >= 0) {
+				const uint32_t tb = __float_as_uint(t);                          /* t >= 0: +0 ... +inf, or -0 (0x80000000), which orders as 0 */
+				const unsigned long long key = ((unsigned long long) (tb & 0x7fffffffu) << 32) | ((unsigned long long) idx << 3) | (unsigned long long) ((tb >> 31) << 2) | (unsigned long long) axis;
+				__hip_atomic_fetch_min(best + src, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			}
+		}
+		cq_head += batch;
+		wave_fence();
+	};
 	for (uint32_t base = 0; base < total; base += 64u) {
 		STAT(33);
 		const uint32_t q = base + (uint32_t) lane;
@@ -460,15 +499,11 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, u
 		src = src > 63 ? 63 : src;
 		uint32_t r = q - (from_lane(upto, src) - from_lane(count, src));        /* its r-th cluster */
 		const uint32_t m0 = from_lane(mask[0], src), m1 = from_lane(mask[1], src), m2 = from_lane(mask[2], src), m3 = from_lane(mask[3], src);
-		const V3 so = mk3(from_lane(o.x, src), from_lane(o.y, src), from_lane(o.z, src));
-		const V3 sd = mk3(from_lane(d.x, src), from_lane(d.y, src), from_lane(d.z, src));
-		RayPrep sp;
-		sp.inv = mk3(from_lane(rp.inv.x, src), from_lane(rp.inv.y, src), from_lane(rp.inv.z, src));
-		sp.dd = from_lane(rp.dd, src);
+		const V3 sinv = mk3(from_lane(rp.inv.x, src), from_lane(rp.inv.y, src), from_lane(rp.inv.z, src));
 		const V3 soi = mk3(from_lane(oi.x, src), from_lane(oi.y, src), from_lane(oi.z, src));
+		const unsigned short *member = reinterpret_cast<const unsigned short*>(cl.members);
+		uint32_t cand = 0u;
 		if (mine) {
-			sp.inv_ok = true;
-			sp.den = (double) (2.0f * sp.dd); sp.den_ok = near_one(sp.dd); sp.rden = rcp_twice_near_one(sp.dd);     /* as prepare_ray() forms them */
 			int word = 0;
 			uint32_t mm = m0;
 			const uint32_t c0 = (uint32_t) __popc(m0), c1 = (uint32_t) __popc(m1), c2 = (uint32_t) __popc(m2);
@@ -481,8 +516,7 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, u
 			t_ = (uint32_t) __popc(mm & 0x3u);    if (r >= t_) { pos += 2;  r -= t_; mm >>= 2; }
 			t_ = mm & 1u;                         if (r >= t_) { pos += 1; }
 			const int c = 32 * word + pos;
-			const unsigned short *member = reinterpret_cast<const unsigned short*>(cl.rec + RT_CLUSTER_F4 * c + 2);
-			uint32_t cand = 0u;
+			member = reinterpret_cast<const unsigned short*>(cl.members + RT_CLUSTER_MEMBER_F4 * c);
 #pragma unroll
 			for (int j = 0; j < RT_CLUSTER_SIZE; j++) {
 				const uint32_t idx = member[j];
@@ -493,27 +527,26 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, u
 					const float e = box ? cl.margin : g1.x;                       /* a sphere's record carries its half extent (rt_cull.h) */
 					const V3 lo = mk3(g0.x - e, g0.y - e, g0.z - e);
 					const V3 hi = mk3((box ? g0.w : g0.x) + e, (box ? g1.x : g0.y) + e, (box ? g1.y : g0.z) + e);
-					if (slab_may_touch(soi, sp.inv, lo, hi)) cand |= 1u << j;
-				}
-			}
-			while (cand != 0u) {
-				STAT(35);
-				const uint32_t idx = member[__builtin_ctz(cand)];
-				cand &= cand - 1u;
-				const float4 g0 = sc.geom[2 * idx], g1 = sc.geom[2 * idx + 1];
-				float t = 0.0f; int axis = 0; bool hit = false;
-				if (__float_as_int(g1.z) == RT_GEOM_CUBE)
-					hit = box_entry_fast(so, sd, sp, true, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), t, axis);
-				else
-					hit = ball_entry_fast(so, sd, sp, mk3(g0.x, g0.y, g0.z), g0.w, t);
-				if (hit && t >= 0) {
-					const uint32_t tb = __float_as_uint(t);                          /* t >= 0: +0 ... +inf, or -0 (0x80000000), which orders as 0 */
-					const unsigned long long key = ((unsigned long long) (tb & 0x7fffffffu) << 32) | ((unsigned long long) idx << 3) | (unsigned long long) ((tb >> 31) << 2) | (unsigned long long) axis;
-					__hip_atomic_fetch_min(best + src, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+					if (slab_may_touch(soi, sinv, lo, hi)) cand |= 1u << j;
 				}
 			}
 		}
+		/* the members that passed: into the queue, one per lane at a time (at most 63 wait there, so 64 more always fit) */
+		for (;;) {
+			const bool has = cand != 0u;
+			const unsigned long long pm = __ballot(has);
+			if (pm == 0ull) break;
+			if (has) {
+				const uint32_t idx = member[__builtin_ctz(cand)];
+				cand &= cand - 1u;
+				cw->queue[(cq_tail + (uint32_t) lanes_below(pm)) & (CULL_QUEUE - 1)] = (unsigned short) ((uint32_t) src | (idx << 6));
+			}
+			cq_tail += (uint32_t) __popcll(pm);
+			wave_fence();
+			if (cq_tail - cq_head >= 64u) test_queued(64u);
+		}
 	}
+	if (cq_tail != cq_head) test_queued(cq_tail - cq_head);
 	wave_fence();
 	const unsigned long long won = best[lane];
 	Hit hit; hit.t = 3.402823466e+38f; hit.obj = -1; hit.n = mk3(0, 0, 0);
@@ -535,13 +568,14 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, u
 	return hit;
 }
 
-/* the clusters behind the scene records in LDS (the caller has staged the scene: lds[0 .. 6 n)) */
+/* the clusters' member lists behind the geometry in LDS (their boxes stay in memory: scalar loads) */
 RT_DEV ClusterLDS stage_clusters(const rt_launch &L, float4 *dst)
 {
 	const float4 *src = reinterpret_cast<const float4*>(L.clusters);
-	for (int i = threadIdx.x; i < RT_CLUSTER_F4 * L.num_clusters; i += (int) blockDim.x) dst[i] = src[i];
+	for (int i = threadIdx.x; i < RT_CLUSTER_MEMBER_F4 * L.num_clusters; i += (int) blockDim.x)
+		dst[i] = src[RT_CLUSTER_F4 * (i / RT_CLUSTER_MEMBER_F4) + 2 + i % RT_CLUSTER_MEMBER_F4];
 	__syncthreads();
-	ClusterLDS cl; cl.rec = dst; cl.mem = (rt_const_f) (unsigned long long) L.clusters; cl.count = L.num_clusters; cl.margin = L.cull_margin; cl.origin_max = L.cull_origin_max;
+	ClusterLDS cl; cl.members = dst; cl.mem = (rt_const_f) (unsigned long long) L.clusters; cl.count = L.num_clusters; cl.margin = L.cull_margin; cl.origin_max = L.cull_origin_max;
 	return cl;
 }
 
@@ -659,10 +693,6 @@ RT_DEV V3 sky_lookup(const rt_launch &L, V3 dir) { return sky_colour<FAST>(sky_t
 
 /* ---- pixel mapping --------------------------------------------------------------------------- */
 
-RT_DEV int lanes_below(unsigned long long m)      /* number of set bits of m below this lane */
-{
-	return (int) __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u));
-}
 
 RT_DEV int global_row(int row_block, int rank, int world, int local_row)
 {
@@ -812,10 +842,10 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 	extern __shared__ float4 lds[];
 	const int n = L.num_objects;
 	const SceneLDS sc = CULL ? stage_geometry(L, lds, n) : stage_scene(L, lds, n);
-	ClusterLDS cl; cl.rec = nullptr; cl.mem = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
+	ClusterLDS cl; cl.members = nullptr; cl.mem = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
 	if (CULL) cl = stage_clusters(L, lds + CULL_GEOM_F4(n));
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	unsigned long long *cull_best = reinterpret_cast<unsigned long long*>(lds + CULL_GEOM_F4(n) + RT_CLUSTER_F4 * L.num_clusters) + 64 * wave;     /* (CULL) 64 x 8 B per wave */
+	CullWave *cull_wave = reinterpret_cast<CullWave*>(lds + CULL_GEOM_F4(n) + RT_CLUSTER_MEMBER_F4 * L.num_clusters) + wave;     /* (CULL) */
 	const int tiles_x = (L.width + 7) >> 3, tiles_y = (L.local_rows + 7) >> 3;
 	const unsigned int total = (unsigned int) (tiles_x * tiles_y);
 	/* the workgroup's share of the blocks: blocks_per_group consecutive ones.  Its object pixels go to list
@@ -838,7 +868,7 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 		if (CULL) {         /* the culled trace shares its work out over the wave: every lane takes part, with or without a ray of its own */
 			float u = 1.0f - (float) (inside ? i : 0) / (float) L.u_den, v = 1.0f - (float) (inside ? j : 0) / (float) L.v_den;
 			const V3 cd = unit3_fast(primary_dir(L, u, v));
-			culled = nearest_hit_culled(sc, n, cl, cull_best, inside, cam, cd);
+			culled = nearest_hit_culled(sc, n, cl, cull_wave, inside, cam, cd);
 		}
 		if (inside) {
 			float u = (float) i / (float) L.u_den;      /* main.c:293-296 */
@@ -1030,10 +1060,10 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 	const rt_lit_grid *lit_grids_mem = reinterpret_cast<const rt_lit_grid*>(L.lit_grids);
 	const bool grids_in_lds = L.lit_grids_in_lds != 0;
 	/* large scenes: the clusters of rt_cull.h behind the scene records (such scenes have no lit-taps table: it needs <= 64 objects) */
-	ClusterLDS cl; cl.rec = nullptr; cl.mem = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
+	ClusterLDS cl; cl.members = nullptr; cl.mem = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
 	if (CULL) cl = stage_clusters(L, lds + CULL_GEOM_F4(n));
-	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (CULL ? CULL_GEOM_F4(n) + RT_CLUSTER_F4 * L.num_clusters : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
-	unsigned long long *cull_best = reinterpret_cast<unsigned long long*>(reinterpret_cast<WaveLDS*>(lds + CULL_GEOM_F4(n) + RT_CLUSTER_F4 * L.num_clusters) + BLOCK / 64) + 64 * wave;   /* (CULL) */
+	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (CULL ? CULL_GEOM_F4(n) + RT_CLUSTER_MEMBER_F4 * L.num_clusters : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
+	CullWave *cull_wave = reinterpret_cast<CullWave*>(reinterpret_cast<WaveLDS*>(lds + CULL_GEOM_F4(n) + RT_CLUSTER_MEMBER_F4 * L.num_clusters) + BLOCK / 64) + wave;   /* (CULL) */
 
 	/* rt_launch.sum_onto (several interactive passes in one launch): a pixel's samples are added to what the frame holds so far.
 	 * That value takes the window slot BEFORE the pixel's first sample, as if it were a sample: 0 + value is the value (it is
@@ -1414,7 +1444,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				V3 o = mk3(0, 0, 0), d = mk3(1, 0, 0); int meta = 0;
 				if (on) tap_ray((q_head + (unsigned int) lane) & (WF_QUEUE - 1), o, d, meta);
 				const V3 dn = unit3_sel<FAST>(d);
-				const Hit hit = nearest_hit_culled(sc, n, cl, cull_best, on, o, dn, false);
+				const Hit hit = nearest_hit_culled(sc, n, cl, cull_wave, on, o, dn, false);
 				if (on) tap_answer(meta, hit.obj);
 			} else
 			if (lane < count) {
@@ -1467,7 +1497,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			STAT(12);
 			Hit culled; culled.t = 0.0f; culled.obj = -1; culled.n = mk3(0, 0, 0);
 			if (CULL)              /* (all lanes: see trace_taps) */
-				culled = nearest_hit_culled(sc, n, cl, cull_best, emit_main, ray_o, unit3_sel<FAST>(emit_main ? ray_d : mk3(1, 0, 0)), true);
+				culled = nearest_hit_culled(sc, n, cl, cull_wave, emit_main, ray_o, unit3_sel<FAST>(emit_main ? ray_d : mk3(1, 0, 0)), true);
 			if (emit_main) {
 				STAT(13);
 				const V3 dn = unit3_sel<FAST>(ray_d);                                     /* scene.c:158 */
@@ -1992,7 +2022,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	/* (a scene the host has had compiled keeps its compiled kernel: clusters are built from RT_CULL_MIN_OBJECTS objects, scenes
 	 * of up to 64 can be compiled) */
 	const bool cull = L.num_clusters > 0 && L.clusters != nullptr && scene_fast_ok && variant == 0 && !spec_fn;
-	size_t lds = cull ? (size_t) CULL_GEOM_F4(L.num_objects) * 16 + (size_t) L.num_clusters * sizeof(rt_cluster) + (RT_BLOCK / 64) * (sizeof(WaveLDS) + 64 * sizeof(unsigned long long))
+	size_t lds = cull ? (size_t) CULL_GEOM_F4(L.num_objects) * 16 + (size_t) L.num_clusters * RT_CLUSTER_MEMBER_F4 * 16 + (RT_BLOCK / 64) * (sizeof(WaveLDS) + sizeof(CullWave))
 	                  : rt_wavefront_lds_bytes(L.num_objects);
 	int per_cu = (int) ((160u * 1024u) / lds);
 	if (per_cu < 1) per_cu = 1;
@@ -2010,7 +2040,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	/* a large scene whose records leave room for fewer than three workgroups of four waves: one workgroup of twelve (rt_trace_wavefront_wide) */
 	int block = RT_BLOCK;
 	if (cull && per_cu < 3 && workgroups_per_cu < 1) {
-		const size_t wide = (size_t) CULL_GEOM_F4(L.num_objects) * 16 + (size_t) L.num_clusters * sizeof(rt_cluster) + (RT_BLOCK_WIDE / 64) * (sizeof(WaveLDS) + 64 * sizeof(unsigned long long));
+		const size_t wide = (size_t) CULL_GEOM_F4(L.num_objects) * 16 + (size_t) L.num_clusters * RT_CLUSTER_MEMBER_F4 * 16 + (RT_BLOCK_WIDE / 64) * (sizeof(WaveLDS) + sizeof(CullWave));
 		if (wide <= 160u * 1024u) { block = RT_BLOCK_WIDE; lds = wide; per_cu = 1; }
 	}
 	if (workgroups_per_cu >= 1 && workgroups_per_cu < per_cu) per_cu = workgroups_per_cu;     /* rt_tuning */
@@ -2032,7 +2062,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	} else {
 		unsigned int groups; int per_group;
 		rt_primary_geometry(L.width, L.local_rows, num_cus, &groups, &per_group);
-		const size_t plds = cull ? (size_t) CULL_GEOM_F4(L.num_objects) * 16 + (size_t) L.num_clusters * sizeof(rt_cluster) + (RT_BLOCK / 64) * 64 * sizeof(unsigned long long)
+		const size_t plds = cull ? (size_t) CULL_GEOM_F4(L.num_objects) * 16 + (size_t) L.num_clusters * RT_CLUSTER_MEMBER_F4 * 16 + (RT_BLOCK / 64) * sizeof(CullWave)
 		                         : rt_scene_lds_bytes(L.num_objects);
 		if (variant == 2 || !scene_fast_ok)
 			hipLaunchKernelGGL(rt_primary_pass<false>, dim3(groups), dim3(RT_BLOCK), plds, stream, L, per_group);
