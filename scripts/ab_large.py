@@ -15,7 +15,7 @@ for p in libs:
     if sky is None: sky = rt.load_skybox()
     r.set_skybox(sky); r.profile(True); rs.append(r)
 W, H, spp, nb = 1920, 1080, 8, 5
-for n in (128, 256, 512, 1024):
+for n in (40, 64, 128, 256, 512, 1024):
     scene = large_scene(n, seed=17)
     for r in rs:
         rt._lib = r._L; r.set_scene(scene); r.set_camera(**LARGE_SCENE_CAMERA)
