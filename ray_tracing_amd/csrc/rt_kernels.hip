@@ -400,8 +400,9 @@ RT_DEV uint32_t from_lane(uint32_t v, int src) { return (uint32_t) __builtin_amd
 
 /* ALL 64 lanes must call this (on: the lane has a ray); best = 64 words of 8 bytes of LDS of the calling wave.
  *
- * Step 2 is shared out evenly: a ray touches 11 clusters on average but the busiest of 64 rays 31 (1024 random objects,
- * profiles/r04/stats_large_1024.txt) -- walking its own clusters, a wave took 31 steps at a quarter of its lanes.  Instead the
+ * Step 2 is shared out evenly: with the first, Morton-ordered clusters a ray touched 11 clusters on average but the busiest of 64
+ * rays 31 (1024 random objects, profiles/r04/stats_large_1024.txt; median-split clusters: 6.6 on average) -- walking its own
+ * clusters, a wave took 31 steps at a quarter of its lanes.  Instead the
  * (ray, cluster) pairs of the whole wave are numbered by a prefix sum over the lanes' counts and dealt 64 at a time: lane i
  * takes pair 64 k + i, finds the lane whose ray it is by a binary search over the prefix sums, picks that lane's r-th cluster
  * out of its mask, fetches the ray with ds_bpermute (no LDS memory: registers of another lane), tests the members' conservative
