@@ -78,8 +78,9 @@ RT_API void rt_default_params(rt_render_params *p, int width, int height, int sp
  * library never reads environment variables. */
 typedef struct {
 	int    dequeue_shards;      /* lists the object pixels are dealt from: 1 or 64 */
-	int    workgroups_per_cu;   /* resident workgroups per CU, 1..4 (0: all that fit -- half of them for a launch enqueued before the
-	                             * previous one, on the context's other stream, has started: the two are resident side by side) */
+	int    workgroups_per_cu;   /* resident workgroups per CU, 1..8, capped by what fits (0: all that fit -- half of them for a launch
+	                             * enqueued before the previous one, on the context's other stream, has started: the two are resident
+	                             * side by side; any setting also keeps a large scene's culled kernel on workgroups of four waves) */
 	int    jit_waves_per_simd;  /* rt_compile_scene: register budget = 512 / this many VGPRs (default 4) */
 	const char *jit_flags;      /* rt_compile_scene: extra hiprtc options, space separated (copied) */
 	int    force_collective;    /* testing aid: rt_multi_render() runs its ncclGather + de-interleave path even for a
