@@ -210,6 +210,20 @@ static int workgroups_per_cu_for(rt_context *ctx, hipStream_t stream)
 	return q == hipErrorNotReady ? 2 : 0;
 }
 
+/* Does rt_primary_pass classify the object pixels' taps (rt_lit.h: rt_taps_class)?  It looks at every object for every object
+ * pixel -- once per launch --, and what it saves is taps not traced -- per sample.  Where every ray tests every object anyway a
+ * tap costs as much as the classification, and it pays from the second sample on.  A culled scene traces a tap in far fewer
+ * steps than it has objects: there the camera-ray pass took 0.86 / 1.57 / 2.72 ms with the classification against 0.14 / 0.23 /
+ * 0.35 ms without (256 / 512 / 1024 objects, 1080p), for 0.025 ... 0.05 ms less tracing per sample per pixel: it pays from
+ * objects / 9 ... objects / 22 samples on (profiles/r04/classify_probe.txt); the library asks for objects / 8. */
+#define RT_CLASSIFY_OBJECTS_PER_SAMPLE 8
+static int classify_pixels(const rt_context *ctx, int samples)
+{
+	if (ctx->tuning.trace_known_taps || samples < 2) return 0;
+	const bool culled = ctx->cull.num_clusters > 0 && !ctx->tuning.test_every_object && !ctx->spec_fn && ctx->scene_fast_ok;
+	return !culled || (long long) samples * RT_CLASSIFY_OBJECTS_PER_SAMPLE >= (long long) ctx->num_objects;
+}
+
 static int mark_launch(rt_context *ctx, hipStream_t stream)
 {
 	rt_context::launch_slot &sl = ctx->slot[ctx->launches & 1u];
@@ -676,8 +690,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	}
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.sky_wm1 = (float) (ctx->sky_w - 1); L.sky_hm1 = (float) (ctx->sky_h - 1);
 	L.frame = (float*) d_strip;
-	/* classifying a pixel costs about what tracing its taps once costs: it pays from the second sample on */
-	L.skip_known_taps = (ctx->tuning.trace_known_taps || p->spp < 2) ? 0 : 1;
+	L.skip_known_taps = classify_pixels(ctx, p->spp);
 	L.lit_cells = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_cells : nullptr;
 	L.lit_grids = ctx->d_lit_grids;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
@@ -1017,7 +1030,8 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.sky_wm1 = (float) (ctx->sky_w - 1); L.sky_hm1 = (float) (ctx->sky_h - 1);
 	L.frame = g.d_low;
 	L.sum_onto = batch ? g.d_accum : nullptr;
-	L.skip_known_taps = ctx->tuning.trace_known_taps ? 0 : 1;   /* the flags are kept with the lists: paid once per camera position */
+	/* (the flags are kept with the lists: a camera position pays once for all its passes -- reckoned as sixteen) */
+	L.skip_known_taps = classify_pixels(ctx, samples > 16 ? samples : 16);
 	L.lit_cells = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_cells : nullptr;
 	L.lit_grids = ctx->d_lit_grids;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;

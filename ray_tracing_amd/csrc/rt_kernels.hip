@@ -1497,8 +1497,22 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 		if (__ballot(emit_main) != 0ull) {
 			STAT(12);
 			Hit culled; culled.t = 0.0f; culled.obj = -1; culled.n = mk3(0, 0, 0);
-			if (CULL)              /* (all lanes: see trace_taps) */
-				culled = nearest_hit_culled(sc, n, cl, cull_wave, emit_main, ray_o, unit3_sel<FAST>(emit_main ? ray_d : mk3(1, 0, 0)), true);
+			if (CULL) {            /* (all lanes: see trace_taps) */
+				/* A culled trace costs the same for one ray as for 64 (its first step asks every cluster box for every lane), and the
+				 * lanes without a bounce ray -- paths at their last bounce, lanes between samples: a third of them -- have nothing to
+				 * do in it: the oldest taps waiting in the ring ride along in those lanes instead of waiting for a batch of their own. */
+				const unsigned long long idle = ~__ballot(emit_main);
+				const unsigned int waiting = q_tail - q_head, room = (unsigned int) __popcll(idle);
+				const unsigned int take = waiting < room ? waiting : room;
+				const unsigned int place = (unsigned int) lanes_below(idle);
+				const bool rider = !emit_main && place < take;
+				V3 to = ray_o, td = emit_main ? ray_d : mk3(1, 0, 0);
+				int tmeta = 0;
+				if (rider) tap_ray((q_head + place) & (WF_QUEUE - 1), to, td, tmeta);
+				culled = nearest_hit_culled(sc, n, cl, cull_wave, emit_main || rider, to, unit3_sel<FAST>(td), true);
+				if (rider) tap_answer(tmeta, culled.obj);
+				if (take) { q_head += take; wave_fence(); }
+			}
 			if (emit_main) {
 				STAT(13);
 				const V3 dn = unit3_sel<FAST>(ray_d);                                     /* scene.c:158 */

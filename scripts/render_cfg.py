@@ -22,6 +22,7 @@ if scene < 0:
 else:
     g.set_scene(f"{rt.DATA_DIR}/scene_{scene}.txt")
 if os.environ.get("RT_JIT_FLAGS"): g.set_tuning(jit_flags=os.environ["RT_JIT_FLAGS"])     # e.g. -gline-tables-only for PC sampling
+if os.environ.get("RT_TRACE_KNOWN_TAPS"): g.set_tuning(trace_known_taps=True)              # no tap classification (rt_lit.h): every tap is traced
 if not generic:
     g.compile_scene()
 strip = torch.empty((rt.strip_rows(H, 8, world), W, 3), dtype=torch.float32, device="cuda:0")
