@@ -17,12 +17,12 @@ if kind == "hipcc":
     print("hipcc " + next((l.split(":", 1)[1].strip() for l in v if l.startswith("HIP version")), "?"))
 else:
     R = C.CDLL(tool)
-    names = ["rt_math.hip.h", "rt_device.h", "rt_lit.h", "rt_scene_spec.h"]
-    hdrs = [open(os.path.join(HERE, n)).read().encode() for n in names[:3]] + [open(header).read().encode()]
+    names = ["rt_math.hip.h", "rt_device.h", "rt_lit.h", "rt_stats.hip.h", "rt_scene_spec.h"]
+    hdrs = [open(os.path.join(HERE, n)).read().encode() for n in names[:4]] + [open(header).read().encode()]
     prog = C.c_void_p()
     R.hiprtcCreateProgram.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
-    rc = R.hiprtcCreateProgram(C.byref(prog), open(os.path.join(HERE, "rt_kernels.hip")).read().encode(), b"rt_kernels.hip", 4,
-                               (C.c_char_p * 4)(*hdrs), (C.c_char_p * 4)(*[n.encode() for n in names]))
+    rc = R.hiprtcCreateProgram(C.byref(prog), open(os.path.join(HERE, "rt_kernels.hip")).read().encode(), b"rt_kernels.hip", 5,
+                               (C.c_char_p * 5)(*hdrs), (C.c_char_p * 5)(*[n.encode() for n in names]))
     assert rc == 0, rc
     R.hiprtcCompileProgram.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p)]
     rc = R.hiprtcCompileProgram(prog, len(OPTS), (C.c_char_p * len(OPTS))(*[o.encode() for o in OPTS]))

@@ -40,43 +40,16 @@ struct Hit { float t; V3 n; int obj; };
 #define RT_PIX_TAPS_LIT  0x10000     /* flags beside the object index of a pixel record (objects: < 1024): every accepted tap from */
 #define RT_PIX_TAPS_DARK 0x20000     /* the hit point certainly reaches the emitter first / certainly does not (rt_lit.h) */
 
-/* Development instrumentation (make stats): per-site counts of executions and of active lanes,
- * accumulated in a device array.  Compiled out of the product build. */
+/* Development instrumentation hooks (rt_stats.hip.h: `make stats`, rt_tuning.jit_flags "-DRT_STATS"): nothing in the product build */
 #ifdef RT_STATS
-extern "C" { __device__ unsigned long long rt_stats[128]; }     /* sites 0..31: words 0..63 (50..57: the section stamps); 32..63: the culled trace */
-#ifdef RT_STATS_LIFETIMES_ONLY
-/* The per-site atomics slow a launch down a hundredfold and the section stamps by a third; what a look at the end of a
- * launch needs is the real pace: every wave writes four words of its own -- start, the time it found the pixel lists
- * empty, the rounds it ran after that, its end (s_memrealtime, 10 ns) -- and nothing else (scripts/probes/tail_probe.py). */
-extern "C" { __device__ unsigned long long rt_wave_log[4 * 8192]; }
-#define STAT(site) do {} while (0)
-#define STAMP(k) do {} while (0)
-#define STAMP_DECL unsigned long long rt_t0 = __builtin_amdgcn_s_memrealtime(), rt_tdry = 0, rt_dry_rounds = 0
-#define STAMP_DRY do { if (!rt_tdry) rt_tdry = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define STAMP_ROUND do { if (rt_tdry) rt_dry_rounds++; } while (0)
-#define STAMP_FLUSH do { const unsigned int w_ = blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6); if ((threadIdx.x & 63) == 0 && w_ < 8192u) { \
-	rt_wave_log[4 * w_] = rt_t0; rt_wave_log[4 * w_ + 1] = rt_tdry; rt_wave_log[4 * w_ + 2] = rt_dry_rounds; rt_wave_log[4 * w_ + 3] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#include "rt_stats.hip.h"
 #else
-#define STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); rt_tsec[k] += now_ - rt_tlast; rt_tlast = now_; } while (0)
-#define STAMP_DECL unsigned long long rt_tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rt_tlast = __builtin_amdgcn_s_memtime()
-#define STAMP_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&rt_stats[50 + k_], rt_tsec[k_]); } while (0)
+#define STAT(site) do {} while (0)
+#define STAMP_MEMBER
+#define STAMP(k) do {} while (0)
 #define STAMP_DRY do {} while (0)
 #define STAMP_ROUND do {} while (0)
-#ifdef RT_STATS_STAMPS_ONLY     /* the per-site atomics distort the section times: this build keeps the stamps only */
-#define STAT(site) do {} while (0)
-#else
-#define STAT(site) do { const unsigned long long m_ = __ballot(true); \
-	if (__builtin_amdgcn_mbcnt_hi((unsigned int) (m_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_, 0u)) == 0) { \
-		atomicAdd(&rt_stats[2 * (site)], 1ull); atomicAdd(&rt_stats[2 * (site) + 1], (unsigned long long) __popcll(m_)); } } while (0)
-#endif
-#endif
-#else
-#define STAT(site) do {} while (0)
-#define STAMP(k) do {} while (0)
-#define STAMP_DECL do {} while (0)
-#define STAMP_FLUSH do {} while (0)
-#define STAMP_DRY do {} while (0)
-#define STAMP_ROUND do {} while (0)
+#define STAMP_FLUSH(waves_per_block) do {} while (0)
 #endif
 
 /* LDS written by some lanes of a wave is read by others of the same wave */
@@ -96,22 +69,12 @@ struct SceneLDS {
 /* Large scenes (the culled kernels): only the geometry goes to LDS -- 32 B an object, read per lane by the members' tests --;
  * the shading records, 64 B an object and touched once per bounce, are read from memory (L2), so that a scene of 1024 objects
  * leaves room for two workgroups per CU instead of one (one wave per SIMD is latency-bound: 22 vs 12 ms on C1). */
-#ifdef RT_CULL_GEOM_GLOBAL      /* experiment: the members' geometry from memory too -- no LDS for it, three workgroups per CU at 1024 objects */
-#define CULL_GEOM_F4(n) 0
-#else
-#define CULL_GEOM_F4(n) (2 * (n))
-#endif
 RT_DEV SceneLDS stage_geometry(const rt_launch &L, float4 *lds, int n)
 {
 	const float4 *g = reinterpret_cast<const float4*>(L.geom);
-	for (int i = threadIdx.x; i < CULL_GEOM_F4(n); i += (int) blockDim.x) lds[i] = g[i];
+	for (int i = threadIdx.x; i < 2 * n; i += (int) blockDim.x) lds[i] = g[i];
 	__syncthreads();
-	SceneLDS sc; sc.shade = reinterpret_cast<const float4*>(L.shade);
-#ifdef RT_CULL_GEOM_GLOBAL
-	sc.geom = g;
-#else
-	sc.geom = lds;
-#endif
+	SceneLDS sc; sc.shade = reinterpret_cast<const float4*>(L.shade); sc.geom = lds;
 	return sc;
 }
 
@@ -844,9 +807,9 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 	const int n = L.num_objects;
 	const SceneLDS sc = CULL ? stage_geometry(L, lds, n) : stage_scene(L, lds, n);
 	ClusterLDS cl; cl.members = nullptr; cl.mem = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
-	if (CULL) cl = stage_clusters(L, lds + CULL_GEOM_F4(n));
+	if (CULL) cl = stage_clusters(L, lds + 2 * n);
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	CullWave *cull_wave = reinterpret_cast<CullWave*>(lds + CULL_GEOM_F4(n) + RT_CLUSTER_MEMBER_F4 * L.num_clusters) + wave;     /* (CULL) */
+	CullWave *cull_wave = reinterpret_cast<CullWave*>(lds + 2 * n + RT_CLUSTER_MEMBER_F4 * L.num_clusters) + wave;     /* (CULL) */
 	const int tiles_x = (L.width + 7) >> 3, tiles_y = (L.local_rows + 7) >> 3;
 	const unsigned int total = (unsigned int) (tiles_x * tiles_y);
 	/* the workgroup's share of the blocks: blocks_per_group consecutive ones.  Its object pixels go to list
@@ -957,9 +920,7 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
  * Results are bit-identical to rt_trace_simple and to the CPU oracle.
  * ============================================================================================= */
 
-#ifndef RT_SUM_EVERY
-#define RT_SUM_EVERY 2                 /* rounds between two passes of the in-order sum (section 6) when a pixel has >= 32 samples */
-#endif
+#define WF_SUM_EVERY 2u                /* rounds between two passes of the in-order sum (section 6) when a pixel has >= 32 samples */
 #define WF_SHARDS  64                  /* pixel lists (at most); each has a fill counter and a dequeue counter, 128 B apart */
 #define RT_COUNTER_BYTES ((2 * WF_SHARDS + 1) * 128)   /* + one line of launch control words (rt_launch.control) */
 #define WF_QUEUE   128                 /* tap ring: at most 63 waiting + 64 pushed at a time */
@@ -1038,118 +999,163 @@ RT_DEV PixelRec load_pixel(rt_launch_cold C, size_t c)
 	return p;
 }
 
-template <bool FAST, bool CULL = false, int BLOCK = RT_BLOCK>      /* BLOCK: threads per workgroup (the culled variant also comes with RT_BLOCK_WIDE) */
-RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
-{
-	extern __shared__ float4 lds[];
+/* Scene-wide constants of a trace kernel: literals in a compiled scene's kernel (no scalar registers, every LDS offset a
+ * literal), launch arguments otherwise. */
+template <bool FAST>
+struct SceneConsts {
 #ifdef RT_SPEC_HEADER
-	constexpr int n = SPEC_N;              /* the compiled scene's object count: every LDS offset below is a literal */
+	static constexpr int  n = SPEC_N;
+	static constexpr bool only_light = FAST && SPEC_ONLY_LIGHT_EMITS != 0 && SPEC_LIGHT >= 0;
+	static constexpr bool have_light = SPEC_LIGHT >= 0;
+	static constexpr int  light_obj = SPEC_LIGHT;
+	RT_DEV explicit SceneConsts(const rt_launch &) {}
+	RT_DEV V3 light_pos() const { return mk3(SPEC_LIGHT_POS[0], SPEC_LIGHT_POS[1], SPEC_LIGHT_POS[2]); }
 #else
-	const int n = L.num_objects;
+	const int  n;
+	const bool only_light, have_light;
+	const int  light_obj;
+	const V3   lp;
+	RT_DEV explicit SceneConsts(const rt_launch &L)
+		: n(L.num_objects), only_light(FAST && L.only_light_emits != 0 && L.light_index >= 0), have_light(L.light_index >= 0),
+		  light_obj(L.light_index), lp(ld3(L.light_pos)) {}
+	RT_DEV V3 light_pos() const { return lp; }
 #endif
-	const SceneLDS sc = CULL ? stage_geometry(L, lds, n) : stage_scene(L, lds, n);
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	/* the grids of the "taps certainly lit" table (rt_lit.h), when the launcher found room for them: 3 x float4 per object */
-	if (L.lit_grids_in_lds) {
-		const float4 *gsrc = reinterpret_cast<const float4*>(L.lit_grids);
-		for (int i = threadIdx.x; i < 3 * n; i += BLOCK) lds[6 * n + i] = gsrc[i];
-		__syncthreads();
-	}
-	/* (two pointers, not one chosen at run time: a pointer that may be LDS or memory makes every access a flat load with a
-	 * 64-bit address -- ten per bounce ray) */
-	const rt_lit_grid *lit_grids_lds = reinterpret_cast<const rt_lit_grid*>(lds + 6 * n);
-	const rt_lit_grid *lit_grids_mem = reinterpret_cast<const rt_lit_grid*>(L.lit_grids);
-	const bool grids_in_lds = L.lit_grids_in_lds != 0;
-	/* large scenes: the clusters of rt_cull.h behind the scene records (such scenes have no lit-taps table: it needs <= 64 objects) */
-	ClusterLDS cl; cl.members = nullptr; cl.mem = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
-	if (CULL) cl = stage_clusters(L, lds + CULL_GEOM_F4(n));
-	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (CULL ? CULL_GEOM_F4(n) + RT_CLUSTER_MEMBER_F4 * L.num_clusters : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
-	CullWave *cull_wave = reinterpret_cast<CullWave*>(reinterpret_cast<WaveLDS*>(lds + CULL_GEOM_F4(n) + RT_CLUSTER_MEMBER_F4 * L.num_clusters) + BLOCK / 64) + wave;   /* (CULL) */
+};
 
-	/* rt_launch.sum_onto (several interactive passes in one launch): a pixel's samples are added to what the frame holds so far.
-	 * That value takes the window slot BEFORE the pixel's first sample, as if it were a sample: 0 + value is the value (it is
-	 * >= +0), and section 6 then adds the samples onto it in order; the sum is written as it is. */
-	const bool onto = L.sum_onto != nullptr;
-	const float inv_spp = onto ? 1.0f : 1.0f / (float) L.spp;
-	const unsigned int spp = (unsigned int) L.spp;
-	/* spp == 1 (progressive passes): a pixel is its one sample, nothing has to be ordered -- every lane takes a
-	 * pixel for itself and writes it when the path retires.  Otherwise the wave runs P pixel streams. */
-	const bool direct = L.spp == 1;
-	/* Eight streams of eight lanes.  The lanes of a stream are every second lane of one 16-lane DPP row (streams 2r
-	 * and 2r+1 share row r), so that "the value of the stream's previous lane" is one DPP row_shr:2 -- which hands
-	 * the stream's first lane a zero -- in the in-order sum of section 6. */
-	constexpr int P = WF_STREAMS, G = 64 / P;
-	constexpr unsigned int wn = WF_WINDOW / P;              /* slots per stream */
-	static_assert(P == 8 && G == 8, "the lane layout below is written for 8 streams of 8 lanes");
-	const int g = 2 * (lane >> 4) + (lane & 1);             /* this lane's home stream */
-	const unsigned int j = (unsigned int) (lane & 15) >> 1; /* its place among the stream's lanes */
-	const bool leader = j == 0u;                            /* does the bookkeeping of a stream */
-	const int gshift = (lane & 48) + (lane & 1);            /* position of the stream's first lane */
-	const unsigned long long gmask = 0x5555ull << gshift;
-#ifdef RT_SPEC_HEADER
-	constexpr bool only_light = FAST && SPEC_ONLY_LIGHT_EMITS != 0 && SPEC_LIGHT >= 0;
-	const bool have_light = SPEC_LIGHT >= 0;               /* the compiled scene's emitter: literals, no scalar registers */
-	const V3 light_pos = mk3(SPEC_LIGHT_POS[0], SPEC_LIGHT_POS[1], SPEC_LIGHT_POS[2]);
-	const int light_obj = SPEC_LIGHT;
-#else
-	const bool only_light = FAST && L.only_light_emits != 0 && L.light_index >= 0;
-	const V3 light_pos = ld3(L.light_pos);
-	const bool have_light = L.light_index >= 0;
-	const int light_obj = L.light_index;
-#endif
-
-	for (int k = lane; k < WF_WINDOW; k += 64) W.win[0][k] = __uint_as_float(WF_EMPTY);
-	if (lane < WF_STREAMS) {
-		W.s_nxt[lane] = spp; W.s_seq[lane] = 0u; W.s_drained[lane] = 0u;
-		W.s_sum[0][lane] = 0.0f; W.s_sum[1][lane] = 0.0f; W.s_sum[2][lane] = 0.0f;
-	}
-	wave_fence();
-
-	/* wave-uniform pixel supply: object pixels are dealt from the lists rt_primary_pass filled, each with its own
-	 * dequeue counter on its own 128-byte line (one counter saturates at ~88 dequeues/us, MI355X_MICROARCH.md).  A
-	 * wave starts at the list of its workgroup and moves on to the next one when a list has run out. */
-	unsigned int shard = blockIdx.x % (unsigned int) L.num_shards;
-	bool exhausted = false;                 /* no pixels left to fetch */
-	bool cancelled = false;                 /* rt_cancel(): nothing more is handed out, the paths in flight finish, the wave leaves */
-
-	/* per-lane path state.  A path is worked on at two places two rounds apart.  The FRONT (section 2) turns the
-	 * pending hit into the next rays: it owns rng, bounce, the hit and f_slot.  The BACK (section 5) does the
-	 * radiance arithmetic of a bounce (main.c:232,248,257-261) two rounds later, when its shadow taps are certainly
-	 * traced: it owns rad and carry.  rec1 / rec2 are the records of the bounces the front shaded one and two rounds
-	 * ago, with their slot words and sky texels.  A slot word is the window slot the sample's colour goes to
-	 * (| WF_LAST); in direct mode, the pixel's frame offset. */
+/* Per-lane path state.  A path is worked on at two places two rounds apart.  The FRONT (shade) turns the
+ * pending hit into the next rays: it owns rng, bounce, the hit and f_slot.  The BACK (retire) does the
+ * radiance arithmetic of a bounce (main.c:232,248,257-261) two rounds later, when its shadow taps are certainly
+ * traced: it owns rad and carry.  rec1 / rec2 are the records of the bounces the front shaded one and two rounds
+ * ago, with their slot words and sky texels.  A slot word is the window slot the sample's colour goes to
+ * (| WF_LAST); in direct mode, the pixel's frame offset. */
+struct PathLane {
 	bool  f_live = false;                   /* the front is on a sample */
 	int   f_slot = 0, slot1 = 0, slot2 = 0;
 	int   bounce = 0;
 	bool  has_hit = false;
-	V3    carry = mk3(1, 1, 1), rad = mk3(0, 0, 0);
-	V3    hp = mk3(0, 0, 0), hn = mk3(0, 0, 0), hdir = mk3(0, 0, 0);
+	V3    carry = { 1, 1, 1 }, rad = { 0, 0, 0 };
+	V3    hp = { 0, 0, 0 }, hn = { 0, 0, 0 }, hdir = { 0, 0, 0 };
 	uint32_t sky1 = 0, sky2 = 0;            /* sky texel that ends the sample of rec1 / rec2 (REC_SKY): fetched when the bounce ray
 	                                         * is found to have left the scene, converted two rounds later when it is used */
 	int   hobj = -1;
 	uint32_t lit_next = 0;                  /* != 0: the taps from the pending hit point certainly reach the emitter, none is traced (rt_lit.h) */
 	int   rec1 = 0, rec2 = 0;               /* REC_* | tapmask << 4 | object << 8 of the bounces shaded one and two rounds ago */
 	uint64_t rng = 0;
+};
+
+/* what the front of one round hands to the tap queue, the bounce trace and the back of the same round */
+struct RoundOut {
+	int  tapmask = 0, cur = 0;
+	bool emit_main = false;
+	V3   ray_o = { 0, 0, 0 }, ray_d = { 0, 0, 0 };
+	V3   tap_j0 = { 0, 0, 0 }, tap_j1 = { 0, 0, 0 }, tap_j2 = { 0, 0, 0 };   /* accepted rand_dir of each tap (main.c:193) */
+};
+
+/* One wave of a trace kernel: the six sections of a round as member functions over the wave's state.
+ * BLOCK: threads per workgroup (the culled variant also comes with RT_BLOCK_WIDE). */
+template <bool FAST, bool CULL = false, int BLOCK = RT_BLOCK>
+struct Wavefront {
+	/* Eight streams of eight lanes.  The lanes of a stream are every second lane of one 16-lane DPP row (streams 2r
+	 * and 2r+1 share row r), so that "the value of the stream's previous lane" is one DPP row_shr:2 -- which hands
+	 * the stream's first lane a zero -- in the in-order sum of section 6. */
+	static constexpr int P = WF_STREAMS, G = 64 / P;
+	static constexpr unsigned int wn = WF_WINDOW / P;              /* slots per stream */
+	static_assert(P == 8 && G == 8, "the lane layout below is written for 8 streams of 8 lanes");
+
+	const rt_launch &L;
+	unsigned int *const block_counter;
+	const SceneConsts<FAST> K;
+	SceneLDS sc;
+	ClusterLDS cl;
+	CullWave *cull_wave;
+	WaveLDS *Wp;
+	bool grids_in_lds;
+	int  wave, lane;
+	int  g;                                 /* this lane's home stream */
+	unsigned int j;                         /* its place among the stream's lanes */
+	bool leader;                            /* does the bookkeeping of a stream */
+	int  gshift;                            /* position of the stream's first lane */
+	unsigned long long gmask;
+	/* rt_launch.sum_onto (several interactive passes in one launch): a pixel's samples are added to what the frame holds so far.
+	 * That value takes the window slot BEFORE the pixel's first sample, as if it were a sample: 0 + value is the value (it is
+	 * >= +0), and section 6 then adds the samples onto it in order; the sum is written as it is. */
+	bool  onto;
+	float inv_spp;
+	unsigned int spp;
+	/* spp == 1 (progressive passes): a pixel is its one sample, nothing has to be ordered -- every lane takes a
+	 * pixel for itself and writes it when the path retires.  Otherwise the wave runs P pixel streams. */
+	bool  direct;
+
+	/* wave-uniform pixel supply: object pixels are dealt from the lists rt_primary_pass filled, each with its own
+	 * dequeue counter on its own 128-byte line (one counter saturates at ~88 dequeues/us, MI355X_MICROARCH.md).  A
+	 * wave starts at the list of its workgroup and moves on to the next one when a list has run out. */
+	unsigned int shard;
+	bool exhausted = false;                 /* no pixels left to fetch */
+	bool cancelled = false;                 /* rt_cancel(): nothing more is handed out, the paths in flight finish, the wave leaves */
 	/* the tap queue persists across rounds: taps that do not fill a batch wait, at most two rounds */
 	unsigned int q_head = 0, q_tail = 0, phase = 0;     /* phase = round number mod 3 */
-	unsigned int sum_tick = 0;
-	const unsigned int sum_every = L.spp >= 32 ? RT_SUM_EVERY : 1u;
+	unsigned int sum_tick = 0, sum_every;
 
-	/* Section 6 of a round: adding the finished samples in sample order (main.c:394).  Lane j of a stream looks at
+	PathLane p;
+	STAMP_MEMBER
+
+	RT_DEV WaveLDS &W() const { return *Wp; }
+
+	RT_DEV Wavefront(const rt_launch &L_, unsigned int *block_counter_) : L(L_), block_counter(block_counter_), K(L_)
+	{
+		extern __shared__ float4 lds[];
+		const int n = K.n;
+		sc = CULL ? stage_geometry(L, lds, n) : stage_scene(L, lds, n);
+		wave = threadIdx.x >> 6; lane = threadIdx.x & 63;
+		/* the grids of the "taps certainly lit" table (rt_lit.h), when the launcher found room for them: 3 x float4 per object */
+		if (L.lit_grids_in_lds) {
+			const float4 *gsrc = reinterpret_cast<const float4*>(L.lit_grids);
+			for (int i = threadIdx.x; i < 3 * n; i += BLOCK) lds[6 * n + i] = gsrc[i];
+			__syncthreads();
+		}
+		grids_in_lds = L.lit_grids_in_lds != 0;
+		/* large scenes: the clusters of rt_cull.h behind the scene records (such scenes have no lit-taps table: it needs <= 64 objects) */
+		cl.members = nullptr; cl.mem = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
+		if (CULL) cl = stage_clusters(L, lds + 2 * n);
+		Wp = &reinterpret_cast<WaveLDS*>(lds + (CULL ? 2 * n + RT_CLUSTER_MEMBER_F4 * L.num_clusters : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
+		cull_wave = reinterpret_cast<CullWave*>(reinterpret_cast<WaveLDS*>(lds + 2 * n + RT_CLUSTER_MEMBER_F4 * L.num_clusters) + BLOCK / 64) + wave;   /* (CULL) */
+
+		onto = L.sum_onto != nullptr;
+		inv_spp = onto ? 1.0f : 1.0f / (float) L.spp;
+		spp = (unsigned int) L.spp;
+		direct = L.spp == 1;
+		g = 2 * (lane >> 4) + (lane & 1);
+		j = (unsigned int) (lane & 15) >> 1;
+		leader = j == 0u;
+		gshift = (lane & 48) + (lane & 1);
+		gmask = 0x5555ull << gshift;
+
+		for (int k = lane; k < WF_WINDOW; k += 64) W().win[0][k] = __uint_as_float(WF_EMPTY);
+		if (lane < WF_STREAMS) {
+			W().s_nxt[lane] = spp; W().s_seq[lane] = 0u; W().s_drained[lane] = 0u;
+			W().s_sum[0][lane] = 0.0f; W().s_sum[1][lane] = 0.0f; W().s_sum[2][lane] = 0.0f;
+		}
+		wave_fence();
+		shard = blockIdx.x % (unsigned int) L.num_shards;
+		sum_every = L.spp >= 32 ? WF_SUM_EVERY : 1u;
+	}
+
+	/* ---- 6. adding the finished samples in sample order (main.c:394).  Lane j of a stream looks at
 	 * the j-th slot after the stream's last added one.  The slots that are filled without a gap from the first form
 	 * the run (it ends behind the first pixel that is completed in it); their colours are added to the stream's
 	 * running sum one after the other -- lane j's partial sum is lane j-1's plus its own colour, handed on with DPP
 	 * row shifts, all eight streams in lockstep -- and a pixel whose last sample is in the run is resolved
 	 * (main.c:476) and written to the frame.  Every lane of the wave must be active. */
-	auto add_finished_samples = [&]() {
+	RT_DEV void add_finished_samples()
+	{
 		bool again;
 		do {
 			STAT(23);
-			const unsigned int d = W.s_drained[g], seq = W.s_seq[g];
+			const unsigned int d = W().s_drained[g], seq = W().s_seq[g];
 			const unsigned int slot = d + j;
 			const unsigned int e = (unsigned int) g * wn + (slot % wn);
 			uint32_t xb = WF_EMPTY;
-			if ((int) (seq - slot) > 0) xb = __float_as_uint(W.win[0][e]);
+			if ((int) (seq - slot) > 0) xb = __float_as_uint(W().win[0][e]);
 			const bool filled = xb != WF_EMPTY;
 			const unsigned long long fm = __ballot(filled);
 			const unsigned long long lm = __ballot(filled && (xb >> 31) != 0u);      /* last samples of their pixels */
@@ -1163,8 +1169,8 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 			const bool active = (int) j < k;
 			const bool offset_slot = boundary && (int) j == lastpos + 1 && active;
 			V3 c = mk3(0, 0, 0);
-			if (active && !offset_slot) c = mk3(__uint_as_float(xb & 0x7fffffffu), W.win[1][e], W.win[2][e]);
-			if (leader) c = add3(mk3(W.s_sum[0][g], W.s_sum[1][g], W.s_sum[2][g]), c);   /* the running sum enters at the first lane */
+			if (active && !offset_slot) c = mk3(__uint_as_float(xb & 0x7fffffffu), W().win[1][e], W().win[2][e]);
+			if (leader) c = add3(mk3(W().s_sum[0][g], W().s_sum[1][g], W().s_sum[2][g]), c);   /* the running sum enters at the first lane */
 			V3 sum = c;
 #pragma unroll
 			for (int t = 1; t < G; t++)             /* after step t lanes j <= t hold their final partial sums */
@@ -1174,130 +1180,52 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				float *dst = L.frame + (size_t) xb * 3;
 				dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
 			}
-			if (active) W.win[0][e] = __uint_as_float(WF_EMPTY);
+			if (active) W().win[0][e] = __uint_as_float(WF_EMPTY);
 			if (active && (int) j == k - 1) {
-				W.s_drained[g] = d + (unsigned int) k;
-				W.s_sum[0][g] = offset_slot ? 0.0f : sum.x; W.s_sum[1][g] = offset_slot ? 0.0f : sum.y; W.s_sum[2][g] = offset_slot ? 0.0f : sum.z;
+				W().s_drained[g] = d + (unsigned int) k;
+				W().s_sum[0][g] = offset_slot ? 0.0f : sum.x; W().s_sum[1][g] = offset_slot ? 0.0f : sum.y; W().s_sum[2][g] = offset_slot ? 0.0f : sum.z;
 			}
 			/* more may be waiting behind the run; it can wait for the next round unless the window is filling up */
 			again = __ballot(k > 0 && (k == G || boundary) && seq - (d + (unsigned int) k) > 3u * wn / 4u) != 0ull;
 			wave_fence();
 		} while (again);
-	};
+	}
 
-	STAMP_DECL;
-	for (;; phase = phase == 2u ? 0u : phase + 1u) {
-		STAMP(7);
-		STAMP_ROUND;
-		/* ---- 1. sample supply ---------------------------------------------------------------
-		 * Lanes whose front is free take new samples.  A lane asks its home stream first and, in the following
-		 * attempts, the streams next to it (stream (g + attempt) mod P is asked by exactly one group of lanes per
-		 * attempt, so the group's leader lane does that stream's bookkeeping).  A stream hands out the samples of
-		 * its pixel in order, each with the next slot of the stream's window; when the pixel has none left the
-		 * stream takes the next object pixel of the wave's work item. */
+	/* ---- 1. sample supply ---------------------------------------------------------------
+	 * Lanes whose front is free take new samples.  A lane asks its home stream first and, in the following
+	 * attempts, the streams next to it (stream (g + attempt) mod P is asked by exactly one group of lanes per
+	 * attempt, so the group's leader lane does that stream's bookkeeping).  A stream hands out the samples of
+	 * its pixel in order, each with the next slot of the stream's window; when the pixel has none left the
+	 * stream takes the next object pixel of the wave's work item. */
+	RT_DEV void supply_samples()
+	{
 #pragma unroll 1
 		for (int attempt = 0; attempt < P; attempt++) {
-			const bool want = !f_live;
+			const bool want = !p.f_live;
 			const unsigned long long wmask = __ballot(want);
 			if (wmask == 0ull || cancelled) break;
 			/* the lists have run out: go on only while some stream still has samples (and slots) to give */
 			if (exhausted && (direct || (attempt > 0 &&
-			    __ballot(leader && W.s_nxt[g] < spp && W.s_seq[g] - W.s_drained[g] < wn - 1u) == 0ull))) break;
+			    __ballot(leader && W().s_nxt[g] < spp && W().s_seq[g] - W().s_drained[g] < wn - 1u) == 0ull))) break;
 			const int sg = (g + attempt) & (P - 1);
 			const unsigned long long gm = wmask & gmask;              /* wanting lanes of my group */
 			STAT(20);
 			unsigned int nxt = 0;
 			bool need_pixel = want;
 			if (!direct) {
-				nxt = W.s_nxt[sg];
+				nxt = W().s_nxt[sg];
 				need_pixel = leader && gm != 0ull && nxt >= spp;
-				if (onto) need_pixel = need_pixel && W.s_seq[sg] - W.s_drained[sg] < wn - 1u;      /* (the slot for what the frame holds so far) */
+				if (onto) need_pixel = need_pixel && W().s_seq[sg] - W().s_drained[sg] < wn - 1u;      /* (the slot for what the frame holds so far) */
 			}
 			const unsigned long long nmask = __ballot(need_pixel);
 			STAMP(0);
 			if (nmask != 0ull) {
-				STAT(21);
-				const rt_launch_cold C = cold_view();
-				const int asked = __popcll(nmask);
-				int got = 0;
-				size_t first = 0;
-				if (!exhausted) {
-					typedef const __attribute__((address_space(1))) unsigned int *guint;
-					typedef __attribute__((address_space(1))) unsigned int *gwuint;
-					/* rt_cancel() (main.c:316-317: the frame has been invalidated).  The host stores its request in a word of host
-					 * memory: "the launches up to this number are to stop".  Reading that is slow (a read over the link takes the
-					 * place of 75 ns of everybody else's: 4 096 waves asking at once cost a strip a third of its time), so only eight
-					 * waves of the launch do, when they fetch pixels, and pass the news on through control[2] in device memory, which
-					 * every other wave reads when it fetches pixels.  Told to stop, a wave hands out nothing more, lets the paths in
-					 * flight finish and leaves; the launch is marked incomplete.  (A wave that has no pixels left to fetch does not
-					 * ask any more: it is about to leave anyway.) */
-					unsigned int word = 0u, k = 0u;
-					if (lane == 0) {
-						word = (blockIdx.x < 8u && wave == 0) ? __hip_atomic_load((guint) C->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - C->launch_id
-						                                      : __hip_atomic_load((guint) C->control + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
-						k = atomicAdd(block_counter + shard * 32u, (unsigned int) asked);
-					}
-					k = (unsigned int) __builtin_amdgcn_readfirstlane((int) k);
-					if ((int) __builtin_amdgcn_readfirstlane((int) word) >= 0) {      /* the request covers this launch / another wave has seen it */
-						cancelled = true;
-						if (lane == 0) { C->control[1] = 1u; __hip_atomic_store((gwuint) C->control + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-					}
-					const guint fill_counts = (guint) C->pix_count;
-					const unsigned int filled = (unsigned int) __builtin_amdgcn_readfirstlane((int) fill_counts[shard * 32u]);
-					got = k < filled && !cancelled ? (filled - k < (unsigned int) asked ? (int) (filled - k) : asked) : 0;
-					first = (size_t) shard * (size_t) C->pix_shard_cap + k;
-					if (got < asked) {
-						/* This list has run out: look at all of them at once (lane s reads list s's two counters; a stale
-						 * dequeue count can only show more pixels left than there are, never fewer) and move to the next
-						 * one that still has pixels.  None: the launch has no pixels left to hand out. */
-						unsigned int left = 0, taken = 0;
-						if (lane < C->num_shards) {
-							taken = __hip_atomic_load(block_counter + (unsigned int) lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-							const unsigned int have = fill_counts[(unsigned int) lane * 32u];
-							left = have > taken ? have - taken : 0u;
-						}
-						const unsigned long long some = __ballot(left != 0u);
-						if (some == 0ull || cancelled) { exhausted = true; STAMP_DRY; }
-						else {      /* the waves spread over the lists that are left (one address takes ~88 atomics per microsecond) */
-							const int pick = (int) ((blockIdx.x * (BLOCK / 64) + (unsigned int) wave) % (unsigned int) __popcll(some));
-							shard = (unsigned int) __builtin_ctzll(__ballot(left != 0u && lanes_below(some) == pick));
-						}
-					}
-				}
-				const int rr = lanes_below(nmask);
-				if (need_pixel && rr < got) {
-					const PixelRec px = load_pixel(C, first + (size_t) rr);
-					if (direct) {
-						f_slot = px.off; f_live = true;
-						rng = (uint64_t) px.index;                /* (pixel index, sample 0): seeded where the sample is first shaded (section 2) */
-						bounce = 0;
-						hp = px.a; hn = px.n; hobj = px.obj & (RT_PIX_TAPS_LIT - 1); hdir = px.dir;
-						lit_next = ((uint32_t) px.obj >> 16) & 3u;
-						has_hit = true;
-					} else {
-						W.rec[0][sg] = px.a.x;   W.rec[1][sg] = px.a.y;   W.rec[2][sg] = px.a.z;
-						W.rec[3][sg] = px.n.x;   W.rec[4][sg] = px.n.y;   W.rec[5][sg] = px.n.z;
-						W.rec[6][sg] = __int_as_float(px.obj);
-						W.rec[7][sg] = px.dir.x; W.rec[8][sg] = px.dir.y; W.rec[9][sg] = px.dir.z;
-						W.rec[10][sg] = __uint_as_float(px.index);
-						W.rec[11][sg] = __int_as_float(px.off);
-						W.s_nxt[sg] = 0u;
-						if (onto) {
-							typedef const __attribute__((address_space(1))) float *gfloat;
-							const gfloat held = (gfloat) C->sum_onto + (size_t) px.off * 3;
-							const unsigned int sq = W.s_seq[sg], e = (unsigned int) sg * wn + sq % wn;
-							W.win[1][e] = held[1]; W.win[2][e] = held[2];
-							W.win[0][e] = held[0];
-							W.s_seq[sg] = sq + 1u;
-						}
-					}
-				}
-				wave_fence();
+				fetch_pixels(need_pixel, nmask, sg);
 				STAMP(5);
 			}
 			if (!direct) {
-				nxt = W.s_nxt[sg];
-				const unsigned int seq = W.s_seq[sg], drained = W.s_drained[sg];
+				nxt = W().s_nxt[sg];
+				const unsigned int seq = W().s_seq[sg], drained = W().s_drained[sg];
 				/* samples the pixel still has, and slots free in the stream's window (one is kept back for the
 				 * frame-offset slot that follows a pixel's last sample) */
 				const int left = (int) spp - (int) nxt, room = (int) wn - 1 - (int) (seq - drained);
@@ -1307,266 +1235,351 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 					STAT(22);
 					const unsigned int s = nxt + (unsigned int) r, slot = seq + (unsigned int) r;
 					const bool last = s + 1u == spp;
-					f_slot = (int) ((unsigned int) sg * wn + (slot % wn)) | (last ? WF_LAST : 0);
-					if (last) W.win[0][(unsigned int) sg * wn + ((slot + 1u) % wn)] = W.rec[11][sg];
-					rng = ((uint64_t) s << 32) | (uint64_t) __float_as_uint(W.rec[10][sg]);   /* (pixel index, sample): seeded where the sample is first shaded (section 2) */
-					bounce = 0;
-					hp = mk3(W.rec[0][sg], W.rec[1][sg], W.rec[2][sg]);
-					hn = mk3(W.rec[3][sg], W.rec[4][sg], W.rec[5][sg]);
-					hobj = __float_as_int(W.rec[6][sg]) & (RT_PIX_TAPS_LIT - 1);
-					lit_next = (__float_as_uint(W.rec[6][sg]) >> 16) & 3u;
-					hdir = mk3(W.rec[7][sg], W.rec[8][sg], W.rec[9][sg]);
-					has_hit = true; f_live = true;
+					p.f_slot = (int) ((unsigned int) sg * wn + (slot % wn)) | (last ? WF_LAST : 0);
+					if (last) W().win[0][(unsigned int) sg * wn + ((slot + 1u) % wn)] = W().rec[11][sg];
+					p.rng = ((uint64_t) s << 32) | (uint64_t) __float_as_uint(W().rec[10][sg]);   /* (pixel index, sample): seeded where the sample is first shaded (section 2) */
+					p.bounce = 0;
+					p.hp = mk3(W().rec[0][sg], W().rec[1][sg], W().rec[2][sg]);
+					p.hn = mk3(W().rec[3][sg], W().rec[4][sg], W().rec[5][sg]);
+					p.hobj = __float_as_int(W().rec[6][sg]) & (RT_PIX_TAPS_LIT - 1);
+					p.lit_next = (__float_as_uint(W().rec[6][sg]) >> 16) & 3u;
+					p.hdir = mk3(W().rec[7][sg], W().rec[8][sg], W().rec[9][sg]);
+					p.has_hit = true; p.f_live = true;
 				}
 				if (leader && gm != 0ull && avail > 0) {
 					const int asked = __popcll(gm);
 					const unsigned int handed = (unsigned int) (asked < avail ? asked : avail);
-					W.s_nxt[sg] = nxt + handed;
-					W.s_seq[sg] = seq + handed + (nxt + handed == spp ? 1u : 0u);
+					W().s_nxt[sg] = nxt + handed;
+					W().s_seq[sg] = seq + handed + (nxt + handed == spp ? 1u : 0u);
 				}
 				wave_fence();
 				STAMP(6);
 			}
 		}
-#ifdef RT_STATS
-		if (!f_live) STAT(24);                  /* lanes that start the round without a sample */
-#endif
-		if (__ballot(f_live || ((rec1 | rec2) & REC_VALID) != 0) == 0ull) {
-			/* nothing in flight: every reserved slot is filled, so whatever is still waiting can be added now */
-			if (!direct && __ballot(W.s_drained[g] != W.s_seq[g]) != 0ull) { add_finished_samples(); continue; }
-			if (exhausted) break;
-			continue;
-		}
+	}
 
-		STAMP(0);
-		/* ---- 2. shade the pending hit of every live path (main.c:180-261) ------------------- */
-		int  tapmask = 0, cur = 0;
-		bool emit_main = false;
-		V3   ray_o = mk3(0, 0, 0), ray_d = mk3(0, 0, 0);
-		V3   tap_j0 = mk3(0, 0, 0), tap_j1 = mk3(0, 0, 0), tap_j2 = mk3(0, 0, 0);   /* accepted rand_dir of each tap (main.c:193) */
+	/* the lanes of `nmask` (need_pixel) take the next object pixels of the wave's list: for themselves (direct) or for
+	 * stream `sg`, whose bookkeeping they do */
+	RT_DEV void fetch_pixels(bool need_pixel, unsigned long long nmask, int sg)
+	{
+		STAT(21);
+		const rt_launch_cold C = cold_view();
+		const int asked = __popcll(nmask);
+		int got = 0;
+		size_t first = 0;
+		if (!exhausted) {
+			typedef const __attribute__((address_space(1))) unsigned int *guint;
+			typedef __attribute__((address_space(1))) unsigned int *gwuint;
+			/* rt_cancel() (main.c:316-317: the frame has been invalidated).  The host stores its request in a word of host
+			 * memory: "the launches up to this number are to stop".  Reading that is slow (a read over the link takes the
+			 * place of 75 ns of everybody else's: 4 096 waves asking at once cost a strip a third of its time), so only eight
+			 * waves of the launch do, when they fetch pixels, and pass the news on through control[2] in device memory, which
+			 * every other wave reads when it fetches pixels.  Told to stop, a wave hands out nothing more, lets the paths in
+			 * flight finish and leaves; the launch is marked incomplete.  (A wave that has no pixels left to fetch does not
+			 * ask any more: it is about to leave anyway.) */
+			unsigned int word = 0u, k = 0u;
+			if (lane == 0) {
+				word = (blockIdx.x < 8u && wave == 0) ? __hip_atomic_load((guint) C->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - C->launch_id
+				                                      : __hip_atomic_load((guint) C->control + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
+				k = atomicAdd(block_counter + shard * 32u, (unsigned int) asked);
+			}
+			k = (unsigned int) __builtin_amdgcn_readfirstlane((int) k);
+			if ((int) __builtin_amdgcn_readfirstlane((int) word) >= 0) {      /* the request covers this launch / another wave has seen it */
+				cancelled = true;
+				if (lane == 0) { C->control[1] = 1u; __hip_atomic_store((gwuint) C->control + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+			}
+			const guint fill_counts = (guint) C->pix_count;
+			const unsigned int filled = (unsigned int) __builtin_amdgcn_readfirstlane((int) fill_counts[shard * 32u]);
+			got = k < filled && !cancelled ? (filled - k < (unsigned int) asked ? (int) (filled - k) : asked) : 0;
+			first = (size_t) shard * (size_t) C->pix_shard_cap + k;
+			if (got < asked) {
+				/* This list has run out: look at all of them at once (lane s reads list s's two counters; a stale
+				 * dequeue count can only show more pixels left than there are, never fewer) and move to the next
+				 * one that still has pixels.  None: the launch has no pixels left to hand out. */
+				unsigned int left = 0, taken = 0;
+				if (lane < C->num_shards) {
+					taken = __hip_atomic_load(block_counter + (unsigned int) lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					const unsigned int have = fill_counts[(unsigned int) lane * 32u];
+					left = have > taken ? have - taken : 0u;
+				}
+				const unsigned long long some = __ballot(left != 0u);
+				if (some == 0ull || cancelled) { exhausted = true; STAMP_DRY; }
+				else {      /* the waves spread over the lists that are left (one address takes ~88 atomics per microsecond) */
+					const int pick = (int) ((blockIdx.x * (BLOCK / 64) + (unsigned int) wave) % (unsigned int) __popcll(some));
+					shard = (unsigned int) __builtin_ctzll(__ballot(left != 0u && lanes_below(some) == pick));
+				}
+			}
+		}
+		const int rr = lanes_below(nmask);
+		if (need_pixel && rr < got) {
+			const PixelRec px = load_pixel(C, first + (size_t) rr);
+			if (direct) {
+				p.f_slot = px.off; p.f_live = true;
+				p.rng = (uint64_t) px.index;                /* (pixel index, sample 0): seeded where the sample is first shaded (section 2) */
+				p.bounce = 0;
+				p.hp = px.a; p.hn = px.n; p.hobj = px.obj & (RT_PIX_TAPS_LIT - 1); p.hdir = px.dir;
+				p.lit_next = ((uint32_t) px.obj >> 16) & 3u;
+				p.has_hit = true;
+			} else {
+				W().rec[0][sg] = px.a.x;   W().rec[1][sg] = px.a.y;   W().rec[2][sg] = px.a.z;
+				W().rec[3][sg] = px.n.x;   W().rec[4][sg] = px.n.y;   W().rec[5][sg] = px.n.z;
+				W().rec[6][sg] = __int_as_float(px.obj);
+				W().rec[7][sg] = px.dir.x; W().rec[8][sg] = px.dir.y; W().rec[9][sg] = px.dir.z;
+				W().rec[10][sg] = __uint_as_float(px.index);
+				W().rec[11][sg] = __int_as_float(px.off);
+				W().s_nxt[sg] = 0u;
+				if (onto) {
+					typedef const __attribute__((address_space(1))) float *gfloat;
+					const gfloat held = (gfloat) C->sum_onto + (size_t) px.off * 3;
+					const unsigned int sq = W().s_seq[sg], e = (unsigned int) sg * wn + sq % wn;
+					W().win[1][e] = held[1]; W().win[2][e] = held[2];
+					W().win[0][e] = held[0];
+					W().s_seq[sg] = sq + 1u;
+				}
+			}
+		}
+		wave_fence();
+	}
+
+	/* ---- 2. shade the pending hit of every live path (main.c:180-261) ------------------- */
+	RT_DEV void shade_pending_hits(RoundOut &r)
+	{
 		STAT(7);
-		if (has_hit) {
-			STAT(8);
-			/* a camera-ray hit point from which every tap certainly reaches the emitter (flagged by rt_primary_pass): the taps
-			 * are drawn and accepted as always (main.c:193-195), but not traced */
-			/* a sample's first bounce: its path is seeded here, once per round for all the lanes that start one, not once per hand-out attempt */
-			if (bounce == 0) rng = path_seed(L.seed, (uint32_t) rng, (uint32_t) L.sample_base + (uint32_t) (rng >> 32));
-			const bool taps_lit = lit_next != 0u;      /* ... or a hit point of a later bounce in such a cell of the scene's table (section 4);
-			                                            * 1: they reach the emitter, 2: they certainly do not (and nothing else emits) */
+		if (!p.has_hit) return;
+		STAT(8);
+		/* a sample's first bounce: its path is seeded here, once per round for all the lanes that start one, not once per hand-out attempt */
+		if (p.bounce == 0) p.rng = path_seed(L.seed, (uint32_t) p.rng, (uint32_t) L.sample_base + (uint32_t) (p.rng >> 32));
+		/* a camera-ray hit point from which every tap certainly reaches the emitter (flagged by rt_primary_pass), or a hit point of
+		 * a later bounce in such a cell of the scene's table (section 4): the taps are drawn and accepted as always (main.c:193-195),
+		 * but not traced.  1: they reach the emitter, 2: they certainly do not (and nothing else emits) */
+		const bool taps_lit = p.lit_next != 0u;
 #ifdef RT_STATS
-			{	/* what kind of shading event this is (scripts/stats_c1.py): a sample's first or a later one, on a box or a sphere, taps known or not */
-				const bool on_box = __float_as_int(sc.geom[2 * hobj + 1].z) == RT_GEOM_CUBE;
-				if (bounce == 0) STAT(0);            /* (sites 25-28 are the section stamps' words) */
-				if (bounce == 0 && taps_lit) STAT(10);
-				if (on_box) STAT(11);
-				if (bounce == 0 && on_box) STAT(18);
-				if (bounce == 0 && on_box && taps_lit) STAT(19);
-				if (taps_lit) STAT(29);
-				if (bounce == 1) STAT(30);
-			}
-#endif
-			if (have_light) {
-				/* main.c:191-195: three rand_dir draws, a tap is skipped when it points into the surface.  Only the sign of
-				 * dot(rand_dir, normal) is needed here, and random_vector() has it before normalize() does (rt_math.hip.h:
-				 * side_is_certain): the tap is queued as drawn, and normalised -- with its direction and origin, main.c:197-198 --
-				 * where it is traced, on a full batch, if it is traced at all. */
-				tap_j0 = rng_vector(rng); tap_j1 = rng_vector(rng); tap_j2 = rng_vector(rng);
-				const float side0 = dot3(tap_j0, hn), side1 = dot3(tap_j1, hn), side2 = dot3(tap_j2, hn);
-				if (FAST && wave_all(side_is_certain(side0) && side_is_certain(side1) && side_is_certain(side2)))
-					tapmask = (side0 > 0 ? 1 : 0) | (side1 > 0 ? 2 : 0) | (side2 > 0 ? 4 : 0);
-				else
-					tapmask = (dot3(unit3_of_vector<FAST>(tap_j0), hn) > 0 ? 1 : 0) | (dot3(unit3_of_vector<FAST>(tap_j1), hn) > 0 ? 2 : 0) |
-					          (dot3(unit3_of_vector<FAST>(tap_j2), hn) > 0 ? 4 : 0);
-			}
-			const float4 m0 = sc.shade[4 * hobj], m1 = sc.shade[4 * hobj + 1];
-			const V3 f0 = mk3(m0.x, m0.y, m0.z), omf0 = mk3(m1.x, m1.y, m1.z);
-
-			const float n_dot_v = clamp01(dot3(hn, neg3(hdir)));
-			/* main.c:128: (float) pow(1.0 - (double) u, 5.0) == x2*x2*x in fp64 for every float u in [0,1] (tests/test_pow5.py) */
-			const double xg = 1.0 - (double) n_dot_v;
-			const double xg2 = xg * xg;
-			const float grazing = (float) (xg2 * xg2 * xg);
-			const V3 fresnel = madd3(f0, omf0, grazing);
-
-			V3 scatter = rng_direction<FAST>(rng);
-			if (dot3(scatter, hn) < 0) scatter = neg3(scatter);
-
-			bool specular = __float_as_int(m1.w) != 0;
-			if (!specular)
-				specular = rng_draw(rng) <= (FAST ? third_of(fresnel.x + fresnel.y + fresnel.z) : (fresnel.x + fresnel.y + fresnel.z) / 3.0f);
-			V3 out_dir;
-			if (specular) {
-				STAT(15);
-				const V3 nneg = neg3(hn);
-				const float f = -2.0f * dot3(nneg, hdir);
-				out_dir = unit3_sel<FAST>(lin2(scatter, madd3(hdir, nneg, f), m0.w, 1.0f));
-			} else
-				out_dir = scatter;
-			bounce++;
-			emit_main = bounce < L.max_bounces;
-			ray_o = madd3(hp, out_dir, 0.001f);
-			ray_d = out_dir;
-			hdir = out_dir;
-			has_hit = false;
-			cur = REC_VALID | (specular ? REC_SPECULAR : 0) | (emit_main ? 0 : REC_LAST) | (tapmask << 4) | (hobj << 8);
-			if (taps_lit) { cur |= lit_next == 1u ? REC_TAPS_LIT : REC_TAPS_DARK; tapmask = 0; }      /* the record keeps the accepted taps, the queue gets none */
+		{	/* what kind of shading event this is (scripts/stats_c1.py): a sample's first or a later one, on a box or a sphere, taps known or not */
+			const bool on_box = __float_as_int(sc.geom[2 * p.hobj + 1].z) == RT_GEOM_CUBE;
+			if (p.bounce == 0) STAT(0);            /* (sites 25-28 are the section stamps' words) */
+			if (p.bounce == 0 && taps_lit) STAT(10);
+			if (on_box) STAT(11);
+			if (p.bounce == 0 && on_box) STAT(18);
+			if (p.bounce == 0 && on_box && taps_lit) STAT(19);
+			if (taps_lit) STAT(29);
+			if (p.bounce == 1) STAT(30);
 		}
+#endif
+		if (K.have_light) {
+			/* main.c:191-195: three rand_dir draws, a tap is skipped when it points into the surface.  Only the sign of
+			 * dot(rand_dir, normal) is needed here, and random_vector() has it before normalize() does (rt_math.hip.h:
+			 * side_is_certain): the tap is queued as drawn, and normalised -- with its direction and origin, main.c:197-198 --
+			 * where it is traced, on a full batch, if it is traced at all. */
+			r.tap_j0 = rng_vector(p.rng); r.tap_j1 = rng_vector(p.rng); r.tap_j2 = rng_vector(p.rng);
+			const float side0 = dot3(r.tap_j0, p.hn), side1 = dot3(r.tap_j1, p.hn), side2 = dot3(r.tap_j2, p.hn);
+			if (FAST && wave_all(side_is_certain(side0) && side_is_certain(side1) && side_is_certain(side2)))
+				r.tapmask = (side0 > 0 ? 1 : 0) | (side1 > 0 ? 2 : 0) | (side2 > 0 ? 4 : 0);
+			else
+				r.tapmask = (dot3(unit3_of_vector<FAST>(r.tap_j0), p.hn) > 0 ? 1 : 0) | (dot3(unit3_of_vector<FAST>(r.tap_j1), p.hn) > 0 ? 2 : 0) |
+				            (dot3(unit3_of_vector<FAST>(r.tap_j2), p.hn) > 0 ? 4 : 0);
+		}
+		const float4 m0 = sc.shade[4 * p.hobj], m1 = sc.shade[4 * p.hobj + 1];
+		const V3 f0 = mk3(m0.x, m0.y, m0.z), omf0 = mk3(m1.x, m1.y, m1.z);
 
-		STAMP(1);
-		/* ---- 3. the shadow taps go into the wave's ring (ballot + mbcnt prefix), one kind at a time; whenever 64 are
-		 * queued, any lane traces any tap (scene.c:156-190 on full waves).  A tap is queued as (hit point, random_vector());
-		 * its normalisation, direction and origin (main.c:193-198) are formed where it is traced.  Taps that do not fill a
-		 * batch wait: the bounce they belong to is retired two rounds from now ------------------------------------------------------- */
-		auto push = [&](bool on, V3 qo, V3 qd, int k) {
-			const unsigned long long m = __ballot(on);
-			if (on) {
-				const unsigned int slot = (q_tail + (unsigned int) lanes_below(m)) & (WF_QUEUE - 1);
-				W.q[0][slot] = qo.x; W.q[1][slot] = qo.y; W.q[2][slot] = qo.z;
-				W.q[3][slot] = qd.x; W.q[4][slot] = qd.y; W.q[5][slot] = qd.z;
-				W.qmeta[slot] = (unsigned short) (lane | (k << 8) | (int) (phase << 12));
-			}
-			q_tail += (unsigned int) __popcll(m);
-			wave_fence();
-		};
-		/* the ray of the queued tap in ring slot `slot`, and where its answer goes */
-		auto tap_ray = [&](unsigned int slot, V3 &o, V3 &d, int &meta) {
-			o = mk3(W.q[0][slot], W.q[1][slot], W.q[2][slot]);
-			d = mk3(W.q[3][slot], W.q[4][slot], W.q[5][slot]);
-			meta = W.qmeta[slot];
-			d = unit3_of_vector<FAST>(d);                                                /* main.c:193: normalize(random_vector()) */
-			d = unit3_sel<FAST>(lin2(d, sub3(light_pos, o), 0.5f, 1.0f));               /* main.c:186,197 */
-			o = madd3(o, d, 0.001f);                                                     /* main.c:198 */
-		};
-		auto tap_answer = [&](int meta, int obj) { W.tap[(meta >> 12) & 3][((meta >> 8) & 15) - 2][meta & 255] = (short) obj; };
-		auto trace_taps = [&](int count) {         /* the `count` <= 64 oldest taps */
-			STAT(12);
-			if (CULL) {            /* every lane takes part in the culled trace (its work is shared out over the wave); lanes without a tap pass `on` = false */
-				const bool on = lane < count;
-				V3 o = mk3(0, 0, 0), d = mk3(1, 0, 0); int meta = 0;
-				if (on) tap_ray((q_head + (unsigned int) lane) & (WF_QUEUE - 1), o, d, meta);
-				const V3 dn = unit3_sel<FAST>(d);
-				const Hit hit = nearest_hit_culled(sc, n, cl, cull_wave, on, o, dn, false);
-				if (on) tap_answer(meta, hit.obj);
-			} else
-			if (lane < count) {
-				STAT(13);
-				V3 o, d; int meta;
-				tap_ray((q_head + (unsigned int) lane) & (WF_QUEUE - 1), o, d, meta);
-				const V3 dn = unit3_sel<FAST>(d);                                         /* scene.c:158 */
-				const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, n, o, dn, false) : nearest_hit(sc, n, o, dn);
-				tap_answer(meta, hit.obj);
-			}
-			q_head += (unsigned int) count;
-			wave_fence();
-		};
-#ifndef RT_PUSH_APART
+		const float n_dot_v = clamp01(dot3(p.hn, neg3(p.hdir)));
+		/* main.c:128: (float) pow(1.0 - (double) u, 5.0) == x2*x2*x in fp64 for every float u in [0,1] (tests/test_pow5.py) */
+		const double xg = 1.0 - (double) n_dot_v;
+		const double xg2 = xg * xg;
+		const float grazing = (float) (xg2 * xg2 * xg);
+		const V3 fresnel = madd3(f0, omf0, grazing);
+
+		V3 scatter = rng_direction<FAST>(p.rng);
+		if (dot3(scatter, p.hn) < 0) scatter = neg3(scatter);
+
+		bool specular = __float_as_int(m1.w) != 0;
+		if (!specular)
+			specular = rng_draw(p.rng) <= (FAST ? third_of(fresnel.x + fresnel.y + fresnel.z) : (fresnel.x + fresnel.y + fresnel.z) / 3.0f);
+		V3 out_dir;
+		if (specular) {
+			STAT(15);
+			const V3 nneg = neg3(p.hn);
+			const float f = -2.0f * dot3(nneg, p.hdir);
+			out_dir = unit3_sel<FAST>(lin2(scatter, madd3(p.hdir, nneg, f), m0.w, 1.0f));
+		} else
+			out_dir = scatter;
+		p.bounce++;
+		r.emit_main = p.bounce < L.max_bounces;
+		r.ray_o = madd3(p.hp, out_dir, 0.001f);
+		r.ray_d = out_dir;
+		p.hdir = out_dir;
+		p.has_hit = false;
+		r.cur = REC_VALID | (specular ? REC_SPECULAR : 0) | (r.emit_main ? 0 : REC_LAST) | (r.tapmask << 4) | (p.hobj << 8);
+		if (taps_lit) { r.cur |= p.lit_next == 1u ? REC_TAPS_LIT : REC_TAPS_DARK; r.tapmask = 0; }      /* the record keeps the accepted taps, the queue gets none */
+	}
+
+	/* ---- 3. the shadow taps go into the wave's ring (ballot + mbcnt prefix), one kind at a time; whenever 64 are
+	 * queued, any lane traces any tap (scene.c:156-190 on full waves).  A tap is queued as (hit point, random_vector());
+	 * its normalisation, direction and origin (main.c:193-198) are formed where it is traced.  Taps that do not fill a
+	 * batch wait: the bounce they belong to is retired two rounds from now ------------------------------------------------------- */
+	RT_DEV void push_taps(bool on, V3 qo, V3 qd, int k)
+	{
+		const unsigned long long m = __ballot(on);
+		if (on) {
+			const unsigned int slot = (q_tail + (unsigned int) lanes_below(m)) & (WF_QUEUE - 1);
+			W().q[0][slot] = qo.x; W().q[1][slot] = qo.y; W().q[2][slot] = qo.z;
+			W().q[3][slot] = qd.x; W().q[4][slot] = qd.y; W().q[5][slot] = qd.z;
+			W().qmeta[slot] = (unsigned short) (lane | (k << 8) | (int) (phase << 12));
+		}
+		q_tail += (unsigned int) __popcll(m);
+		wave_fence();
+	}
+	/* the ray of the queued tap in ring slot `slot`, and where its answer goes */
+	RT_DEV void tap_ray(unsigned int slot, V3 &o, V3 &d, int &meta) const
+	{
+		o = mk3(W().q[0][slot], W().q[1][slot], W().q[2][slot]);
+		d = mk3(W().q[3][slot], W().q[4][slot], W().q[5][slot]);
+		meta = W().qmeta[slot];
+		d = unit3_of_vector<FAST>(d);                                                /* main.c:193: normalize(random_vector()) */
+		d = unit3_sel<FAST>(lin2(d, sub3(K.light_pos(), o), 0.5f, 1.0f));            /* main.c:186,197 */
+		o = madd3(o, d, 0.001f);                                                     /* main.c:198 */
+	}
+	RT_DEV void tap_answer(int meta, int obj) const { W().tap[(meta >> 12) & 3][((meta >> 8) & 15) - 2][meta & 255] = (short) obj; }
+	RT_DEV void trace_taps(int count)          /* the `count` <= 64 oldest taps */
+	{
+		STAT(12);
+		if (CULL) {            /* every lane takes part in the culled trace (its work is shared out over the wave); lanes without a tap pass `on` = false */
+			const bool on = lane < count;
+			V3 o = mk3(0, 0, 0), d = mk3(1, 0, 0); int meta = 0;
+			if (on) tap_ray((q_head + (unsigned int) lane) & (WF_QUEUE - 1), o, d, meta);
+			const V3 dn = unit3_sel<FAST>(d);
+			const Hit hit = nearest_hit_culled(sc, K.n, cl, cull_wave, on, o, dn, false);
+			if (on) tap_answer(meta, hit.obj);
+		} else
+		if (lane < count) {
+			STAT(13);
+			V3 o, d; int meta;
+			tap_ray((q_head + (unsigned int) lane) & (WF_QUEUE - 1), o, d, meta);
+			const V3 dn = unit3_sel<FAST>(d);                                         /* scene.c:158 */
+			const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, K.n, o, dn, false) : nearest_hit(sc, K.n, o, dn);
+			tap_answer(meta, hit.obj);
+		}
+		q_head += (unsigned int) count;
+		wave_fence();
+	}
+	RT_DEV void queue_taps(const RoundOut &r)
+	{
 		/* all three kinds in one go when the ring has room for them (it has, unless most taps of most lanes are traced): one
 		 * prefix sum over the lanes' tap counts instead of three ballots, one fence instead of three (C1 -2.1 %, strip -4.6 %, C2 +0.4 %:
 		 * profiles/r03/ab_push_together.txt) */
-		const unsigned int mine = (unsigned int) __popc((unsigned int) tapmask);
+		const unsigned int mine = (unsigned int) __popc((unsigned int) r.tapmask);
 		const unsigned long long c0 = __ballot((mine & 1u) != 0u), c1 = __ballot((mine & 2u) != 0u);
 		const unsigned int all = (unsigned int) __popcll(c0) + 2u * (unsigned int) __popcll(c1);
 		if (q_tail - q_head + all <= (unsigned int) WF_QUEUE) {
 			unsigned int slot = q_tail + (unsigned int) lanes_below(c0) + 2u * (unsigned int) lanes_below(c1);
 #pragma unroll
 			for (int t = 0; t < 3; t++)
-				if ((tapmask >> t) & 1) {
+				if ((r.tapmask >> t) & 1) {
 					const unsigned int e = slot & (WF_QUEUE - 1);
-					const V3 qd = t == 0 ? tap_j0 : (t == 1 ? tap_j1 : tap_j2);
-					W.q[0][e] = hp.x; W.q[1][e] = hp.y; W.q[2][e] = hp.z;
-					W.q[3][e] = qd.x; W.q[4][e] = qd.y; W.q[5][e] = qd.z;
-					W.qmeta[e] = (unsigned short) (lane | ((t + 2) << 8) | (int) (phase << 12));
+					const V3 qd = t == 0 ? r.tap_j0 : (t == 1 ? r.tap_j1 : r.tap_j2);
+					W().q[0][e] = p.hp.x; W().q[1][e] = p.hp.y; W().q[2][e] = p.hp.z;
+					W().q[3][e] = qd.x; W().q[4][e] = qd.y; W().q[5][e] = qd.z;
+					W().qmeta[e] = (unsigned short) (lane | ((t + 2) << 8) | (int) (phase << 12));
 					slot++;
 				}
 			q_tail += all;
 			wave_fence();
 			while (q_tail - q_head >= 64u) trace_taps(64);
 		} else
-#endif
 #pragma unroll 1
 		for (int kind = 2; kind < 5; kind++) {
 			switch (kind) {
-			case 2:  push((tapmask & 1) != 0, hp, tap_j0, 2); break;
-			case 3:  push((tapmask & 2) != 0, hp, tap_j1, 3); break;
-			default: push((tapmask & 4) != 0, hp, tap_j2, 4); break;
+			case 2:  push_taps((r.tapmask & 1) != 0, p.hp, r.tap_j0, 2); break;
+			case 3:  push_taps((r.tapmask & 2) != 0, p.hp, r.tap_j1, 3); break;
+			default: push_taps((r.tapmask & 4) != 0, p.hp, r.tap_j2, 4); break;
 			}
 			while (q_tail - q_head >= 64u) trace_taps(64);
 		}
+	}
 
-		/* ---- 4. the bounce rays: every lane traces its own, straight from its registers -- no queue, no LDS ---------- */
-		if (__ballot(emit_main) != 0ull) {
+	/* ---- 4. the bounce rays: every lane traces its own, straight from its registers -- no queue, no LDS ---------- */
+	RT_DEV void trace_bounce_rays(const RoundOut &r)
+	{
+		if (__ballot(r.emit_main) != 0ull) {
 			STAT(12);
 			Hit culled; culled.t = 0.0f; culled.obj = -1; culled.n = mk3(0, 0, 0);
 			if (CULL) {            /* (all lanes: see trace_taps) */
 				/* A culled trace costs the same for one ray as for 64 (its first step asks every cluster box for every lane), and the
 				 * lanes without a bounce ray -- paths at their last bounce, lanes between samples: a third of them -- have nothing to
 				 * do in it: the oldest taps waiting in the ring ride along in those lanes instead of waiting for a batch of their own. */
-				const unsigned long long idle = ~__ballot(emit_main);
+				const unsigned long long idle = ~__ballot(r.emit_main);
 				const unsigned int waiting = q_tail - q_head, room = (unsigned int) __popcll(idle);
 				const unsigned int take = waiting < room ? waiting : room;
 				const unsigned int place = (unsigned int) lanes_below(idle);
-				const bool rider = !emit_main && place < take;
-				V3 to = ray_o, td = emit_main ? ray_d : mk3(1, 0, 0);
+				const bool rider = !r.emit_main && place < take;
+				V3 to = r.ray_o, td = r.emit_main ? r.ray_d : mk3(1, 0, 0);
 				int tmeta = 0;
 				if (rider) tap_ray((q_head + place) & (WF_QUEUE - 1), to, td, tmeta);
-				culled = nearest_hit_culled(sc, n, cl, cull_wave, emit_main || rider, to, unit3_sel<FAST>(td), true);
+				culled = nearest_hit_culled(sc, K.n, cl, cull_wave, r.emit_main || rider, to, unit3_sel<FAST>(td), true);
 				if (rider) tap_answer(tmeta, culled.obj);
 				if (take) { q_head += take; wave_fence(); }
 			}
-			if (emit_main) {
+			if (r.emit_main) {
 				STAT(13);
-				const V3 dn = unit3_sel<FAST>(ray_d);                                     /* scene.c:158 */
-				const Hit hit = CULL ? culled : (FAST ? NEAREST_HIT_TUNED(sc, n, ray_o, dn, true) : nearest_hit(sc, n, ray_o, dn));
-				hobj = hit.obj; hn = hit.n;
-				hp = hit.obj >= 0 ? madd3(ray_o, dn, hit.t)                               /* scene.c:186 */
-				                  : dn;                 /* left the scene: the sky is looked up in that direction (main.c:170) */
+				const V3 dn = unit3_sel<FAST>(r.ray_d);                                     /* scene.c:158 */
+				const Hit hit = CULL ? culled : (FAST ? NEAREST_HIT_TUNED(sc, K.n, r.ray_o, dn, true) : nearest_hit(sc, K.n, r.ray_o, dn));
+				p.hobj = hit.obj; p.hn = hit.n;
+				p.hp = hit.obj >= 0 ? madd3(r.ray_o, dn, hit.t)                             /* scene.c:186 */
+				                    : dn;                 /* left the scene: the sky is looked up in that direction (main.c:170) */
 				/* will the taps from this hit point need tracing?  The scene's table (rt_lit.h) has one entry per cell of a grid
 				 * over every object: 1 = every surface point in the cell certainly sees the emitter.  The load is in flight
 				 * until the next round's front asks */
-				lit_next = 0u;
-				if (FAST && L.lit_cells != nullptr && hit.obj >= 0 && hit.obj != light_obj &&
-				    rt_lit_point_on_surface(reinterpret_cast<const float*>(sc.geom) + 8 * hit.obj, hp.x, hp.y, hp.z, hn.x, hn.y, hn.z))
-					lit_next = L.lit_cells[grids_in_lds ? rt_lit_bit_of(lit_grids_lds + hit.obj, hp.x, hp.y, hp.z)
-					                                    : rt_lit_bit_of(lit_grids_mem + hit.obj, hp.x, hp.y, hp.z)];
+				p.lit_next = 0u;
+				/* (two pointers, not one chosen at run time: a pointer that may be LDS or memory makes every access a flat load with a
+				 * 64-bit address -- ten per bounce ray) */
+				extern __shared__ float4 lds[];
+				const rt_lit_grid *lit_grids_lds = reinterpret_cast<const rt_lit_grid*>(lds + 6 * K.n);
+				const rt_lit_grid *lit_grids_mem = reinterpret_cast<const rt_lit_grid*>(L.lit_grids);
+				if (FAST && L.lit_cells != nullptr && hit.obj >= 0 && hit.obj != K.light_obj &&
+				    rt_lit_point_on_surface(reinterpret_cast<const float*>(sc.geom) + 8 * hit.obj, p.hp.x, p.hp.y, p.hp.z, p.hn.x, p.hn.y, p.hn.z))
+					p.lit_next = L.lit_cells[grids_in_lds ? rt_lit_bit_of(lit_grids_lds + hit.obj, p.hp.x, p.hp.y, p.hp.z)
+					                                      : rt_lit_bit_of(lit_grids_mem + hit.obj, p.hp.x, p.hp.y, p.hp.z)];
 			}
 		}
 		/* the bounces retired below were shaded two rounds ago: whatever is left of their taps (the oldest in the queue) is
 		 * traced now, in a batch that need not be full */
 		const unsigned int due = phase == 2u ? 0u : phase + 1u;
-		while (q_tail != q_head && ((unsigned int) __builtin_amdgcn_readfirstlane((int) W.qmeta[q_head & (WF_QUEUE - 1)]) >> 12 & 3u) == due)
+		while (q_tail != q_head && ((unsigned int) __builtin_amdgcn_readfirstlane((int) W().qmeta[q_head & (WF_QUEUE - 1)]) >> 12 & 3u) == due)
 			trace_taps(q_tail - q_head < 64u ? (int) (q_tail - q_head) : 64);
+	}
 
-		STAMP(2);
-		/* ---- 5. back: retire the bounce shaded two rounds ago (its taps are traced by now), take this round's
-		 * bounce-ray result, and free the front when the path has ended --------------------------------------- */
+	/* ---- 5. back: retire the bounce shaded two rounds ago (its taps are traced by now), take this round's
+	 * bounce-ray result, and free the front when the path has ended --------------------------------------- */
+	RT_DEV void retire_bounces(const RoundOut &r)
+	{
+		const unsigned int due = phase == 2u ? 0u : phase + 1u;
 		STAT(16);
-		if (rec2 & REC_VALID) {
+		if (p.rec2 & REC_VALID) {
 			STAT(17);
-			const int pobj = (rec2 >> 8) & 1023, ptaps = (rec2 >> 4) & 7;
+			const int pobj = (p.rec2 >> 8) & 1023, ptaps = (p.rec2 >> 4) & 7;
 			const float4 m2 = sc.shade[4 * pobj + 2], m3 = sc.shade[4 * pobj + 3];
-			rad = add3(rad, had3(mk3(m3.x, m3.y, m3.z), carry));                    /* main.c:232 */
-			if (!(rec2 & REC_SPECULAR)) carry = had3(carry, mk3(m2.x, m2.y, m2.z));  /* main.c:248 */
+			p.rad = add3(p.rad, had3(mk3(m3.x, m3.y, m3.z), p.carry));                    /* main.c:232 */
+			if (!(p.rec2 & REC_SPECULAR)) p.carry = had3(p.carry, mk3(m2.x, m2.y, m2.z));  /* main.c:248 */
 			if (ptaps) {
 				V3 lit = mk3(0, 0, 0);
 				int taps = 0;
-				if (only_light) {
+				if (K.only_light) {
 					/* The emitter is the only object whose emission is not all (signed) zeros, so main.c:200-204 adds its emission once
 					 * per tap that reaches it and a zero otherwise -- which changes nothing: the sum starts as +0 and is never -0.
 					 * n equal terms e: e, 2e (exact), RN(2e + e) = RN(3e): the product n x e, and "+ 0" makes a -0 product the +0 the
 					 * sum would be.  No emission is looked up per tap, nothing branches per tap. */
-					const int t0 = W.tap[due][0][lane], t1 = W.tap[due][1][lane], t2 = W.tap[due][2][lane];
+					const int t0 = W().tap[due][0][lane], t1 = W().tap[due][1][lane], t2 = W().tap[due][2][lane];
 					taps = __popc((unsigned int) ptaps);
-					int n_hit = ((ptaps & 1) && t0 == light_obj ? 1 : 0) + ((ptaps & 2) && t1 == light_obj ? 1 : 0) + ((ptaps & 4) && t2 == light_obj ? 1 : 0);
-					if (rec2 & REC_TAPS_LIT) n_hit = taps;
-					if (rec2 & REC_TAPS_DARK) n_hit = 0;
-					const float4 e = sc.shade[4 * light_obj + 3];
+					int n_hit = ((ptaps & 1) && t0 == K.light_obj ? 1 : 0) + ((ptaps & 2) && t1 == K.light_obj ? 1 : 0) + ((ptaps & 4) && t2 == K.light_obj ? 1 : 0);
+					if (p.rec2 & REC_TAPS_LIT) n_hit = taps;
+					if (p.rec2 & REC_TAPS_DARK) n_hit = 0;
+					const float4 e = sc.shade[4 * K.light_obj + 3];
 					const float nf = (float) n_hit;
 					lit = mk3(e.x * nf + 0.0f, e.y * nf + 0.0f, e.z * nf + 0.0f);
 				} else
 #pragma unroll
 				for (int k = 0; k < 3; k++)
 					if ((ptaps >> k) & 1) {
-						const int obj = (rec2 & REC_TAPS_LIT) ? light_obj : ((rec2 & REC_TAPS_DARK) ? -1 : W.tap[due][k][lane]);
+						const int obj = (p.rec2 & REC_TAPS_LIT) ? K.light_obj : ((p.rec2 & REC_TAPS_DARK) ? -1 : W().tap[due][k][lane]);
 						if (obj >= 0) { const float4 e = sc.shade[4 * obj + 3]; lit = add3(lit, mk3(e.x, e.y, e.z)); }
 						taps++;
 					}
@@ -1576,53 +1589,84 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
 				                       : (tiny_f(lit.x) && tiny_f(lit.y) && tiny_f(lit.z));
 				if (!dark) {                                                      /* main.c:257-261 */
 					const float w = 0.05f;
-					rad = madd3(rad, had3(lit, carry), w);
-					carry = scale3(carry, 1.0f - w);
+					p.rad = madd3(p.rad, had3(lit, p.carry), w);
+					p.carry = scale3(p.carry, 1.0f - w);
 				}
 			}
-			if (rec2 & REC_LAST) {              /* the path ended with that bounce: sky (main.c:171) or bounce limit (main.c:158) */
-				if (rec2 & REC_SKY) rad = add3(rad, had3(sky_colour<FAST>(sky2), carry));
-				const V3 col = mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z));     /* main.c:267-269 */
+			if (p.rec2 & REC_LAST) {              /* the path ended with that bounce: sky (main.c:171) or bounce limit (main.c:158) */
+				if (p.rec2 & REC_SKY) p.rad = add3(p.rad, had3(sky_colour<FAST>(p.sky2), p.carry));
+				const V3 col = mk3(clamp01(p.rad.x), clamp01(p.rad.y), clamp01(p.rad.z));     /* main.c:267-269 */
 				if (direct) {                   /* the pixel's only sample: 0 + colour (main.c:394), resolved (main.c:476) */
 					const V3 res = scale3(add3(mk3(0, 0, 0), col), inv_spp);
-					float *dst = L.frame + (size_t) slot2 * 3;
+					float *dst = L.frame + (size_t) p.slot2 * 3;
 					dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
 				} else {                        /* into its slot of the window; section 6 adds it when its turn comes */
-					const unsigned int e = (unsigned int) slot2 & (WF_LAST - 1);
-					W.win[1][e] = col.y; W.win[2][e] = col.z;
-					W.win[0][e] = __uint_as_float((__float_as_uint(col.x) & 0x7fffffffu) | ((slot2 & WF_LAST) ? 0x80000000u : 0u));
+					const unsigned int e = (unsigned int) p.slot2 & (WF_LAST - 1);
+					W().win[1][e] = col.y; W().win[2][e] = col.z;
+					W().win[0][e] = __uint_as_float((__float_as_uint(col.x) & 0x7fffffffu) | ((p.slot2 & WF_LAST) ? 0x80000000u : 0u));
 				}
-				carry = mk3(1, 1, 1); rad = mk3(0, 0, 0);
+				p.carry = mk3(1, 1, 1); p.rad = mk3(0, 0, 0);
 			}
 		}
-		rec2 = rec1; sky2 = sky1; slot2 = slot1;
-		rec1 = cur;
-		if (cur & REC_VALID) {
-			slot1 = f_slot;
+		p.rec2 = p.rec1; p.sky2 = p.sky1; p.slot2 = p.slot1;
+		p.rec1 = r.cur;
+		if (r.cur & REC_VALID) {
+			p.slot1 = p.f_slot;
 			bool path_ended = true;                                  /* bounce limit (main.c:158) */
-			if (emit_main) {
-				if (hobj < 0) {
+			if (r.emit_main) {
+				if (p.hobj < 0) {
 					STAT(14);
-					sky1 = sky_texel<FAST>(L, hp); rec1 |= REC_LAST | REC_SKY;                  /* main.c:163-172 */
+					p.sky1 = sky_texel<FAST>(L, p.hp); p.rec1 |= REC_LAST | REC_SKY;                  /* main.c:163-172 */
 				} else {
-					has_hit = true; path_ended = false;
+					p.has_hit = true; path_ended = false;
 				}
 			}
-			if (path_ended) f_live = false;      /* the front takes its next sample at the top of the next round */
+			if (path_ended) p.f_live = false;      /* the front takes its next sample at the top of the next round */
 		}
 		wave_fence();
-
-		STAMP(3);
-		/* ---- 6. add the finished samples in sample order (main.c:394) ---------------------------------------- */
-		/* Every second round when a pixel has many samples: a stream's eight lanes add up to eight slots per pass and a round finishes
-		 * three or four samples per stream (C1), so one pass has room for two rounds' worth, and the pass costs the same 140
-		 * instructions whether it finds one slot or eight.  C1 -0.5 %, C2 -3.4 %, strips -0.3 % (`RT_SUM_EVERY`, profiles/r03/ab_sum_every.txt;
-		 * every third round: the window fills and lanes wait for slots, +1.5 ... +7 %).  Pixels of few samples complete too fast for
-		 * that -- a pass resolves at most one pixel per stream. */
-		if (!direct && (++sum_tick >= sum_every)) { sum_tick = 0u; add_finished_samples(); }
-		STAMP(4);
 	}
-	STAMP_FLUSH;
+
+	RT_DEV void run()
+	{
+		for (;; phase = phase == 2u ? 0u : phase + 1u) {
+			STAMP(7);
+			STAMP_ROUND;
+			supply_samples();
+#ifdef RT_STATS
+			if (!p.f_live) STAT(24);                  /* lanes that start the round without a sample */
+#endif
+			if (__ballot(p.f_live || ((p.rec1 | p.rec2) & REC_VALID) != 0) == 0ull) {
+				/* nothing in flight: every reserved slot is filled, so whatever is still waiting can be added now */
+				if (!direct && __ballot(W().s_drained[g] != W().s_seq[g]) != 0ull) { add_finished_samples(); continue; }
+				if (exhausted) break;
+				continue;
+			}
+			STAMP(0);
+			RoundOut r;
+			shade_pending_hits(r);
+			STAMP(1);
+			queue_taps(r);
+			trace_bounce_rays(r);
+			STAMP(2);
+			retire_bounces(r);
+			STAMP(3);
+			/* Every second round when a pixel has many samples: a stream's eight lanes add up to eight slots per pass and a round finishes
+			 * three or four samples per stream (C1), so one pass has room for two rounds' worth, and the pass costs the same 140
+			 * instructions whether it finds one slot or eight.  C1 -0.5 %, C2 -3.4 %, strips -0.3 % (profiles/r03/ab_sum_every.txt;
+			 * every third round: the window fills and lanes wait for slots, +1.5 ... +7 %).  Pixels of few samples complete too fast for
+			 * that -- a pass resolves at most one pixel per stream. */
+			if (!direct && (++sum_tick >= sum_every)) { sum_tick = 0u; add_finished_samples(); }
+			STAMP(4);
+		}
+		STAMP_FLUSH(BLOCK / 64);
+	}
+};
+
+template <bool FAST, bool CULL = false, int BLOCK = RT_BLOCK>
+RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
+{
+	Wavefront<FAST, CULL, BLOCK> wf(L, block_counter);
+	wf.run();
 }
 
 #ifndef RT_SPEC_ONLY
@@ -1970,18 +2014,6 @@ hipError_t rt_launch_selftest(int which, uint64_t seed, int blocks, int iters, u
 	return hipGetLastError();
 }
 
-#ifdef RT_STATS
-extern "C" __attribute__((visibility("default"))) int rt_stats_read(unsigned long long out[128], int reset)
-{
-	if (hipDeviceSynchronize() != hipSuccess) return -2;
-	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rt_stats), 128 * sizeof(unsigned long long)) != hipSuccess) return -2;
-	if (reset) {
-		unsigned long long zero[128] = {0};
-		if (hipMemcpyToSymbol(HIP_SYMBOL(rt_stats), zero, sizeof(zero)) != hipSuccess) return -2;
-	}
-	return 0;
-}
-#endif
 
 /* ---- host-callable launchers (C++ linkage inside the library; the C ABI lives in rt_api.cpp) -- */
 
@@ -2037,7 +2069,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	/* (a scene the host has had compiled keeps its compiled kernel: clusters are built from RT_CULL_MIN_OBJECTS objects, scenes
 	 * of up to 64 can be compiled) */
 	const bool cull = L.num_clusters > 0 && L.clusters != nullptr && scene_fast_ok && variant == 0 && !spec_fn;
-	size_t lds = cull ? (size_t) CULL_GEOM_F4(L.num_objects) * 16 + (size_t) L.num_clusters * RT_CLUSTER_MEMBER_F4 * 16 + (RT_BLOCK / 64) * (sizeof(WaveLDS) + sizeof(CullWave))
+	size_t lds = cull ? (size_t) 2 * L.num_objects * 16 + (size_t) L.num_clusters * RT_CLUSTER_MEMBER_F4 * 16 + (RT_BLOCK / 64) * (sizeof(WaveLDS) + sizeof(CullWave))
 	                  : rt_wavefront_lds_bytes(L.num_objects);
 	int per_cu = (int) ((160u * 1024u) / lds);
 	if (per_cu < 1) per_cu = 1;
@@ -2055,7 +2087,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	/* a large scene whose records leave room for fewer than three workgroups of four waves: one workgroup of twelve (rt_trace_wavefront_wide) */
 	int block = RT_BLOCK;
 	if (cull && per_cu < 3 && workgroups_per_cu < 1) {
-		const size_t wide = (size_t) CULL_GEOM_F4(L.num_objects) * 16 + (size_t) L.num_clusters * RT_CLUSTER_MEMBER_F4 * 16 + (RT_BLOCK_WIDE / 64) * (sizeof(WaveLDS) + sizeof(CullWave));
+		const size_t wide = (size_t) 2 * L.num_objects * 16 + (size_t) L.num_clusters * RT_CLUSTER_MEMBER_F4 * 16 + (RT_BLOCK_WIDE / 64) * (sizeof(WaveLDS) + sizeof(CullWave));
 		if (wide <= 160u * 1024u) { block = RT_BLOCK_WIDE; lds = wide; per_cu = 1; }
 	}
 	if (workgroups_per_cu >= 1 && workgroups_per_cu < per_cu) per_cu = workgroups_per_cu;     /* rt_tuning */
@@ -2077,7 +2109,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	} else {
 		unsigned int groups; int per_group;
 		rt_primary_geometry(L.width, L.local_rows, num_cus, &groups, &per_group);
-		const size_t plds = cull ? (size_t) CULL_GEOM_F4(L.num_objects) * 16 + (size_t) L.num_clusters * RT_CLUSTER_MEMBER_F4 * 16 + (RT_BLOCK / 64) * sizeof(CullWave)
+		const size_t plds = cull ? (size_t) 2 * L.num_objects * 16 + (size_t) L.num_clusters * RT_CLUSTER_MEMBER_F4 * 16 + (RT_BLOCK / 64) * sizeof(CullWave)
 		                         : rt_scene_lds_bytes(L.num_objects);
 		if (variant == 2 || !scene_fast_ok)
 			hipLaunchKernelGGL(rt_primary_pass<false>, dim3(groups), dim3(RT_BLOCK), plds, stream, L, per_group);

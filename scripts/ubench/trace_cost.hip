@@ -4,7 +4,7 @@
 //
 // build (from the repo root; rt_scene_spec.h = scripts/spec_asm.py's header for data/scene_0.txt):
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -std=c++17 -DRT_SPEC_ONLY \
-//         -DRT_SPEC_HEADER='"rt_scene_spec.h"' -Ibuild_variants -Iray_tracing_amd/csrc -o build_variants/trace_cost scripts/ubench/trace_cost.hip
+//         -DRT_SPEC_HEADER='"rt_scene_spec.h"' -I$TMPDIR/spec -Iray_tracing_amd/csrc -o $TMPDIR/trace_cost scripts/ubench/trace_cost.hip
 #include "rt_kernels.hip"
 #include <cstdio>
 #include <vector>
