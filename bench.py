@@ -381,7 +381,8 @@ def main():
     # Set-up, before the W warm-up steps the contract asks for: a few frames through the whole loop, so that every stream,
     # scratch set, strip buffer and pinned destination the loop rotates through has been used once (first use allocates and
     # loads code: with --warmup 0 or 1 the timed region would pay ~20 ms for the second stream's first launch)
-    run_steps(seed, 4)
+    SETUP_STEPS = 4               # (reported in the line as `setup_steps`: they are not part of `warmup`)
+    run_steps(seed, SETUP_STEPS)
     fence()
     # step k of the run renders seed k (warm-up first): a stale or re-ordered frame cannot hide behind equal seeds
     run_steps(seed, args.warmup)
@@ -409,12 +410,20 @@ def main():
     kernel_ms = min(per_launch_ms, span_ms) if launches and span_ms > 0 else per_launch_ms
     if native:
         marks = [t0] + stamps
-        step_ms = sorted((marks[i + 1] - marks[i]) * 1e3 for i in range(1, len(marks) - 1))   # (the first interval holds the pipeline fill)
+        step_list = [(marks[i + 1] - marks[i]) * 1e3 for i in range(1, len(marks) - 1)]   # (the first interval holds the pipeline fill)
+        first_listed = 1
     else:
         tiled.record_events = False
         marks = [start] + tiled.done_events
-        step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)) if len(marks) > 1 else []
+        step_list = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)] if len(marks) > 1 else []
+        first_listed = 0
         tiled.done_events = []; tiled.render_events = []
+    step_ms = sorted(step_list)
+    # the slowest interval between two delivered frames, by name: timed step i delivers the frame of seed first_timed + i
+    slowest = None
+    if step_list:
+        i_max = max(range(len(step_list)), key=lambda i: step_list[i])
+        slowest = {"timed_step": i_max + first_listed, "seed": first_timed + i_max + first_listed, "ms": round(step_list[i_max], 4)}
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -531,7 +540,7 @@ def main():
         dt_dev = (time.perf_counter() - t1) / n_dev
         device_resident = {"ms_per_step": round(dt_dev * 1e3, 4), "value": round(samples_per_step / dt_dev / 1e6, 2), "unit": "Msamples/s", "steps": n_dev,
                            "region": "K frames through rt_frame_submit_device / rt_frame_wait, two in flight: the frame stays in HBM, only the "
-                                     "launch's control word goes to the host"}
+                                     "launch's control words (64 bytes) go to the host"}
     # ---- the interactive ladder at full resolution (main.c:354-408): passes of one sample per pixel, one launch
     # each (rt_progressive_pass) and RT_PROGRESSIVE_BATCH to a launch (rt_progressive_passes: same sums, bit for bit)
     interactive = None
@@ -560,7 +569,7 @@ def main():
         out = {
             "metric": metric,
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": ngpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "warmup": args.warmup, "setup_steps": SETUP_STEPS, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "verified": bool(verified and verified["ok"]), "verification": verified,
             "config": {"workload": f"{w['name']}: {w['scene']} {W}x{H}, {spp} spp, {nb} bounces, default camera, "
@@ -574,7 +583,7 @@ def main():
                        "partition": f"interleaved blocks of {ROW_BLOCK} rows over {ngpus} " + ("rank(s) SHARING ONE GPU (testing aid)" if (args.share_gpu or args.one_device) else "GPU(s)")
                                     + (f"; collective: {primitive}" if multi_path else "")
                                     + (" (one-rank group: testing aid)" if args.force_collective and ngpus == 1 else ""),
-                       "kernel": {0: "wavefront" + ("+scene-specialised (hiprtc)" if compiled else ""), 1: "simple",
+                       "kernel": {0: "wavefront" + (f"+scene-specialised ({scene_kernel_info})" if compiled else ""), 1: "simple",
                                   2: "wavefront, plain IEEE ops"}.get(args.kernel, str(args.kernel))},
         }
         if collective is not None:
@@ -583,6 +592,7 @@ def main():
             med = step_ms[len(step_ms) // 2]
             out["ms_per_step_median"] = round(med, 4)
             out["ms_per_step_p90_max"] = [round(step_ms[(len(step_ms) * 9) // 10], 4), round(step_ms[-1], 4)]
+            out["slowest_step"] = slowest
             out["value_at_median_step"] = round(samples_per_step / med / 1e3, 2)
         if latency is not None:
             out["frame_latency"] = {"median_ms": round(latency, 4), "runs": 7,

@@ -91,6 +91,13 @@ typedef struct {
 	                             * every tap provably reaches the emitter first (csrc/rt_lit.h; normally answered untraced) */
 	int    test_every_object;   /* testing / measurement aid: scenes of 32 objects and more are rendered without the cluster cull
 	                             * (csrc/rt_cull.h) -- every ray tests every object, as the reference does; same frames, slower */
+	int    audit_known_taps;    /* csrc/rt_lit.h audited in production: k >= 1 -- of the bounces whose soft-shadow taps are answered without
+	                             * tracing, one in 2^k (k = -1: every one) has its taps traced all the same and compared; the frame is
+	                             * unchanged, a disagreement fails the launch (RT_ERR_DEVICE, rt_launch_report.taps_disagreeing).  0: off */
+	int    test_drop_pixels;    /* TESTING AID: the trace kernel's waves see every pixel list this many entries shorter -- a launch that
+	                             * loses its tail, which every delivering call must then refuse (RT_ERR_DEVICE) */
+	int    test_corrupt_lit_table; /* TESTING AID, read by rt_set_scene(): every cell of the scene's lit-taps table says "certainly lit" --
+	                             * a wrong csrc/rt_lit.h, which audit_known_taps must then catch */
 } rt_tuning;
 RT_API void rt_default_tuning(rt_tuning *t);
 
@@ -136,8 +143,8 @@ RT_API int rt_set_tuning(rt_context *ctx, const rt_tuning *tuning);
 /* Renders the whole frame (world must be 1) into caller-allocated host memory: width*height
  * Vector3, row-major, frame[j*width+i], row 0 = bottom of the displayed image, values in [0,1] --
  * exactly what update_frame() hands to move_frame_to_the_gpu() (main.c:467-479).  Returns RT_CANCELLED when rt_cancel() cut the
- * launch short, and -- the blocking call looks at the launch's counters before it returns -- RT_ERR_DEVICE when the launch ended
- * with object pixels that no wave fetched: an incomplete frame is an error, never a frame with a hole in it. */
+ * launch short, and RT_ERR_DEVICE when the launch did not account for every pixel ("every delivered frame is a complete frame"
+ * below): an incomplete frame is an error, never a frame with a hole in it; frame_out is then undefined. */
 RT_API int rt_render(rt_context *ctx, const rt_render_params *params, Vector3 *frame_out);
 
 /* Same, but the destination is DEVICE memory (rt_strip_rows()*width*12 bytes) and the call only
@@ -240,6 +247,41 @@ RT_API int rt_was_cancelled(rt_context *ctx);
  * counters -- object pixels listed by the camera-ray pass, how many of them the trace kernel's waves fetched (all of them unless
  * the launch was cut short), and the launch's four control words ([1] != 0: a wave gave up after rt_cancel).  Waits for it. */
 RT_API int rt_last_launch_counts(rt_context *ctx, unsigned long long *pixels_listed, unsigned long long *pixels_fetched, unsigned int control[4]);
+
+/* ---- every delivered frame is a complete frame ---------------------------------------------------------------------------
+ * The reference publishes a column when render_column() has returned for all of it, under the mutex, or not at all
+ * (main.c:377-396).  A GPU launch can fail in ways a function call cannot -- waves that never ran or never finished, a list
+ * entry nobody fetched -- so every launch of the trace kernels accounts for itself: the camera-ray pass counts the 8x8 blocks
+ * it finished and the object pixels it listed, every wave counts the pixels it wrote, and the LAST wave to leave adds the
+ * lists up and stamps the launch with its number.  Those sixteen words travel to the host behind the frame, and every call
+ * that delivers a frame -- rt_render(), rt_frame_wait() / rt_frame_poll(), rt_multi_frame_wait() / _poll() / rt_multi_render(),
+ * rt_launch_check_wait(), and through the device-side publish step rt_progressive_resolve() / rt_progressive_state() and
+ * their rt_multi_ forms -- returns RT_ERR_DEVICE, with the numbers in rt_last_error(), unless
+ *     the stamp is the launch's  &&  fetched == listed  &&  written == listed  &&  blocks done == blocks of the frame
+ *     &&  no audited tap (rt_tuning.audit_known_taps) contradicts csrc/rt_lit.h.
+ * RT_CANCELLED (rt_cancel() cut the launch short) takes precedence: that frame is incomplete on request.  The contents of
+ * frame_out are undefined after RT_ERR_DEVICE.  An interactive pass that is incomplete is not published (its weight is not
+ * counted either) and the error is reported by the next call that looks at the count.  Cost: one LDS add per pixel, three
+ * atomics per wave, 64 bytes instead of 4 in the copy that already fetched the cancel word. */
+typedef struct {
+	int                launch_checked;      /* 0: the kernel does not account for itself (RT_KERNEL_SIMPLE, the cross-check kernel) */
+	unsigned int       launch_id, stamp;    /* the launch's number; the stamp its last wave left (0: none) */
+	unsigned int       cancelled;
+	unsigned int       waves_left;          /* waves of the trace kernel that left */
+	unsigned int       primary_blocks_expected, primary_blocks_done;
+	unsigned long long pixels_listed, pixels_fetched, pixels_written;
+	unsigned long long taps_audited, taps_disagreeing;
+} rt_launch_report;
+/* the context's most recent launch, judged: waits for it, fills *report (optional) and returns RT_OK / RT_CANCELLED / RT_ERR_DEVICE */
+RT_API int rt_last_launch_report(rt_context *ctx, rt_launch_report *report);
+/* For hosts that enqueue launches themselves (rt_render_device() + their own collective: one process per GPU): ticket t of
+ * RT_CHECK_TICKETS takes the control words of the context's most recent launch -- rt_launch_check_submit() enqueues their
+ * copy on `hip_stream`, which the caller has ordered behind that launch (not the launch's own stream: a copy between two
+ * kernels there costs the overlap of consecutive launches) -- and rt_launch_check_wait() waits for the copy and judges.  A
+ * ticket holds one launch at a time; at most one ticket per launch. */
+#define RT_CHECK_TICKETS 8
+RT_API int rt_launch_check_submit(rt_context *ctx, int ticket, void *hip_stream);
+RT_API int rt_launch_check_wait(rt_context *ctx, int ticket, rt_launch_report *report);
 
 /* ---- several GPUs of one node, one host process: replaces start_workers()'s fan-out (main.c:695-718) ----
  * rt_multi_create() makes one context per listed device and, for n > 1, the RCCL communicators of the group

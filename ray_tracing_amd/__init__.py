@@ -50,7 +50,19 @@ class RenderParams(C.Structure):
 class Tuning(C.Structure):
     _fields_ = [("dequeue_shards", C.c_int),
                 ("workgroups_per_cu", C.c_int), ("jit_waves_per_simd", C.c_int), ("jit_flags", C.c_char_p),
-                ("force_collective", C.c_int), ("poison_frame", C.c_int), ("trace_known_taps", C.c_int), ("test_every_object", C.c_int)]
+                ("force_collective", C.c_int), ("poison_frame", C.c_int), ("trace_known_taps", C.c_int), ("test_every_object", C.c_int),
+                ("audit_known_taps", C.c_int), ("test_drop_pixels", C.c_int), ("test_corrupt_lit_table", C.c_int)]
+
+
+class LaunchReport(C.Structure):
+    """rt_launch_report: what a launch left in its control words, and what it was expected to leave."""
+    _fields_ = [("launch_checked", C.c_int), ("launch_id", C.c_uint), ("stamp", C.c_uint), ("cancelled", C.c_uint), ("waves_left", C.c_uint),
+                ("primary_blocks_expected", C.c_uint), ("primary_blocks_done", C.c_uint),
+                ("pixels_listed", C.c_ulonglong), ("pixels_fetched", C.c_ulonglong), ("pixels_written", C.c_ulonglong),
+                ("taps_audited", C.c_ulonglong), ("taps_disagreeing", C.c_ulonglong)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
 STREAM_LEGACY = C.c_void_p(-1).value      # RT_STREAM_LEGACY: the device's legacy null stream
@@ -70,7 +82,7 @@ EXPORTS = [
     "rt_multi_frame_submit", "rt_multi_frame_wait", "rt_multi_frame_poll", "rt_profile_collect_span",
     "rt_progressive_begin_rank", "rt_progressive_resolve_device", "rt_multi_progressive_begin", "rt_multi_progressive_pass", "rt_multi_progressive_passes", "rt_progressive_passes",
     "rt_multi_progressive_resolve", "rt_multi_progressive_invalidate", "rt_multi_progressive_state",
-    "rt_synchronize", "rt_cancel", "rt_was_cancelled", "rt_last_launch_counts", "rt_primary_passes_run", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
+    "rt_synchronize", "rt_cancel", "rt_was_cancelled", "rt_last_launch_counts", "rt_last_launch_report", "rt_launch_check_submit", "rt_launch_check_wait", "rt_primary_passes_run", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
     "rt_progressive_invalidate", "rt_progressive_state", "rt_selftest", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
     "rt_parse_scene_string", "rt_load_cubemap", "rt_free_cubemap", "rt_decode_jpeg_file",
     "rt_camera_default", "rt_camera_basis_for", "rt_mouse_state_default", "rt_move_camera",
@@ -166,6 +178,10 @@ def lib():
         L.rt_multi_progressive_resolve.argtypes = [C.c_void_p, C.c_void_p]
         L.rt_multi_progressive_invalidate.argtypes = [C.c_void_p]
         L.rt_multi_progressive_state.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+    if hasattr(L, "rt_last_launch_report"):
+        L.rt_last_launch_report.argtypes = [C.c_void_p, C.POINTER(LaunchReport)]
+        L.rt_launch_check_submit.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.rt_launch_check_wait.argtypes = [C.c_void_p, C.c_int, C.POINTER(LaunchReport)]
     L.rt_progressive_begin.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
     L.rt_progressive_pass.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     if hasattr(L, "rt_progressive_passes"):
@@ -260,6 +276,7 @@ def strip_rows(height, row_block, world):
 # ---- the GPU path ---------------------------------------------------------------------------------
 
 FRAME_SLOTS = 4          # RT_FRAME_SLOTS
+CHECK_TICKETS = 8        # RT_CHECK_TICKETS
 PENDING, CANCELLED = 2, 1
 
 
@@ -384,8 +401,10 @@ class Renderer(_FrameQueue):
         _check(lib().rt_set_camera(self._ctx, C.byref(cam)), "rt_set_camera")
 
     def set_tuning(self, dequeue_shards=0, workgroups_per_cu=0,
-                   jit_waves_per_simd=0, jit_flags=None, poison_frame=None, trace_known_taps=None, test_every_object=None):
-        """rt_set_tuning(): scheduling knobs (0 / None = automatic).  They never change a frame."""
+                   jit_waves_per_simd=0, jit_flags=None, poison_frame=None, trace_known_taps=None, test_every_object=None,
+                   audit_known_taps=None, test_drop_pixels=None, test_corrupt_lit_table=None):
+        """rt_set_tuning(): scheduling knobs (0 / None = automatic).  They never change a frame.  poison_frame, trace_known_taps,
+        test_every_object, audit_known_taps and test_drop_pixels stay as last set until set again."""
         t = Tuning()
         lib().rt_default_tuning(C.byref(t))
         t.dequeue_shards = dequeue_shards
@@ -400,6 +419,15 @@ class Renderer(_FrameQueue):
         if test_every_object is not None:
             self._every_object = bool(test_every_object)
         t.test_every_object = 1 if getattr(self, "_every_object", False) else 0
+        if audit_known_taps is not None:
+            self._audit = int(audit_known_taps)
+        t.audit_known_taps = getattr(self, "_audit", 0)
+        if test_drop_pixels is not None:
+            self._drop = int(test_drop_pixels)
+        t.test_drop_pixels = getattr(self, "_drop", 0)
+        if test_corrupt_lit_table is not None:
+            self._corrupt_lit = int(test_corrupt_lit_table)
+        t.test_corrupt_lit_table = getattr(self, "_corrupt_lit", 0)
         _check(lib().rt_set_tuning(self._ctx, C.byref(t)), "rt_set_tuning")
 
     @staticmethod
@@ -508,6 +536,25 @@ class Renderer(_FrameQueue):
         f.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)]
         _check(f(self._ctx, C.byref(a), C.byref(b), w), "rt_last_launch_counts")
         return {"pixels_listed": a.value, "pixels_fetched": b.value, "control": list(w)}
+
+    def last_launch_report(self):
+        """rt_last_launch_report(): (status, dict) of the most recent launch -- status 0 complete, 1 cancelled, < 0 incomplete
+        (rt_last_error() has the text); waits for the launch."""
+        r = LaunchReport()
+        rc = lib().rt_last_launch_report(self._ctx, C.byref(r))
+        return rc, r.as_dict()
+
+    def launch_check_submit(self, ticket, stream=None):
+        """rt_launch_check_submit(): the control words of the most recent launch are copied on `stream` (ordered behind it by the caller)."""
+        _check(lib().rt_launch_check_submit(self._ctx, ticket, self._stream_arg(stream)), "rt_launch_check_submit")
+
+    def launch_check_wait(self, ticket):
+        """rt_launch_check_wait(): True if the ticket's launch is complete, False if rt_cancel() cut it short; raises RtError if it
+        did not account for every pixel."""
+        rc = lib().rt_launch_check_wait(self._ctx, ticket, None)
+        if rc < 0:
+            _check(rc, "rt_launch_check_wait")
+        return rc == 0
 
     def profile(self, on=True):
         _check(lib().rt_profile_enable(self._ctx, 1 if on else 0), "rt_profile_enable")

@@ -60,7 +60,14 @@ int rt_fail(int code, const char *fmt, ...)      /* for the library's other tran
 			return fail(RT_ERR_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
 	} while (0)
 
-#define RT_STOP_WORD 16
+/* the context's pinned host words (h_words), in blocks of RT_CTL_WORDS: block 0 takes the control words of rt_render()'s launch,
+ * blocks 1 ... RT_FRAME_SLOTS those of the frames in flight, the next RT_CHECK_TICKETS the tickets of rt_launch_check_*(); behind
+ * them rt_cancel()'s request (read by the trace kernels through rt_launch.stop) and the ladder's count words */
+#define RT_WORDS_FRAME(slot)   ((1 + (slot)) * RT_CTL_WORDS)
+#define RT_WORDS_TICKET(t)     ((1 + RT_FRAME_SLOTS + (t)) * RT_CTL_WORDS)
+#define RT_STOP_WORD           ((1 + RT_FRAME_SLOTS + RT_CHECK_TICKETS) * RT_CTL_WORDS)
+#define RT_COUNT_WORD          (RT_STOP_WORD + 16)
+#define RT_HOST_WORDS          (RT_COUNT_WORD + 16)
 
 struct rt_context {
 	int          device = 0;
@@ -117,14 +124,15 @@ struct rt_context {
 		hipEvent_t   readback = nullptr;     /* behind the copy of this set's control word to the host (rt_context_read_control) */
 		hipStream_t  readback_stream = nullptr;
 		bool         readback_pending = false; /* ... which the set's next launch, which clears the word, has to wait for */
+		rt_launch_expect expect = { 0u, 0, 0u };   /* what the set's most recent launch must leave in its control words (rt_judge_launch) */
 	} slot[2];
 	unsigned     launches = 0;           /* launch n uses slot[n & 1] */
+	unsigned int last_id = 0;            /* launch numbers handed out so far (prepare_launch): a number is never used twice */
 	int          cur = 0;                /* set of the most recent launch */
 	hipStream_t  stream2 = nullptr;      /* rt_stream(ctx, 1): made on first request */
 	std::once_flag stream2_once;
-	std::atomic<unsigned int> enqueued{0}; /* = launches, for rt_cancel() on another thread: the launches enqueued so far are numbers 1 ... enqueued */
-	unsigned int *h_words = nullptr;     /* pinned: [0] = read-back of control[1], [1 ...] = per frame slot, [8] = the ladder's count;
-	                                      * [RT_STOP_WORD] = rt_cancel()'s request, read by the trace kernels (rt_launch.stop): "launches up to this number stop" */
+	std::atomic<unsigned int> enqueued{0}; /* for rt_cancel() on another thread: the launches announced so far are numbers 1 ... enqueued */
+	unsigned int *h_words = nullptr;     /* pinned, RT_HOST_WORDS of them (layout above); [RT_STOP_WORD] = rt_cancel()'s request: "launches up to this number stop" */
 	unsigned int *d_stop = nullptr;      /* the device's address of that word */
 	int          num_cus = 256;
 
@@ -138,7 +146,13 @@ struct rt_context {
 		hipEvent_t copied = nullptr;     /* behind the copy of the frame (and of the launch's control word) to the host */
 		hipEvent_t rendered = nullptr;   /* behind the render, on its stream: what rt_frame_submit_device() hands to the caller */
 		bool       busy = false;         /* submitted and not waited for yet */
+		rt_launch_expect expect = { 0u, 0, 0u };
 	} fq[RT_FRAME_SLOTS];
+	struct check_ticket {                /* rt_launch_check_submit / _wait */
+		hipEvent_t copied = nullptr;
+		bool       busy = false;
+		rt_launch_expect expect = { 0u, 0, 0u };
+	} tickets[RT_CHECK_TICKETS];
 	unsigned long long frames_submitted = 0;   /* frame n renders on the context's stream n & 1 */
 	hipStream_t  copy_stream = nullptr;  /* made by the first rt_frame_submit() */
 
@@ -150,7 +164,8 @@ struct rt_context {
 		uint64_t seed = 0;
 		uint32_t generation = 0;
 		float   *d_accum = nullptr, *d_low = nullptr, *d_out = nullptr;
-		float   *d_count = nullptr;          /* sum of the published passes' weights (accum_counts[], main.c:396): written by rt_accumulate */
+		float   *d_count = nullptr;          /* RT_COUNT_WORDS words (rt_device.h): the sum of the published passes' weights (accum_counts[], main.c:396), written by
+		                                      * rt_accumulate; a word that stays zero; the launches not published because they were incomplete */
 		size_t   accum_bytes = 0, low_bytes = 0;
 	} prog;
 
@@ -230,7 +245,7 @@ static int mark_launch(rt_context *ctx, hipStream_t stream)
 	HIP_TRY(hipEventRecord(sl.done, stream));
 	sl.stream = stream; sl.used = true;
 	ctx->cur = (int) (ctx->launches & 1u);
-	ctx->launches++;               /* (== ctx->enqueued, published by prepare_launch() before the launch's first kernel) */
+	ctx->launches++;               /* (its number, ctx->last_id, was published by prepare_launch() before the launch's first kernel) */
 	return RT_OK;
 }
 
@@ -242,19 +257,46 @@ static hipStream_t pick_stream(rt_context *ctx, void *hip_stream)
 
 void *rt_context_stream(rt_context *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
 
-/* The control word of the context's most recent launch (non-zero: rt_cancel() cut it short) is copied to *h_dst (pinned)
+/* The control words of the context's most recent launch (rt_device.h RT_CTL_*) are copied to h_dst[0 ... RT_CTL_WORDS) (pinned)
  * on `stream`, which the caller has already ordered behind that launch -- NOT the launch's own stream: a copy between
  * two kernels of a render stream costs the overlap of consecutive launches (measured: +0.15 ms per C1 frame).  The
  * scratch set's next launch clears the word: it is ordered behind this copy.  *behind (optional) = an event recorded
  * behind the copy. */
-int rt_context_read_control(rt_context *ctx, unsigned int *h_dst, hipStream_t stream, hipEvent_t *behind)
+int rt_context_read_control(rt_context *ctx, unsigned int *h_dst, hipStream_t stream, hipEvent_t *behind, rt_launch_expect *expect)
 {
 	rt_context::launch_slot &sl = ctx->slot[ctx->cur];
 	if (!sl.readback) HIP_TRY(hipEventCreateWithFlags(&sl.readback, hipEventDisableTiming));
-	HIP_TRY(hipMemcpyAsync(h_dst, sl.d_counter + 128 * 32 + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+	if (expect) *expect = sl.expect;
+	HIP_TRY(hipMemcpyAsync(h_dst, sl.d_counter + 128 * 32, RT_CTL_WORDS * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
 	HIP_TRY(hipEventRecord(sl.readback, stream));
 	sl.readback_pending = true; sl.readback_stream = stream;
 	if (behind) *behind = sl.readback;
+	return RT_OK;
+}
+
+/* The verdict on a launch from its control words (rt_internal.h). */
+int rt_judge_launch(const unsigned int *w, const rt_launch_expect &x, const char *who, rt_launch_report *report)
+{
+	rt_launch_report r;
+	memset(&r, 0, sizeof(r));
+	r.launch_checked = x.stamped; r.launch_id = x.launch_id; r.stamp = w[RT_CTL_STAMP]; r.cancelled = w[RT_CTL_CANCELLED];
+	r.waves_left = w[RT_CTL_WAVES_LEFT];
+	r.primary_blocks_expected = x.primary_blocks; r.primary_blocks_done = w[RT_CTL_PRIMARY];
+	r.pixels_listed = w[RT_CTL_LISTED]; r.pixels_fetched = w[RT_CTL_FETCHED]; r.pixels_written = w[RT_CTL_WRITTEN];
+	r.taps_audited = (unsigned long long) w[RT_CTL_AUDITED] | ((unsigned long long) w[RT_CTL_AUDITED + 1] << 32);
+	r.taps_disagreeing = (unsigned long long) w[RT_CTL_DISAGREE] | ((unsigned long long) w[RT_CTL_DISAGREE + 1] << 32);
+	if (report) *report = r;
+	if (r.cancelled) return RT_CANCELLED;
+	if (!x.stamped) return RT_OK;
+	if (r.stamp != x.launch_id)
+		return fail(RT_ERR_DEVICE, "%s: launch %u ended without the stamp of its last wave (stamp %u, %u waves left it, %llu pixels written): the frame is incomplete",
+		            who, x.launch_id, r.stamp, r.waves_left, r.pixels_written);
+	if (r.pixels_fetched != r.pixels_listed || r.pixels_written != r.pixels_listed || r.primary_blocks_done != r.primary_blocks_expected)
+		return fail(RT_ERR_DEVICE, "%s: launch %u is incomplete: object pixels listed %llu, fetched %llu, written %llu; camera-ray blocks %u of %u",
+		            who, x.launch_id, r.pixels_listed, r.pixels_fetched, r.pixels_written, r.primary_blocks_done, r.primary_blocks_expected);
+	if (r.taps_disagreeing)
+		return fail(RT_ERR_DEVICE, "%s: launch %u: %llu of %llu audited soft-shadow taps contradict the answer rt_lit.h gave without tracing them: the frame is wrong",
+		            who, x.launch_id, r.taps_disagreeing, r.taps_audited);
 	return RT_OK;
 }
 
@@ -288,7 +330,8 @@ int rt_set_tuning(rt_context *ctx, const rt_tuning *t)
 {
 	if (!ctx || !t) return fail(RT_ERR_ARGUMENT, "rt_set_tuning: NULL argument");
 	if ((t->dequeue_shards != 0 && t->dequeue_shards != 1 && t->dequeue_shards != 64) ||
-	    t->workgroups_per_cu < 0 || t->workgroups_per_cu > 8 || t->jit_waves_per_simd < 0 || t->jit_waves_per_simd > 8)
+	    t->workgroups_per_cu < 0 || t->workgroups_per_cu > 8 || t->jit_waves_per_simd < 0 || t->jit_waves_per_simd > 8 ||
+	    t->audit_known_taps < -1 || t->audit_known_taps > 30 || t->test_drop_pixels < 0)
 		return fail(RT_ERR_ARGUMENT, "rt_set_tuning: value out of range");
 	ctx->tuning = *t;
 	ctx->jit_flags = t->jit_flags ? t->jit_flags : "";
@@ -328,8 +371,8 @@ int rt_create(rt_context **out, int device_id)
 			if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
 			if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.started, hipEventDisableTiming);
 		}
-		if (e == hipSuccess) e = hipHostMalloc((void**) &ctx->h_words, (size_t) 64 * sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent);
-		if (e == hipSuccess) { for (int k = 0; k < 64; k++) ctx->h_words[k] = 0u; }
+		if (e == hipSuccess) e = hipHostMalloc((void**) &ctx->h_words, (size_t) RT_HOST_WORDS * sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent);
+		if (e == hipSuccess) { for (int k = 0; k < RT_HOST_WORDS; k++) ctx->h_words[k] = 0u; }
 		if (e == hipSuccess) e = hipHostGetDevicePointer((void**) &ctx->d_stop, &ctx->h_words[RT_STOP_WORD], 0);
 		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 		if (e != hipSuccess) {
@@ -361,6 +404,7 @@ void rt_destroy(rt_context *ctx)
 	}
 	if (ctx->copy_stream) { (void) hipStreamSynchronize(ctx->copy_stream); (void) hipStreamDestroy(ctx->copy_stream); }
 	for (auto &f : ctx->fq) { if (f.copied) (void) hipEventDestroy(f.copied); if (f.rendered) (void) hipEventDestroy(f.rendered); (void) hipFree(f.d_buf); }
+	for (auto &t : ctx->tickets) if (t.copied) (void) hipEventDestroy(t.copied);
 	if (ctx->stream2) { (void) hipStreamSynchronize(ctx->stream2); (void) hipStreamDestroy(ctx->stream2); }
 	if (ctx->h_words) (void) hipHostFree(ctx->h_words);
 	/* (the compiled scene's module belongs to the process-wide cache of rt_jit.cpp: never unloaded) */
@@ -436,7 +480,8 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 			             dark.empty() ? nullptr : dark.data(), bits);
 			std::vector<unsigned char> cells((size_t) bits);          /* a byte per cell on the device: one load, no shift; 1 lit, 2 dark */
 			for (long long b = 0; b < bits; b++)
-				cells[(size_t) b] = (unsigned char) (((words[(size_t) (b >> 5)] >> (b & 31)) & 1u) ? 1u :
+				cells[(size_t) b] = (unsigned char) (ctx->tuning.test_corrupt_lit_table ? 1u :       /* (testing aid: a table that is wrong) */
+				                                     ((words[(size_t) (b >> 5)] >> (b & 31)) & 1u) ? 1u :
 				                                     (!dark.empty() && ((dark[(size_t) (b >> 5)] >> (b & 31)) & 1u)) ? 2u : 0u);
 			if (cells.size() > ctx->lit_cells_capacity) {
 				(void) hipFree(ctx->d_lit_cells); ctx->d_lit_cells = nullptr; ctx->lit_cells_capacity = 0;
@@ -603,7 +648,7 @@ static void give_event(rt_context *ctx, hipEvent_t e) { if (e) ctx->event_pool.p
 
 /* Scheduling parameters of the wavefront kernels for one launch (rt_device.h) and the pixel lists rt_primary_pass
  * fills for the trace kernel (grown on demand).  Any schedule renders the same frame. */
-static int prepare_launch(rt_context *ctx, rt_launch &L, unsigned which)
+static int prepare_scratch(rt_context *ctx, rt_launch &L, unsigned which)
 {
 	rt_context::launch_slot &sl = ctx->slot[which & 1u];
 	const long long pixel_blocks = (long long) ((L.width + 7) / 8) * ((L.local_rows + 7) / 8);
@@ -626,16 +671,29 @@ static int prepare_launch(rt_context *ctx, rt_launch &L, unsigned which)
 	L.pix_count = sl.d_counter + 64 * 32;      /* counter block: 64 dequeue counters, 64 fill counters, one control line */
 	L.control = sl.d_counter + 128 * 32;
 	L.stop = ctx->d_stop;
-	L.launch_id = ctx->launches + 1u;              /* mark_launch() counts it */
-	/* rt_cancel() on another thread must cover this launch from the moment its first kernel can be on the GPU: the number is
-	 * published BEFORE anything of the launch is enqueued (a request that arrives in between stops a launch that has not
-	 * started yet, at its first pixel fetch).  A launch that then fails to enqueue takes the number back (unpublish_launch). */
+	return RT_OK;
+}
+
+/* ... and the launch gets its number.  rt_cancel() on another thread must cover this launch from the moment its first kernel
+ * can be on the GPU: the number is published BEFORE anything of the launch is enqueued (a request that arrives in between
+ * stops a launch that has not started yet, at its first pixel fetch).  A launch that then fails to enqueue keeps its number:
+ * numbers are never handed out twice, so a request that named it can only stop launches that were announced when it was made
+ * (such a number is simply never seen on the device; unpublish_launch() below is what the failure paths call, and does
+ * nothing more than say so). */
+static int prepare_launch(rt_context *ctx, rt_launch &L, unsigned which)
+{
+	const int rc = prepare_scratch(ctx, L, which);
+	if (rc != RT_OK) return rc;
+	L.launch_id = ++ctx->last_id;
+	if (L.launch_id == 0u) L.launch_id = ++ctx->last_id;      /* (0 is "no stamp") */
+	const int k = ctx->tuning.audit_known_taps;
+	L.audit_taps = k == 0 ? 0u : (k < 0 ? 1u : 1u << k);
+	L.test_drop_pixels = (unsigned int) ctx->tuning.test_drop_pixels;
 	ctx->enqueued.store(L.launch_id, std::memory_order_release);
 	return RT_OK;
 }
 
-/* the launch prepare_launch() announced was not enqueued after all */
-static void unpublish_launch(rt_context *ctx) { ctx->enqueued.store(ctx->launches, std::memory_order_release); }
+static void unpublish_launch(rt_context *) { }
 
 /* The launch scratch (pixel lists) and rt_render()'s device frame for frames up to width x height, allocated now
  * instead of inside the first render call of that size. */
@@ -649,7 +707,7 @@ int rt_reserve(rt_context *ctx, int width, int height)
 	rt_launch L;
 	memset(&L, 0, sizeof(L));
 	L.width = width; L.local_rows = rt_strip_rows(height, 8, 1);
-	for (unsigned which = 0; which < 2; which++) { const int rc = prepare_launch(ctx, L, which); unpublish_launch(ctx); if (rc != RT_OK) return rc; }
+	for (unsigned which = 0; which < 2; which++) { const int rc = prepare_scratch(ctx, L, which); if (rc != RT_OK) return rc; }     /* (nothing is announced: nothing is launched) */
 	const size_t need = (size_t) L.local_rows * width * 3 * sizeof(float);
 	if (need > ctx->frame_bytes) {
 		(void) hipFree(ctx->d_frame); ctx->d_frame = nullptr; ctx->frame_bytes = 0;
@@ -710,7 +768,8 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	}
 	ctx->slot[ctx->launches & 1u].lists_key = 0;
 	ctx->primary_passes++;
-	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->slot[ctx->launches & 1u].d_counter, e0, ctx->slot[ctx->launches & 1u].started, ctx->num_cus, workgroups_per_cu_for(ctx, stream), stream);
+	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->slot[ctx->launches & 1u].d_counter, e0, ctx->slot[ctx->launches & 1u].started, ctx->num_cus, workgroups_per_cu_for(ctx, stream), stream,
+	                                false, &ctx->slot[ctx->launches & 1u].expect);
 	if (le == hipSuccess && ctx->profiling) le = hipEventRecord(e1, stream);
 	if (ctx->profiling) {
 		if (le == hipSuccess) ctx->events.emplace_back(e0, e1);
@@ -738,19 +797,12 @@ int rt_render(rt_context *ctx, const rt_render_params *p, Vector3 *frame_out)
 	if (rc != RT_OK) return rc;
 	HIP_TRY(hipMemcpyAsync(frame_out, ctx->d_frame, (size_t) p->height * p->width * 3 * sizeof(float),
 	                       hipMemcpyDeviceToHost, ctx->stream));
-	HIP_TRY(hipMemcpyAsync(&ctx->h_words[0], ctx->slot[ctx->cur].d_counter + 128 * 32 + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+	/* the launch's control words follow the frame in the same stream: one synchronisation, then the verdict (rt_judge_launch: a
+	 * launch that did not account for every pixel gives an error, not a frame with a hole in it -- round 3 saw a blocking render
+	 * lose the pixels a launch deals last, twice, cause unknown: docs/lab/r04.md) */
+	HIP_TRY(hipMemcpyAsync(&ctx->h_words[0], ctx->slot[ctx->cur].d_counter + 128 * 32, RT_CTL_WORDS * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
-	if (ctx->h_words[0]) return RT_CANCELLED;
-	/* The blocking call can afford to look: every object pixel the camera-ray pass listed must have been fetched by a wave of the
-	 * trace kernel.  A launch that ended with pixels left in its lists did not render them; the caller gets an error, not a frame
-	 * with a hole in it (round 3 saw a blocking render lose the pixels a launch deals last, twice, cause unknown: docs/lab/r04.md). */
-	unsigned long long listed = 0, fetched = 0;
-	unsigned int control[4];
-	{ const int crc = rt_last_launch_counts(ctx, &listed, &fetched, control); if (crc != RT_OK) return crc; }
-	if (fetched != listed)
-		return fail(RT_ERR_DEVICE, "rt_render: the launch ended with %llu of %llu object pixels not fetched (control words %u %u %u %u): the frame is incomplete",
-		            listed - fetched, listed, control[0], control[1], control[2], control[3]);
-	return RT_OK;
+	return rt_judge_launch(&ctx->h_words[0], ctx->slot[ctx->cur].expect, "rt_render", nullptr);
 }
 
 /* ---- frames in flight (include/rt_hip.h): the reference's workers keep accumulating while its main thread presents
@@ -801,7 +853,7 @@ static int frame_submit(rt_context *ctx, const rt_render_params *p, int slot, Ve
 	HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, f.rendered, 0));
 	if (frame_out)
 		HIP_TRY(hipMemcpyAsync(frame_out, f.d_buf, (size_t) p->height * p->width * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->copy_stream));
-	rc = rt_context_read_control(ctx, &ctx->h_words[1 + slot], ctx->copy_stream, nullptr);
+	rc = rt_context_read_control(ctx, &ctx->h_words[RT_WORDS_FRAME(slot)], ctx->copy_stream, nullptr, &f.expect);
 	if (rc != RT_OK) return rc;
 	HIP_TRY(hipEventRecord(f.copied, ctx->copy_stream));
 	f.busy = true;
@@ -830,7 +882,46 @@ int rt_frame_wait(rt_context *ctx, int slot)
 	HIP_TRY(hipSetDevice(ctx->device));
 	HIP_TRY(hipEventSynchronize(f.copied));
 	f.busy = false;
-	return ctx->h_words[1 + slot] ? RT_CANCELLED : RT_OK;
+	return rt_judge_launch(&ctx->h_words[RT_WORDS_FRAME(slot)], f.expect, "rt_frame_wait", nullptr);
+}
+
+/* ---- launches a host enqueued itself (rt_render_device), judged like the library's own (include/rt_hip.h) ---- */
+int rt_launch_check_submit(rt_context *ctx, int ticket, void *hip_stream)
+{
+	if (!ctx || ticket < 0 || ticket >= RT_CHECK_TICKETS) return fail(RT_ERR_ARGUMENT, "rt_launch_check_submit: bad argument");
+	rt_context::check_ticket &t = ctx->tickets[ticket];
+	if (t.busy) return fail(RT_ERR_STATE, "rt_launch_check_submit: ticket %d holds a launch that has not been waited for", ticket);
+	if (!ctx->launches) return fail(RT_ERR_STATE, "rt_launch_check_submit: nothing has been launched");
+	HIP_TRY(hipSetDevice(ctx->device));
+	if (!t.copied) HIP_TRY(hipEventCreateWithFlags(&t.copied, hipEventDisableTiming));
+	hipStream_t stream = pick_stream(ctx, hip_stream);
+	const int rc = rt_context_read_control(ctx, &ctx->h_words[RT_WORDS_TICKET(ticket)], stream, nullptr, &t.expect);
+	if (rc != RT_OK) return rc;
+	HIP_TRY(hipEventRecord(t.copied, stream));
+	t.busy = true;
+	return RT_OK;
+}
+
+int rt_launch_check_wait(rt_context *ctx, int ticket, rt_launch_report *report)
+{
+	if (!ctx || ticket < 0 || ticket >= RT_CHECK_TICKETS) return fail(RT_ERR_ARGUMENT, "rt_launch_check_wait: bad argument");
+	rt_context::check_ticket &t = ctx->tickets[ticket];
+	if (!t.busy) return fail(RT_ERR_STATE, "rt_launch_check_wait: ticket %d holds nothing", ticket);
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipEventSynchronize(t.copied));
+	t.busy = false;
+	return rt_judge_launch(&ctx->h_words[RT_WORDS_TICKET(ticket)], t.expect, "rt_launch_check_wait", report);
+}
+
+int rt_last_launch_report(rt_context *ctx, rt_launch_report *report)
+{
+	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_last_launch_report: NULL context");
+	if (!ctx->launches) return fail(RT_ERR_STATE, "rt_last_launch_report: nothing has been launched");
+	HIP_TRY(hipSetDevice(ctx->device));
+	{ const int rc = wait_for_launches(ctx); if (rc != RT_OK) return rc; }
+	unsigned int words[RT_CTL_WORDS];
+	HIP_TRY(hipMemcpy(words, ctx->slot[ctx->cur].d_counter + 128 * 32, sizeof(words), hipMemcpyDeviceToHost));
+	return rt_judge_launch(words, ctx->slot[ctx->cur].expect, "rt_last_launch_report", report);
 }
 
 int rt_frame_poll(rt_context *ctx, int slot)
@@ -881,7 +972,7 @@ int rt_was_cancelled(rt_context *ctx)
 	HIP_TRY(hipSetDevice(ctx->device));
 	{ const int rc = wait_for_launches(ctx); if (rc != RT_OK) return rc; }
 	unsigned int w = 0;
-	HIP_TRY(hipMemcpy(&w, ctx->slot[ctx->cur].d_counter + 128 * 32 + 1, sizeof(w), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(&w, ctx->slot[ctx->cur].d_counter + 128 * 32 + RT_CTL_CANCELLED, sizeof(w), hipMemcpyDeviceToHost));
 	return w ? RT_CANCELLED : RT_OK;
 }
 
@@ -958,7 +1049,7 @@ int rt_progressive_begin_rank(rt_context *ctx, int width, int height, int init_s
 		HIP_TRY(hipMalloc((void**) &g.d_out, accum_bytes));
 		g.accum_bytes = accum_bytes;
 	}
-	if (!g.d_count) HIP_TRY(hipMalloc((void**) &g.d_count, 2 * sizeof(float)));     /* [1]: a word that stays zero */
+	if (!g.d_count) HIP_TRY(hipMalloc((void**) &g.d_count, RT_COUNT_WORDS * sizeof(float)));
 	if (low_bytes != g.low_bytes) {
 		(void) hipFree(g.d_low); g.d_low = nullptr; g.low_bytes = 0;
 		HIP_TRY(hipMalloc((void**) &g.d_low, low_bytes));
@@ -984,7 +1075,7 @@ int rt_progressive_invalidate(rt_context *ctx)
 	 * (main.c:382: rt_accumulate looks at control[1]); the clear below is ordered behind it */
 	if (ctx->launches) { const int rc = rt_cancel(ctx); if (rc != RT_OK) return rc; }
 	HIP_TRY(hipMemsetAsync(g.d_accum, 0, g.accum_bytes, ctx->stream));
-	HIP_TRY(hipMemsetAsync(g.d_count, 0, 2 * sizeof(float), ctx->stream));
+	HIP_TRY(hipMemsetAsync(g.d_count, 0, RT_COUNT_WORDS * sizeof(float), ctx->stream));
 	g.passes = 0; g.scale = g.init_scale; g.generation++;
 	return RT_OK;
 }
@@ -1049,7 +1140,7 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 		/* a rank without rows at this scale -- its few frame rows lie below the last whole low-resolution row -- renders
 		 * nothing and adds nothing, but the pass counts (main.c:396): those rows are divided by the same count as all others */
 		for (int k = 0; k < samples; k++)
-			HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), reinterpret_cast<unsigned int*>(g.d_count + 1), g.d_count,
+			HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), nullptr, rt_launch_expect{ 0u, 0, 0u }, g.d_count,
 			                             RT_PROGRESSIVE_ROW_BLOCK, g.rank, g.world, 0, ctx->stream));
 		g.passes += samples;
 		if (g.scale > 1) g.scale >>= 1;
@@ -1075,7 +1166,7 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 	const bool reuse = !ctx->tuning.poison_frame && !batch && sl.lists_key == key;      /* (a batch's sky pixels are sums: never the same twice) */
 	sl.lists_key = 0;
 	{
-		const hipError_t le = rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, sl.d_counter, nullptr, sl.started, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream, reuse);
+		const hipError_t le = rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, sl.d_counter, nullptr, sl.started, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream, reuse, &sl.expect);
 		if (le != hipSuccess) { unpublish_launch(ctx); return fail(RT_ERR_DEVICE, "trace launch: %s", hipGetErrorString(le)); }
 	}
 	if (!reuse) ctx->primary_passes++;
@@ -1090,9 +1181,9 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 	/* accum += pass * weight and accum_counts += weight (main.c:394-396), both on the device and both skipped for a pass
 	 * that rt_cancel() cut short (main.c:382): the count can never include a pass the buffer does not */
 	if (batch)        /* the launch wrote sums-so-far + its samples: they become the sums, and `samples` passes count */
-		HIP_TRY(rt_launch_commit_sums(g.d_accum, g.d_low, (size_t) g.width * L.local_rows * 3, samples, L.control + 1, g.d_count, ctx->stream));
+		HIP_TRY(rt_launch_commit_sums(g.d_accum, g.d_low, (size_t) g.width * L.local_rows * 3, samples, L.control, sl.expect, g.d_count, ctx->stream));
 	else
-	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), L.control + 1, g.d_count,
+	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), L.control, sl.expect, g.d_count,
 	                             RT_PROGRESSIVE_ROW_BLOCK, g.rank, g.world, g.rows, ctx->stream));
 	{ const int rc = mark_launch(ctx, ctx->stream); if (rc != RT_OK) return rc; }
 	g.passes += samples;
@@ -1159,10 +1250,15 @@ int rt_progressive_count(rt_context *ctx, float *count)
 {
 	if (!ctx || !ctx->prog.active || !count) return fail(RT_ERR_STATE, "rt_progressive_state: call rt_progressive_begin first");
 	HIP_TRY(hipSetDevice(ctx->device));
-	float *h_count = reinterpret_cast<float*>(&ctx->h_words[8]);
-	HIP_TRY(hipMemcpyAsync(h_count, ctx->prog.d_count, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+	float *h_count = reinterpret_cast<float*>(&ctx->h_words[RT_COUNT_WORD]);
+	HIP_TRY(hipMemcpyAsync(h_count, ctx->prog.d_count, RT_COUNT_WORDS * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	*count = *h_count;
+	/* passes whose launch was incomplete were not published (rt_accumulate / rt_commit_sums looked at the launch's control words
+	 * on the device): the sums are those of the other passes, and the caller is told */
+	const unsigned int incomplete = ctx->h_words[RT_COUNT_WORD + RT_COUNT_INCOMPLETE];
+	if (incomplete)
+		return fail(RT_ERR_DEVICE, "rt_progressive: %u launch(es) since the last rt_progressive_invalidate() were incomplete and were not published (rt_last_launch_report() has the most recent launch's numbers)", incomplete);
 	return RT_OK;
 }
 

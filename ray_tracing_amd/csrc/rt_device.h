@@ -60,6 +60,33 @@ typedef struct {
 	unsigned short member[RT_CLUSTER_SIZE];
 } rt_cluster;
 
+/* The control words of a launch: one 128-byte line behind the pixel lists' counters (rt_launch.control), cleared when the
+ * launch is enqueued, copied to the host behind it (the first RT_CTL_WORDS words) and judged there (rt_api.cpp judge_launch):
+ * a frame is delivered whole or not at all -- the reference publishes a column only when render_column() has returned for all
+ * of it (main.c:377-396). */
+#define RT_CTL_STAMP       0    /* the launch's number, written by the LAST wave of the trace kernel to leave, behind the sums below:
+                                 * a launch whose waves did not all leave has no stamp */
+#define RT_CTL_CANCELLED   1    /* a wave gave up because of rt_cancel(): the frame is incomplete, and meant to be */
+#define RT_CTL_STOP_RELAY  2    /* the request, relayed from the waves that read the host's word to all others */
+#define RT_CTL_WAVES_LEFT  3    /* waves of the trace kernel that have left */
+#define RT_CTL_WRITTEN     4    /* object pixels resolved and written to the frame, summed over the waves as they leave */
+#define RT_CTL_PRIMARY     5    /* by the last wave: 8x8 pixel blocks the camera-ray pass finished (sum over the lists' lines) */
+#define RT_CTL_LISTED      6    /* by the last wave: object pixels the camera-ray pass listed */
+#define RT_CTL_FETCHED     7    /* by the last wave: ... of which the trace kernel's waves fetched */
+#define RT_CTL_AUDITED     8    /* (64 bits) soft-shadow taps answered by rt_lit.h that were traced all the same (rt_launch.audit_taps) */
+#define RT_CTL_DISAGREE    10   /* (64 bits) ... whose trace contradicts the answer */
+#define RT_CTL_WORDS       16
+/* What a launch is expected to leave in those words, kept by the host until they have been copied back and judged. */
+typedef struct {
+	unsigned int launch_id;
+	int          stamped;          /* the kernel stamps the launch (the persistent trace kernels do; rt_trace_simple, the cross-check kernel, does not) */
+	unsigned int primary_blocks;   /* 8x8 pixel blocks of the camera-ray pass */
+} rt_launch_expect;
+/* the ladder's count words (rt_progressive_*): [0] the sum of the published passes' weights (float), [1] a word that stays
+ * zero, [RT_COUNT_INCOMPLETE] launches that were not published because they were incomplete (unsigned) */
+#define RT_COUNT_INCOMPLETE 2
+#define RT_COUNT_WORDS      4
+
 typedef struct {
 	/* camera.c:99-118, frame constants */
 	float pos[3], llc[3], horiz[3], vert[3];
@@ -95,6 +122,11 @@ typedef struct {
 	 * written to `frame` as it is, not divided by the sample count -- worker()'s publish step (main.c:394) `spp` times over.
 	 * NULL: a frame of its own. */
 	const float *sum_onto;
+	/* rt_lit.h audited in production (rt_tuning.audit_known_taps): 0 = no; a power of two 2^k = the taps of one in 2^k bounces
+	 * whose taps are answered without tracing are traced all the same and compared (the frame still uses the answer; a
+	 * disagreement is counted into control[RT_CTL_DISAGREE] and fails the launch on the host) */
+	unsigned int audit_taps;
+	unsigned int test_drop_pixels;   /* TESTING AID (rt_tuning.test_drop_pixels): the trace kernel's waves see every pixel list this many entries shorter */
 	int    skip_known_taps;    /* rt_primary_pass flags the pixels whose bounce-0 taps need no tracing (rt_lit.h); 0: every tap is traced */
 	/* the same answer for hit points of any bounce, from a table built once per scene (rt_lit.h: one entry per cell of a grid
 	 * over every object's bounding box, rt_lit_grid per object); NULL: no table (no sphere emitter, or every tap is traced) */
@@ -108,9 +140,9 @@ typedef struct {
 	 * point xyz, normal xyz, object, camera ray xyz, RNG pixel index, offset in the strip), word k of record c at
 	 * pix[k * num_shards * pix_shard_cap + c]; list s holds records s * pix_shard_cap ... + pix_count[32 * s] */
 	float *pix;
-	unsigned int *pix_count;   /* one fill counter per list, 128 bytes apart */
+	unsigned int *pix_count;   /* one fill counter per list, 128 bytes apart; the word behind it: 8x8 blocks finished by the waves that append to the list */
 	int    pix_shard_cap;
-	/* control[1]: set by a wave that gave up because of rt_cancel() -- the frame is incomplete.  The request itself is a word
+	/* the launch's control words (RT_CTL_* above).  [RT_CTL_CANCELLED]: set by a wave that gave up because of rt_cancel() -- the frame is incomplete.  The request itself is a word
 	 * in host memory the device can read (`stop`, written by a plain store of the calling thread: nothing has to get past the
 	 * kernel that fills the chip): "the launches up to this number are to stop"; this launch is number launch_id. */
 	unsigned int *control;

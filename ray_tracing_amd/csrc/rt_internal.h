@@ -6,14 +6,20 @@
 #include <string>
 #include <vector>
 #include "rt_device.h"
+#include "../../include/rt_hip.h"
 
 struct rt_context;
 /* rt_api.cpp: sets the thread's error text (rt_last_error()) and returns `code`; the context's own stream */
 int        rt_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 void      *rt_context_stream(rt_context *ctx);
-/* copies the control word of the context's most recent launch (non-zero: cut short by rt_cancel) to pinned *h_dst on `stream`,
- * which the caller has ordered behind that launch (not the launch's own stream); *behind (optional) = an event behind the copy */
-int        rt_context_read_control(rt_context *ctx, unsigned int *h_dst, hipStream_t stream, hipEvent_t *behind);
+/* copies the RT_CTL_WORDS control words of the context's most recent launch to pinned h_dst[] on `stream`, which the caller has
+ * ordered behind that launch (not the launch's own stream); *behind (optional) = an event behind the copy; *expect = what
+ * rt_judge_launch() is to hold the words against */
+int        rt_context_read_control(rt_context *ctx, unsigned int *h_dst, hipStream_t stream, hipEvent_t *behind, rt_launch_expect *expect);
+/* the verdict on a launch from its control words: RT_OK, RT_CANCELLED (rt_cancel() cut it short), or RT_ERR_DEVICE with the counts
+ * in rt_last_error() -- no stamp of the last wave, listed pixels not fetched or not written, camera-ray blocks missing, audited
+ * taps that contradict rt_lit.h: the frame is not to be delivered.  report (optional) receives the numbers. */
+int        rt_judge_launch(const unsigned int *words, const rt_launch_expect &expect, const char *who, rt_launch_report *report);
 void      *rt_context_launch_done(rt_context *ctx);                   /* hipEvent_t recorded behind the context's most recent launch, on that launch's stream */
 #define RT_PROGRESSIVE_ROW_BLOCK 16      /* == the header's: a multiple of every scale of the ladder */
 int        rt_progressive_count(rt_context *ctx, float *count);      /* the ladder's sum of published weights, read from the device (waits for the passes enqueued so far) */
@@ -28,17 +34,21 @@ size_t     rt_pixel_list_capacity(int width, int local_rows, int num_cus, int nu
  * `primary_done` in front of the trace kernel (behind the whole launch when there is no separate primary pass) */
 hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, hipFunction_t spec_fn,
                            unsigned int *block_counter, hipEvent_t cleared, hipEvent_t primary_done, int num_cus, int workgroups_per_cu, hipStream_t stream,
-                           bool reuse_pixel_lists = false);   /* the scratch set still holds rt_primary_pass's output for this very launch */
+                           bool reuse_pixel_lists = false,    /* the scratch set still holds rt_primary_pass's output for this very launch */
+                           rt_launch_expect *expect = nullptr);
 int        rt_jit_build(const rt_geom *geom, int n, int light_index, const float light_pos[3], int only_light_emits, int waves_per_simd, const char *extra_flags, hipModule_t *module, hipFunction_t *function, std::string &message,
                         std::vector<char> *code_out = nullptr,    /* the code object (development aid) */
                         std::string *compiler = nullptr);         /* where it came from: "embedded, compiled with the library by ..." / "hiprtc x.y at run time" */
 hipError_t rt_launch_deinterleave(const float *strips, float *frame, int width, int height,
                                   int row_block, int world, int rows_per_rank, int first, hipStream_t stream);
 
+/* the publish steps look at the launch's control words ON THE DEVICE (`control`, `expect`; control = nullptr: nothing was
+ * launched, the step always publishes): a launch cut short by rt_cancel() is not published (main.c:382), an incomplete one is not
+ * published either and counted in count[RT_COUNT_INCOMPLETE] */
 hipError_t rt_launch_accumulate(float *accum, const float *lowres, int width, int height, int scale,
-                                int low_w, int low_h, float k, const unsigned int *cancelled, float *count,
+                                int low_w, int low_h, float k, const unsigned int *control, const rt_launch_expect &expect, float *count,
                                 int row_block, int rank, int world, int local_rows, hipStream_t stream);
-hipError_t rt_launch_commit_sums(float *accum, const float *sums, size_t floats, int passes, const unsigned int *cancelled, float *count, hipStream_t stream);
+hipError_t rt_launch_commit_sums(float *accum, const float *sums, size_t floats, int passes, const unsigned int *control, const rt_launch_expect &expect, float *count, hipStream_t stream);
 hipError_t rt_launch_resolve(const float *accum, float *frame, size_t floats, const float *count, hipStream_t stream);
 hipError_t rt_launch_selftest(int which, uint64_t seed, int blocks, int iters, unsigned long long *d_out, hipStream_t stream);
 

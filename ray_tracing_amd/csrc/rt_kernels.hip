@@ -820,7 +820,8 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 	const V3 cam = ld3(L.pos);
 	const float inv_spp = L.sum_onto ? 1.0f : 1.0f / (float) L.spp;
 	const unsigned int first = blockIdx.x * (unsigned int) blocks_per_group;
-	for (unsigned int k = (unsigned int) wave; k < (unsigned int) blocks_per_group; k += RT_BLOCK / 64) {
+	unsigned int blocks_done = 0u;
+	for (unsigned int k = (unsigned int) wave; k < (unsigned int) blocks_per_group; k += RT_BLOCK / 64, blocks_done++) {
 		const unsigned int blk = first + k;
 		if (blk >= total) break;
 		const int i = (int) (blk % (unsigned int) tiles_x) * 8 + (lane & 7), lr = (int) (blk / (unsigned int) tiles_x) * 8 + (lane >> 3);
@@ -884,6 +885,9 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 			}
 		}
 	}
+	/* the blocks this wave finished, on the line of the list it appends to: the trace kernel's last wave adds the lines up and
+	 * the host compares the sum with the number of blocks the frame has (RT_CTL_PRIMARY) */
+	if (lane == 0 && blocks_done) atomicAdd(L.pix_count + shard * 32u + 1u, blocks_done);
 }
 #endif /* RT_SPEC_ONLY */
 
@@ -933,6 +937,7 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 #define REC_LAST     4                /* the path ends after this bounce ...               */
 #define REC_SKY      8                /* ... because its bounce ray left the scene (sky1 / sky2) */
 #define REC_TAPS_LIT 128              /* the bounce's accepted taps are known to hit the emitter (rt_lit.h): none was queued */
+#define REC_AUDIT     0x80000         /* (rt_launch.audit_taps) the bounce's taps are known AND were queued: the back compares the two */
 #define REC_TAPS_DARK 0x40000         /* ... known NOT to have the emitter as their nearest hit: they add nothing (above the object index, < 1024 << 8) */
 
 struct WaveLDS {
@@ -949,6 +954,8 @@ struct WaveLDS {
 	unsigned int s_seq[WF_STREAMS];    /* slots reserved so far (sequence number of the next one) */
 	unsigned int s_drained[WF_STREAMS];/* slots added up and released so far */
 	float s_sum[3][WF_STREAMS];        /* running sum of the pixel being added up */
+	/* what the wave reports when it leaves (RT_CTL_*): object pixels it wrote; audited taps and those whose trace contradicts rt_lit.h */
+	unsigned int n_written, n_audited, n_disagree, pad_;
 };
 
 /* The launch record as the code that takes a new pixel block reads it.  Kernel arguments are invariant, so the
@@ -1135,6 +1142,7 @@ struct Wavefront {
 			W().s_nxt[lane] = spp; W().s_seq[lane] = 0u; W().s_drained[lane] = 0u;
 			W().s_sum[0][lane] = 0.0f; W().s_sum[1][lane] = 0.0f; W().s_sum[2][lane] = 0.0f;
 		}
+		if (lane == 0) { W().n_written = 0u; W().n_audited = 0u; W().n_disagree = 0u; }
 		wave_fence();
 		shard = blockIdx.x % (unsigned int) L.num_shards;
 		sum_every = L.spp >= 32 ? WF_SUM_EVERY : 1u;
@@ -1179,6 +1187,7 @@ struct Wavefront {
 				const V3 res = scale3(sum, inv_spp);
 				float *dst = L.frame + (size_t) xb * 3;
 				dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+				__hip_atomic_fetch_add(&W().n_written, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 			}
 			if (active) W().win[0][e] = __uint_as_float(WF_EMPTY);
 			if (active && (int) j == k - 1) {
@@ -1280,16 +1289,18 @@ struct Wavefront {
 			unsigned int word = 0u, k = 0u;
 			if (lane == 0) {
 				word = (blockIdx.x < 8u && wave == 0) ? __hip_atomic_load((guint) C->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - C->launch_id
-				                                      : __hip_atomic_load((guint) C->control + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
+				                                      : __hip_atomic_load((guint) C->control + RT_CTL_STOP_RELAY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
 				k = atomicAdd(block_counter + shard * 32u, (unsigned int) asked);
 			}
 			k = (unsigned int) __builtin_amdgcn_readfirstlane((int) k);
 			if ((int) __builtin_amdgcn_readfirstlane((int) word) >= 0) {      /* the request covers this launch / another wave has seen it */
 				cancelled = true;
-				if (lane == 0) { C->control[1] = 1u; __hip_atomic_store((gwuint) C->control + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+				if (lane == 0) { C->control[RT_CTL_CANCELLED] = 1u; __hip_atomic_store((gwuint) C->control + RT_CTL_STOP_RELAY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 			}
 			const guint fill_counts = (guint) C->pix_count;
-			const unsigned int filled = (unsigned int) __builtin_amdgcn_readfirstlane((int) fill_counts[shard * 32u]);
+			const unsigned int drop = C->test_drop_pixels;          /* (testing aid: 0 in production) */
+			unsigned int filled = (unsigned int) __builtin_amdgcn_readfirstlane((int) fill_counts[shard * 32u]);
+			filled -= filled < drop ? filled : drop;
 			got = k < filled && !cancelled ? (filled - k < (unsigned int) asked ? (int) (filled - k) : asked) : 0;
 			first = (size_t) shard * (size_t) C->pix_shard_cap + k;
 			if (got < asked) {
@@ -1299,7 +1310,8 @@ struct Wavefront {
 				unsigned int left = 0, taken = 0;
 				if (lane < C->num_shards) {
 					taken = __hip_atomic_load(block_counter + (unsigned int) lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					const unsigned int have = fill_counts[(unsigned int) lane * 32u];
+					unsigned int have = fill_counts[(unsigned int) lane * 32u];
+					have -= have < drop ? have : drop;
 					left = have > taken ? have - taken : 0u;
 				}
 				const unsigned long long some = __ballot(left != 0u);
@@ -1409,7 +1421,14 @@ struct Wavefront {
 		p.hdir = out_dir;
 		p.has_hit = false;
 		r.cur = REC_VALID | (specular ? REC_SPECULAR : 0) | (r.emit_main ? 0 : REC_LAST) | (r.tapmask << 4) | (p.hobj << 8);
-		if (taps_lit) { r.cur |= p.lit_next == 1u ? REC_TAPS_LIT : REC_TAPS_DARK; r.tapmask = 0; }      /* the record keeps the accepted taps, the queue gets none */
+		if (taps_lit) {             /* the record keeps the accepted taps, the queue gets none ... */
+			r.cur |= p.lit_next == 1u ? REC_TAPS_LIT : REC_TAPS_DARK;
+			/* ... unless this bounce is one of those the launch audits (rt_launch.audit_taps, 2^k: one in 2^k, picked by bits of the
+			 * path's generator state): its taps are traced like unknown ones and the back compares */
+			bool audit = false;
+			if (L.audit_taps != 0u) audit = r.tapmask != 0 && (((uint32_t) (p.rng >> 21)) & (L.audit_taps - 1u)) == 0u;
+			if (audit) r.cur |= REC_AUDIT; else r.tapmask = 0;
+		}
 	}
 
 	/* ---- 3. the shadow taps go into the wave's ring (ballot + mbcnt prefix), one kind at a time; whenever 64 are
@@ -1570,6 +1589,7 @@ struct Wavefront {
 					const int t0 = W().tap[due][0][lane], t1 = W().tap[due][1][lane], t2 = W().tap[due][2][lane];
 					taps = __popc((unsigned int) ptaps);
 					int n_hit = ((ptaps & 1) && t0 == K.light_obj ? 1 : 0) + ((ptaps & 2) && t1 == K.light_obj ? 1 : 0) + ((ptaps & 4) && t2 == K.light_obj ? 1 : 0);
+					if (p.rec2 & REC_AUDIT) audit_taps(taps, (p.rec2 & REC_TAPS_LIT) ? taps - n_hit : n_hit);
 					if (p.rec2 & REC_TAPS_LIT) n_hit = taps;
 					if (p.rec2 & REC_TAPS_DARK) n_hit = 0;
 					const float4 e = sc.shade[4 * K.light_obj + 3];
@@ -1580,6 +1600,7 @@ struct Wavefront {
 				for (int k = 0; k < 3; k++)
 					if ((ptaps >> k) & 1) {
 						const int obj = (p.rec2 & REC_TAPS_LIT) ? K.light_obj : ((p.rec2 & REC_TAPS_DARK) ? -1 : W().tap[due][k][lane]);
+						if (p.rec2 & REC_AUDIT) audit_taps(1, ((p.rec2 & REC_TAPS_LIT) != 0) != (W().tap[due][k][lane] == K.light_obj) ? 1 : 0);
 						if (obj >= 0) { const float4 e = sc.shade[4 * obj + 3]; lit = add3(lit, mk3(e.x, e.y, e.z)); }
 						taps++;
 					}
@@ -1600,6 +1621,7 @@ struct Wavefront {
 					const V3 res = scale3(add3(mk3(0, 0, 0), col), inv_spp);
 					float *dst = L.frame + (size_t) p.slot2 * 3;
 					dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+					__hip_atomic_fetch_add(&W().n_written, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 				} else {                        /* into its slot of the window; section 6 adds it when its turn comes */
 					const unsigned int e = (unsigned int) p.slot2 & (WF_LAST - 1);
 					W().win[1][e] = col.y; W().win[2][e] = col.z;
@@ -1624,6 +1646,54 @@ struct Wavefront {
 			if (path_ended) p.f_live = false;      /* the front takes its next sample at the top of the next round */
 		}
 		wave_fence();
+	}
+
+	/* `taps` taps whose answer rt_lit.h gave were traced all the same; `wrong` of them contradict it */
+	RT_DEV void audit_taps(int taps, int wrong)
+	{
+		__hip_atomic_fetch_add(&W().n_audited, (unsigned int) taps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+		if (wrong) __hip_atomic_fetch_add(&W().n_disagree, (unsigned int) wrong, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+	}
+
+	/* A wave leaves the launch: it adds what it wrote to the launch's control words, and the LAST wave to leave adds up the
+	 * pixel lists -- listed by the camera-ray pass, fetched by the waves -- and stamps the launch with its number.  The host
+	 * reads the words behind the launch and delivers the frame only if the stamp is there and the sums agree (rt_api.cpp
+	 * judge_launch): every wave left, every listed pixel was fetched, every fetched pixel was written.  The reference publishes a
+	 * column whole or not at all (main.c:377-396). */
+	RT_DEV void leave_launch()
+	{
+		typedef __attribute__((address_space(1))) unsigned int *gwuint;
+		typedef __attribute__((address_space(1))) unsigned long long *gwulong;
+		wave_fence();
+		const rt_launch_cold C = cold_view();
+		const gwuint ctl = (gwuint) C->control;
+		unsigned int before = 0u;
+		if (lane == 0) {
+			const unsigned int nw = W().n_written, na = W().n_audited, nd = W().n_disagree;
+			if (nw) __hip_atomic_fetch_add(ctl + RT_CTL_WRITTEN, nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (na) __hip_atomic_fetch_add((gwulong) (ctl + RT_CTL_AUDITED), (unsigned long long) na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (nd) __hip_atomic_fetch_add((gwulong) (ctl + RT_CTL_DISAGREE), (unsigned long long) nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			before = __hip_atomic_fetch_add(ctl + RT_CTL_WAVES_LEFT, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		before = (unsigned int) __builtin_amdgcn_readfirstlane((int) before);
+		if (before + 1u != gridDim.x * (unsigned int) (BLOCK / 64)) return;
+		/* the last one: lane s adds up list s */
+		unsigned int listed = 0u, fetched = 0u, blocks = 0u;
+		if (lane < C->num_shards) {
+			const gwuint fill = (gwuint) C->pix_count + (unsigned int) lane * 32u;
+			listed = __hip_atomic_load(fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			blocks = __hip_atomic_load(fill + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const unsigned int taken = __hip_atomic_load(block_counter + (unsigned int) lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			fetched = taken < listed ? taken : listed;
+		}
+#pragma unroll
+		for (int m = 1; m < 64; m <<= 1) {
+			listed += from_lane(listed, lane ^ m); fetched += from_lane(fetched, lane ^ m); blocks += from_lane(blocks, lane ^ m);
+		}
+		if (lane == 0) {
+			ctl[RT_CTL_LISTED] = listed; ctl[RT_CTL_FETCHED] = fetched; ctl[RT_CTL_PRIMARY] = blocks;
+			__hip_atomic_store(ctl + RT_CTL_STAMP, C->launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		}
 	}
 
 	RT_DEV void run()
@@ -1659,6 +1729,7 @@ struct Wavefront {
 			STAMP(4);
 		}
 		STAMP_FLUSH(BLOCK / 64);
+		leave_launch();
 	}
 };
 
@@ -1702,11 +1773,31 @@ rt_trace_spec(const rt_launch L, unsigned int *block_counter)
 #ifndef RT_SPEC_ONLY
 /* ---- progressive accumulation: worker()'s publish step (main.c:387-396) and update_frame()'s
  * resolve (main.c:467-477) ------------------------------------------------------------------ */
+/* May the launch whose control words are `control` be published?  Not when rt_cancel() cut it short (main.c:382) -- and not when it
+ * is incomplete (rt_device.h RT_CTL_*: no stamp of its last wave, listed pixels not fetched or not written, camera-ray blocks
+ * missing, audited taps that contradict rt_lit.h): a column is published whole or not at all (main.c:377-396).  The second case
+ * is an error, counted in count[RT_COUNT_INCOMPLETE] for the host's next look (rt_progressive_count). */
+RT_DEV bool launch_may_be_published(const unsigned int *control, unsigned int launch_id, int stamped, unsigned int primary_blocks, float *count)
+{
+	if (!control) return true;            /* nothing was launched (a rank without rows at this scale) */
+	if (control[RT_CTL_CANCELLED]) return false;
+	if (!stamped) return true;
+	const bool complete = control[RT_CTL_STAMP] == launch_id && control[RT_CTL_FETCHED] == control[RT_CTL_LISTED] &&
+	                      control[RT_CTL_WRITTEN] == control[RT_CTL_LISTED] && control[RT_CTL_PRIMARY] == primary_blocks &&
+	                      control[RT_CTL_DISAGREE] == 0u && control[RT_CTL_DISAGREE + 1] == 0u;
+	if (!complete && blockIdx.x == 0 && threadIdx.x == 0) {
+		unsigned int *errors = reinterpret_cast<unsigned int*>(count) + RT_COUNT_INCOMPLETE;
+		*errors = *errors + 1u;
+	}
+	return complete;
+}
+
 extern "C" __global__ void __launch_bounds__(RT_BLOCK)
-rt_accumulate(float *accum, const float *lowres, int width, int height, int scale, int low_w, int low_h, float k, const unsigned int *cancelled, float *count,
+rt_accumulate(float *accum, const float *lowres, int width, int height, int scale, int low_w, int low_h, float k,
+              const unsigned int *control, unsigned int launch_id, int stamped, unsigned int primary_blocks, float *count,
               int row_block, int rank, int world, int local_rows)
 {
-	if (*cancelled) return;               /* the pass was given up: it is not published (main.c:382) */
+	if (!launch_may_be_published(control, launch_id, stamped, primary_blocks, count)) return;
 	/* accum_counts[] += weight (main.c:396) lives beside the buffer it describes: a pass that rt_cancel() cut short
 	 * leaves both untouched, whatever the host believed when it enqueued the pass */
 	if (blockIdx.x == 0 && threadIdx.x == 0) *count = *count + k;
@@ -1730,9 +1821,10 @@ rt_accumulate(float *accum, const float *lowres, int width, int height, int scal
 /* the publish step of `passes` full-resolution passes that one launch rendered onto the sums so far (rt_launch.sum_onto):
  * the new sums take the old ones' place, and the passes count (weight 1 each, main.c:396) -- unless the launch was cut short */
 extern "C" __global__ void __launch_bounds__(RT_BLOCK)
-rt_commit_sums(float *accum, const float *sums, size_t floats, int passes, const unsigned int *cancelled, float *count)
+rt_commit_sums(float *accum, const float *sums, size_t floats, int passes,
+               const unsigned int *control, unsigned int launch_id, int stamped, unsigned int primary_blocks, float *count)
 {
-	if (*cancelled) return;
+	if (!launch_may_be_published(control, launch_id, stamped, primary_blocks, count)) return;
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		float c = *count;
 		for (int k = 0; k < passes; k++) c = c + 1.0f;
@@ -1988,17 +2080,18 @@ rt_selftest_kernel(int which, uint64_t seed, int iters, unsigned long long *out)
 }
 
 hipError_t rt_launch_accumulate(float *accum, const float *lowres, int width, int height, int scale,
-                                int low_w, int low_h, float k, const unsigned int *cancelled, float *count,
+                                int low_w, int low_h, float k, const unsigned int *control, const rt_launch_expect &expect, float *count,
                                 int row_block, int rank, int world, int local_rows, hipStream_t stream)
 {
-	hipLaunchKernelGGL(rt_accumulate, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, lowres, width, height, scale, low_w, low_h, k, cancelled, count,
-	                   row_block, rank, world, local_rows);
+	hipLaunchKernelGGL(rt_accumulate, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, lowres, width, height, scale, low_w, low_h, k,
+	                   control, expect.launch_id, expect.stamped, expect.primary_blocks, count, row_block, rank, world, local_rows);
 	return hipGetLastError();
 }
 
-hipError_t rt_launch_commit_sums(float *accum, const float *sums, size_t floats, int passes, const unsigned int *cancelled, float *count, hipStream_t stream)
+hipError_t rt_launch_commit_sums(float *accum, const float *sums, size_t floats, int passes, const unsigned int *control, const rt_launch_expect &expect, float *count, hipStream_t stream)
 {
-	hipLaunchKernelGGL(rt_commit_sums, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, sums, floats, passes, cancelled, count);
+	hipLaunchKernelGGL(rt_commit_sums, dim3(2048), dim3(RT_BLOCK), 0, stream, accum, sums, floats, passes,
+	                   control, expect.launch_id, expect.stamped, expect.primary_blocks, count);
 	return hipGetLastError();
 }
 
@@ -2047,8 +2140,11 @@ size_t rt_pixel_list_capacity(int width, int local_rows, int num_cus, int num_sh
 
 hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, hipFunction_t spec_fn,
                            unsigned int *block_counter, hipEvent_t cleared, hipEvent_t primary_done, int num_cus, int workgroups_per_cu, hipStream_t stream,
-                           bool reuse_pixel_lists)
+                           bool reuse_pixel_lists, rt_launch_expect *expect)
 {
+	rt_launch_expect unused;
+	if (!expect) expect = &unused;
+	expect->launch_id = L.launch_id; expect->stamped = 0; expect->primary_blocks = 0u;
 	if (L.local_rows <= 0 || L.width <= 0) {
 		hipError_t e = cleared ? hipEventRecord(cleared, stream) : hipSuccess;
 		return e != hipSuccess ? e : hipEventRecord(primary_done, stream);
@@ -2092,6 +2188,9 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	}
 	if (workgroups_per_cu >= 1 && workgroups_per_cu < per_cu) per_cu = workgroups_per_cu;     /* rt_tuning */
 	const long long blocks = (long long) ((L.width + 7) / 8) * ((L.local_rows + 7) / 8);
+	/* what the launch must leave in its control words (rt_device.h RT_CTL_*): the stamp of its last wave, and -- the lists'
+	 * lines keep the count when the lists are kept -- every 8x8 block finished by the camera-ray pass */
+	expect->stamped = 1; expect->primary_blocks = (unsigned int) blocks;
 	long long grid = (long long) num_cus * per_cu;
 	const long long useful = (blocks + (block / 64) - 1) / (block / 64);
 	if (grid > useful) grid = useful;

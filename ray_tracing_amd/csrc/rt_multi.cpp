@@ -104,7 +104,7 @@ struct rt_multi {
 	float *d_strips[STRIP_BUFFERS] = { nullptr, nullptr, nullptr };   /* n strips back to back: the gather's destination */
 	size_t strips_floats = 0;
 	hipStream_t copy_stream = nullptr;
-	unsigned int *h_cancel = nullptr;           /* pinned: [slot * 64 + device] = that launch's control word */
+	unsigned int *h_control = nullptr;          /* pinned: RT_CTL_WORDS control words of the launch of (slot, device) at (slot * 64 + device) * RT_CTL_WORDS */
 	struct frame_slot {
 		float     *d_frame = nullptr;           /* the frame in row order */
 		size_t     floats = 0;
@@ -112,6 +112,7 @@ struct rt_multi {
 		hipEvent_t copied = nullptr;            /* behind the copy to the caller's memory */
 		bool       busy = false;
 		bool       plain = false;               /* the frame went through rt_frame_submit() of the only context */
+		std::vector<rt_launch_expect> expect;   /* per device: what its launch must leave in its control words (rt_judge_launch) */
 	} fq[RT_FRAME_SLOTS];
 	unsigned long long frames = 0;              /* frame k: render streams k & 1, strip buffers k % 3 */
 	int prog_w = 0, prog_h = 0;                 /* rt_multi_progressive_begin's frame */
@@ -200,11 +201,12 @@ static int prepare(rt_multi *m, int W, int H, int rb, int slot)
 		if (hipStreamCreateWithPriority(&m->copy_stream, hipStreamNonBlocking, greatest) != hipSuccess)
 			MULTI_HIP(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
 	}
-	if (!m->h_cancel) {
-		MULTI_HIP(hipHostMalloc((void **) &m->h_cancel, (size_t) RT_FRAME_SLOTS * 64 * sizeof(unsigned int), hipHostMallocPortable));   /* every device writes its word */
-		memset(m->h_cancel, 0, (size_t) RT_FRAME_SLOTS * 64 * sizeof(unsigned int));
+	if (!m->h_control) {
+		MULTI_HIP(hipHostMalloc((void **) &m->h_control, (size_t) RT_FRAME_SLOTS * 64 * RT_CTL_WORDS * sizeof(unsigned int), hipHostMallocPortable));   /* every device writes its words */
+		memset(m->h_control, 0, (size_t) RT_FRAME_SLOTS * 64 * RT_CTL_WORDS * sizeof(unsigned int));
 	}
 	rt_multi::frame_slot &f = m->fq[slot];
+	f.expect.assign((size_t) n, rt_launch_expect{ 0u, 0, 0u });
 	if (!f.copied) MULTI_HIP(hipEventCreateWithFlags(&f.copied, hipEventDisableTiming));
 	if (!f.assembled) MULTI_HIP(hipEventCreateWithFlags(&f.assembled, hipEventDisableTiming));
 	if (frame_floats > f.floats) {
@@ -276,7 +278,7 @@ void rt_multi_destroy(rt_multi *m)
 			for (int j = 0; j < STRIP_BUFFERS; j++) (void) hipFree(m->d_strips[j]);
 			for (auto &f : m->fq) { (void) hipFree(f.d_frame); if (f.copied) (void) hipEventDestroy(f.copied); if (f.assembled) (void) hipEventDestroy(f.assembled); }
 			if (m->copy_stream) (void) hipStreamDestroy(m->copy_stream);
-			if (m->h_cancel) (void) hipHostFree(m->h_cancel);
+			if (m->h_control) (void) hipHostFree(m->h_control);
 		}
 	}
 	for (ncclComm_t c : m->comms) if (c) (void) rccl().comm_destroy(c);
@@ -375,11 +377,11 @@ static int multi_frame_submit(rt_multi *m, const rt_render_params *params, int s
 		rc = rt_render_device(ctx, &p, d.d_strip[j], rs);
 		if (rc != RT_OK) break;
 		enqueued++;
-		/* the collective stream takes over behind the render; first this launch's control word (set by a wave that
-		 * rt_cancel() stopped), for rt_multi_frame_wait() -- not on the render stream: a copy between two kernels there costs
-		 * the overlap of consecutive launches */
+		/* the collective stream takes over behind the render; first this launch's control words (rt_device.h RT_CTL_*: did a wave
+		 * give up after rt_cancel(), did the launch account for every pixel), for rt_multi_frame_wait() -- not on the render
+		 * stream: a copy between two kernels there costs the overlap of consecutive launches */
 		e = hipStreamWaitEvent(d.gather_stream, (hipEvent_t) rt_context_launch_done(ctx), 0);
-		if (e == hipSuccess) { rc = rt_context_read_control(ctx, &m->h_cancel[slot * 64 + i], d.gather_stream, nullptr); if (rc != RT_OK) break; }
+		if (e == hipSuccess) { rc = rt_context_read_control(ctx, &m->h_control[(size_t) (slot * 64 + i) * RT_CTL_WORDS], d.gather_stream, nullptr, &f.expect[(size_t) i]); if (rc != RT_OK) break; }
 		if (e != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: device %d: %s", m->devices[(size_t) i], hipGetErrorString(e));
 	}
 	/* ONE gather of the finished strips to device 0, each rank's part on its own collective stream */
@@ -461,9 +463,15 @@ static int finish_slot(rt_multi *m, int slot)
 	if (f.plain) return rt_frame_wait(m->ctx[0], slot);
 	MULTI_HIP(hipSetDevice(m->devices[0]));
 	MULTI_HIP(hipEventSynchronize(f.copied));      /* behind the gather, hence behind every device's render and control-word copy ... */
-	int cancelled = 0;
-	for (int i = 0; i < m->n; i++) cancelled |= m->h_cancel[slot * 64 + i] != 0u;
-	return cancelled ? RT_CANCELLED : RT_OK;
+	/* every device's launch is judged (rt_judge_launch): the frame is delivered if all of them accounted for every pixel; one
+	 * incomplete strip is an error (its text names the launch), one cancelled strip a cancelled frame */
+	int verdict = RT_OK;
+	for (int i = 0; i < m->n; i++) {
+		const int rc = rt_judge_launch(&m->h_control[(size_t) (slot * 64 + i) * RT_CTL_WORDS], f.expect[(size_t) i], "rt_multi_frame_wait", nullptr);
+		if (rc < 0) return rc;
+		if (rc == RT_CANCELLED) verdict = RT_CANCELLED;
+	}
+	return verdict;
 }
 
 int rt_multi_frame_wait(rt_multi *m, int slot)

@@ -161,6 +161,10 @@ class TiledFrame:
         self.copied = [None, None]        # event: the host copy that read frame / strip buffer k & 1 has finished
         self.gathered = [None] * self.depth    # event (post): the gather that read strip[j] (and wrote strips[j]) is complete
         self.assembled = [None] * self.depth   # event (post): the de-interleave that read strips[j] is complete
+        # every strip launch accounts for itself (rt_launch_check_*): ticket k % CHECK_TICKETS takes frame k's control words on the
+        # copy stream; a frame's ticket is judged when the frame `depth` steps later is enqueued (by then it is long complete)
+        # and by flush() -- an incomplete or wrong launch raises RtError on the rank that rendered it
+        self.tickets = []
         self.k = 0
         self.done_events = []             # one per completed frame when record_events is set
         self.render_events = []           # one behind every strip render when record_events is set
@@ -184,6 +188,7 @@ class TiledFrame:
             p = self.r.params(self.W, self.H, self.spp, self.max_bounces, seed=self.seed if seed is None else seed,
                               row_block=self.row_block, rank=self.strip_index, world=self.world, kernel=self.kernel)
             self.r.render_device(p, self.strip[j].data_ptr(), s.cuda_stream)
+            self._check_launch(k, s)
             if self.record_events:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(s)
@@ -218,6 +223,19 @@ class TiledFrame:
                 self.assembled[j] = read
                 self._deliver(frame, f, self.post)
 
+    def _check_launch(self, k, s):
+        """The control words of the launch just enqueued on `s` travel to the host on the copy stream (not on the render stream:
+        a copy between two kernels there costs the overlap of consecutive launches); older tickets are judged."""
+        import ray_tracing_amd as rt
+        while len(self.tickets) >= min(self.depth, rt.CHECK_TICKETS - 1):
+            self.r.launch_check_wait(self.tickets.pop(0))
+        rendered = torch.cuda.Event()
+        rendered.record(s)
+        self.copy_stream.wait_event(rendered)
+        t = k % rt.CHECK_TICKETS
+        self.r.launch_check_submit(t, self.copy_stream.cuda_stream)
+        self.tickets.append(t)
+
     def _deliver(self, frame, slot, source):
         """frame (device, complete on stream `source`) -> pinned host memory, on the copy stream."""
         if self.to_host:
@@ -244,6 +262,8 @@ class TiledFrame:
         if self.post is not None:
             self.post.synchronize()
         self.copy_stream.synchronize()
+        while self.tickets:
+            self.r.launch_check_wait(self.tickets.pop(0))
 
     def render_now(self, seed=None):
         """One frame, start to finish (no overlap): returns the host frame on rank 0 (a view of host_frame)."""

@@ -2,6 +2,7 @@
 declared function must link against librt_hip.so.  No GPU call is made."""
 import os
 import subprocess
+import sys
 import textwrap
 
 import pytest
@@ -107,3 +108,49 @@ def test_header_compiles_against_the_reference_headers(tmp_path):
     src.write_text(REF_HOST)
     subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-c", "-I", REF_SRC, "-I", os.path.join(ROOT, "include"),
                     str(src), "-o", str(tmp_path / "ref_host.o")], check=True, capture_output=True, text=True)
+
+
+GLFW_SYMBOLS = ["glfwInit", "glfwTerminate", "glfwWindowHint", "glfwCreateWindow", "glfwDestroyWindow", "glfwSetKeyCallback",
+                "glfwSetFramebufferSizeCallback", "glfwSetCursorPosCallback", "glfwSetInputMode", "glfwMakeContextCurrent",
+                "glfwGetProcAddress", "glfwSwapInterval", "glfwGetWindowSize", "glfwSwapBuffers", "glfwPollEvents", "glfwGetKey",
+                "glfwWindowShouldClose", "glfwGetCursorPos", "glfwSetErrorCallback"]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="the reference checkout is not on this machine")
+def test_the_integration_patch_applies_compiles_and_links(tmp_path):
+    """INTEGRATION.md section 2 as a build: scripts/patches/reference_main_rt.py turns the reference's main.c -- start_workers()
+    at :516, update_frame() at :450-482, invalidate_accumulation() at :115-124, stop_workers() -- into the host that calls
+    librt_hip.so, and adds the two camera getters camera.c lacks.  The patched text is piped into the compiler (nothing of the
+    reference is written to disk), compiled with the reference's own flags and headers, and linked with the reference's other
+    translation units against the library: with --no-undefined, so every rt_* call resolves; the only symbols allowed to stay
+    open are the 19 entry points of GLFW the reference's window code uses (this image has no libglfw: main() is compiled and
+    linked, never run).  Compile and link only."""
+    ref = os.path.dirname(REF_SRC)
+    patch = os.path.join(ROOT, "scripts", "patches", "reference_main_rt.py")
+    flags = ["-std=c11", "-O2", "-DNDEBUG", "-fPIC", "-ffunction-sections", "-fdata-sections", "-Werror=implicit-function-declaration",
+             "-Werror=incompatible-pointer-types", "-Werror=int-conversion",
+             "-I", REF_SRC, "-I", os.path.join(ref, "3p"), "-I", os.path.join(ref, "3p", "glad", "include"),
+             "-I", os.path.join(ref, "3p", "glfw-3.4.bin.WIN64", "include"), "-I", os.path.join(ROOT, "include")]
+    objs = []
+    for which, src in (("main", "main.c"), ("camera", "camera.c")):
+        text = subprocess.run([sys.executable, patch, which], stdin=open(os.path.join(REF_SRC, src)), check=True, capture_output=True, text=True).stdout
+        assert "rt_render(rt, &p, frame)" in text or which == "camera"
+        obj = tmp_path / (which + "_rt.o")
+        subprocess.run(["gcc"] + flags + ["-x", "c", "-c", "-", "-o", str(obj)], input=text, check=True, capture_output=True, text=True)
+        objs.append(str(obj))
+    # the patched main() calls into the library and nothing else of the workers is left in it
+    syms = subprocess.run(["nm", "--undefined-only", objs[0]], check=True, capture_output=True, text=True).stdout.split()
+    for name in ("rt_create", "rt_set_scene", "rt_set_skybox", "rt_compile_scene", "rt_set_camera", "rt_render", "rt_cancel", "rt_reserve",
+                 "rt_destroy", "rt_default_params", "rt_last_error", "get_camera_front", "get_camera_up", "move_frame_to_the_gpu"):
+        assert name in syms, name
+    others = [os.path.join(REF_SRC, f) for f in ("scene.c", "vector.c", "os.c", "utils.c", "gpu_and_windowing.c")] + [os.path.join(ref, "3p", "glad", "src", "glad.c")]
+    out = tmp_path / "ray_trace_rt.so"
+    link = (["gcc", "-shared", "-o", str(out)] + objs + [f for f in flags if not f.startswith("-Werror")] + ["-w"] + others +
+            ["-L", os.path.dirname(rt.LIB_PATH), "-lrt_hip", "-Wl,-rpath," + os.path.dirname(rt.LIB_PATH), "-Wl,--gc-sections", "-Wl,--no-undefined"] +
+            ["-Wl,--ignore-unresolved-symbol," + g for g in GLFW_SYMBOLS] + ["-lm", "-lpthread", "-ldl"])
+    r = subprocess.run(link, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    needed = subprocess.run(["readelf", "-d", str(out)], check=True, capture_output=True, text=True).stdout
+    assert "librt_hip.so" in needed
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", str(out)], check=True, capture_output=True, text=True).stdout
+    assert "rt_render" in undefined and "glfwInit" in undefined      # (bound to the library at load time / left to a GLFW the box lacks)
