@@ -131,7 +131,66 @@ def algorithmic_work(oracle_count, W, H, max_bounces, seed):
     oracle_count.render_counter(W, H, 1, max_bounces, seed=seed)
     c = oracle_count.counters()
     n = max(c["samples"], 1)
-    return {k: c[k] / n for k in ("flops", "rays", "object_tests", "rng_draws", "sky_fetches")}
+    return {k: c[k] / n for k in ("flops", "rays", "object_tests", "rng_draws", "sky_fetches",
+                                  "box_tests", "box_flops", "sphere_tests", "sphere_flops", "sky_samples", "sky_sample_flops")}
+
+
+# measured issue cost of a wave64 VALU instruction per SIMD, four waves per SIMD (profiles/r02/valu_rates.txt, cycles)
+VALU_CLASS_CLK = {"f32_add_mul_fma": 2.4, "int32": 3.0, "int64": 4.35, "f64": 4.28, "trans_f32": 8.2, "cvt": 4.2, "other": 4.0}
+
+
+def simd_issue_estimate(k, kernel_ms):
+    """Share of the SIMDs' issue time the kernel's VALU instructions account for: instructions by class (rocprofv3 PMC passes of
+    the committed profile) x the measured cost of the class / (1024 SIMDs x 2.4 GHz x kernel time).  Replaces the derived counter
+    VALUBusy, which reads above 100 % on gfx950."""
+    need = ("SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64")
+    if not k or any(c not in k for c in need):
+        return None
+    n = {"f32_add_mul_fma": k["SQ_INSTS_VALU_ADD_F32"] + k["SQ_INSTS_VALU_MUL_F32"] + k["SQ_INSTS_VALU_FMA_F32"],
+         "int32": k["SQ_INSTS_VALU_INT32"], "int64": k["SQ_INSTS_VALU_INT64"],
+         "f64": k.get("SQ_INSTS_VALU_FMA_F64", 0) + k.get("SQ_INSTS_VALU_ADD_F64", 0) + k.get("SQ_INSTS_VALU_MUL_F64", 0),
+         "trans_f32": k.get("SQ_INSTS_VALU_TRANS_F32", 0), "cvt": k.get("SQ_INSTS_VALU_CVT", 0)}
+    n["other"] = max(k["SQ_INSTS_VALU"] - sum(n.values()), 0.0)
+    cycles = sum(n[c] * VALU_CLASS_CLK[c] for c in n)
+    return {"valu_instructions_per_launch": round(k["SQ_INSTS_VALU"]), "by_class": {c: round(v) for c, v in n.items()}, "class_clk": VALU_CLASS_CLK,
+            "simd_issue_share": round(cycles / (1024 * 2.4e9 * kernel_ms * 1e-3), 4),
+            "lanes_active": round(k["SQ_THREAD_CYCLES_VALU"] / k["SQ_ACTIVE_INST_VALU"] / 64, 4) if k.get("SQ_ACTIVE_INST_VALU") else None,
+            "note": "sum over classes of instructions x cycles per wave64 instruction (measured, profiles/r02/valu_rates.txt) / (1024 SIMDs x 2.4 GHz x kernel time); "
+                    "'other' = compares, selects, min/max, moves, cross-lane; lanes_active = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64"}
+
+
+def executed_work_of_culled_scene(rt, scene, camera, sky, W, H, spp, nb, seed):
+    """What the culled trace of a large scene EXECUTES per sample, counted by the instrumented build of the library
+    (librt_hip_stats.so, `make -C ray_tracing_amd/csrc stats`; per-site lane counts, rt_stats.hip.h) on a frame of 1/16 of the
+    pixels: exact box / sphere tests (the reference's own, lanes), conservative slab tests of the cull (cluster boxes, member
+    boxes), rays, shading events.  None when that build is absent."""
+    import ctypes as C
+    path = os.path.join(os.path.dirname(rt.LIB_PATH), "librt_hip_stats.so")
+    if not os.path.exists(path):
+        return None
+    keep_lib, keep_path = rt._lib, rt.LIB_PATH
+    try:
+        rt._lib, rt.LIB_PATH = None, path
+        L = rt.lib()
+        g = rt.Renderer(0)
+        g.set_scene(scene); g.set_skybox(sky); g.set_camera(**camera)
+        out = (C.c_ulonglong * 128)()
+        L.rt_stats_read(out, 1)
+        w, h = max(W // 4, 64), max(H // 4, 36)
+        g.render(w, h, spp, nb, seed=seed)
+        L.rt_stats_read(out, 1)
+        g.close()
+    finally:
+        rt._lib, rt.LIB_PATH = keep_lib, keep_path
+    lanes = lambda site: out[2 * site + 1]      # noqa: E731
+    execs = lambda site: out[2 * site]          # noqa: E731
+    n = float(w * h * spp)
+    return {"per_sample": {"box_tests": lanes(1) / n, "sphere_tests": lanes(3) / n, "sphere_roots": lanes(4) / n,
+                           "cluster_slab_tests": lanes(32) / n, "member_slab_tests": lanes(34) / n,
+                           "rays": lanes(13) / n + lanes(9) / n, "shading_events": lanes(8) / n, "culled_traces_of_a_wave": execs(9) / n},
+            "frame": f"{w}x{h}x{spp} spp, {nb} bounces (1/16 of the bench frame's pixels, same camera and samples per pixel)",
+            "source": "librt_hip_stats.so (-DRT_STATS per-site lane counters, csrc/rt_stats.hip.h), this run"}
+
 
 
 def cpu_baseline(rt, w, sky):
@@ -404,7 +463,7 @@ def main():
     # per-kernel durations.  (b) the span from the first launch's first compute unit to the end of the last trace kernel,
     # over the launches in it: no double counting, but it contains idle time when the launches wait for something else (C3:
     # for the host copy of the frame before last).  Both are upper bounds of the time the GPU needs per launch.
-    per_launch_ms, launches, span_ms = prof.profile_collect_span()
+    per_launch_ms, launches, span_ms, primary_ms_total = prof.profile_collect_split()
     prof.profile(False)
     span_launches = launches
     kernel_ms = min(per_launch_ms, span_ms) if launches and span_ms > 0 else per_launch_ms
@@ -509,8 +568,10 @@ def main():
 
     # ---- the same frame with nothing overlapped: first launch -> frame on the host (SURVEY.md 8d protocol)
     latency = None
+    split = None        # (camera-ray pass ms, trace kernel ms) per launch with nothing else on the GPU: the two kernels priced apart (roofline.kernels)
     if not args.no_extras:
         runs = []
+        prof.profile(2)
         for _ in range(7):
             fence()
             t1 = time.perf_counter()
@@ -520,6 +581,10 @@ def main():
             runs.append((time.perf_counter() - t1) * 1e3)
         runs.sort()
         latency = runs[len(runs) // 2]
+        s_ms, s_n, _, s_primary = prof.profile_collect_split()
+        prof.profile(False)
+        if s_n:
+            split = (s_primary / s_n, (s_ms - s_primary) / s_n)
 
     samples_per_step = W * H * spp
     # ---- the same loop with the frame LEFT ON THE DEVICE (rt_frame_submit_device): what a presenter that takes the frame from
@@ -612,7 +677,9 @@ def main():
             out["device_resident"] = device_resident
         if interactive is not None:
             out["interactive"] = interactive
-        # ---- roofline of the dominant kernel (rank 0's launches; every rank runs the same kernel on 1/N of the rows)
+        # ---- roofline (rank 0's launches; every rank runs the same kernels on 1/N of the rows).  Two kernels, bound differently, are
+        # priced apart: rt_primary_pass (camera rays once per pixel; sky pixels finished: texel gather + frame write -> HBM side) and
+        # the trace kernel (VALU issue).  The top-level fields describe the kernel that takes more of the launch.
         from rtlibs import Oracle
         try:
             oc = into(Oracle(counters=True))
@@ -624,72 +691,108 @@ def main():
         if work and launches:
             avg_ms = kernel_ms / launches
             span_launches = launches
+            # the two kernels apart: only from launches that had the GPU to themselves (the latency leg) -- in the timed region the next
+            # launch's camera-ray pass waits for workgroup slots of the previous launch's trace kernel, and the event between the two
+            # kernels would book that wait to the pass
+            primary_ms, trace_ms = split if split else (primary_ms_total / launches, max(avg_ms - primary_ms_total / launches, 1e-6))
+            split_from = "launches with the GPU to themselves (frame_latency leg)" if split else "the timed region (launches overlap: the split is approximate)"
             samples_per_launch = samples_per_step / ngpus
-            flops = work["flops"] * samples_per_launch
-            # algorithmic bytes: 3 B per skybox fetch + 12 B per pixel written once per launch
-            bytes_ = 3.0 * work["sky_fetches"] * samples_per_launch + 12.0 * (samples_per_launch / spp)
-            achieved = flops / (avg_ms * 1e-3) / 1e12
+            pixels_per_launch = samples_per_launch / spp
+            trace_name = "rt_trace_spec" if compiled else ("rt_trace_wavefront (culled)" if synthetic and not args.every_object else "rt_trace_wavefront")
             out["rays_per_s"] = round(value * 1e6 * work["rays"], 1)
-            valu = {"achieved": round(achieved, 3), "peak": round(PEAK_VALU_NOFMA_TFLOPS, 2), "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_VALU_NOFMA_TFLOPS, 4)}
-            hbm = {"achieved": round(bytes_ / (avg_ms * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                   "frac": round(bytes_ / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 6),
-                   "bytes_per_sample": round(bytes_ / samples_per_launch, 3)}
-            # Sky-dominated frames (C3: 97 % of the samples are one camera ray + one texel) are bound by the texel gather and
-            # the frame write, not by VALU issue: there the ALGORITHMIC flops (every sample traces its camera ray) exceed
-            # what the kernels execute, because the camera ray is traced once per pixel and a sky pixel's spp equal samples
-            # are added without being re-traced (bit-exact), so a VALU fraction would read above 1.
-            gather_bound = work["rays"] < 1.25
-            out["roofline"] = dict(hbm if gather_bound else valu)
-            out["roofline"].update({
-                "bound": "hbm" if gather_bound else "valu", "traffic": None,
-                "kernel": ("rt_primary_pass + " if gather_bound else "") + ("rt_trace_spec" if compiled else "rt_trace_wavefront"),
-                "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
-                "avg_kernel_ms_per_launch_events": round(per_launch_ms / launches, 4),
-                "avg_kernel_ms_span": round(span_ms / span_launches, 4) if span_launches else None,
-                "flops_per_sample": round(work["flops"], 1), "rays_per_sample": round(work["rays"], 3),
-                "object_tests_per_sample": round(work["object_tests"], 2),
-                "rng_draws_per_sample": round(work["rng_draws"], 2),
-                "valu" if gather_bound else "hbm": valu if gather_bound else hbm,
-                "note": "peak (valu) = fp32 VALU issue rate without FMA (parity forbids contraction) = 157.3/2 TFLOP/s, flops counted as "
-                        "written in the reference (SURVEY.md 8d); peak (hbm) = 8 TB/s, bytes = 3 B per sky texel fetch + 12 B per pixel; "
-                        "avg_kernel_ms = rt_primary_pass + the trace kernel (which contains the in-order sample sum), HIP events over "
-                        "the timed region: the smaller of (per launch: first compute unit -> end of the trace kernel; consecutive "
-                        "launches overlap on two streams and the shared time is in both) and (span from the first launch to the end "
-                        "of the last trace kernel / launches; contains idle time when launches wait for host copies)",
-            })
             tr = traffic_from_profiles(args.config, compiled) if ngpus == 1 else None
+            pk = (tr or {}).get("kernels", {})
+
+            # -- the trace kernel against the fp32 VALU issue peak without FMA
+            flops_as_written = work["flops"] * samples_per_launch
+            # (the samples whose camera ray leaves the scene never reach the trace kernel: the camera-ray pass finishes their pixels)
+            flops_object_samples = (work["flops"] - work["sky_sample_flops"]) * samples_per_launch
+            trace = {"kernel": trace_name, "bound": "valu", "ms": round(trace_ms, 4), "peak": round(PEAK_VALU_NOFMA_TFLOPS, 2), "unit": "TFLOP/s"}
+            executed = None
+            if synthetic and not args.every_object:
+                try:
+                    executed = executed_work_of_culled_scene(rt, scene_path, camera, sky, W, H, spp, nb, seed)
+                except Exception as e:
+                    out["executed_work_error"] = repr(e)
+            if executed:
+                # A culled scene: the numerator is the work the kernel EXECUTES, priced with the reference's cost table (the
+                # oracle's per-test averages: a box test 21 flops incl. its far corner, a sphere test ~38), so that frac <= 1 by
+                # construction; the every-object count the reference would do is printed beside it.
+                x = executed["per_sample"]
+                box_cost = work["box_flops"] / max(work["box_tests"], 1e-9)
+                sphere_cost = work["sphere_flops"] / max(work["sphere_tests"], 1e-9)
+                other = work["flops"] - work["box_flops"] - work["sphere_flops"]          # shading, draws, normalisations, sky: executed as written
+                ex_flops = other + x["box_tests"] * box_cost + x["sphere_tests"] * sphere_cost + 6.0 * (x["cluster_slab_tests"] + x["member_slab_tests"])
+                trace.update({"achieved": round(ex_flops * samples_per_launch / (trace_ms * 1e-3) / 1e12, 3), "numerator": "executed",
+                              "executed_flops_per_sample": round(ex_flops, 1),
+                              "executed": {k: round(v, 3) for k, v in x.items()}, "executed_frame": executed["frame"], "executed_source": executed["source"],
+                              "cost_table": {"box_test": round(box_cost, 2), "sphere_test": round(sphere_cost, 2), "conservative_slab_test": 6.0,
+                                             "everything_else_as_written": round(other, 1)},
+                              "algorithmic_as_written": {"flops_per_sample": round(work["flops"], 1), "object_tests_per_sample": round(work["object_tests"], 2),
+                                                         "TFLOPs_if_executed": round(flops_as_written / (trace_ms * 1e-3) / 1e12, 3),
+                                                         "note": "what scene.c:163-173 does: every ray tests every object; the kernel does not execute it"}})
+            else:
+                trace.update({"achieved": round(flops_object_samples / (trace_ms * 1e-3) / 1e12, 3),
+                              "numerator": "as written, the samples of object pixels (sky pixels are finished by rt_primary_pass and never reach this kernel)",
+                              "flops_per_object_sample": round((work["flops"] - work["sky_sample_flops"]) / max(1.0 - work["sky_samples"], 1e-9), 1)})
+            if executed:       # (the instrumented build counts both kernels' work: the culled scene's executed flops are priced against the launch below)
+                trace.pop("achieved", None)
+            if "achieved" in trace:
+                trace["frac"] = round(trace["achieved"] / PEAK_VALU_NOFMA_TFLOPS, 4)
+            iss = simd_issue_estimate(pk.get("rt_trace"), trace_ms)
+            if iss:
+                trace["issue"] = iss
+
+            # -- the camera-ray pass against HBM: what it has to move is 4 B of texel + 12 B of frame per sky pixel, 48 B of record per
+            # object pixel; what it moved is the PMC traffic of the committed passes
+            sky_px = work["sky_samples"] * pixels_per_launch
+            obj_px = pixels_per_launch - sky_px
+            p_bytes = sky_px * (4.0 + 12.0) + obj_px * 48.0
+            primary = {"kernel": "rt_primary_pass", "bound": "hbm", "ms": round(primary_ms, 4), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                       "algorithmic_bytes": round(p_bytes), "algorithmic_GBps": round(p_bytes / max(primary_ms, 1e-6) / 1e6, 2)}
+            pp = pk.get("rt_primary_pass")
+            if pp and "fetch_bytes" in pp and "write_bytes" in pp:
+                moved = pp["fetch_bytes"] + pp["write_bytes"]
+                primary.update({"traffic": round(moved), "achieved": round(moved / max(primary_ms, 1e-6) / 1e6, 2),
+                                "frac": round(moved / max(primary_ms, 1e-6) / 1e6 / PEAK_HBM_GBPS, 4), "achieved_from": "PMC traffic of the committed passes / this run's kernel time"})
+            else:
+                primary.update({"traffic": None, "achieved": primary["algorithmic_GBps"], "frac": round(primary["algorithmic_GBps"] / PEAK_HBM_GBPS, 4),
+                                "achieved_from": "algorithmic bytes / this run's kernel time (no PMC pass committed for this kernel)"})
+
+            # The line's own roofline fields.  Where most samples are traced (C1, C2, the large scenes) they price the LAUNCH -- both kernels'
+            # time against all the flops the reference would spend on the frame (or, culled scenes, the flops executed) -- as every round
+            # before did; where most samples are sky (C3: 97 %, one camera ray per PIXEL and its colour added spp times) a launch-level
+            # flop count is not what the kernels do, and the fields are those of the kernel that takes more of the launch.
+            if work["rays"] < 1.25:
+                dominant = trace if trace_ms >= primary_ms else primary
+            else:
+                num = (trace["executed_flops_per_sample"] if executed else work["flops"]) * samples_per_launch
+                ach = num / (avg_ms * 1e-3) / 1e12
+                dominant = {"bound": "valu", "achieved": round(ach, 3), "peak": round(PEAK_VALU_NOFMA_TFLOPS, 2), "unit": "TFLOP/s",
+                            "frac": round(ach / PEAK_VALU_NOFMA_TFLOPS, 4), "kernel": "rt_primary_pass + " + trace_name}
+                if executed:
+                    dominant["numerator"] = "executed (kernels.trace has the counts and the cost table; algorithmic_as_written beside it)"
+            out["roofline"] = {"bound": dominant["bound"], "achieved": dominant["achieved"], "peak": dominant["peak"], "unit": dominant["unit"], "frac": dominant["frac"],
+                               "kernel": dominant["kernel"], "traffic": None,
+                               "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
+                               "avg_kernel_ms_per_launch_events": round(per_launch_ms / launches, 4),
+                               "avg_kernel_ms_span": round(span_ms / span_launches, 4) if span_launches else None,
+                               "kernels": {"rt_primary_pass": primary, "trace": trace, "times_from": split_from},
+                               "flops_per_sample": round(work["flops"], 1), "rays_per_sample": round(work["rays"], 3),
+                               "object_tests_per_sample": round(work["object_tests"], 2), "rng_draws_per_sample": round(work["rng_draws"], 2),
+                               "sky_samples_share": round(work["sky_samples"], 4),
+                               "note": "two kernels per launch, priced apart (`kernels`); the top-level fields are those of the one that takes more of the "
+                                       "launch.  peak (valu) = fp32 VALU issue rate without FMA (parity forbids contraction) = 157.3/2 TFLOP/s, flops counted "
+                                       "as written in the reference (SURVEY.md 8d) unless `numerator` says executed; peak (hbm) = 8 TB/s.  Kernel times: HIP "
+                                       "events inside the library over the timed region -- first compute unit -> event between the kernels -> end of the "
+                                       "trace kernel (which contains the in-order sample sum); avg_kernel_ms = the smaller of the per-launch sum (overlapping "
+                                       "launches share time) and the span / launches"}
             if tr:
                 out["roofline"]["traffic"] = round(tr["fetch_bytes"] + tr["write_bytes"])
                 out["roofline"]["traffic_note"] = tr.get("source", "")
-            if gather_bound:
-                # A memory-bound line says what was MOVED: `achieved` = the bytes the PMC passes counted between L2 and the fabric
-                # per launch over the measured kernel time.  The algorithmic bytes (one texel per sample) are not moved -- a sky
-                # pixel's spp samples are one fetch (bit-exact: the reference has no sub-pixel jitter, main.c:293-296) -- and go to
-                # a side key.
-                out["roofline"]["algorithmic"] = {"GBps": hbm["achieved"], "frac_of_peak": hbm["frac"], "bytes_per_sample": hbm["bytes_per_sample"],
-                                                  "note": f"3 B per sky fetch + 12 B per pixel, as if every sample fetched its texel; the kernels fetch once per "
-                                                          f"sky pixel and add the value {spp} times in sample order ({spp}x reuse), so these bytes are not traffic"}
-                if tr:
-                    moved = float(tr["fetch_bytes"] + tr["write_bytes"])
-                    out["roofline"].update({"achieved": round(moved / (avg_ms * 1e-3) / 1e9, 3), "frac": round(moved / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
-                                            "achieved_from": "traffic / avg_kernel_ms (PMC bytes of the committed passes, this run's kernel time)"})
-                else:
-                    out["roofline"].update({"achieved": None, "frac": None, "achieved_from": "no PMC pass committed for this config (profiles/pmc_latest.json)"})
-                out["roofline"].pop("bytes_per_sample", None)
-                if tr.get("valu_instructions"):
-                    # The same launch against the ISSUE ceiling of the SIMDs, which is what binds it: VALU instructions per launch
-                    # (committed rocprofv3 PMC pass of this build) x 2 clk per wave64 instruction -- the guide's rate for the
-                    # cheapest class -- over SIMDs x clock x measured time.  Only ~29 % of these instructions carry a flop of the
-                    # reference's count (the rest: compares, selects, min/max, the generator's 64-bit integer products, fp64
-                    # islands), and most of those issue at 4 clk: VALUBusy reads > 100 %.
-                    simds, clock_hz = 256 * 4, 2.4e9
-                    insts = float(tr["valu_instructions"])
-                    out["roofline"]["issue"] = {
-                        "valu_instructions_per_launch": round(insts), "source": "SQ_INSTS_VALU, rocprofv3 PMC pass, profiles/pmc_latest.json",
-                        "frac_of_issue_peak_at_2clk": round(insts * 2.0 / (simds * clock_hz * avg_ms * 1e-3), 4),
-                        "valu_busy_pct": tr.get("valu_busy_pct"), "valu_lane_utilisation_pct": tr.get("valu_lane_utilisation_pct"),
-                        "note": "instructions x 2 clk / (1024 SIMDs x 2.4 GHz x avg_kernel_ms); VALUBusy / VALUUtilization from the same PMC passes"}
+                # the bytes the trace kernel HAS to move: a 4-byte texel per sample that leaves the scene (3 B of it used) and 12 B per pixel
+                t_bytes = 3.0 * work["sky_fetches"] * samples_per_launch + 12.0 * obj_px
+                out["roofline"]["traffic_over_algorithmic"] = round((tr["fetch_bytes"] + tr["write_bytes"]) / max(t_bytes + p_bytes, 1.0), 2)
         # ---- the generic kernel (no hiprtc): same frames, same events
         if native and not multi_path and compiled and not args.no_extras:
             gpu.set_scene(scene_path)                 # drops the compiled kernel

@@ -91,9 +91,10 @@ typedef struct {
 	                             * every tap provably reaches the emitter first (csrc/rt_lit.h; normally answered untraced) */
 	int    test_every_object;   /* testing / measurement aid: scenes of 32 objects and more are rendered without the cluster cull
 	                             * (csrc/rt_cull.h) -- every ray tests every object, as the reference does; same frames, slower */
-	int    audit_known_taps;    /* csrc/rt_lit.h audited in production: k >= 1 -- of the bounces whose soft-shadow taps are answered without
-	                             * tracing, one in 2^k (k = -1: every one) has its taps traced all the same and compared; the frame is
-	                             * unchanged, a disagreement fails the launch (RT_ERR_DEVICE, rt_launch_report.taps_disagreeing).  0: off */
+	int    audit_known_taps;    /* csrc/rt_lit.h audited in production: k >= 1 -- of the answers "these soft-shadow taps need no tracing" (per
+	                             * camera-ray hit point, per cell of the scene's table), one in 2^k (k = -1: every one) is marked: bounces that
+	                             * use a marked answer have their taps traced all the same and compared; the frame is unchanged, a
+	                             * disagreement fails the launch (RT_ERR_DEVICE, rt_launch_report.taps_disagreeing).  0: off */
 	int    test_drop_pixels;    /* TESTING AID: the trace kernel's waves see every pixel list this many entries shorter -- a launch that
 	                             * loses its tail, which every delivering call must then refuse (RT_ERR_DEVICE) */
 	int    test_corrupt_lit_table; /* TESTING AID, read by rt_set_scene(): every cell of the scene's lit-taps table says "certainly lit" --
@@ -396,6 +397,12 @@ RT_API int rt_profile_collect(rt_context *ctx, double *kernel_ms_total, int *lau
 /* the same, plus the time from the first of those launches getting its first compute unit to the end of the last one's
  * trace kernel (no double counting of the time overlapping launches share, but idle time between launches is in it) */
 RT_API int rt_profile_collect_span(rt_context *ctx, double *kernel_ms_total, int *launches, double *span_ms);
+/* the same, plus the part of kernel_ms_total that was the camera-ray pass (rt_primary_pass): first compute unit -> an event
+ * between the two kernels; the rest is the trace kernel.  The two are bound differently (bench.py reports them apart).  That
+ * event is only recorded after rt_profile_enable(ctx, 2) -- it costs a launch about 20 us, so the plain mode (1) leaves it out and
+ * reports 0 here -- and only means something for launches that have the GPU to themselves: a launch that overlaps its
+ * predecessor waits for workgroup slots between its two kernels. */
+RT_API int rt_profile_collect_split(rt_context *ctx, double *kernel_ms_total, int *launches, double *span_ms, double *primary_ms_total);
 
 /* On-GPU self-test of the exact-arithmetic shortcuts the tuned kernel uses (shared-reciprocal
  * division, vector normalisation): compares them bit-for-bit with the plain IEEE forms on

@@ -41,14 +41,21 @@ static void flush_counters(void)
 	g_cnt.samples += tl_cnt.samples;           g_cnt.rays += tl_cnt.rays;
 	g_cnt.object_tests += tl_cnt.object_tests; g_cnt.rng_draws += tl_cnt.rng_draws;
 	g_cnt.sky_fetches += tl_cnt.sky_fetches;   g_cnt.flops += tl_cnt.flops;
+	g_cnt.box_tests += tl_cnt.box_tests;       g_cnt.box_flops += tl_cnt.box_flops;
+	g_cnt.sphere_tests += tl_cnt.sphere_tests; g_cnt.sphere_flops += tl_cnt.sphere_flops;
+	g_cnt.sky_samples += tl_cnt.sky_samples;   g_cnt.sky_sample_flops += tl_cnt.sky_sample_flops;
 	pthread_mutex_unlock(&g_cnt_lock);
 	memset(&tl_cnt, 0, sizeof(tl_cnt));
 }
 void orc_counters_reset(void) { memset(&g_cnt, 0, sizeof(g_cnt)); memset(&tl_cnt, 0, sizeof(tl_cnt)); }
 void orc_counters_get(orc_counters *out) { flush_counters(); *out = g_cnt; }
 int  orc_has_counters(void) { return 1; }
+#define FLOPS_NOW() (tl_cnt.flops)
+#define COUNT_SPAN(tests, flops_field, since) (tl_cnt.tests += 1, tl_cnt.flops_field += tl_cnt.flops - (since))
 #else
 #define COUNT(field, n) ((void) 0)
+#define FLOPS_NOW() ((uint64_t) 0)
+#define COUNT_SPAN(tests, flops_field, since) ((void) (since))
 static void flush_counters(void) {}
 void orc_counters_reset(void) {}
 void orc_counters_get(orc_counters *out) { memset(out, 0, sizeof(*out)); }
@@ -292,12 +299,19 @@ static Hit nearest_hit(Ray ray)
 		const Object *obj = &G.scene.objects[i];
 		COUNT(object_tests, 1);
 		float t; V3 n;
+		const uint64_t before = FLOPS_NOW();
 		if (obj->type == OBJECT_CUBE) {
-			if (!box_entry(o, d, &obj->cube, &t, &n)) continue;
+			const int hit = box_entry(o, d, &obj->cube, &t, &n);
+			COUNT_SPAN(box_tests, box_flops, before);
+			if (!hit) continue;
 		} else if (obj->type == OBJECT_SPHERE) {
-			if (!ball_entry(o, d, &obj->sphere, &t)) continue;
-			V3 p = lin2(o, d, 1, t);                                 /* scene.c:146 */
-			n = unit(lin2(p, obj->sphere.center, 1, -1));            /* scene.c:147: outward, never flipped */
+			const int hit = ball_entry(o, d, &obj->sphere, &t);
+			if (hit) {
+				V3 p = lin2(o, d, 1, t);                             /* scene.c:146 */
+				n = unit(lin2(p, obj->sphere.center, 1, -1));        /* scene.c:147: outward, never flipped */
+			}
+			COUNT_SPAN(sphere_tests, sphere_flops, before);
+			if (!hit) continue;
 		} else
 			continue;
 		if (t >= 0 && t < best.t) { best.t = t; best.normal = n; best.object = i; }
@@ -372,6 +386,8 @@ void orc_sample_cubemap(const float d[3], float out[3])
 static V3 shade_path(float px, float py, float aspect, int max_bounces, uint64_t *state)
 {
 	COUNT(samples, 1);
+	const uint64_t sample_began = FLOPS_NOW();
+	int left_at_once = 0;             /* (counters) the camera ray left the scene: a sky sample */
 	const Scene *sc = &G.scene;
 	Ray ray = primary_ray(px, py, aspect);                           /* main.c:135 */
 
@@ -385,6 +401,7 @@ static V3 shade_path(float px, float py, float aspect, int max_bounces, uint64_t
 	for (int bounce = 0; bounce < max_bounces; bounce++) {
 		Hit hit = nearest_hit(ray);                                  /* main.c:161 */
 		if (hit.object < 0) {
+			left_at_once = bounce == 0;
 			V3 sky = sky_lookup(unit(ray.direction));                /* main.c:170 */
 			radiance = lin2(radiance, hadamard(sky, carry), 1, 1);   /* main.c:171 */
 			break;
@@ -449,6 +466,8 @@ static V3 shade_path(float px, float py, float aspect, int max_bounces, uint64_t
 		}
 		ray = next;
 	}
+	if (left_at_once) COUNT_SPAN(sky_samples, sky_sample_flops, sample_began);
+	(void) sample_began; (void) left_at_once;
 	return v3(clampf(radiance.x, 0, 1), clampf(radiance.y, 0, 1), clampf(radiance.z, 0, 1));
 }
 

@@ -79,7 +79,7 @@ EXPORTS = [
     "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_compiled_scene_info", "rt_compiled_scene_counts", "rt_compiled_scene_cache_cap", "rt_spec_stats_read", "rt_spec_symbol_read", "rt_render", "rt_render_device", "rt_stream", "rt_reserve", "rt_strip_rows", "rt_deinterleave_device", "rt_deinterleave_rotated_device", "rt_strip_of_rank",
     "rt_frame_submit", "rt_frame_submit_device", "rt_frame_wait", "rt_frame_poll", "rt_host_alloc", "rt_host_free",
     "rt_multi_frame_submit_device", "rt_multi_collective_info", "rt_multi_create_on_one_device",
-    "rt_multi_frame_submit", "rt_multi_frame_wait", "rt_multi_frame_poll", "rt_profile_collect_span",
+    "rt_multi_frame_submit", "rt_multi_frame_wait", "rt_multi_frame_poll", "rt_profile_collect_span", "rt_profile_collect_split",
     "rt_progressive_begin_rank", "rt_progressive_resolve_device", "rt_multi_progressive_begin", "rt_multi_progressive_pass", "rt_multi_progressive_passes", "rt_progressive_passes",
     "rt_multi_progressive_resolve", "rt_multi_progressive_invalidate", "rt_multi_progressive_state",
     "rt_synchronize", "rt_cancel", "rt_was_cancelled", "rt_last_launch_counts", "rt_last_launch_report", "rt_launch_check_submit", "rt_launch_check_wait", "rt_primary_passes_run", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
@@ -168,6 +168,8 @@ def lib():
         L.rt_multi_frame_wait.argtypes = [C.c_void_p, C.c_int]
         L.rt_multi_frame_poll.argtypes = [C.c_void_p, C.c_int]
         L.rt_profile_collect_span.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        if hasattr(L, "rt_profile_collect_split"):
+            L.rt_profile_collect_split.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if hasattr(L, "rt_progressive_begin_rank"):
         L.rt_progressive_begin_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int]
         L.rt_progressive_resolve_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -557,12 +559,19 @@ class Renderer(_FrameQueue):
         return rc == 0
 
     def profile(self, on=True):
-        _check(lib().rt_profile_enable(self._ctx, 1 if on else 0), "rt_profile_enable")
+        """on = 2: also time the camera-ray pass apart (profile_collect_split)."""
+        _check(lib().rt_profile_enable(self._ctx, int(on)), "rt_profile_enable")
 
     def profile_collect(self):
         ms, n = C.c_double(), C.c_int()
         _check(lib().rt_profile_collect(self._ctx, C.byref(ms), C.byref(n)), "rt_profile_collect")
         return ms.value, n.value
+
+    def profile_collect_split(self):
+        """(summed per-launch kernel ms, launches, span ms, the part of the first that was the camera-ray pass)"""
+        ms, n, span, prim = C.c_double(), C.c_int(), C.c_double(), C.c_double()
+        _check(lib().rt_profile_collect_split(self._ctx, C.byref(ms), C.byref(n), C.byref(span), C.byref(prim)), "rt_profile_collect_split")
+        return ms.value, n.value, span.value, prim.value
 
     def profile_collect_span(self):
         """(summed per-launch kernel ms, launches, ms from the first launch's start to the end of the last one's trace kernel)"""

@@ -90,6 +90,8 @@ struct rt_context {
 	/* rt_lit.h: which hit points need no soft-shadow tap traced -- one bit per cell of a grid over every object, built
 	 * by rt_set_scene on the host (a few milliseconds) */
 	unsigned char *d_lit_cells = nullptr;
+	std::vector<unsigned char> h_lit_cells;   /* the table as built (values 1 / 2 / 0), for re-marking when the audit setting changes */
+	int          lit_audit_marked = 0;        /* the rt_tuning.audit_known_taps the device's copy is marked for (bit 2 of one cell in 2^k) */
 	void        *d_lit_grids = nullptr;
 	size_t       lit_cells_capacity = 0;
 	int          lit_grids_capacity = 0;
@@ -173,7 +175,9 @@ struct rt_context {
 	std::string  jit_flags;              /* owns tuning.jit_flags */
 
 	bool         profiling = false;
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+	bool         profiling_split = false;   /* rt_profile_enable(ctx, 2): also an event BETWEEN the camera-ray pass and the trace kernel (it costs a launch ~20 us) */
+	struct launch_events { hipEvent_t first, mid, second; };   /* first compute unit; between the camera-ray pass and the trace kernel; end of the trace kernel */
+	std::vector<launch_events> events;
 	std::vector<hipEvent_t> event_pool;
 };
 
@@ -393,7 +397,7 @@ void rt_destroy(rt_context *ctx)
 	if (!ctx) return;
 	(void) hipSetDevice(ctx->device);
 	(void) hipStreamSynchronize(ctx->stream);
-	for (auto &p : ctx->events) { (void) hipEventDestroy(p.first); (void) hipEventDestroy(p.second); }
+	for (auto &p : ctx->events) { (void) hipEventDestroy(p.first); if (p.mid) (void) hipEventDestroy(p.mid); (void) hipEventDestroy(p.second); }
 	for (auto &e : ctx->event_pool) (void) hipEventDestroy(e);
 	for (auto &sl : ctx->slot) {
 		if (sl.used) (void) hipEventSynchronize(sl.done);
@@ -493,6 +497,8 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 				HIP_TRY(hipMalloc(&ctx->d_lit_grids, (size_t) n * sizeof(rt_lit_grid)));
 				ctx->lit_grids_capacity = n;
 			}
+			ctx->h_lit_cells = cells;
+			ctx->lit_audit_marked = 0;                        /* (mark_audited_cells() before the next launch, if the audit is on) */
 			HIP_TRY(hipMemcpy(ctx->d_lit_cells, cells.data(), cells.size(), hipMemcpyHostToDevice));
 			HIP_TRY(hipMemcpy(ctx->d_lit_grids, grids.data(), (size_t) n * sizeof(rt_lit_grid), hipMemcpyHostToDevice));
 			ctx->have_lit = true;
@@ -717,6 +723,25 @@ int rt_reserve(rt_context *ctx, int width, int height)
 	return RT_OK;
 }
 
+/* rt_tuning.audit_known_taps: the scene's lit-taps table carries the audit mark itself -- bit 2 of one answered cell in 2^k,
+ * picked by a hash of the cell's index -- so that the trace kernel needs no launch constant for it (a scalar register through
+ * every round of a kernel at its register limit).  The device's copy is re-marked, between launches, when the setting changed. */
+static int mark_audited_cells(rt_context *ctx)
+{
+	const int k = ctx->tuning.audit_known_taps;
+	if (!ctx->have_lit || ctx->lit_audit_marked == k) return RT_OK;
+	{ const int rc = wait_for_launches(ctx); if (rc != RT_OK) return rc; }       /* launches in flight read the table */
+	std::vector<unsigned char> cells = ctx->h_lit_cells;
+	if (k != 0) {
+		const uint32_t mask = k < 0 ? 0u : (1u << k) - 1u;
+		for (size_t b = 0; b < cells.size(); b++)
+			if (cells[b] && ((uint32_t) ((b * 0x9E3779B97F4A7C15ull) >> 40) & mask) == 0u) cells[b] |= 4u;
+	}
+	HIP_TRY(hipMemcpy(ctx->d_lit_cells, cells.data(), cells.size(), hipMemcpyHostToDevice));
+	ctx->lit_audit_marked = k;
+	return RT_OK;
+}
+
 int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, void *hip_stream)
 {
 	int rc = check_params(ctx, p);
@@ -724,6 +749,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	if (!d_strip) return fail(RT_ERR_ARGUMENT, "rt_render_device: d_strip is NULL");
 	HIP_TRY(hipSetDevice(ctx->device));
 	hipStream_t stream = pick_stream(ctx, hip_stream);
+	{ const int mrc = mark_audited_cells(ctx); if (mrc != RT_OK) return mrc; }
 
 	rt_launch L;
 	memset(&L, 0, sizeof(L));
@@ -761,19 +787,19 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 		const hipError_t pe = hipMemsetAsync(d_strip, 0xff, (size_t) rt_strip_rows(p->height, p->row_block, p->world) * p->width * 3 * sizeof(float), stream);
 		if (pe != hipSuccess) { unpublish_launch(ctx); return fail(RT_ERR_DEVICE, "hipMemsetAsync(poison): %s", hipGetErrorString(pe)); }
 	}
-	hipEvent_t e0 = nullptr, e1 = nullptr;
+	hipEvent_t e0 = nullptr, em = nullptr, e1 = nullptr;
 	if (ctx->profiling) {
-		e0 = take_event(ctx); e1 = take_event(ctx);
-		if (!e0 || !e1) { give_event(ctx, e0); give_event(ctx, e1); unpublish_launch(ctx); return fail(RT_ERR_DEVICE, "rt_render_device: hipEventCreate failed"); }
+		e0 = take_event(ctx); em = ctx->profiling_split ? take_event(ctx) : nullptr; e1 = take_event(ctx);
+		if (!e0 || (!em && ctx->profiling_split) || !e1) { give_event(ctx, e0); give_event(ctx, em); give_event(ctx, e1); unpublish_launch(ctx); return fail(RT_ERR_DEVICE, "rt_render_device: hipEventCreate failed"); }
 	}
 	ctx->slot[ctx->launches & 1u].lists_key = 0;
 	ctx->primary_passes++;
 	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->slot[ctx->launches & 1u].d_counter, e0, ctx->slot[ctx->launches & 1u].started, ctx->num_cus, workgroups_per_cu_for(ctx, stream), stream,
-	                                false, &ctx->slot[ctx->launches & 1u].expect);
+	                                false, &ctx->slot[ctx->launches & 1u].expect, em);
 	if (le == hipSuccess && ctx->profiling) le = hipEventRecord(e1, stream);
 	if (ctx->profiling) {
-		if (le == hipSuccess) ctx->events.emplace_back(e0, e1);
-		else { give_event(ctx, e0); give_event(ctx, e1); }                 /* a failed launch keeps no events */
+		if (le == hipSuccess) ctx->events.push_back({ e0, em, e1 });
+		else { give_event(ctx, e0); give_event(ctx, em); give_event(ctx, e1); }                 /* a failed launch keeps no events */
 	}
 	if (le != hipSuccess) { unpublish_launch(ctx); return fail(RT_ERR_DEVICE, "trace launch: %s", hipGetErrorString(le)); }
 	return mark_launch(ctx, stream);
@@ -1089,6 +1115,7 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 	if (!ctx->have_scene) return fail(RT_ERR_STATE, "render: no scene set (rt_set_scene)");
 	if (!ctx->have_sky)   return fail(RT_ERR_STATE, "render: no skybox set (rt_set_skybox)");
 	HIP_TRY(hipSetDevice(ctx->device));
+	{ const int mrc = mark_audited_cells(ctx); if (mrc != RT_OK) return mrc; }
 	auto &g = ctx->prog;
 	const int s = g.scale;
 	const int lw = g.width / s, lh = g.height / s, lcw = g.width / s + 1;     /* main.c:284-286 */
@@ -1304,6 +1331,7 @@ int rt_profile_enable(rt_context *ctx, int on)
 {
 	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_profile_enable: NULL context");
 	ctx->profiling = on != 0;
+	ctx->profiling_split = on == 2;
 	return RT_OK;
 }
 
@@ -1313,6 +1341,11 @@ int rt_profile_collect(rt_context *ctx, double *kernel_ms_total, int *launches)
 }
 
 int rt_profile_collect_span(rt_context *ctx, double *kernel_ms_total, int *launches, double *span_ms)
+{
+	return rt_profile_collect_split(ctx, kernel_ms_total, launches, span_ms, nullptr);
+}
+
+int rt_profile_collect_split(rt_context *ctx, double *kernel_ms_total, int *launches, double *span_ms, double *primary_ms_total)
 {
 	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_profile_collect: NULL context");
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -1327,14 +1360,17 @@ int rt_profile_collect_span(rt_context *ctx, double *kernel_ms_total, int *launc
 			*span_ms = ms;
 		}
 	}
+	double primary = 0;
 	for (auto &p : ctx->events) {
 		HIP_TRY(hipEventSynchronize(p.second));
-		float ms = 0;
+		float ms = 0, pms = 0;
 		HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
-		total += ms; n++;
-		ctx->event_pool.push_back(p.first); ctx->event_pool.push_back(p.second);
+		if (p.mid) HIP_TRY(hipEventElapsedTime(&pms, p.first, p.mid));
+		total += ms; primary += pms; n++;
+		ctx->event_pool.push_back(p.first); if (p.mid) ctx->event_pool.push_back(p.mid); ctx->event_pool.push_back(p.second);
 	}
 	ctx->events.clear();
+	if (primary_ms_total) *primary_ms_total = primary;
 	if (kernel_ms_total) *kernel_ms_total = total;
 	if (launches) *launches = n;
 	return RT_OK;

@@ -68,13 +68,14 @@ typedef struct {
                                  * a launch whose waves did not all leave has no stamp */
 #define RT_CTL_CANCELLED   1    /* a wave gave up because of rt_cancel(): the frame is incomplete, and meant to be */
 #define RT_CTL_STOP_RELAY  2    /* the request, relayed from the waves that read the host's word to all others */
-#define RT_CTL_WAVES_LEFT  3    /* waves of the trace kernel that have left */
-#define RT_CTL_WRITTEN     4    /* object pixels resolved and written to the frame, summed over the waves as they leave */
+#define RT_CTL_WAVES_LEFT  3    /* by the last wave: waves of the trace kernel that have left (the workgroups count themselves on the lists' dequeue lines) */
+#define RT_CTL_WRITTEN     4    /* by the last wave: object pixels resolved and written to the frame (the workgroups report them on the lists' dequeue lines as they leave) */
 #define RT_CTL_PRIMARY     5    /* by the last wave: 8x8 pixel blocks the camera-ray pass finished (sum over the lists' lines) */
 #define RT_CTL_LISTED      6    /* by the last wave: object pixels the camera-ray pass listed */
 #define RT_CTL_FETCHED     7    /* by the last wave: ... of which the trace kernel's waves fetched */
 #define RT_CTL_AUDITED     8    /* (64 bits) soft-shadow taps answered by rt_lit.h that were traced all the same (rt_launch.audit_taps) */
 #define RT_CTL_DISAGREE    10   /* (64 bits) ... whose trace contradicts the answer */
+#define RT_CTL_LINES_DONE  12   /* dequeue lines whose workgroups have all left: the workgroup that completes the last one is the launch's last */
 #define RT_CTL_WORDS       16
 /* What a launch is expected to leave in those words, kept by the host until they have been copied back and judged. */
 typedef struct {
@@ -126,11 +127,13 @@ typedef struct {
 	 * whose taps are answered without tracing are traced all the same and compared (the frame still uses the answer; a
 	 * disagreement is counted into control[RT_CTL_DISAGREE] and fails the launch on the host) */
 	unsigned int audit_taps;
+	int    trace_workgroups;   /* workgroups of the trace kernel (set by the launcher): the last one to leave stamps the launch */
 	unsigned int test_drop_pixels;   /* TESTING AID (rt_tuning.test_drop_pixels): the trace kernel's waves see every pixel list this many entries shorter */
 	int    skip_known_taps;    /* rt_primary_pass flags the pixels whose bounce-0 taps need no tracing (rt_lit.h); 0: every tap is traced */
 	/* the same answer for hit points of any bounce, from a table built once per scene (rt_lit.h: one entry per cell of a grid
 	 * over every object's bounding box, rt_lit_grid per object); NULL: no table (no sphere emitter, or every tap is traced) */
-	const unsigned char *lit_cells;     /* one byte per cell: 1 = every surface point in it is such a point, 2 = from every one the accepted taps certainly do NOT reach the emitter first */
+	const unsigned char *lit_cells;     /* one byte per cell: 1 = every surface point in it is such a point, 2 = from every one the accepted taps certainly do NOT reach the emitter first;
+	                                     * | 4: the launch audits this cell's answer (the host marks one cell in audit_taps when the audit is on) */
 	const void     *lit_grids;
 	int             lit_grids_in_lds;   /* the trace kernel's workgroups keep a copy of the grids behind the scene records */
 	/* scheduling of the wavefront kernels (any values give the same frame):

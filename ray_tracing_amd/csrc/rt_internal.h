@@ -35,7 +35,8 @@ size_t     rt_pixel_list_capacity(int width, int local_rows, int num_cus, int nu
 hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, hipFunction_t spec_fn,
                            unsigned int *block_counter, hipEvent_t cleared, hipEvent_t primary_done, int num_cus, int workgroups_per_cu, hipStream_t stream,
                            bool reuse_pixel_lists = false,    /* the scratch set still holds rt_primary_pass's output for this very launch */
-                           rt_launch_expect *expect = nullptr);
+                           rt_launch_expect *expect = nullptr,
+                           hipEvent_t primary_timed = nullptr);   /* recorded between the camera-ray pass and the trace kernel (profiling) */
 int        rt_jit_build(const rt_geom *geom, int n, int light_index, const float light_pos[3], int only_light_emits, int waves_per_simd, const char *extra_flags, hipModule_t *module, hipFunction_t *function, std::string &message,
                         std::vector<char> *code_out = nullptr,    /* the code object (development aid) */
                         std::string *compiler = nullptr);         /* where it came from: "embedded, compiled with the library by ..." / "hiprtc x.y at run time" */

@@ -39,13 +39,14 @@
 struct Hit { float t; V3 n; int obj; };
 #define RT_PIX_TAPS_LIT  0x10000     /* flags beside the object index of a pixel record (objects: < 1024): every accepted tap from */
 #define RT_PIX_TAPS_DARK 0x20000     /* the hit point certainly reaches the emitter first / certainly does not (rt_lit.h) */
+#define RT_PIX_TAPS_AUDIT 0x40000    /* ... and the launch audits this pixel's answer: its taps are traced all the same and compared (rt_launch.audit_taps) */
 
 /* Development instrumentation hooks (rt_stats.hip.h: `make stats`, rt_tuning.jit_flags "-DRT_STATS"): nothing in the product build */
 #ifdef RT_STATS
 #include "rt_stats.hip.h"
 #else
 #define STAT(site) do {} while (0)
-#define STAMP_MEMBER
+#define STAMP_LOCAL do {} while (0)
 #define STAMP(k) do {} while (0)
 #define STAMP_DRY do {} while (0)
 #define STAMP_ROUND do {} while (0)
@@ -853,6 +854,9 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 					const int cls = rt_taps_class(reinterpret_cast<const float*>(sc.geom), n, L.light_index, L.light_pos[0], L.light_pos[1], L.light_pos[2],
 					                              L.only_light_emits, obj, a.x, a.y, a.z, nn.x, nn.y, nn.z);
 					known = cls == 1 ? RT_PIX_TAPS_LIT : (cls == 2 ? RT_PIX_TAPS_DARK : 0);
+					/* audited in production: one in audit_taps (a power of two) of the classified pixels, picked by a hash of the pixel and the seed */
+					if (known && L.audit_taps != 0u &&
+					    ((uint32_t) (path_seed(L.seed, (uint32_t) (lr * L.width + i), 0x7a9u) >> 24) & (L.audit_taps - 1u)) == 0u) known |= RT_PIX_TAPS_AUDIT;
 				}
 			} else {
 				const V3 sky = sky_lookup<FAST>(L, dn);                                  /* main.c:170 */
@@ -955,7 +959,11 @@ struct WaveLDS {
 	unsigned int s_drained[WF_STREAMS];/* slots added up and released so far */
 	float s_sum[3][WF_STREAMS];        /* running sum of the pixel being added up */
 	/* what the wave reports when it leaves (RT_CTL_*): object pixels it wrote; audited taps and those whose trace contradicts rt_lit.h */
-	unsigned int n_written, n_audited, n_disagree, pad_;
+	unsigned int n_written, n_audited, n_disagree;
+	/* ... added up per workgroup in the first wave's copy of this struct (g_left: waves of the workgroup that have left): 4 096
+	 * waves reporting to one address each would queue up for 50 us at the end of every launch (an address takes ~88 atomics per
+	 * microsecond); the last wave of a workgroup reports for all of them */
+	unsigned int g_written, g_audited, g_disagree, g_left, pad_;
 };
 
 /* The launch record as the code that takes a new pixel block reads it.  Kernel arguments are invariant, so the
@@ -1006,164 +1014,214 @@ RT_DEV PixelRec load_pixel(rt_launch_cold C, size_t c)
 	return p;
 }
 
-/* Scene-wide constants of a trace kernel: literals in a compiled scene's kernel (no scalar registers, every LDS offset a
- * literal), launch arguments otherwise. */
-template <bool FAST>
-struct SceneConsts {
-#ifdef RT_SPEC_HEADER
-	static constexpr int  n = SPEC_N;
-	static constexpr bool only_light = FAST && SPEC_ONLY_LIGHT_EMITS != 0 && SPEC_LIGHT >= 0;
-	static constexpr bool have_light = SPEC_LIGHT >= 0;
-	static constexpr int  light_obj = SPEC_LIGHT;
-	RT_DEV explicit SceneConsts(const rt_launch &) {}
-	RT_DEV V3 light_pos() const { return mk3(SPEC_LIGHT_POS[0], SPEC_LIGHT_POS[1], SPEC_LIGHT_POS[2]); }
-#else
-	const int  n;
-	const bool only_light, have_light;
-	const int  light_obj;
-	const V3   lp;
-	RT_DEV explicit SceneConsts(const rt_launch &L)
-		: n(L.num_objects), only_light(FAST && L.only_light_emits != 0 && L.light_index >= 0), have_light(L.light_index >= 0),
-		  light_obj(L.light_index), lp(ld3(L.light_pos)) {}
-	RT_DEV V3 light_pos() const { return lp; }
-#endif
-};
+/* The dequeue counters (the trace kernels' second argument) are read from the kernarg segment where they are used -- a pixel
+ * fetch, the end of the launch -- instead of living in two scalar registers through every round: the compiled kernel runs at its
+ * register limit, and a value that the cold ends of the kernel keep alive costs the rounds a spill. */
+typedef __attribute__((address_space(1))) unsigned int *gcounters;
+RT_DEV gcounters counters_of(rt_launch_cold C)
+{
+	typedef const __attribute__((address_space(1))) unsigned long long *gaddr;
+	return (gcounters) *(gaddr) ((const __attribute__((address_space(1))) char *) C + ((sizeof(rt_launch) + 7) & ~(size_t) 7));
+}
 
-/* Per-lane path state.  A path is worked on at two places two rounds apart.  The FRONT (shade) turns the
- * pending hit into the next rays: it owns rng, bounce, the hit and f_slot.  The BACK (retire) does the
- * radiance arithmetic of a bounce (main.c:232,248,257-261) two rounds later, when its shadow taps are certainly
- * traced: it owns rad and carry.  rec1 / rec2 are the records of the bounces the front shaded one and two rounds
- * ago, with their slot words and sky texels.  A slot word is the window slot the sample's colour goes to
- * (| WF_LAST); in direct mode, the pixel's frame offset. */
-struct PathLane {
+/* A wave leaves the launch: it adds what it wrote to the launch's control words, and the LAST wave to leave adds up the
+ * pixel lists -- listed by the camera-ray pass, fetched by the waves -- and stamps the launch with its number.  The host
+ * reads the words behind the launch and delivers the frame only if the stamp is there and the sums agree (rt_api.cpp
+ * judge_launch): every wave left, every listed pixel was fetched, every fetched pixel was written.  The reference publishes a
+ * column whole or not at all (main.c:377-396). */
+template <int BLOCK>
+RT_DEV void leave_launch(WaveLDS *Wp, int wave)
+{
+	WaveLDS &Wv = *Wp;
+	typedef __attribute__((address_space(1))) unsigned int *gwuint;
+	typedef __attribute__((address_space(1))) unsigned long long *gwulong;
+	/* (the lane number is formed here, not handed in: whatever this cold end of the kernel derives from a value that lives through
+	 * the rounds is kept in a register through the rounds -- and the compiled kernel runs at its register limit) */
+	const int lane = (int) __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+	const rt_launch_cold C = cold_view();
+	wave_fence();
+	/* The pixels this wave wrote.  In direct mode (one sample per pixel) the lanes counted them; otherwise nothing was counted in the
+	 * rounds: a stream drains spp slots per pixel, one more for the frame offset that releases the write (section 6), and one more
+	 * for the sums held so far when the launch adds onto them -- so a stream's drained-slot count says how many pixels it completed. */
+	unsigned int wrote = Wv.n_written;
+	if (C->spp != 1) {
+		const unsigned int per_pixel = (unsigned int) C->spp + 1u + (C->sum_onto != nullptr ? 1u : 0u);
+		unsigned int mine = lane < WF_STREAMS ? Wv.s_drained[lane & (WF_STREAMS - 1)] / per_pixel : 0u;
+#pragma unroll
+		for (int m = 1; m < WF_STREAMS; m <<= 1) mine += from_lane(mine, lane ^ m);
+		wrote = mine;
+	}
+	/* the workgroup's waves add up in its first wave's LDS; the last of them to leave reports for the workgroup: 4 096 waves
+	 * reporting to one address each would queue up for 50 us at the end of every launch (an address takes ~88 atomics per us) */
+	WaveLDS &G = Wp[-wave];
+	unsigned int before = 0u;
+	if (lane == 0) {
+		if (wrote) __hip_atomic_fetch_add(&G.g_written, wrote, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (Wv.n_audited) __hip_atomic_fetch_add(&G.g_audited, Wv.n_audited, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (Wv.n_disagree) __hip_atomic_fetch_add(&G.g_disagree, Wv.n_disagree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		before = __hip_atomic_fetch_add(&G.g_left, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+	before = (unsigned int) __builtin_amdgcn_readfirstlane((int) before);
+	if (before + 1u != (unsigned int) (BLOCK / 64)) return;
+	/* ... on the dequeue line of the workgroup's first list (word 1: pixels written, word 2: workgroups that have left): 64 lines share
+	 * the launch's ~1 000 reports; the workgroup that completes a line reports the line, and the one that completes the last line is
+	 * the launch's last */
+	const gcounters block_counter = counters_of(C);
+	const gwuint ctl = (gwuint) C->control;
+	const unsigned int lists = (unsigned int) C->num_shards, groups = (unsigned int) C->trace_workgroups;
+	const unsigned int line = blockIdx.x % lists;
+	const unsigned int on_line = (groups - line + lists - 1u) / lists;             /* workgroups w of the grid with w % lists == line */
+	bool last = false;
+	if (lane == 0) {
+		const unsigned int nw = G.g_written, na = G.g_audited, nd = G.g_disagree;
+		const gwuint mine = (gwuint) block_counter + line * 32u;
+		if (nw) __hip_atomic_fetch_add(mine + 1, nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (na) __hip_atomic_fetch_add((gwulong) (ctl + RT_CTL_AUDITED), (unsigned long long) na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (nd) __hip_atomic_fetch_add((gwulong) (ctl + RT_CTL_DISAGREE), (unsigned long long) nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (__hip_atomic_fetch_add(mine + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == on_line)
+			last = __hip_atomic_fetch_add(ctl + RT_CTL_LINES_DONE, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == (groups < lists ? groups : lists);
+	}
+	if (__ballot(last) == 0ull) return;
+	/* the launch's last workgroup: lane s adds up list s */
+	unsigned int listed = 0u, fetched = 0u, blocks = 0u, written = 0u, left = 0u;
+	if (lane < C->num_shards) {
+		const gwuint fill = (gwuint) C->pix_count + (unsigned int) lane * 32u, taken_at = (gwuint) block_counter + (unsigned int) lane * 32u;
+		listed = __hip_atomic_load(fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		blocks = __hip_atomic_load(fill + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		/* (the dequeue counter counts what was ASKED for, so it passes the fill count at the end of every list: a list whose
+		 * counter stayed below it was not dealt out to the end) */
+		const unsigned int taken = __hip_atomic_load(taken_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		fetched = taken < listed ? taken : listed;
+		written = __hip_atomic_load(taken_at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		left = __hip_atomic_load(taken_at + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+#pragma unroll
+	for (int m = 1; m < 64; m <<= 1) {
+		listed += from_lane(listed, lane ^ m); fetched += from_lane(fetched, lane ^ m);
+		blocks += from_lane(blocks, lane ^ m); written += from_lane(written, lane ^ m); left += from_lane(left, lane ^ m);
+	}
+	if (lane == 0) {
+		ctl[RT_CTL_LISTED] = listed; ctl[RT_CTL_FETCHED] = fetched; ctl[RT_CTL_PRIMARY] = blocks; ctl[RT_CTL_WRITTEN] = written;
+		ctl[RT_CTL_WAVES_LEFT] = left * (unsigned int) (BLOCK / 64);
+		__hip_atomic_store(ctl + RT_CTL_STAMP, C->launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+
+
+template <bool FAST, bool CULL = false, int BLOCK = RT_BLOCK>      /* BLOCK: threads per workgroup (the culled variant also comes with RT_BLOCK_WIDE) */
+RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter_arg)
+{
+	extern __shared__ float4 lds[];
+#ifdef RT_SPEC_HEADER
+	constexpr int n = SPEC_N;              /* the compiled scene's object count: every LDS offset below is a literal */
+#else
+	const int n = L.num_objects;
+#endif
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (CULL ? 2 * n + RT_CLUSTER_MEMBER_F4 * L.num_clusters : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
+	if (threadIdx.x == 0) { W.g_written = 0u; W.g_audited = 0u; W.g_disagree = 0u; W.g_left = 0u; }     /* (ordered before any wave's report at the end by the staging barrier) */
+	const SceneLDS sc = CULL ? stage_geometry(L, lds, n) : stage_scene(L, lds, n);
+	/* the grids of the "taps certainly lit" table (rt_lit.h), when the launcher found room for them: 3 x float4 per object */
+	if (L.lit_grids_in_lds) {
+		const float4 *gsrc = reinterpret_cast<const float4*>(L.lit_grids);
+		for (int i = threadIdx.x; i < 3 * n; i += BLOCK) lds[6 * n + i] = gsrc[i];
+		__syncthreads();
+	}
+	/* (two pointers, not one chosen at run time: a pointer that may be LDS or memory makes every access a flat load with a
+	 * 64-bit address -- ten per bounce ray) */
+	const rt_lit_grid *lit_grids_lds = reinterpret_cast<const rt_lit_grid*>(lds + 6 * n);
+	const rt_lit_grid *lit_grids_mem = reinterpret_cast<const rt_lit_grid*>(L.lit_grids);
+	const bool grids_in_lds = L.lit_grids_in_lds != 0;
+	/* large scenes: the clusters of rt_cull.h behind the scene records (such scenes have no lit-taps table: it needs <= 64 objects) */
+	ClusterLDS cl; cl.members = nullptr; cl.mem = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
+	if (CULL) cl = stage_clusters(L, lds + 2 * n);
+	CullWave *cull_wave = reinterpret_cast<CullWave*>(reinterpret_cast<WaveLDS*>(lds + 2 * n + RT_CLUSTER_MEMBER_F4 * L.num_clusters) + BLOCK / 64) + wave;   /* (CULL) */
+
+	/* rt_launch.sum_onto (several interactive passes in one launch): a pixel's samples are added to what the frame holds so far.
+	 * That value takes the window slot BEFORE the pixel's first sample, as if it were a sample: 0 + value is the value (it is
+	 * >= +0), and section 6 then adds the samples onto it in order; the sum is written as it is. */
+	const bool onto = L.sum_onto != nullptr;
+	const float inv_spp = onto ? 1.0f : 1.0f / (float) L.spp;
+	const unsigned int spp = (unsigned int) L.spp;
+	/* spp == 1 (progressive passes): a pixel is its one sample, nothing has to be ordered -- every lane takes a
+	 * pixel for itself and writes it when the path retires.  Otherwise the wave runs P pixel streams. */
+	const bool direct = L.spp == 1;
+	/* Eight streams of eight lanes.  The lanes of a stream are every second lane of one 16-lane DPP row (streams 2r
+	 * and 2r+1 share row r), so that "the value of the stream's previous lane" is one DPP row_shr:2 -- which hands
+	 * the stream's first lane a zero -- in the in-order sum of section 6. */
+	constexpr int P = WF_STREAMS, G = 64 / P;
+	constexpr unsigned int wn = WF_WINDOW / P;              /* slots per stream */
+	static_assert(P == 8 && G == 8, "the lane layout below is written for 8 streams of 8 lanes");
+	const int g = 2 * (lane >> 4) + (lane & 1);             /* this lane's home stream */
+	const unsigned int j = (unsigned int) (lane & 15) >> 1; /* its place among the stream's lanes */
+	const bool leader = j == 0u;                            /* does the bookkeeping of a stream */
+	const int gshift = (lane & 48) + (lane & 1);            /* position of the stream's first lane */
+	const unsigned long long gmask = 0x5555ull << gshift;
+#ifdef RT_SPEC_HEADER
+	constexpr bool only_light = FAST && SPEC_ONLY_LIGHT_EMITS != 0 && SPEC_LIGHT >= 0;
+	const bool have_light = SPEC_LIGHT >= 0;               /* the compiled scene's emitter: literals, no scalar registers */
+	const V3 light_pos = mk3(SPEC_LIGHT_POS[0], SPEC_LIGHT_POS[1], SPEC_LIGHT_POS[2]);
+	const int light_obj = SPEC_LIGHT;
+#else
+	const bool only_light = FAST && L.only_light_emits != 0 && L.light_index >= 0;
+	const V3 light_pos = ld3(L.light_pos);
+	const bool have_light = L.light_index >= 0;
+	const int light_obj = L.light_index;
+#endif
+
+	for (int k = lane; k < WF_WINDOW; k += 64) W.win[0][k] = __uint_as_float(WF_EMPTY);
+	if (lane < WF_STREAMS) {
+		W.s_nxt[lane] = spp; W.s_seq[lane] = 0u; W.s_drained[lane] = 0u;
+		W.s_sum[0][lane] = 0.0f; W.s_sum[1][lane] = 0.0f; W.s_sum[2][lane] = 0.0f;
+	}
+	if (lane == 0) { W.n_written = 0u; W.n_audited = 0u; W.n_disagree = 0u; }
+	wave_fence();
+
+	/* wave-uniform pixel supply: object pixels are dealt from the lists rt_primary_pass filled, each with its own
+	 * dequeue counter on its own 128-byte line (one counter saturates at ~88 dequeues/us, MI355X_MICROARCH.md).  A
+	 * wave starts at the list of its workgroup and moves on to the next one when a list has run out. */
+	unsigned int shard = blockIdx.x % (unsigned int) L.num_shards;
+	bool exhausted = false;                 /* no pixels left to fetch */
+	bool cancelled = false;                 /* rt_cancel(): nothing more is handed out, the paths in flight finish, the wave leaves */
+
+	/* per-lane path state.  A path is worked on at two places two rounds apart.  The FRONT (section 2) turns the
+	 * pending hit into the next rays: it owns rng, bounce, the hit and f_slot.  The BACK (section 5) does the
+	 * radiance arithmetic of a bounce (main.c:232,248,257-261) two rounds later, when its shadow taps are certainly
+	 * traced: it owns rad and carry.  rec1 / rec2 are the records of the bounces the front shaded one and two rounds
+	 * ago, with their slot words and sky texels.  A slot word is the window slot the sample's colour goes to
+	 * (| WF_LAST); in direct mode, the pixel's frame offset. */
 	bool  f_live = false;                   /* the front is on a sample */
 	int   f_slot = 0, slot1 = 0, slot2 = 0;
 	int   bounce = 0;
 	bool  has_hit = false;
-	V3    carry = { 1, 1, 1 }, rad = { 0, 0, 0 };
-	V3    hp = { 0, 0, 0 }, hn = { 0, 0, 0 }, hdir = { 0, 0, 0 };
+	V3    carry = mk3(1, 1, 1), rad = mk3(0, 0, 0);
+	V3    hp = mk3(0, 0, 0), hn = mk3(0, 0, 0), hdir = mk3(0, 0, 0);
 	uint32_t sky1 = 0, sky2 = 0;            /* sky texel that ends the sample of rec1 / rec2 (REC_SKY): fetched when the bounce ray
 	                                         * is found to have left the scene, converted two rounds later when it is used */
 	int   hobj = -1;
 	uint32_t lit_next = 0;                  /* != 0: the taps from the pending hit point certainly reach the emitter, none is traced (rt_lit.h) */
 	int   rec1 = 0, rec2 = 0;               /* REC_* | tapmask << 4 | object << 8 of the bounces shaded one and two rounds ago */
 	uint64_t rng = 0;
-};
-
-/* what the front of one round hands to the tap queue, the bounce trace and the back of the same round */
-struct RoundOut {
-	int  tapmask = 0, cur = 0;
-	bool emit_main = false;
-	V3   ray_o = { 0, 0, 0 }, ray_d = { 0, 0, 0 };
-	V3   tap_j0 = { 0, 0, 0 }, tap_j1 = { 0, 0, 0 }, tap_j2 = { 0, 0, 0 };   /* accepted rand_dir of each tap (main.c:193) */
-};
-
-/* One wave of a trace kernel: the six sections of a round as member functions over the wave's state.
- * BLOCK: threads per workgroup (the culled variant also comes with RT_BLOCK_WIDE). */
-template <bool FAST, bool CULL = false, int BLOCK = RT_BLOCK>
-struct Wavefront {
-	/* Eight streams of eight lanes.  The lanes of a stream are every second lane of one 16-lane DPP row (streams 2r
-	 * and 2r+1 share row r), so that "the value of the stream's previous lane" is one DPP row_shr:2 -- which hands
-	 * the stream's first lane a zero -- in the in-order sum of section 6. */
-	static constexpr int P = WF_STREAMS, G = 64 / P;
-	static constexpr unsigned int wn = WF_WINDOW / P;              /* slots per stream */
-	static_assert(P == 8 && G == 8, "the lane layout below is written for 8 streams of 8 lanes");
-
-	const rt_launch &L;
-	unsigned int *const block_counter;
-	const SceneConsts<FAST> K;
-	SceneLDS sc;
-	ClusterLDS cl;
-	CullWave *cull_wave;
-	WaveLDS *Wp;
-	bool grids_in_lds;
-	int  wave, lane;
-	int  g;                                 /* this lane's home stream */
-	unsigned int j;                         /* its place among the stream's lanes */
-	bool leader;                            /* does the bookkeeping of a stream */
-	int  gshift;                            /* position of the stream's first lane */
-	unsigned long long gmask;
-	/* rt_launch.sum_onto (several interactive passes in one launch): a pixel's samples are added to what the frame holds so far.
-	 * That value takes the window slot BEFORE the pixel's first sample, as if it were a sample: 0 + value is the value (it is
-	 * >= +0), and section 6 then adds the samples onto it in order; the sum is written as it is. */
-	bool  onto;
-	float inv_spp;
-	unsigned int spp;
-	/* spp == 1 (progressive passes): a pixel is its one sample, nothing has to be ordered -- every lane takes a
-	 * pixel for itself and writes it when the path retires.  Otherwise the wave runs P pixel streams. */
-	bool  direct;
-
-	/* wave-uniform pixel supply: object pixels are dealt from the lists rt_primary_pass filled, each with its own
-	 * dequeue counter on its own 128-byte line (one counter saturates at ~88 dequeues/us, MI355X_MICROARCH.md).  A
-	 * wave starts at the list of its workgroup and moves on to the next one when a list has run out. */
-	unsigned int shard;
-	bool exhausted = false;                 /* no pixels left to fetch */
-	bool cancelled = false;                 /* rt_cancel(): nothing more is handed out, the paths in flight finish, the wave leaves */
 	/* the tap queue persists across rounds: taps that do not fill a batch wait, at most two rounds */
 	unsigned int q_head = 0, q_tail = 0, phase = 0;     /* phase = round number mod 3 */
-	unsigned int sum_tick = 0, sum_every;
+	unsigned int sum_tick = 0;
+	const unsigned int sum_every = L.spp >= 32 ? WF_SUM_EVERY : 1u;
 
-	PathLane p;
-	STAMP_MEMBER
-
-	RT_DEV WaveLDS &W() const { return *Wp; }
-
-	RT_DEV Wavefront(const rt_launch &L_, unsigned int *block_counter_) : L(L_), block_counter(block_counter_), K(L_)
-	{
-		extern __shared__ float4 lds[];
-		const int n = K.n;
-		sc = CULL ? stage_geometry(L, lds, n) : stage_scene(L, lds, n);
-		wave = threadIdx.x >> 6; lane = threadIdx.x & 63;
-		/* the grids of the "taps certainly lit" table (rt_lit.h), when the launcher found room for them: 3 x float4 per object */
-		if (L.lit_grids_in_lds) {
-			const float4 *gsrc = reinterpret_cast<const float4*>(L.lit_grids);
-			for (int i = threadIdx.x; i < 3 * n; i += BLOCK) lds[6 * n + i] = gsrc[i];
-			__syncthreads();
-		}
-		grids_in_lds = L.lit_grids_in_lds != 0;
-		/* large scenes: the clusters of rt_cull.h behind the scene records (such scenes have no lit-taps table: it needs <= 64 objects) */
-		cl.members = nullptr; cl.mem = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
-		if (CULL) cl = stage_clusters(L, lds + 2 * n);
-		Wp = &reinterpret_cast<WaveLDS*>(lds + (CULL ? 2 * n + RT_CLUSTER_MEMBER_F4 * L.num_clusters : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
-		cull_wave = reinterpret_cast<CullWave*>(reinterpret_cast<WaveLDS*>(lds + 2 * n + RT_CLUSTER_MEMBER_F4 * L.num_clusters) + BLOCK / 64) + wave;   /* (CULL) */
-
-		onto = L.sum_onto != nullptr;
-		inv_spp = onto ? 1.0f : 1.0f / (float) L.spp;
-		spp = (unsigned int) L.spp;
-		direct = L.spp == 1;
-		g = 2 * (lane >> 4) + (lane & 1);
-		j = (unsigned int) (lane & 15) >> 1;
-		leader = j == 0u;
-		gshift = (lane & 48) + (lane & 1);
-		gmask = 0x5555ull << gshift;
-
-		for (int k = lane; k < WF_WINDOW; k += 64) W().win[0][k] = __uint_as_float(WF_EMPTY);
-		if (lane < WF_STREAMS) {
-			W().s_nxt[lane] = spp; W().s_seq[lane] = 0u; W().s_drained[lane] = 0u;
-			W().s_sum[0][lane] = 0.0f; W().s_sum[1][lane] = 0.0f; W().s_sum[2][lane] = 0.0f;
-		}
-		if (lane == 0) { W().n_written = 0u; W().n_audited = 0u; W().n_disagree = 0u; }
-		wave_fence();
-		shard = blockIdx.x % (unsigned int) L.num_shards;
-		sum_every = L.spp >= 32 ? WF_SUM_EVERY : 1u;
-	}
-
-	/* ---- 6. adding the finished samples in sample order (main.c:394).  Lane j of a stream looks at
+	/* Section 6 of a round: adding the finished samples in sample order (main.c:394).  Lane j of a stream looks at
 	 * the j-th slot after the stream's last added one.  The slots that are filled without a gap from the first form
 	 * the run (it ends behind the first pixel that is completed in it); their colours are added to the stream's
 	 * running sum one after the other -- lane j's partial sum is lane j-1's plus its own colour, handed on with DPP
 	 * row shifts, all eight streams in lockstep -- and a pixel whose last sample is in the run is resolved
 	 * (main.c:476) and written to the frame.  Every lane of the wave must be active. */
-	RT_DEV void add_finished_samples()
-	{
+	auto add_finished_samples = [&]() {
 		bool again;
 		do {
 			STAT(23);
-			const unsigned int d = W().s_drained[g], seq = W().s_seq[g];
+			const unsigned int d = W.s_drained[g], seq = W.s_seq[g];
 			const unsigned int slot = d + j;
 			const unsigned int e = (unsigned int) g * wn + (slot % wn);
 			uint32_t xb = WF_EMPTY;
-			if ((int) (seq - slot) > 0) xb = __float_as_uint(W().win[0][e]);
+			if ((int) (seq - slot) > 0) xb = __float_as_uint(W.win[0][e]);
 			const bool filled = xb != WF_EMPTY;
 			const unsigned long long fm = __ballot(filled);
 			const unsigned long long lm = __ballot(filled && (xb >> 31) != 0u);      /* last samples of their pixels */
@@ -1177,8 +1235,8 @@ struct Wavefront {
 			const bool active = (int) j < k;
 			const bool offset_slot = boundary && (int) j == lastpos + 1 && active;
 			V3 c = mk3(0, 0, 0);
-			if (active && !offset_slot) c = mk3(__uint_as_float(xb & 0x7fffffffu), W().win[1][e], W().win[2][e]);
-			if (leader) c = add3(mk3(W().s_sum[0][g], W().s_sum[1][g], W().s_sum[2][g]), c);   /* the running sum enters at the first lane */
+			if (active && !offset_slot) c = mk3(__uint_as_float(xb & 0x7fffffffu), W.win[1][e], W.win[2][e]);
+			if (leader) c = add3(mk3(W.s_sum[0][g], W.s_sum[1][g], W.s_sum[2][g]), c);   /* the running sum enters at the first lane */
 			V3 sum = c;
 #pragma unroll
 			for (int t = 1; t < G; t++)             /* after step t lanes j <= t hold their final partial sums */
@@ -1186,55 +1244,150 @@ struct Wavefront {
 			if (offset_slot) {                  /* the pixel is complete: resolve and write it (main.c:476); this lane's own colour was zero */
 				const V3 res = scale3(sum, inv_spp);
 				float *dst = L.frame + (size_t) xb * 3;
-				dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
-				__hip_atomic_fetch_add(&W().n_written, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;      /* (counted when the wave leaves: a pixel is spp + 1 drained slots of its stream) */
 			}
-			if (active) W().win[0][e] = __uint_as_float(WF_EMPTY);
+			if (active) W.win[0][e] = __uint_as_float(WF_EMPTY);
 			if (active && (int) j == k - 1) {
-				W().s_drained[g] = d + (unsigned int) k;
-				W().s_sum[0][g] = offset_slot ? 0.0f : sum.x; W().s_sum[1][g] = offset_slot ? 0.0f : sum.y; W().s_sum[2][g] = offset_slot ? 0.0f : sum.z;
+				W.s_drained[g] = d + (unsigned int) k;
+				W.s_sum[0][g] = offset_slot ? 0.0f : sum.x; W.s_sum[1][g] = offset_slot ? 0.0f : sum.y; W.s_sum[2][g] = offset_slot ? 0.0f : sum.z;
 			}
 			/* more may be waiting behind the run; it can wait for the next round unless the window is filling up */
 			again = __ballot(k > 0 && (k == G || boundary) && seq - (d + (unsigned int) k) > 3u * wn / 4u) != 0ull;
 			wave_fence();
 		} while (again);
-	}
+	};
 
-	/* ---- 1. sample supply ---------------------------------------------------------------
-	 * Lanes whose front is free take new samples.  A lane asks its home stream first and, in the following
-	 * attempts, the streams next to it (stream (g + attempt) mod P is asked by exactly one group of lanes per
-	 * attempt, so the group's leader lane does that stream's bookkeeping).  A stream hands out the samples of
-	 * its pixel in order, each with the next slot of the stream's window; when the pixel has none left the
-	 * stream takes the next object pixel of the wave's work item. */
-	RT_DEV void supply_samples()
-	{
+	/* `taps` taps whose answer rt_lit.h gave were traced all the same; `wrong` of them contradict it */
+	auto audit_taps = [&](int taps, int wrong) {
+		__hip_atomic_fetch_add(&W.n_audited, (unsigned int) taps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+		if (wrong) __hip_atomic_fetch_add(&W.n_disagree, (unsigned int) wrong, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+	};
+
+	STAMP_LOCAL;
+	for (;; phase = phase == 2u ? 0u : phase + 1u) {
+		STAMP(7);
+		STAMP_ROUND;
+		/* ---- 1. sample supply ---------------------------------------------------------------
+		 * Lanes whose front is free take new samples.  A lane asks its home stream first and, in the following
+		 * attempts, the streams next to it (stream (g + attempt) mod P is asked by exactly one group of lanes per
+		 * attempt, so the group's leader lane does that stream's bookkeeping).  A stream hands out the samples of
+		 * its pixel in order, each with the next slot of the stream's window; when the pixel has none left the
+		 * stream takes the next object pixel of the wave's work item. */
 #pragma unroll 1
 		for (int attempt = 0; attempt < P; attempt++) {
-			const bool want = !p.f_live;
+			const bool want = !f_live;
 			const unsigned long long wmask = __ballot(want);
 			if (wmask == 0ull || cancelled) break;
 			/* the lists have run out: go on only while some stream still has samples (and slots) to give */
 			if (exhausted && (direct || (attempt > 0 &&
-			    __ballot(leader && W().s_nxt[g] < spp && W().s_seq[g] - W().s_drained[g] < wn - 1u) == 0ull))) break;
+			    __ballot(leader && W.s_nxt[g] < spp && W.s_seq[g] - W.s_drained[g] < wn - 1u) == 0ull))) break;
 			const int sg = (g + attempt) & (P - 1);
 			const unsigned long long gm = wmask & gmask;              /* wanting lanes of my group */
 			STAT(20);
 			unsigned int nxt = 0;
 			bool need_pixel = want;
 			if (!direct) {
-				nxt = W().s_nxt[sg];
+				nxt = W.s_nxt[sg];
 				need_pixel = leader && gm != 0ull && nxt >= spp;
-				if (onto) need_pixel = need_pixel && W().s_seq[sg] - W().s_drained[sg] < wn - 1u;      /* (the slot for what the frame holds so far) */
+				if (onto) need_pixel = need_pixel && W.s_seq[sg] - W.s_drained[sg] < wn - 1u;      /* (the slot for what the frame holds so far) */
 			}
 			const unsigned long long nmask = __ballot(need_pixel);
 			STAMP(0);
 			if (nmask != 0ull) {
-				fetch_pixels(need_pixel, nmask, sg);
+				STAT(21);
+				const rt_launch_cold C = cold_view();
+#ifdef RT_X_NOFETCHX
+				const gcounters block_counter = (gcounters) block_counter_arg;
+#else
+				const gcounters block_counter = counters_of(C);
+#endif
+				const int asked = __popcll(nmask);
+				int got = 0;
+				size_t first = 0;
+				if (!exhausted) {
+					typedef const __attribute__((address_space(1))) unsigned int *guint;
+					typedef __attribute__((address_space(1))) unsigned int *gwuint;
+					/* rt_cancel() (main.c:316-317: the frame has been invalidated).  The host stores its request in a word of host
+					 * memory: "the launches up to this number are to stop".  Reading that is slow (a read over the link takes the
+					 * place of 75 ns of everybody else's: 4 096 waves asking at once cost a strip a third of its time), so only eight
+					 * waves of the launch do, when they fetch pixels, and pass the news on through control[2] in device memory, which
+					 * every other wave reads when it fetches pixels.  Told to stop, a wave hands out nothing more, lets the paths in
+					 * flight finish and leaves; the launch is marked incomplete.  (A wave that has no pixels left to fetch does not
+					 * ask any more: it is about to leave anyway.) */
+					unsigned int word = 0u, k = 0u;
+					if (lane == 0) {
+						word = (blockIdx.x < 8u && wave == 0) ? __hip_atomic_load((guint) C->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - C->launch_id
+						                                      : __hip_atomic_load((guint) C->control + RT_CTL_STOP_RELAY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
+						k = __hip_atomic_fetch_add(block_counter + shard * 32u, (unsigned int) asked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
+					k = (unsigned int) __builtin_amdgcn_readfirstlane((int) k);
+					if ((int) __builtin_amdgcn_readfirstlane((int) word) >= 0) {      /* the request covers this launch / another wave has seen it */
+						cancelled = true;
+						if (lane == 0) { C->control[RT_CTL_CANCELLED] = 1u; __hip_atomic_store((gwuint) C->control + RT_CTL_STOP_RELAY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+					}
+					const guint fill_counts = (guint) C->pix_count;
+#ifdef RT_X_NOFETCHX
+					const unsigned int drop = 0u;
+#else
+					const unsigned int drop = C->test_drop_pixels;          /* (testing aid: 0 in production) */
+#endif
+					unsigned int filled = (unsigned int) __builtin_amdgcn_readfirstlane((int) fill_counts[shard * 32u]);
+					filled -= filled < drop ? filled : drop;
+					got = k < filled && !cancelled ? (filled - k < (unsigned int) asked ? (int) (filled - k) : asked) : 0;
+					first = (size_t) shard * (size_t) C->pix_shard_cap + k;
+					if (got < asked) {
+						/* This list has run out: look at all of them at once (lane s reads list s's two counters; a stale
+						 * dequeue count can only show more pixels left than there are, never fewer) and move to the next
+						 * one that still has pixels.  None: the launch has no pixels left to hand out. */
+						unsigned int left = 0, taken = 0;
+						if (lane < C->num_shards) {
+							taken = __hip_atomic_load(block_counter + (unsigned int) lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							unsigned int have = fill_counts[(unsigned int) lane * 32u];
+							have -= have < drop ? have : drop;
+							left = have > taken ? have - taken : 0u;
+						}
+						const unsigned long long some = __ballot(left != 0u);
+						if (some == 0ull || cancelled) { exhausted = true; STAMP_DRY; }
+						else {      /* the waves spread over the lists that are left (one address takes ~88 atomics per microsecond) */
+							const int pick = (int) ((blockIdx.x * (BLOCK / 64) + (unsigned int) wave) % (unsigned int) __popcll(some));
+							shard = (unsigned int) __builtin_ctzll(__ballot(left != 0u && lanes_below(some) == pick));
+						}
+					}
+				}
+				const int rr = lanes_below(nmask);
+				if (need_pixel && rr < got) {
+					const PixelRec px = load_pixel(C, first + (size_t) rr);
+					if (direct) {
+						f_slot = px.off; f_live = true;
+						rng = (uint64_t) px.index;                /* (pixel index, sample 0): seeded where the sample is first shaded (section 2) */
+						bounce = 0;
+						hp = px.a; hn = px.n; hobj = px.obj & (RT_PIX_TAPS_LIT - 1); hdir = px.dir;
+						lit_next = ((uint32_t) px.obj >> 16) & 7u;
+						has_hit = true;
+					} else {
+						W.rec[0][sg] = px.a.x;   W.rec[1][sg] = px.a.y;   W.rec[2][sg] = px.a.z;
+						W.rec[3][sg] = px.n.x;   W.rec[4][sg] = px.n.y;   W.rec[5][sg] = px.n.z;
+						W.rec[6][sg] = __int_as_float(px.obj);
+						W.rec[7][sg] = px.dir.x; W.rec[8][sg] = px.dir.y; W.rec[9][sg] = px.dir.z;
+						W.rec[10][sg] = __uint_as_float(px.index);
+						W.rec[11][sg] = __int_as_float(px.off);
+						W.s_nxt[sg] = 0u;
+						if (onto) {
+							typedef const __attribute__((address_space(1))) float *gfloat;
+							const gfloat held = (gfloat) C->sum_onto + (size_t) px.off * 3;
+							const unsigned int sq = W.s_seq[sg], e = (unsigned int) sg * wn + sq % wn;
+							W.win[1][e] = held[1]; W.win[2][e] = held[2];
+							W.win[0][e] = held[0];
+							W.s_seq[sg] = sq + 1u;
+						}
+					}
+				}
+				wave_fence();
 				STAMP(5);
 			}
 			if (!direct) {
-				nxt = W().s_nxt[sg];
-				const unsigned int seq = W().s_seq[sg], drained = W().s_drained[sg];
+				nxt = W.s_nxt[sg];
+				const unsigned int seq = W.s_seq[sg], drained = W.s_drained[sg];
 				/* samples the pixel still has, and slots free in the stream's window (one is kept back for the
 				 * frame-offset slot that follows a pixel's last sample) */
 				const int left = (int) spp - (int) nxt, room = (int) wn - 1 - (int) (seq - drained);
@@ -1244,260 +1397,187 @@ struct Wavefront {
 					STAT(22);
 					const unsigned int s = nxt + (unsigned int) r, slot = seq + (unsigned int) r;
 					const bool last = s + 1u == spp;
-					p.f_slot = (int) ((unsigned int) sg * wn + (slot % wn)) | (last ? WF_LAST : 0);
-					if (last) W().win[0][(unsigned int) sg * wn + ((slot + 1u) % wn)] = W().rec[11][sg];
-					p.rng = ((uint64_t) s << 32) | (uint64_t) __float_as_uint(W().rec[10][sg]);   /* (pixel index, sample): seeded where the sample is first shaded (section 2) */
-					p.bounce = 0;
-					p.hp = mk3(W().rec[0][sg], W().rec[1][sg], W().rec[2][sg]);
-					p.hn = mk3(W().rec[3][sg], W().rec[4][sg], W().rec[5][sg]);
-					p.hobj = __float_as_int(W().rec[6][sg]) & (RT_PIX_TAPS_LIT - 1);
-					p.lit_next = (__float_as_uint(W().rec[6][sg]) >> 16) & 3u;
-					p.hdir = mk3(W().rec[7][sg], W().rec[8][sg], W().rec[9][sg]);
-					p.has_hit = true; p.f_live = true;
+					f_slot = (int) ((unsigned int) sg * wn + (slot % wn)) | (last ? WF_LAST : 0);
+					if (last) W.win[0][(unsigned int) sg * wn + ((slot + 1u) % wn)] = W.rec[11][sg];
+					rng = ((uint64_t) s << 32) | (uint64_t) __float_as_uint(W.rec[10][sg]);   /* (pixel index, sample): seeded where the sample is first shaded (section 2) */
+					bounce = 0;
+					hp = mk3(W.rec[0][sg], W.rec[1][sg], W.rec[2][sg]);
+					hn = mk3(W.rec[3][sg], W.rec[4][sg], W.rec[5][sg]);
+					hobj = __float_as_int(W.rec[6][sg]) & (RT_PIX_TAPS_LIT - 1);
+					lit_next = (__float_as_uint(W.rec[6][sg]) >> 16) & 7u;
+					hdir = mk3(W.rec[7][sg], W.rec[8][sg], W.rec[9][sg]);
+					has_hit = true; f_live = true;
 				}
 				if (leader && gm != 0ull && avail > 0) {
 					const int asked = __popcll(gm);
 					const unsigned int handed = (unsigned int) (asked < avail ? asked : avail);
-					W().s_nxt[sg] = nxt + handed;
-					W().s_seq[sg] = seq + handed + (nxt + handed == spp ? 1u : 0u);
+					W.s_nxt[sg] = nxt + handed;
+					W.s_seq[sg] = seq + handed + (nxt + handed == spp ? 1u : 0u);
 				}
 				wave_fence();
 				STAMP(6);
 			}
 		}
-	}
-
-	/* the lanes of `nmask` (need_pixel) take the next object pixels of the wave's list: for themselves (direct) or for
-	 * stream `sg`, whose bookkeeping they do */
-	RT_DEV void fetch_pixels(bool need_pixel, unsigned long long nmask, int sg)
-	{
-		STAT(21);
-		const rt_launch_cold C = cold_view();
-		const int asked = __popcll(nmask);
-		int got = 0;
-		size_t first = 0;
-		if (!exhausted) {
-			typedef const __attribute__((address_space(1))) unsigned int *guint;
-			typedef __attribute__((address_space(1))) unsigned int *gwuint;
-			/* rt_cancel() (main.c:316-317: the frame has been invalidated).  The host stores its request in a word of host
-			 * memory: "the launches up to this number are to stop".  Reading that is slow (a read over the link takes the
-			 * place of 75 ns of everybody else's: 4 096 waves asking at once cost a strip a third of its time), so only eight
-			 * waves of the launch do, when they fetch pixels, and pass the news on through control[2] in device memory, which
-			 * every other wave reads when it fetches pixels.  Told to stop, a wave hands out nothing more, lets the paths in
-			 * flight finish and leaves; the launch is marked incomplete.  (A wave that has no pixels left to fetch does not
-			 * ask any more: it is about to leave anyway.) */
-			unsigned int word = 0u, k = 0u;
-			if (lane == 0) {
-				word = (blockIdx.x < 8u && wave == 0) ? __hip_atomic_load((guint) C->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - C->launch_id
-				                                      : __hip_atomic_load((guint) C->control + RT_CTL_STOP_RELAY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
-				k = atomicAdd(block_counter + shard * 32u, (unsigned int) asked);
-			}
-			k = (unsigned int) __builtin_amdgcn_readfirstlane((int) k);
-			if ((int) __builtin_amdgcn_readfirstlane((int) word) >= 0) {      /* the request covers this launch / another wave has seen it */
-				cancelled = true;
-				if (lane == 0) { C->control[RT_CTL_CANCELLED] = 1u; __hip_atomic_store((gwuint) C->control + RT_CTL_STOP_RELAY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-			}
-			const guint fill_counts = (guint) C->pix_count;
-			const unsigned int drop = C->test_drop_pixels;          /* (testing aid: 0 in production) */
-			unsigned int filled = (unsigned int) __builtin_amdgcn_readfirstlane((int) fill_counts[shard * 32u]);
-			filled -= filled < drop ? filled : drop;
-			got = k < filled && !cancelled ? (filled - k < (unsigned int) asked ? (int) (filled - k) : asked) : 0;
-			first = (size_t) shard * (size_t) C->pix_shard_cap + k;
-			if (got < asked) {
-				/* This list has run out: look at all of them at once (lane s reads list s's two counters; a stale
-				 * dequeue count can only show more pixels left than there are, never fewer) and move to the next
-				 * one that still has pixels.  None: the launch has no pixels left to hand out. */
-				unsigned int left = 0, taken = 0;
-				if (lane < C->num_shards) {
-					taken = __hip_atomic_load(block_counter + (unsigned int) lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					unsigned int have = fill_counts[(unsigned int) lane * 32u];
-					have -= have < drop ? have : drop;
-					left = have > taken ? have - taken : 0u;
-				}
-				const unsigned long long some = __ballot(left != 0u);
-				if (some == 0ull || cancelled) { exhausted = true; STAMP_DRY; }
-				else {      /* the waves spread over the lists that are left (one address takes ~88 atomics per microsecond) */
-					const int pick = (int) ((blockIdx.x * (BLOCK / 64) + (unsigned int) wave) % (unsigned int) __popcll(some));
-					shard = (unsigned int) __builtin_ctzll(__ballot(left != 0u && lanes_below(some) == pick));
-				}
-			}
-		}
-		const int rr = lanes_below(nmask);
-		if (need_pixel && rr < got) {
-			const PixelRec px = load_pixel(C, first + (size_t) rr);
-			if (direct) {
-				p.f_slot = px.off; p.f_live = true;
-				p.rng = (uint64_t) px.index;                /* (pixel index, sample 0): seeded where the sample is first shaded (section 2) */
-				p.bounce = 0;
-				p.hp = px.a; p.hn = px.n; p.hobj = px.obj & (RT_PIX_TAPS_LIT - 1); p.hdir = px.dir;
-				p.lit_next = ((uint32_t) px.obj >> 16) & 3u;
-				p.has_hit = true;
-			} else {
-				W().rec[0][sg] = px.a.x;   W().rec[1][sg] = px.a.y;   W().rec[2][sg] = px.a.z;
-				W().rec[3][sg] = px.n.x;   W().rec[4][sg] = px.n.y;   W().rec[5][sg] = px.n.z;
-				W().rec[6][sg] = __int_as_float(px.obj);
-				W().rec[7][sg] = px.dir.x; W().rec[8][sg] = px.dir.y; W().rec[9][sg] = px.dir.z;
-				W().rec[10][sg] = __uint_as_float(px.index);
-				W().rec[11][sg] = __int_as_float(px.off);
-				W().s_nxt[sg] = 0u;
-				if (onto) {
-					typedef const __attribute__((address_space(1))) float *gfloat;
-					const gfloat held = (gfloat) C->sum_onto + (size_t) px.off * 3;
-					const unsigned int sq = W().s_seq[sg], e = (unsigned int) sg * wn + sq % wn;
-					W().win[1][e] = held[1]; W().win[2][e] = held[2];
-					W().win[0][e] = held[0];
-					W().s_seq[sg] = sq + 1u;
-				}
-			}
-		}
-		wave_fence();
-	}
-
-	/* ---- 2. shade the pending hit of every live path (main.c:180-261) ------------------- */
-	RT_DEV void shade_pending_hits(RoundOut &r)
-	{
-		STAT(7);
-		if (!p.has_hit) return;
-		STAT(8);
-		/* a sample's first bounce: its path is seeded here, once per round for all the lanes that start one, not once per hand-out attempt */
-		if (p.bounce == 0) p.rng = path_seed(L.seed, (uint32_t) p.rng, (uint32_t) L.sample_base + (uint32_t) (p.rng >> 32));
-		/* a camera-ray hit point from which every tap certainly reaches the emitter (flagged by rt_primary_pass), or a hit point of
-		 * a later bounce in such a cell of the scene's table (section 4): the taps are drawn and accepted as always (main.c:193-195),
-		 * but not traced.  1: they reach the emitter, 2: they certainly do not (and nothing else emits) */
-		const bool taps_lit = p.lit_next != 0u;
 #ifdef RT_STATS
-		{	/* what kind of shading event this is (scripts/stats_c1.py): a sample's first or a later one, on a box or a sphere, taps known or not */
-			const bool on_box = __float_as_int(sc.geom[2 * p.hobj + 1].z) == RT_GEOM_CUBE;
-			if (p.bounce == 0) STAT(0);            /* (sites 25-28 are the section stamps' words) */
-			if (p.bounce == 0 && taps_lit) STAT(10);
-			if (on_box) STAT(11);
-			if (p.bounce == 0 && on_box) STAT(18);
-			if (p.bounce == 0 && on_box && taps_lit) STAT(19);
-			if (taps_lit) STAT(29);
-			if (p.bounce == 1) STAT(30);
-		}
+		if (!f_live) STAT(24);                  /* lanes that start the round without a sample */
 #endif
-		if (K.have_light) {
-			/* main.c:191-195: three rand_dir draws, a tap is skipped when it points into the surface.  Only the sign of
-			 * dot(rand_dir, normal) is needed here, and random_vector() has it before normalize() does (rt_math.hip.h:
-			 * side_is_certain): the tap is queued as drawn, and normalised -- with its direction and origin, main.c:197-198 --
-			 * where it is traced, on a full batch, if it is traced at all. */
-			r.tap_j0 = rng_vector(p.rng); r.tap_j1 = rng_vector(p.rng); r.tap_j2 = rng_vector(p.rng);
-			const float side0 = dot3(r.tap_j0, p.hn), side1 = dot3(r.tap_j1, p.hn), side2 = dot3(r.tap_j2, p.hn);
-			if (FAST && wave_all(side_is_certain(side0) && side_is_certain(side1) && side_is_certain(side2)))
-				r.tapmask = (side0 > 0 ? 1 : 0) | (side1 > 0 ? 2 : 0) | (side2 > 0 ? 4 : 0);
-			else
-				r.tapmask = (dot3(unit3_of_vector<FAST>(r.tap_j0), p.hn) > 0 ? 1 : 0) | (dot3(unit3_of_vector<FAST>(r.tap_j1), p.hn) > 0 ? 2 : 0) |
-				            (dot3(unit3_of_vector<FAST>(r.tap_j2), p.hn) > 0 ? 4 : 0);
+		if (__ballot(f_live || ((rec1 | rec2) & REC_VALID) != 0) == 0ull) {
+			/* nothing in flight: every reserved slot is filled, so whatever is still waiting can be added now */
+			if (!direct && __ballot(W.s_drained[g] != W.s_seq[g]) != 0ull) { add_finished_samples(); continue; }
+			if (exhausted) break;
+			continue;
 		}
-		const float4 m0 = sc.shade[4 * p.hobj], m1 = sc.shade[4 * p.hobj + 1];
-		const V3 f0 = mk3(m0.x, m0.y, m0.z), omf0 = mk3(m1.x, m1.y, m1.z);
 
-		const float n_dot_v = clamp01(dot3(p.hn, neg3(p.hdir)));
-		/* main.c:128: (float) pow(1.0 - (double) u, 5.0) == x2*x2*x in fp64 for every float u in [0,1] (tests/test_pow5.py) */
-		const double xg = 1.0 - (double) n_dot_v;
-		const double xg2 = xg * xg;
-		const float grazing = (float) (xg2 * xg2 * xg);
-		const V3 fresnel = madd3(f0, omf0, grazing);
+		STAMP(0);
+		/* ---- 2. shade the pending hit of every live path (main.c:180-261) ------------------- */
+		int  tapmask = 0, cur = 0;
+		bool emit_main = false;
+		V3   ray_o = mk3(0, 0, 0), ray_d = mk3(0, 0, 0);
+		V3   tap_j0 = mk3(0, 0, 0), tap_j1 = mk3(0, 0, 0), tap_j2 = mk3(0, 0, 0);   /* accepted rand_dir of each tap (main.c:193) */
+		STAT(7);
+		if (has_hit) {
+			STAT(8);
+			/* a camera-ray hit point from which every tap certainly reaches the emitter (flagged by rt_primary_pass): the taps
+			 * are drawn and accepted as always (main.c:193-195), but not traced */
+			/* a sample's first bounce: its path is seeded here, once per round for all the lanes that start one, not once per hand-out attempt */
+			if (bounce == 0) rng = path_seed(L.seed, (uint32_t) rng, (uint32_t) L.sample_base + (uint32_t) (rng >> 32));
+#ifdef RT_X_NOAUDIT
+			const bool taps_lit = lit_next != 0u;
+#else
+			const bool taps_lit = (lit_next & 3u) != 0u;
+#endif      /* ... or a hit point of a later bounce in such a cell of the scene's table (section 4);
+			                                            * 1: they reach the emitter, 2: they certainly do not (and nothing else emits) */
+#ifdef RT_STATS
+			{	/* what kind of shading event this is (scripts/stats_c1.py): a sample's first or a later one, on a box or a sphere, taps known or not */
+				const bool on_box = __float_as_int(sc.geom[2 * hobj + 1].z) == RT_GEOM_CUBE;
+				if (bounce == 0) STAT(0);            /* (sites 25-28 are the section stamps' words) */
+				if (bounce == 0 && taps_lit) STAT(10);
+				if (on_box) STAT(11);
+				if (bounce == 0 && on_box) STAT(18);
+				if (bounce == 0 && on_box && taps_lit) STAT(19);
+				if (taps_lit) STAT(29);
+				if (bounce == 1) STAT(30);
+			}
+#endif
+			if (have_light) {
+				/* main.c:191-195: three rand_dir draws, a tap is skipped when it points into the surface.  Only the sign of
+				 * dot(rand_dir, normal) is needed here, and random_vector() has it before normalize() does (rt_math.hip.h:
+				 * side_is_certain): the tap is queued as drawn, and normalised -- with its direction and origin, main.c:197-198 --
+				 * where it is traced, on a full batch, if it is traced at all. */
+				tap_j0 = rng_vector(rng); tap_j1 = rng_vector(rng); tap_j2 = rng_vector(rng);
+				const float side0 = dot3(tap_j0, hn), side1 = dot3(tap_j1, hn), side2 = dot3(tap_j2, hn);
+				if (FAST && wave_all(side_is_certain(side0) && side_is_certain(side1) && side_is_certain(side2)))
+					tapmask = (side0 > 0 ? 1 : 0) | (side1 > 0 ? 2 : 0) | (side2 > 0 ? 4 : 0);
+				else
+					tapmask = (dot3(unit3_of_vector<FAST>(tap_j0), hn) > 0 ? 1 : 0) | (dot3(unit3_of_vector<FAST>(tap_j1), hn) > 0 ? 2 : 0) |
+					          (dot3(unit3_of_vector<FAST>(tap_j2), hn) > 0 ? 4 : 0);
+			}
+			const float4 m0 = sc.shade[4 * hobj], m1 = sc.shade[4 * hobj + 1];
+			const V3 f0 = mk3(m0.x, m0.y, m0.z), omf0 = mk3(m1.x, m1.y, m1.z);
 
-		V3 scatter = rng_direction<FAST>(p.rng);
-		if (dot3(scatter, p.hn) < 0) scatter = neg3(scatter);
+			const float n_dot_v = clamp01(dot3(hn, neg3(hdir)));
+			/* main.c:128: (float) pow(1.0 - (double) u, 5.0) == x2*x2*x in fp64 for every float u in [0,1] (tests/test_pow5.py) */
+			const double xg = 1.0 - (double) n_dot_v;
+			const double xg2 = xg * xg;
+			const float grazing = (float) (xg2 * xg2 * xg);
+			const V3 fresnel = madd3(f0, omf0, grazing);
 
-		bool specular = __float_as_int(m1.w) != 0;
-		if (!specular)
-			specular = rng_draw(p.rng) <= (FAST ? third_of(fresnel.x + fresnel.y + fresnel.z) : (fresnel.x + fresnel.y + fresnel.z) / 3.0f);
-		V3 out_dir;
-		if (specular) {
-			STAT(15);
-			const V3 nneg = neg3(p.hn);
-			const float f = -2.0f * dot3(nneg, p.hdir);
-			out_dir = unit3_sel<FAST>(lin2(scatter, madd3(p.hdir, nneg, f), m0.w, 1.0f));
-		} else
-			out_dir = scatter;
-		p.bounce++;
-		r.emit_main = p.bounce < L.max_bounces;
-		r.ray_o = madd3(p.hp, out_dir, 0.001f);
-		r.ray_d = out_dir;
-		p.hdir = out_dir;
-		p.has_hit = false;
-		r.cur = REC_VALID | (specular ? REC_SPECULAR : 0) | (r.emit_main ? 0 : REC_LAST) | (r.tapmask << 4) | (p.hobj << 8);
-		if (taps_lit) {             /* the record keeps the accepted taps, the queue gets none ... */
-			r.cur |= p.lit_next == 1u ? REC_TAPS_LIT : REC_TAPS_DARK;
-			/* ... unless this bounce is one of those the launch audits (rt_launch.audit_taps, 2^k: one in 2^k, picked by bits of the
-			 * path's generator state): its taps are traced like unknown ones and the back compares */
-			bool audit = false;
-			if (L.audit_taps != 0u) audit = r.tapmask != 0 && (((uint32_t) (p.rng >> 21)) & (L.audit_taps - 1u)) == 0u;
-			if (audit) r.cur |= REC_AUDIT; else r.tapmask = 0;
+			V3 scatter = rng_direction<FAST>(rng);
+			if (dot3(scatter, hn) < 0) scatter = neg3(scatter);
+
+			bool specular = __float_as_int(m1.w) != 0;
+			if (!specular)
+				specular = rng_draw(rng) <= (FAST ? third_of(fresnel.x + fresnel.y + fresnel.z) : (fresnel.x + fresnel.y + fresnel.z) / 3.0f);
+			V3 out_dir;
+			if (specular) {
+				STAT(15);
+				const V3 nneg = neg3(hn);
+				const float f = -2.0f * dot3(nneg, hdir);
+				out_dir = unit3_sel<FAST>(lin2(scatter, madd3(hdir, nneg, f), m0.w, 1.0f));
+			} else
+				out_dir = scatter;
+			bounce++;
+			emit_main = bounce < L.max_bounces;
+			ray_o = madd3(hp, out_dir, 0.001f);
+			ray_d = out_dir;
+			hdir = out_dir;
+			has_hit = false;
+			cur = REC_VALID | (specular ? REC_SPECULAR : 0) | (emit_main ? 0 : REC_LAST) | (tapmask << 4) | (hobj << 8);
+#ifdef RT_X_NOAUDIT
+			if (taps_lit) { cur |= lit_next == 1u ? REC_TAPS_LIT : REC_TAPS_DARK; tapmask = 0; }
+#else
+			if (taps_lit) {             /* the record keeps the accepted taps, the queue gets none ... */
+				cur |= (lit_next & 1u) ? REC_TAPS_LIT : REC_TAPS_DARK;
+				/* ... unless the answer came with the audit bit (rt_launch.audit_taps: the camera-ray pass marks one in 2^k of the pixels it
+				 * classifies, the host one in 2^k cells of the scene's table): the taps are traced like unknown ones and the back compares */
+				if ((lit_next & 4u) != 0u && tapmask != 0) cur |= REC_AUDIT; else tapmask = 0;
+			}
+#endif
 		}
-	}
 
-	/* ---- 3. the shadow taps go into the wave's ring (ballot + mbcnt prefix), one kind at a time; whenever 64 are
-	 * queued, any lane traces any tap (scene.c:156-190 on full waves).  A tap is queued as (hit point, random_vector());
-	 * its normalisation, direction and origin (main.c:193-198) are formed where it is traced.  Taps that do not fill a
-	 * batch wait: the bounce they belong to is retired two rounds from now ------------------------------------------------------- */
-	RT_DEV void push_taps(bool on, V3 qo, V3 qd, int k)
-	{
-		const unsigned long long m = __ballot(on);
-		if (on) {
-			const unsigned int slot = (q_tail + (unsigned int) lanes_below(m)) & (WF_QUEUE - 1);
-			W().q[0][slot] = qo.x; W().q[1][slot] = qo.y; W().q[2][slot] = qo.z;
-			W().q[3][slot] = qd.x; W().q[4][slot] = qd.y; W().q[5][slot] = qd.z;
-			W().qmeta[slot] = (unsigned short) (lane | (k << 8) | (int) (phase << 12));
-		}
-		q_tail += (unsigned int) __popcll(m);
-		wave_fence();
-	}
-	/* the ray of the queued tap in ring slot `slot`, and where its answer goes */
-	RT_DEV void tap_ray(unsigned int slot, V3 &o, V3 &d, int &meta) const
-	{
-		o = mk3(W().q[0][slot], W().q[1][slot], W().q[2][slot]);
-		d = mk3(W().q[3][slot], W().q[4][slot], W().q[5][slot]);
-		meta = W().qmeta[slot];
-		d = unit3_of_vector<FAST>(d);                                                /* main.c:193: normalize(random_vector()) */
-		d = unit3_sel<FAST>(lin2(d, sub3(K.light_pos(), o), 0.5f, 1.0f));            /* main.c:186,197 */
-		o = madd3(o, d, 0.001f);                                                     /* main.c:198 */
-	}
-	RT_DEV void tap_answer(int meta, int obj) const { W().tap[(meta >> 12) & 3][((meta >> 8) & 15) - 2][meta & 255] = (short) obj; }
-	RT_DEV void trace_taps(int count)          /* the `count` <= 64 oldest taps */
-	{
-		STAT(12);
-		if (CULL) {            /* every lane takes part in the culled trace (its work is shared out over the wave); lanes without a tap pass `on` = false */
-			const bool on = lane < count;
-			V3 o = mk3(0, 0, 0), d = mk3(1, 0, 0); int meta = 0;
-			if (on) tap_ray((q_head + (unsigned int) lane) & (WF_QUEUE - 1), o, d, meta);
-			const V3 dn = unit3_sel<FAST>(d);
-			const Hit hit = nearest_hit_culled(sc, K.n, cl, cull_wave, on, o, dn, false);
-			if (on) tap_answer(meta, hit.obj);
-		} else
-		if (lane < count) {
-			STAT(13);
-			V3 o, d; int meta;
-			tap_ray((q_head + (unsigned int) lane) & (WF_QUEUE - 1), o, d, meta);
-			const V3 dn = unit3_sel<FAST>(d);                                         /* scene.c:158 */
-			const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, K.n, o, dn, false) : nearest_hit(sc, K.n, o, dn);
-			tap_answer(meta, hit.obj);
-		}
-		q_head += (unsigned int) count;
-		wave_fence();
-	}
-	RT_DEV void queue_taps(const RoundOut &r)
-	{
+		STAMP(1);
+		/* ---- 3. the shadow taps go into the wave's ring (ballot + mbcnt prefix), one kind at a time; whenever 64 are
+		 * queued, any lane traces any tap (scene.c:156-190 on full waves).  A tap is queued as (hit point, random_vector());
+		 * its normalisation, direction and origin (main.c:193-198) are formed where it is traced.  Taps that do not fill a
+		 * batch wait: the bounce they belong to is retired two rounds from now ------------------------------------------------------- */
+		auto push = [&](bool on, V3 qo, V3 qd, int k) {
+			const unsigned long long m = __ballot(on);
+			if (on) {
+				const unsigned int slot = (q_tail + (unsigned int) lanes_below(m)) & (WF_QUEUE - 1);
+				W.q[0][slot] = qo.x; W.q[1][slot] = qo.y; W.q[2][slot] = qo.z;
+				W.q[3][slot] = qd.x; W.q[4][slot] = qd.y; W.q[5][slot] = qd.z;
+				W.qmeta[slot] = (unsigned short) (lane | (k << 8) | (int) (phase << 12));
+			}
+			q_tail += (unsigned int) __popcll(m);
+			wave_fence();
+		};
+		/* the ray of the queued tap in ring slot `slot`, and where its answer goes */
+		auto tap_ray = [&](unsigned int slot, V3 &o, V3 &d, int &meta) {
+			o = mk3(W.q[0][slot], W.q[1][slot], W.q[2][slot]);
+			d = mk3(W.q[3][slot], W.q[4][slot], W.q[5][slot]);
+			meta = W.qmeta[slot];
+			d = unit3_of_vector<FAST>(d);                                                /* main.c:193: normalize(random_vector()) */
+			d = unit3_sel<FAST>(lin2(d, sub3(light_pos, o), 0.5f, 1.0f));               /* main.c:186,197 */
+			o = madd3(o, d, 0.001f);                                                     /* main.c:198 */
+		};
+		auto tap_answer = [&](int meta, int obj) { W.tap[(meta >> 12) & 3][((meta >> 8) & 15) - 2][meta & 255] = (short) obj; };
+		auto trace_taps = [&](int count) {         /* the `count` <= 64 oldest taps */
+			STAT(12);
+			if (CULL) {            /* every lane takes part in the culled trace (its work is shared out over the wave); lanes without a tap pass `on` = false */
+				const bool on = lane < count;
+				V3 o = mk3(0, 0, 0), d = mk3(1, 0, 0); int meta = 0;
+				if (on) tap_ray((q_head + (unsigned int) lane) & (WF_QUEUE - 1), o, d, meta);
+				const V3 dn = unit3_sel<FAST>(d);
+				const Hit hit = nearest_hit_culled(sc, n, cl, cull_wave, on, o, dn, false);
+				if (on) tap_answer(meta, hit.obj);
+			} else
+			if (lane < count) {
+				STAT(13);
+				V3 o, d; int meta;
+				tap_ray((q_head + (unsigned int) lane) & (WF_QUEUE - 1), o, d, meta);
+				const V3 dn = unit3_sel<FAST>(d);                                         /* scene.c:158 */
+				const Hit hit = FAST ? NEAREST_HIT_TUNED(sc, n, o, dn, false) : nearest_hit(sc, n, o, dn);
+				tap_answer(meta, hit.obj);
+			}
+			q_head += (unsigned int) count;
+			wave_fence();
+		};
 		/* all three kinds in one go when the ring has room for them (it has, unless most taps of most lanes are traced): one
 		 * prefix sum over the lanes' tap counts instead of three ballots, one fence instead of three (C1 -2.1 %, strip -4.6 %, C2 +0.4 %:
 		 * profiles/r03/ab_push_together.txt) */
-		const unsigned int mine = (unsigned int) __popc((unsigned int) r.tapmask);
+		const unsigned int mine = (unsigned int) __popc((unsigned int) tapmask);
 		const unsigned long long c0 = __ballot((mine & 1u) != 0u), c1 = __ballot((mine & 2u) != 0u);
 		const unsigned int all = (unsigned int) __popcll(c0) + 2u * (unsigned int) __popcll(c1);
 		if (q_tail - q_head + all <= (unsigned int) WF_QUEUE) {
 			unsigned int slot = q_tail + (unsigned int) lanes_below(c0) + 2u * (unsigned int) lanes_below(c1);
 #pragma unroll
 			for (int t = 0; t < 3; t++)
-				if ((r.tapmask >> t) & 1) {
+				if ((tapmask >> t) & 1) {
 					const unsigned int e = slot & (WF_QUEUE - 1);
-					const V3 qd = t == 0 ? r.tap_j0 : (t == 1 ? r.tap_j1 : r.tap_j2);
-					W().q[0][e] = p.hp.x; W().q[1][e] = p.hp.y; W().q[2][e] = p.hp.z;
-					W().q[3][e] = qd.x; W().q[4][e] = qd.y; W().q[5][e] = qd.z;
-					W().qmeta[e] = (unsigned short) (lane | ((t + 2) << 8) | (int) (phase << 12));
+					const V3 qd = t == 0 ? tap_j0 : (t == 1 ? tap_j1 : tap_j2);
+					W.q[0][e] = hp.x; W.q[1][e] = hp.y; W.q[2][e] = hp.z;
+					W.q[3][e] = qd.x; W.q[4][e] = qd.y; W.q[5][e] = qd.z;
+					W.qmeta[e] = (unsigned short) (lane | ((t + 2) << 8) | (int) (phase << 12));
 					slot++;
 				}
 			q_tail += all;
@@ -1507,100 +1587,93 @@ struct Wavefront {
 #pragma unroll 1
 		for (int kind = 2; kind < 5; kind++) {
 			switch (kind) {
-			case 2:  push_taps((r.tapmask & 1) != 0, p.hp, r.tap_j0, 2); break;
-			case 3:  push_taps((r.tapmask & 2) != 0, p.hp, r.tap_j1, 3); break;
-			default: push_taps((r.tapmask & 4) != 0, p.hp, r.tap_j2, 4); break;
+			case 2:  push((tapmask & 1) != 0, hp, tap_j0, 2); break;
+			case 3:  push((tapmask & 2) != 0, hp, tap_j1, 3); break;
+			default: push((tapmask & 4) != 0, hp, tap_j2, 4); break;
 			}
 			while (q_tail - q_head >= 64u) trace_taps(64);
 		}
-	}
 
-	/* ---- 4. the bounce rays: every lane traces its own, straight from its registers -- no queue, no LDS ---------- */
-	RT_DEV void trace_bounce_rays(const RoundOut &r)
-	{
-		if (__ballot(r.emit_main) != 0ull) {
+		/* ---- 4. the bounce rays: every lane traces its own, straight from its registers -- no queue, no LDS ---------- */
+		if (__ballot(emit_main) != 0ull) {
 			STAT(12);
 			Hit culled; culled.t = 0.0f; culled.obj = -1; culled.n = mk3(0, 0, 0);
 			if (CULL) {            /* (all lanes: see trace_taps) */
 				/* A culled trace costs the same for one ray as for 64 (its first step asks every cluster box for every lane), and the
 				 * lanes without a bounce ray -- paths at their last bounce, lanes between samples: a third of them -- have nothing to
 				 * do in it: the oldest taps waiting in the ring ride along in those lanes instead of waiting for a batch of their own. */
-				const unsigned long long idle = ~__ballot(r.emit_main);
+				const unsigned long long idle = ~__ballot(emit_main);
 				const unsigned int waiting = q_tail - q_head, room = (unsigned int) __popcll(idle);
 				const unsigned int take = waiting < room ? waiting : room;
 				const unsigned int place = (unsigned int) lanes_below(idle);
-				const bool rider = !r.emit_main && place < take;
-				V3 to = r.ray_o, td = r.emit_main ? r.ray_d : mk3(1, 0, 0);
+				const bool rider = !emit_main && place < take;
+				V3 to = ray_o, td = emit_main ? ray_d : mk3(1, 0, 0);
 				int tmeta = 0;
 				if (rider) tap_ray((q_head + place) & (WF_QUEUE - 1), to, td, tmeta);
-				culled = nearest_hit_culled(sc, K.n, cl, cull_wave, r.emit_main || rider, to, unit3_sel<FAST>(td), true);
+				culled = nearest_hit_culled(sc, n, cl, cull_wave, emit_main || rider, to, unit3_sel<FAST>(td), true);
 				if (rider) tap_answer(tmeta, culled.obj);
 				if (take) { q_head += take; wave_fence(); }
 			}
-			if (r.emit_main) {
+			if (emit_main) {
 				STAT(13);
-				const V3 dn = unit3_sel<FAST>(r.ray_d);                                     /* scene.c:158 */
-				const Hit hit = CULL ? culled : (FAST ? NEAREST_HIT_TUNED(sc, K.n, r.ray_o, dn, true) : nearest_hit(sc, K.n, r.ray_o, dn));
-				p.hobj = hit.obj; p.hn = hit.n;
-				p.hp = hit.obj >= 0 ? madd3(r.ray_o, dn, hit.t)                             /* scene.c:186 */
-				                    : dn;                 /* left the scene: the sky is looked up in that direction (main.c:170) */
+				const V3 dn = unit3_sel<FAST>(ray_d);                                     /* scene.c:158 */
+				const Hit hit = CULL ? culled : (FAST ? NEAREST_HIT_TUNED(sc, n, ray_o, dn, true) : nearest_hit(sc, n, ray_o, dn));
+				hobj = hit.obj; hn = hit.n;
+				hp = hit.obj >= 0 ? madd3(ray_o, dn, hit.t)                               /* scene.c:186 */
+				                  : dn;                 /* left the scene: the sky is looked up in that direction (main.c:170) */
 				/* will the taps from this hit point need tracing?  The scene's table (rt_lit.h) has one entry per cell of a grid
 				 * over every object: 1 = every surface point in the cell certainly sees the emitter.  The load is in flight
 				 * until the next round's front asks */
-				p.lit_next = 0u;
-				/* (two pointers, not one chosen at run time: a pointer that may be LDS or memory makes every access a flat load with a
-				 * 64-bit address -- ten per bounce ray) */
-				extern __shared__ float4 lds[];
-				const rt_lit_grid *lit_grids_lds = reinterpret_cast<const rt_lit_grid*>(lds + 6 * K.n);
-				const rt_lit_grid *lit_grids_mem = reinterpret_cast<const rt_lit_grid*>(L.lit_grids);
-				if (FAST && L.lit_cells != nullptr && hit.obj >= 0 && hit.obj != K.light_obj &&
-				    rt_lit_point_on_surface(reinterpret_cast<const float*>(sc.geom) + 8 * hit.obj, p.hp.x, p.hp.y, p.hp.z, p.hn.x, p.hn.y, p.hn.z))
-					p.lit_next = L.lit_cells[grids_in_lds ? rt_lit_bit_of(lit_grids_lds + hit.obj, p.hp.x, p.hp.y, p.hp.z)
-					                                      : rt_lit_bit_of(lit_grids_mem + hit.obj, p.hp.x, p.hp.y, p.hp.z)];
+				lit_next = 0u;
+				if (FAST && L.lit_cells != nullptr && hit.obj >= 0 && hit.obj != light_obj &&
+				    rt_lit_point_on_surface(reinterpret_cast<const float*>(sc.geom) + 8 * hit.obj, hp.x, hp.y, hp.z, hn.x, hn.y, hn.z))
+					lit_next = L.lit_cells[grids_in_lds ? rt_lit_bit_of(lit_grids_lds + hit.obj, hp.x, hp.y, hp.z)
+					                                    : rt_lit_bit_of(lit_grids_mem + hit.obj, hp.x, hp.y, hp.z)];
 			}
 		}
 		/* the bounces retired below were shaded two rounds ago: whatever is left of their taps (the oldest in the queue) is
 		 * traced now, in a batch that need not be full */
 		const unsigned int due = phase == 2u ? 0u : phase + 1u;
-		while (q_tail != q_head && ((unsigned int) __builtin_amdgcn_readfirstlane((int) W().qmeta[q_head & (WF_QUEUE - 1)]) >> 12 & 3u) == due)
+		while (q_tail != q_head && ((unsigned int) __builtin_amdgcn_readfirstlane((int) W.qmeta[q_head & (WF_QUEUE - 1)]) >> 12 & 3u) == due)
 			trace_taps(q_tail - q_head < 64u ? (int) (q_tail - q_head) : 64);
-	}
 
-	/* ---- 5. back: retire the bounce shaded two rounds ago (its taps are traced by now), take this round's
-	 * bounce-ray result, and free the front when the path has ended --------------------------------------- */
-	RT_DEV void retire_bounces(const RoundOut &r)
-	{
-		const unsigned int due = phase == 2u ? 0u : phase + 1u;
+		STAMP(2);
+		/* ---- 5. back: retire the bounce shaded two rounds ago (its taps are traced by now), take this round's
+		 * bounce-ray result, and free the front when the path has ended --------------------------------------- */
 		STAT(16);
-		if (p.rec2 & REC_VALID) {
+		if (rec2 & REC_VALID) {
 			STAT(17);
-			const int pobj = (p.rec2 >> 8) & 1023, ptaps = (p.rec2 >> 4) & 7;
+			const int pobj = (rec2 >> 8) & 1023, ptaps = (rec2 >> 4) & 7;
 			const float4 m2 = sc.shade[4 * pobj + 2], m3 = sc.shade[4 * pobj + 3];
-			p.rad = add3(p.rad, had3(mk3(m3.x, m3.y, m3.z), p.carry));                    /* main.c:232 */
-			if (!(p.rec2 & REC_SPECULAR)) p.carry = had3(p.carry, mk3(m2.x, m2.y, m2.z));  /* main.c:248 */
+			rad = add3(rad, had3(mk3(m3.x, m3.y, m3.z), carry));                    /* main.c:232 */
+			if (!(rec2 & REC_SPECULAR)) carry = had3(carry, mk3(m2.x, m2.y, m2.z));  /* main.c:248 */
 			if (ptaps) {
 				V3 lit = mk3(0, 0, 0);
 				int taps = 0;
-				if (K.only_light) {
+				if (only_light) {
 					/* The emitter is the only object whose emission is not all (signed) zeros, so main.c:200-204 adds its emission once
 					 * per tap that reaches it and a zero otherwise -- which changes nothing: the sum starts as +0 and is never -0.
 					 * n equal terms e: e, 2e (exact), RN(2e + e) = RN(3e): the product n x e, and "+ 0" makes a -0 product the +0 the
 					 * sum would be.  No emission is looked up per tap, nothing branches per tap. */
-					const int t0 = W().tap[due][0][lane], t1 = W().tap[due][1][lane], t2 = W().tap[due][2][lane];
+					const int t0 = W.tap[due][0][lane], t1 = W.tap[due][1][lane], t2 = W.tap[due][2][lane];
 					taps = __popc((unsigned int) ptaps);
-					int n_hit = ((ptaps & 1) && t0 == K.light_obj ? 1 : 0) + ((ptaps & 2) && t1 == K.light_obj ? 1 : 0) + ((ptaps & 4) && t2 == K.light_obj ? 1 : 0);
-					if (p.rec2 & REC_AUDIT) audit_taps(taps, (p.rec2 & REC_TAPS_LIT) ? taps - n_hit : n_hit);
-					if (p.rec2 & REC_TAPS_LIT) n_hit = taps;
-					if (p.rec2 & REC_TAPS_DARK) n_hit = 0;
-					const float4 e = sc.shade[4 * K.light_obj + 3];
+					int n_hit = ((ptaps & 1) && t0 == light_obj ? 1 : 0) + ((ptaps & 2) && t1 == light_obj ? 1 : 0) + ((ptaps & 4) && t2 == light_obj ? 1 : 0);
+#ifndef RT_X_NOAUDIT
+					if (rec2 & REC_AUDIT) audit_taps(taps, (rec2 & REC_TAPS_LIT) ? taps - n_hit : n_hit);
+#endif
+					if (rec2 & REC_TAPS_LIT) n_hit = taps;
+					if (rec2 & REC_TAPS_DARK) n_hit = 0;
+					const float4 e = sc.shade[4 * light_obj + 3];
 					const float nf = (float) n_hit;
 					lit = mk3(e.x * nf + 0.0f, e.y * nf + 0.0f, e.z * nf + 0.0f);
 				} else
 #pragma unroll
 				for (int k = 0; k < 3; k++)
 					if ((ptaps >> k) & 1) {
-						const int obj = (p.rec2 & REC_TAPS_LIT) ? K.light_obj : ((p.rec2 & REC_TAPS_DARK) ? -1 : W().tap[due][k][lane]);
-						if (p.rec2 & REC_AUDIT) audit_taps(1, ((p.rec2 & REC_TAPS_LIT) != 0) != (W().tap[due][k][lane] == K.light_obj) ? 1 : 0);
+						const int obj = (rec2 & REC_TAPS_LIT) ? light_obj : ((rec2 & REC_TAPS_DARK) ? -1 : W.tap[due][k][lane]);
+#ifndef RT_X_NOAUDIT
+						if (rec2 & REC_AUDIT) audit_taps(1, ((rec2 & REC_TAPS_LIT) != 0) != (W.tap[due][k][lane] == light_obj) ? 1 : 0);
+#endif
 						if (obj >= 0) { const float4 e = sc.shade[4 * obj + 3]; lit = add3(lit, mk3(e.x, e.y, e.z)); }
 						taps++;
 					}
@@ -1610,134 +1683,57 @@ struct Wavefront {
 				                       : (tiny_f(lit.x) && tiny_f(lit.y) && tiny_f(lit.z));
 				if (!dark) {                                                      /* main.c:257-261 */
 					const float w = 0.05f;
-					p.rad = madd3(p.rad, had3(lit, p.carry), w);
-					p.carry = scale3(p.carry, 1.0f - w);
+					rad = madd3(rad, had3(lit, carry), w);
+					carry = scale3(carry, 1.0f - w);
 				}
 			}
-			if (p.rec2 & REC_LAST) {              /* the path ended with that bounce: sky (main.c:171) or bounce limit (main.c:158) */
-				if (p.rec2 & REC_SKY) p.rad = add3(p.rad, had3(sky_colour<FAST>(p.sky2), p.carry));
-				const V3 col = mk3(clamp01(p.rad.x), clamp01(p.rad.y), clamp01(p.rad.z));     /* main.c:267-269 */
+			if (rec2 & REC_LAST) {              /* the path ended with that bounce: sky (main.c:171) or bounce limit (main.c:158) */
+				if (rec2 & REC_SKY) rad = add3(rad, had3(sky_colour<FAST>(sky2), carry));
+				const V3 col = mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z));     /* main.c:267-269 */
 				if (direct) {                   /* the pixel's only sample: 0 + colour (main.c:394), resolved (main.c:476) */
 					const V3 res = scale3(add3(mk3(0, 0, 0), col), inv_spp);
-					float *dst = L.frame + (size_t) p.slot2 * 3;
+					float *dst = L.frame + (size_t) slot2 * 3;
 					dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
-					__hip_atomic_fetch_add(&W().n_written, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+					__hip_atomic_fetch_add(&W.n_written, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 				} else {                        /* into its slot of the window; section 6 adds it when its turn comes */
-					const unsigned int e = (unsigned int) p.slot2 & (WF_LAST - 1);
-					W().win[1][e] = col.y; W().win[2][e] = col.z;
-					W().win[0][e] = __uint_as_float((__float_as_uint(col.x) & 0x7fffffffu) | ((p.slot2 & WF_LAST) ? 0x80000000u : 0u));
+					const unsigned int e = (unsigned int) slot2 & (WF_LAST - 1);
+					W.win[1][e] = col.y; W.win[2][e] = col.z;
+					W.win[0][e] = __uint_as_float((__float_as_uint(col.x) & 0x7fffffffu) | ((slot2 & WF_LAST) ? 0x80000000u : 0u));
 				}
-				p.carry = mk3(1, 1, 1); p.rad = mk3(0, 0, 0);
+				carry = mk3(1, 1, 1); rad = mk3(0, 0, 0);
 			}
 		}
-		p.rec2 = p.rec1; p.sky2 = p.sky1; p.slot2 = p.slot1;
-		p.rec1 = r.cur;
-		if (r.cur & REC_VALID) {
-			p.slot1 = p.f_slot;
+		rec2 = rec1; sky2 = sky1; slot2 = slot1;
+		rec1 = cur;
+		if (cur & REC_VALID) {
+			slot1 = f_slot;
 			bool path_ended = true;                                  /* bounce limit (main.c:158) */
-			if (r.emit_main) {
-				if (p.hobj < 0) {
+			if (emit_main) {
+				if (hobj < 0) {
 					STAT(14);
-					p.sky1 = sky_texel<FAST>(L, p.hp); p.rec1 |= REC_LAST | REC_SKY;                  /* main.c:163-172 */
+					sky1 = sky_texel<FAST>(L, hp); rec1 |= REC_LAST | REC_SKY;                  /* main.c:163-172 */
 				} else {
-					p.has_hit = true; path_ended = false;
+					has_hit = true; path_ended = false;
 				}
 			}
-			if (path_ended) p.f_live = false;      /* the front takes its next sample at the top of the next round */
+			if (path_ended) f_live = false;      /* the front takes its next sample at the top of the next round */
 		}
 		wave_fence();
-	}
 
-	/* `taps` taps whose answer rt_lit.h gave were traced all the same; `wrong` of them contradict it */
-	RT_DEV void audit_taps(int taps, int wrong)
-	{
-		__hip_atomic_fetch_add(&W().n_audited, (unsigned int) taps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-		if (wrong) __hip_atomic_fetch_add(&W().n_disagree, (unsigned int) wrong, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+		STAMP(3);
+		/* ---- 6. add the finished samples in sample order (main.c:394) ---------------------------------------- */
+		/* Every second round when a pixel has many samples: a stream's eight lanes add up to eight slots per pass and a round finishes
+		 * three or four samples per stream (C1), so one pass has room for two rounds' worth, and the pass costs the same 140
+		 * instructions whether it finds one slot or eight.  C1 -0.5 %, C2 -3.4 %, strips -0.3 % (profiles/r03/ab_sum_every.txt;
+		 * every third round: the window fills and lanes wait for slots, +1.5 ... +7 %).  Pixels of few samples complete too fast for
+		 * that -- a pass resolves at most one pixel per stream. */
+		if (!direct && (++sum_tick >= sum_every)) { sum_tick = 0u; add_finished_samples(); }
+		STAMP(4);
 	}
-
-	/* A wave leaves the launch: it adds what it wrote to the launch's control words, and the LAST wave to leave adds up the
-	 * pixel lists -- listed by the camera-ray pass, fetched by the waves -- and stamps the launch with its number.  The host
-	 * reads the words behind the launch and delivers the frame only if the stamp is there and the sums agree (rt_api.cpp
-	 * judge_launch): every wave left, every listed pixel was fetched, every fetched pixel was written.  The reference publishes a
-	 * column whole or not at all (main.c:377-396). */
-	RT_DEV void leave_launch()
-	{
-		typedef __attribute__((address_space(1))) unsigned int *gwuint;
-		typedef __attribute__((address_space(1))) unsigned long long *gwulong;
-		wave_fence();
-		const rt_launch_cold C = cold_view();
-		const gwuint ctl = (gwuint) C->control;
-		unsigned int before = 0u;
-		if (lane == 0) {
-			const unsigned int nw = W().n_written, na = W().n_audited, nd = W().n_disagree;
-			if (nw) __hip_atomic_fetch_add(ctl + RT_CTL_WRITTEN, nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (na) __hip_atomic_fetch_add((gwulong) (ctl + RT_CTL_AUDITED), (unsigned long long) na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (nd) __hip_atomic_fetch_add((gwulong) (ctl + RT_CTL_DISAGREE), (unsigned long long) nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			before = __hip_atomic_fetch_add(ctl + RT_CTL_WAVES_LEFT, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-		}
-		before = (unsigned int) __builtin_amdgcn_readfirstlane((int) before);
-		if (before + 1u != gridDim.x * (unsigned int) (BLOCK / 64)) return;
-		/* the last one: lane s adds up list s */
-		unsigned int listed = 0u, fetched = 0u, blocks = 0u;
-		if (lane < C->num_shards) {
-			const gwuint fill = (gwuint) C->pix_count + (unsigned int) lane * 32u;
-			listed = __hip_atomic_load(fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			blocks = __hip_atomic_load(fill + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			const unsigned int taken = __hip_atomic_load(block_counter + (unsigned int) lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			fetched = taken < listed ? taken : listed;
-		}
-#pragma unroll
-		for (int m = 1; m < 64; m <<= 1) {
-			listed += from_lane(listed, lane ^ m); fetched += from_lane(fetched, lane ^ m); blocks += from_lane(blocks, lane ^ m);
-		}
-		if (lane == 0) {
-			ctl[RT_CTL_LISTED] = listed; ctl[RT_CTL_FETCHED] = fetched; ctl[RT_CTL_PRIMARY] = blocks;
-			__hip_atomic_store(ctl + RT_CTL_STAMP, C->launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-		}
-	}
-
-	RT_DEV void run()
-	{
-		for (;; phase = phase == 2u ? 0u : phase + 1u) {
-			STAMP(7);
-			STAMP_ROUND;
-			supply_samples();
-#ifdef RT_STATS
-			if (!p.f_live) STAT(24);                  /* lanes that start the round without a sample */
+	STAMP_FLUSH(BLOCK / 64);
+#ifndef RT_X_NOLEAVE
+	leave_launch<BLOCK>(&W, wave);
 #endif
-			if (__ballot(p.f_live || ((p.rec1 | p.rec2) & REC_VALID) != 0) == 0ull) {
-				/* nothing in flight: every reserved slot is filled, so whatever is still waiting can be added now */
-				if (!direct && __ballot(W().s_drained[g] != W().s_seq[g]) != 0ull) { add_finished_samples(); continue; }
-				if (exhausted) break;
-				continue;
-			}
-			STAMP(0);
-			RoundOut r;
-			shade_pending_hits(r);
-			STAMP(1);
-			queue_taps(r);
-			trace_bounce_rays(r);
-			STAMP(2);
-			retire_bounces(r);
-			STAMP(3);
-			/* Every second round when a pixel has many samples: a stream's eight lanes add up to eight slots per pass and a round finishes
-			 * three or four samples per stream (C1), so one pass has room for two rounds' worth, and the pass costs the same 140
-			 * instructions whether it finds one slot or eight.  C1 -0.5 %, C2 -3.4 %, strips -0.3 % (profiles/r03/ab_sum_every.txt;
-			 * every third round: the window fills and lanes wait for slots, +1.5 ... +7 %).  Pixels of few samples complete too fast for
-			 * that -- a pass resolves at most one pixel per stream. */
-			if (!direct && (++sum_tick >= sum_every)) { sum_tick = 0u; add_finished_samples(); }
-			STAMP(4);
-		}
-		STAMP_FLUSH(BLOCK / 64);
-		leave_launch();
-	}
-};
-
-template <bool FAST, bool CULL = false, int BLOCK = RT_BLOCK>
-RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter)
-{
-	Wavefront<FAST, CULL, BLOCK> wf(L, block_counter);
-	wf.run();
 }
 
 #ifndef RT_SPEC_ONLY
@@ -2140,7 +2136,7 @@ size_t rt_pixel_list_capacity(int width, int local_rows, int num_cus, int num_sh
 
 hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, hipFunction_t spec_fn,
                            unsigned int *block_counter, hipEvent_t cleared, hipEvent_t primary_done, int num_cus, int workgroups_per_cu, hipStream_t stream,
-                           bool reuse_pixel_lists, rt_launch_expect *expect)
+                           bool reuse_pixel_lists, rt_launch_expect *expect, hipEvent_t primary_timed)
 {
 	rt_launch_expect unused;
 	if (!expect) expect = &unused;
@@ -2195,6 +2191,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	const long long useful = (blocks + (block / 64) - 1) / (block / 64);
 	if (grid > useful) grid = useful;
 	if (grid < 1) grid = 1;
+	Lq.trace_workgroups = (int) grid;
 	/* counter block: WF_SHARDS dequeue counters, WF_SHARDS fill counters, one line of control words.  When the lists of the
 	 * previous launch of this scratch set are this launch's lists (an interactive pass with nothing changed but the
 	 * sample number: rt_api.cpp), the fill counters and the records stay and rt_primary_pass is not run */
@@ -2220,6 +2217,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 		if (e == hipSuccess) e = hipEventRecord(primary_done, stream);       /* the next launch of the context may start (rt_api.cpp) */
 		if (e != hipSuccess) return e;
 	}
+	if (primary_timed) { e = hipEventRecord(primary_timed, stream); if (e != hipSuccess) return e; }      /* (rt_profile_*: between the two kernels) */
 	if (variant == 0 /* RT_KERNEL_AUTO */ && scene_fast_ok && spec_fn) {
 		/* same kernel, trace loop specialised for this scene by rt_compile_scene() */
 		rt_launch Lc = Lq;

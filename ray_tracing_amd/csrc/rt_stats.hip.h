@@ -55,7 +55,7 @@ struct RtStamps {
 #endif
 #endif
 
-#define STAMP_MEMBER RtStamps rt_stamps;
+#define STAMP_LOCAL  RtStamps rt_stamps
 #define STAMP(k)     rt_stamps.mark(k)
 #define STAMP_DRY    rt_stamps.dry()
 #define STAMP_ROUND  rt_stamps.round()

@@ -228,13 +228,25 @@ class TiledFrame:
         a copy between two kernels there costs the overlap of consecutive launches); older tickets are judged."""
         import ray_tracing_amd as rt
         while len(self.tickets) >= min(self.depth, rt.CHECK_TICKETS - 1):
-            self.r.launch_check_wait(self.tickets.pop(0))
+            self._judge(self.tickets.pop(0))
         rendered = torch.cuda.Event()
         rendered.record(s)
         self.copy_stream.wait_event(rendered)
         t = k % rt.CHECK_TICKETS
         self.r.launch_check_submit(t, self.copy_stream.cuda_stream)
         self.tickets.append(t)
+
+    def _judge(self, ticket):
+        """rt_launch_check_wait(); a launch that is refused leaves no ticket of this loop behind (the renderer may be used again)."""
+        try:
+            self.r.launch_check_wait(ticket)
+        except Exception:
+            while self.tickets:
+                try:
+                    self.r.launch_check_wait(self.tickets.pop(0))
+                except Exception:
+                    pass
+            raise
 
     def _deliver(self, frame, slot, source):
         """frame (device, complete on stream `source`) -> pinned host memory, on the copy stream."""
@@ -263,7 +275,7 @@ class TiledFrame:
             self.post.synchronize()
         self.copy_stream.synchronize()
         while self.tickets:
-            self.r.launch_check_wait(self.tickets.pop(0))
+            self._judge(self.tickets.pop(0))
 
     def render_now(self, seed=None):
         """One frame, start to finish (no overlap): returns the host frame on rank 0 (a view of host_frame)."""

@@ -56,8 +56,17 @@ if len(sys.argv) > 3:
     write = sum(v.get("WRITE_SIZE", 0.0) for v in totals.values()) * 1024
     valu = sum(v.get("SQ_INSTS_VALU", 0.0) for v in totals.values())
     lanes = totals.get("rt_trace", {}).get("VALUUtilization")
+    # per kernel: every counter's mean per launch (bench.py prices the two kernels apart: they are bound differently), with the
+    # traffic in bytes; `source` names the TRACKED summary these numbers are printed in, beside this json
+    kernels = {}
+    for k, c in totals.items():
+        e = dict(c)
+        if "FETCH_SIZE" in c: e["fetch_bytes"] = c["FETCH_SIZE"] * 1024
+        if "WRITE_SIZE" in c: e["write_bytes"] = c["WRITE_SIZE"] * 1024
+        kernels[k] = e
+    tag = os.environ.get("PMC_SOURCE", root)
     table[config] = {"kernel": "rt_primary_pass + rt_trace_*", "fetch_bytes": fetch, "write_bytes": write,
-                     "valu_instructions": valu, "valu_lane_utilisation_pct": lanes, "valu_busy_pct": totals.get("rt_trace", {}).get("VALUBusy"),
-                     "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB x 1024, per frame = all kernels of one launch), {root}; "
+                     "valu_instructions": valu, "valu_lane_utilisation_pct": lanes, "kernels": kernels,
+                     "source": f"rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in KiB x 1024, separate passes; means per launch and kernel), {tag}; "
                                "reads are scattered 4-byte skybox gathers served by the Infinity Cache, so the x2 streaming correction is not applied"}
     json.dump(table, open(path, "w"), indent=1, sort_keys=True)

@@ -33,7 +33,8 @@ class CameraBasis(C.Structure):
 
 
 class Counters(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "object_tests", "rng_draws", "sky_fetches", "flops")]
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "object_tests", "rng_draws", "sky_fetches", "flops",
+                                          "box_tests", "box_flops", "sphere_tests", "sphere_flops", "sky_samples", "sky_sample_flops")]
 
 
 # numpy view of the reference's Object (scene.h:24-31): 68 bytes
