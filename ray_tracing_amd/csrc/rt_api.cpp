@@ -83,6 +83,8 @@ struct rt_context {
 	std::vector<char> spec_code;         /* its code object (rt_spec_symbol_read("") hands it out) */
 	std::string  spec_compiler;          /* where it came from (rt_compiled_scene_info) */
 	hipFunction_t spec_fn = nullptr;
+	hipFunction_t spec_fn_audit = nullptr;  /* the same scene's kernel in its audit variant (rt_tuning.audit_known_taps), built when first asked for; valid like spec_fn */
+	bool         spec_audit_failed = false; /* ... could not be built (no hiprtc): audited launches use the generic kernel's audit variant */
 	bool         scene_fast_ok = false;  /* every cube has 0 <= size, plane coordinates +0 or 2^-76 <= |x| <= 2^29, sphere data |x| <= 2^29 */
 	int          light_index = -1;
 	float        light_pos[3] = {0, 0, 0};
@@ -453,6 +455,7 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 	}
 	ctx->h_geom.assign(geom.begin(), geom.begin() + n);
 	ctx->spec_module = nullptr; ctx->spec_fn = nullptr;      /* (not unloaded: rt_jit.cpp keeps compiled scenes for the life of the process) */
+	ctx->spec_fn_audit = nullptr; ctx->spec_audit_failed = false;
 	if (n > ctx->capacity || !ctx->d_geom) {
 		(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
 		ctx->d_geom = nullptr; ctx->d_shade = nullptr; ctx->capacity = 0;
@@ -723,6 +726,22 @@ int rt_reserve(rt_context *ctx, int width, int height)
 	return RT_OK;
 }
 
+/* The trace kernel of an audited launch (rt_tuning.audit_known_taps != 0) is a VARIANT that carries the comparison; a compiled
+ * scene gets its variant from a second build (-DRT_SPEC_AUDIT: hiprtc at run time, about half a second, once per scene and
+ * process).  Where that is not possible the generic kernel's audit variant renders the audited launches: same frames. */
+static hipFunction_t trace_kernel_for(rt_context *ctx, bool audit)
+{
+	if (!audit || !ctx->spec_fn) return ctx->spec_fn;
+	if (!ctx->spec_fn_audit && !ctx->spec_audit_failed) {
+		hipModule_t module = nullptr;
+		std::string message, flags = ctx->jit_flags + (ctx->jit_flags.empty() ? "" : " ") + "-DRT_SPEC_AUDIT";
+		const int rc = rt_jit_build(ctx->h_geom.data(), ctx->num_objects, ctx->light_index, ctx->light_pos, ctx->only_light_emits ? 1 : 0, ctx->tuning.jit_waves_per_simd,
+		                            flags.c_str(), &module, &ctx->spec_fn_audit, message);
+		if (rc != RT_OK) { ctx->spec_fn_audit = nullptr; ctx->spec_audit_failed = true; }
+	}
+	return ctx->spec_fn_audit;        /* (nullptr: the generic kernel) */
+}
+
 /* rt_tuning.audit_known_taps: the scene's lit-taps table carries the audit mark itself -- bit 2 of one answered cell in 2^k,
  * picked by a hash of the cell's index -- so that the trace kernel needs no launch constant for it (a scalar register through
  * every round of a kernel at its register limit).  The device's copy is re-marked, between launches, when the setting changed. */
@@ -794,8 +813,9 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	}
 	ctx->slot[ctx->launches & 1u].lists_key = 0;
 	ctx->primary_passes++;
-	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, ctx->spec_fn, ctx->slot[ctx->launches & 1u].d_counter, e0, ctx->slot[ctx->launches & 1u].started, ctx->num_cus, workgroups_per_cu_for(ctx, stream), stream,
-	                                false, &ctx->slot[ctx->launches & 1u].expect, em);
+	const bool audit = ctx->tuning.audit_known_taps != 0;
+	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, trace_kernel_for(ctx, audit), ctx->slot[ctx->launches & 1u].d_counter, e0, ctx->slot[ctx->launches & 1u].started, ctx->num_cus, workgroups_per_cu_for(ctx, stream), stream,
+	                                false, &ctx->slot[ctx->launches & 1u].expect, em, audit);
 	if (le == hipSuccess && ctx->profiling) le = hipEventRecord(e1, stream);
 	if (ctx->profiling) {
 		if (le == hipSuccess) ctx->events.push_back({ e0, em, e1 });
@@ -1193,7 +1213,9 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 	const bool reuse = !ctx->tuning.poison_frame && !batch && sl.lists_key == key;      /* (a batch's sky pixels are sums: never the same twice) */
 	sl.lists_key = 0;
 	{
-		const hipError_t le = rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, ctx->spec_fn, sl.d_counter, nullptr, sl.started, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream, reuse, &sl.expect);
+		const bool audit = ctx->tuning.audit_known_taps != 0;
+		const hipError_t le = rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, trace_kernel_for(ctx, audit), sl.d_counter, nullptr, sl.started, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream, reuse, &sl.expect,
+		                                      nullptr, audit);
 		if (le != hipSuccess) { unpublish_launch(ctx); return fail(RT_ERR_DEVICE, "trace launch: %s", hipGetErrorString(le)); }
 	}
 	if (!reuse) ctx->primary_passes++;

@@ -36,7 +36,8 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
                            unsigned int *block_counter, hipEvent_t cleared, hipEvent_t primary_done, int num_cus, int workgroups_per_cu, hipStream_t stream,
                            bool reuse_pixel_lists = false,    /* the scratch set still holds rt_primary_pass's output for this very launch */
                            rt_launch_expect *expect = nullptr,
-                           hipEvent_t primary_timed = nullptr);   /* recorded between the camera-ray pass and the trace kernel (profiling) */
+                           hipEvent_t primary_timed = nullptr,    /* recorded between the camera-ray pass and the trace kernel (profiling) */
+                           bool audit = false);                   /* the kernel variant that compares audited answers of rt_lit.h with a trace (spec_fn, if given, must be that variant) */
 int        rt_jit_build(const rt_geom *geom, int n, int light_index, const float light_pos[3], int only_light_emits, int waves_per_simd, const char *extra_flags, hipModule_t *module, hipFunction_t *function, std::string &message,
                         std::vector<char> *code_out = nullptr,    /* the code object (development aid) */
                         std::string *compiler = nullptr);         /* where it came from: "embedded, compiled with the library by ..." / "hiprtc x.y at run time" */

@@ -1108,8 +1108,10 @@ RT_DEV void leave_launch(WaveLDS *Wp, int wave)
 }
 
 
-template <bool FAST, bool CULL = false, int BLOCK = RT_BLOCK>      /* BLOCK: threads per workgroup (the culled variant also comes with RT_BLOCK_WIDE) */
-RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter_arg)
+/* BLOCK: threads per workgroup (the culled variant also comes with RT_BLOCK_WIDE); AUDIT: the variant that compares the answers
+ * of rt_lit.h it is asked to audit with a trace of the taps (rt_tuning.audit_known_taps) */
+template <bool FAST, bool CULL = false, int BLOCK = RT_BLOCK, bool AUDIT = false>
+RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 {
 	extern __shared__ float4 lds[];
 #ifdef RT_SPEC_HEADER
@@ -1296,11 +1298,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter_arg)
 			if (nmask != 0ull) {
 				STAT(21);
 				const rt_launch_cold C = cold_view();
-#ifdef RT_X_NOFETCHX
-				const gcounters block_counter = (gcounters) block_counter_arg;
-#else
 				const gcounters block_counter = counters_of(C);
-#endif
 				const int asked = __popcll(nmask);
 				int got = 0;
 				size_t first = 0;
@@ -1326,11 +1324,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter_arg)
 						if (lane == 0) { C->control[RT_CTL_CANCELLED] = 1u; __hip_atomic_store((gwuint) C->control + RT_CTL_STOP_RELAY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 					}
 					const guint fill_counts = (guint) C->pix_count;
-#ifdef RT_X_NOFETCHX
-					const unsigned int drop = 0u;
-#else
 					const unsigned int drop = C->test_drop_pixels;          /* (testing aid: 0 in production) */
-#endif
 					unsigned int filled = (unsigned int) __builtin_amdgcn_readfirstlane((int) fill_counts[shard * 32u]);
 					filled -= filled < drop ? filled : drop;
 					got = k < filled && !cancelled ? (filled - k < (unsigned int) asked ? (int) (filled - k) : asked) : 0;
@@ -1441,11 +1435,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter_arg)
 			 * are drawn and accepted as always (main.c:193-195), but not traced */
 			/* a sample's first bounce: its path is seeded here, once per round for all the lanes that start one, not once per hand-out attempt */
 			if (bounce == 0) rng = path_seed(L.seed, (uint32_t) rng, (uint32_t) L.sample_base + (uint32_t) (rng >> 32));
-#ifdef RT_X_NOAUDIT
-			const bool taps_lit = lit_next != 0u;
-#else
-			const bool taps_lit = (lit_next & 3u) != 0u;
-#endif      /* ... or a hit point of a later bounce in such a cell of the scene's table (section 4);
+			const bool taps_lit = AUDIT ? (lit_next & 3u) != 0u : lit_next != 0u;      /* ... or a hit point of a later bounce in such a cell of the scene's table (section 4);
 			                                            * 1: they reach the emitter, 2: they certainly do not (and nothing else emits) */
 #ifdef RT_STATS
 			{	/* what kind of shading event this is (scripts/stats_c1.py): a sample's first or a later one, on a box or a sphere, taps known or not */
@@ -1503,16 +1493,14 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter_arg)
 			hdir = out_dir;
 			has_hit = false;
 			cur = REC_VALID | (specular ? REC_SPECULAR : 0) | (emit_main ? 0 : REC_LAST) | (tapmask << 4) | (hobj << 8);
-#ifdef RT_X_NOAUDIT
-			if (taps_lit) { cur |= lit_next == 1u ? REC_TAPS_LIT : REC_TAPS_DARK; tapmask = 0; }
-#else
 			if (taps_lit) {             /* the record keeps the accepted taps, the queue gets none ... */
-				cur |= (lit_next & 1u) ? REC_TAPS_LIT : REC_TAPS_DARK;
-				/* ... unless the answer came with the audit bit (rt_launch.audit_taps: the camera-ray pass marks one in 2^k of the pixels it
-				 * classifies, the host one in 2^k cells of the scene's table): the taps are traced like unknown ones and the back compares */
-				if ((lit_next & 4u) != 0u && tapmask != 0) cur |= REC_AUDIT; else tapmask = 0;
+				cur |= (AUDIT ? (lit_next & 1u) != 0u : lit_next == 1u) ? REC_TAPS_LIT : REC_TAPS_DARK;
+				/* ... unless (AUDIT kernels: rt_tuning.audit_known_taps) the answer came with the audit bit -- the camera-ray pass marks one in
+				 * 2^k of the pixels it classifies, the host one in 2^k cells of the scene's table --: the taps are traced like unknown ones
+				 * and the back compares.  The comparison is a kernel VARIANT, not a launch constant: a round of the compiled kernel is
+				 * ~500 instructions, and the eleven this costs are 2 % of the frame (profiles/r05/ab_audit_variant.txt) */
+				if (AUDIT && (lit_next & 4u) != 0u && tapmask != 0) cur |= REC_AUDIT; else tapmask = 0;
 			}
-#endif
 		}
 
 		STAMP(1);
@@ -1658,9 +1646,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter_arg)
 					const int t0 = W.tap[due][0][lane], t1 = W.tap[due][1][lane], t2 = W.tap[due][2][lane];
 					taps = __popc((unsigned int) ptaps);
 					int n_hit = ((ptaps & 1) && t0 == light_obj ? 1 : 0) + ((ptaps & 2) && t1 == light_obj ? 1 : 0) + ((ptaps & 4) && t2 == light_obj ? 1 : 0);
-#ifndef RT_X_NOAUDIT
-					if (rec2 & REC_AUDIT) audit_taps(taps, (rec2 & REC_TAPS_LIT) ? taps - n_hit : n_hit);
-#endif
+					if (AUDIT && (rec2 & REC_AUDIT)) audit_taps(taps, (rec2 & REC_TAPS_LIT) ? taps - n_hit : n_hit);
 					if (rec2 & REC_TAPS_LIT) n_hit = taps;
 					if (rec2 & REC_TAPS_DARK) n_hit = 0;
 					const float4 e = sc.shade[4 * light_obj + 3];
@@ -1671,9 +1657,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter_arg)
 				for (int k = 0; k < 3; k++)
 					if ((ptaps >> k) & 1) {
 						const int obj = (rec2 & REC_TAPS_LIT) ? light_obj : ((rec2 & REC_TAPS_DARK) ? -1 : W.tap[due][k][lane]);
-#ifndef RT_X_NOAUDIT
-						if (rec2 & REC_AUDIT) audit_taps(1, ((rec2 & REC_TAPS_LIT) != 0) != (W.tap[due][k][lane] == light_obj) ? 1 : 0);
-#endif
+						if (AUDIT && (rec2 & REC_AUDIT)) audit_taps(1, ((rec2 & REC_TAPS_LIT) != 0) != (W.tap[due][k][lane] == light_obj) ? 1 : 0);
 						if (obj >= 0) { const float4 e = sc.shade[4 * obj + 3]; lit = add3(lit, mk3(e.x, e.y, e.z)); }
 						taps++;
 					}
@@ -1731,28 +1715,27 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *block_counter_arg)
 		STAMP(4);
 	}
 	STAMP_FLUSH(BLOCK / 64);
-#ifndef RT_X_NOLEAVE
 	leave_launch<BLOCK>(&W, wave);
-#endif
 }
 
 #ifndef RT_SPEC_ONLY
 /* (a large scene's records leave room for one or two workgroups per CU anyway: the culled variant may use 256 registers) */
-template <bool FAST, bool CULL = false>
+template <bool FAST, bool CULL = false, bool AUDIT = false>
 __global__ void __launch_bounds__(RT_BLOCK, CULL ? 2 : 4)
 rt_trace_wavefront(const rt_launch L, unsigned int *block_counter)
 {
-	wavefront_body<FAST, CULL>(L, block_counter);
+	wavefront_body<FAST, CULL, RT_BLOCK, AUDIT>(L, block_counter);
 }
 /* The culled trace is bound by the latency of its LDS reads and cross-lane fetches, i.e. by the waves a SIMD has to switch
  * between, and the scene's records are per workgroup while a wave's own LDS is 10 KB: one workgroup of twelve waves shares
  * one copy of 1024 objects' records (36 + 12 x 10 = 156 KB: three waves per SIMD) where two workgroups of four hold two
  * copies (2 x 77 KB: two waves per SIMD). */
 #define RT_BLOCK_WIDE 768
+template <bool AUDIT = false>
 __global__ void __launch_bounds__(RT_BLOCK_WIDE, 1)
 rt_trace_wavefront_wide(const rt_launch L, unsigned int *block_counter)
 {
-	wavefront_body<true, true, RT_BLOCK_WIDE>(L, block_counter);
+	wavefront_body<true, true, RT_BLOCK_WIDE, AUDIT>(L, block_counter);
 }
 #endif
 
@@ -1761,7 +1744,11 @@ rt_trace_wavefront_wide(const rt_launch L, unsigned int *block_counter)
 extern "C" __global__ void __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD)
 rt_trace_spec(const rt_launch L, unsigned int *block_counter)
 {
+#ifdef RT_SPEC_AUDIT        /* (rt_compile_scene's second build of a scene, made when the audit is first asked for) */
+	wavefront_body<true, false, RT_BLOCK, true>(L, block_counter);
+#else
 	wavefront_body<true>(L, block_counter);
+#endif
 }
 #endif
 
@@ -2136,7 +2123,7 @@ size_t rt_pixel_list_capacity(int width, int local_rows, int num_cus, int num_sh
 
 hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, hipFunction_t spec_fn,
                            unsigned int *block_counter, hipEvent_t cleared, hipEvent_t primary_done, int num_cus, int workgroups_per_cu, hipStream_t stream,
-                           bool reuse_pixel_lists, rt_launch_expect *expect, hipEvent_t primary_timed)
+                           bool reuse_pixel_lists, rt_launch_expect *expect, hipEvent_t primary_timed, bool audit)
 {
 	rt_launch_expect unused;
 	if (!expect) expect = &unused;
@@ -2227,12 +2214,16 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	}
 	if (variant == 2 /* RT_KERNEL_WAVEFRONT: same schedule, plain IEEE operations */ || !scene_fast_ok)
 		hipLaunchKernelGGL(rt_trace_wavefront<false>, dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, Lq, block_counter);
-	else if (cull && block == RT_BLOCK_WIDE)
-		hipLaunchKernelGGL(rt_trace_wavefront_wide, dim3((unsigned int) grid), dim3(RT_BLOCK_WIDE), lds, stream, Lq, block_counter);
-	else if (cull)
-		hipLaunchKernelGGL((rt_trace_wavefront<true, true>), dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, Lq, block_counter);
-	else
-		hipLaunchKernelGGL(rt_trace_wavefront<true>, dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, Lq, block_counter);
+	else if (cull && block == RT_BLOCK_WIDE) {
+		if (audit) hipLaunchKernelGGL(rt_trace_wavefront_wide<true>, dim3((unsigned int) grid), dim3(RT_BLOCK_WIDE), lds, stream, Lq, block_counter);
+		else hipLaunchKernelGGL(rt_trace_wavefront_wide<false>, dim3((unsigned int) grid), dim3(RT_BLOCK_WIDE), lds, stream, Lq, block_counter);
+	} else if (cull) {
+		if (audit) hipLaunchKernelGGL((rt_trace_wavefront<true, true, true>), dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, Lq, block_counter);
+		else hipLaunchKernelGGL((rt_trace_wavefront<true, true>), dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, Lq, block_counter);
+	} else {
+		if (audit) hipLaunchKernelGGL((rt_trace_wavefront<true, false, true>), dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, Lq, block_counter);
+		else hipLaunchKernelGGL(rt_trace_wavefront<true>, dim3((unsigned int) grid), dim3(RT_BLOCK), lds, stream, Lq, block_counter);
+	}
 	return hipGetLastError();
 }
 
