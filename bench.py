@@ -91,7 +91,7 @@ def parse_args(argv=None):
     ap.add_argument("--leave-early", action="store_true",
                     help="testing aid (scripts/repro_verify_race.py): ranks other than 0 do not wait for rank 0's verification before they "
                          "tear their contexts down -- the bench's behaviour when its verification failed intermittently in round 3")
-    ap.add_argument("--depth", type=int, default=0, help="frames in flight in the C ABI's frame queue (default 2; 3 with --force-collective)")
+    ap.add_argument("--depth", type=int, default=0, help="frames in flight in the C ABI's frame queue (default 2; 4 on the N-GPU path)")
     return ap.parse_args(argv)
 
 
@@ -394,7 +394,10 @@ def main():
                 collective["note"] = "testing aid: all contexts on one GPU, the gather is device copies (no communicator: ranks_seen 0)"
         else:
             prof = gpu
-        depth = args.depth or (3 if multi_path else 2)
+        # (one GPU: two frames in flight measure better than three -- 5.465 against 5.52 ms per C1 step, profiles/r05/bench_depth.txt: a
+        # third frame enqueued ahead makes every launch take half the workgroup slots; the N-GPU path keeps a strip draining, one
+        # running and one starting, plus the gather of the one before)
+        depth = args.depth or (4 if multi_path else 2)
         loop = FrameLoop(queue, W, H, spp, nb, depth=depth, row_block=ROW_BLOCK, kernel=args.kernel)
         primitive = ("device copies on one GPU (testing aid)" if args.one_device else "ncclGather (native, one process)") if multi_path else None
 
@@ -413,7 +416,7 @@ def main():
         tiled = TiledFrame(gpu, W, H, spp, nb, seed=seed, row_block=ROW_BLOCK, rank=rank, world=world,
                            kernel=args.kernel, device=dev, to_host=True, force_collective=args.force_collective)
         prof = gpu
-        depth = 3 if tiled.multi else 2
+        depth = tiled.depth
         primitive = tiled.primitive
         if tiled.multi:
             # what the process group itself reports: its size, and the device every rank really is on
@@ -451,7 +454,7 @@ def main():
     if not native:
         tiled.record_events = True
         start = torch.cuda.Event(enable_timing=True)
-        start.record(tiled.streams[tiled.k & 1])
+        start.record(tiled.streams[tiled.k % len(tiled.streams)])
     t0, stamps = run_steps(first_timed, args.steps)
     fence()
     elapsed = time.perf_counter() - t0

@@ -158,6 +158,7 @@ RT_API int rt_render(rt_context *ctx, const rt_render_params *params, Vector3 *f
  * millisecond; they must of course write different destinations).  Launches on one stream run in stream order as
  * always.  rt_set_scene / rt_set_skybox wait for the context's own launches only, not for the whole device. */
 #define RT_STREAM_LEGACY ((void *) (intptr_t) -1)
+#define RT_LAUNCH_SETS 3        /* scratch sets, and streams (rt_stream), a context rotates its launches through */
 RT_API int rt_render_device(rt_context *ctx, const rt_render_params *params, void *d_strip, void *hip_stream);
 
 /* The context's streams as hipStream_t: which = 0 the stream NULL stands for above; which = 1 a second one (created on

@@ -113,9 +113,12 @@ struct rt_context {
 	rt_camera    camera;
 	bool         have_camera = false;
 
-	/* Scratch of a launch.  There are two sets, used alternately, so that two consecutive launches enqueued on
-	 * different streams can be on the GPU together: the waves of the second fill the compute units as the waves of the
-	 * first run out of pixels (the last wave of a launch leaves 100 us after the average one). */
+	/* Scratch of a launch.  There are RT_LAUNCH_SETS sets, used in rotation, so that consecutive launches enqueued on
+	 * different streams can be on the GPU together: the waves of the next fill the compute units as the waves of the
+	 * first run out of pixels (the last wave of a launch leaves 100 us after the average one).  Three sets:
+	 * with two, launch n + 2 had to wait for the END of launch n, whose scratch it took over -- and for all of launch n's tail the
+	 * workgroup slots its waves left stayed empty beside launch n + 1 (a strip of an eighth of a frame: 0.748 ms per step against
+	 * 0.672 ideal); with three, launch n + 2 is resident while launch n drains. */
 	struct launch_slot {
 		unsigned int *d_counter = nullptr;   /* dequeue + fill counters of the pixel lists, launch control words */
 		float       *d_pix = nullptr;        /* rt_primary_pass output: pixel records (rt_device.h) */
@@ -129,12 +132,12 @@ struct rt_context {
 		hipStream_t  readback_stream = nullptr;
 		bool         readback_pending = false; /* ... which the set's next launch, which clears the word, has to wait for */
 		rt_launch_expect expect = { 0u, 0, 0u };   /* what the set's most recent launch must leave in its control words (rt_judge_launch) */
-	} slot[2];
-	unsigned     launches = 0;           /* launch n uses slot[n & 1] */
+	} slot[RT_LAUNCH_SETS];
+	unsigned     launches = 0;           /* launch n uses slot[n % RT_LAUNCH_SETS] */
 	unsigned int last_id = 0;            /* launch numbers handed out so far (prepare_launch): a number is never used twice */
 	int          cur = 0;                /* set of the most recent launch */
-	hipStream_t  stream2 = nullptr;      /* rt_stream(ctx, 1): made on first request */
-	std::once_flag stream2_once;
+	hipStream_t  more_streams[RT_LAUNCH_SETS - 1] = {};   /* rt_stream(ctx, 1 ...): made on first request */
+	std::once_flag more_streams_once[RT_LAUNCH_SETS - 1];
 	std::atomic<unsigned int> enqueued{0}; /* for rt_cancel() on another thread: the launches announced so far are numbers 1 ... enqueued */
 	unsigned int *h_words = nullptr;     /* pinned, RT_HOST_WORDS of them (layout above); [RT_STOP_WORD] = rt_cancel()'s request: "launches up to this number stop" */
 	unsigned int *d_stop = nullptr;      /* the device's address of that word */
@@ -157,7 +160,7 @@ struct rt_context {
 		bool       busy = false;
 		rt_launch_expect expect = { 0u, 0, 0u };
 	} tickets[RT_CHECK_TICKETS];
-	unsigned long long frames_submitted = 0;   /* frame n renders on the context's stream n & 1 */
+	unsigned long long frames_submitted = 0;   /* frame n renders on the context's stream n % RT_LAUNCH_SETS */
 	hipStream_t  copy_stream = nullptr;  /* made by the first rt_frame_submit() */
 
 	/* progressive accumulation (rt_progressive_*) */
@@ -193,19 +196,19 @@ static int wait_for_launches(rt_context *ctx)
 	return RT_OK;
 }
 
-/* Called before launch number ctx->launches is enqueued on `stream`: the launch before the previous one used the
- * same scratch set, so this one is ordered behind it when that ran on a different stream.  (The previous launch has
- * the other set: the two may overlap.) */
+/* Called before launch number ctx->launches is enqueued on `stream`: launch n - RT_LAUNCH_SETS used the same scratch set,
+ * so this one is ordered behind it when that ran on a different stream.  (The launches in between have the other sets:
+ * they may overlap with this one.) */
 static int order_behind_previous(rt_context *ctx, hipStream_t stream)
 {
-	rt_context::launch_slot &sl = ctx->slot[ctx->launches & 1u];
+	rt_context::launch_slot &sl = ctx->slot[ctx->launches % RT_LAUNCH_SETS];
 	if (sl.used && sl.stream != stream) HIP_TRY(hipStreamWaitEvent(stream, sl.done, 0));
 	/* ... and it starts when the previous launch's trace kernel is next in line on its stream: that kernel's workgroups
 	 * take the whole chip first, and this launch gets the compute units as they leave.  (Two launches that become ready
 	 * together would share the chip half and half from start to end, and finish together: nothing gained, and the late
 	 * half of either grid finds no pixels left.) */
-	rt_context::launch_slot &prev = ctx->slot[(ctx->launches + 1u) & 1u];
-	if (prev.used && prev.stream != stream) HIP_TRY(hipStreamWaitEvent(stream, prev.started, 0));
+	rt_context::launch_slot &prev = ctx->slot[ctx->cur];
+	if (ctx->launches && prev.used && prev.stream != stream) HIP_TRY(hipStreamWaitEvent(stream, prev.started, 0));
 	/* ... and a frame in flight must have read them (rt_frame_submit) */
 	if (sl.readback_pending) { sl.readback_pending = false; if (sl.readback_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, sl.readback, 0)); }
 	return RT_OK;
@@ -224,8 +227,8 @@ static int order_behind_previous(rt_context *ctx, hipStream_t stream)
 static int workgroups_per_cu_for(rt_context *ctx, hipStream_t stream)
 {
 	if (ctx->tuning.workgroups_per_cu > 0) return ctx->tuning.workgroups_per_cu;
-	const rt_context::launch_slot &prev = ctx->slot[(ctx->launches + 1u) & 1u];
-	if (!prev.used || prev.stream == stream) return 0;
+	const rt_context::launch_slot &prev = ctx->slot[ctx->cur];
+	if (!ctx->launches || !prev.used || prev.stream == stream) return 0;
 	const hipError_t q = hipEventQuery(prev.started);
 	(void) hipGetLastError();           /* "not ready" is an answer, not an error the launch below should find */
 	return q == hipErrorNotReady ? 2 : 0;
@@ -247,10 +250,10 @@ static int classify_pixels(const rt_context *ctx, int samples)
 
 static int mark_launch(rt_context *ctx, hipStream_t stream)
 {
-	rt_context::launch_slot &sl = ctx->slot[ctx->launches & 1u];
+	rt_context::launch_slot &sl = ctx->slot[ctx->launches % RT_LAUNCH_SETS];
 	HIP_TRY(hipEventRecord(sl.done, stream));
 	sl.stream = stream; sl.used = true;
-	ctx->cur = (int) (ctx->launches & 1u);
+	ctx->cur = (int) (ctx->launches % RT_LAUNCH_SETS);
 	ctx->launches++;               /* (its number, ctx->last_id, was published by prepare_launch() before the launch's first kernel) */
 	return RT_OK;
 }
@@ -311,19 +314,21 @@ void *rt_context_launch_done(rt_context *ctx) { return ctx ? (void *) ctx->slot[
 
 extern "C" void *rt_stream(rt_context *ctx, int which)
 {
-	if (!ctx || which < 0 || which > 1) return nullptr;
+	if (!ctx || which < 0 || which >= RT_LAUNCH_SETS) return nullptr;
 	if (which == 0) return (void *) ctx->stream;
 	/* Made on first request (a stream nobody uses only makes busy ones share a hardware queue), with the lowest priority
-	 * the device offers: streams of different priority never share a queue, so the launches of the two streams overlap. */
-	std::call_once(ctx->stream2_once, [ctx]() {
+	 * the device offers: streams of different priority never share a queue, so their launches overlap those of stream 0
+	 * (and each other's: the runtime deals the streams of one priority over several hardware queues). */
+	hipStream_t &st = ctx->more_streams[which - 1];
+	std::call_once(ctx->more_streams_once[which - 1], [ctx, &st]() {
 		if (hipSetDevice(ctx->device) != hipSuccess) return;
 		int least = 0, greatest = 0;
 		if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-		if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, least) != hipSuccess &&
-		    hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) ctx->stream2 = nullptr;
+		if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least) != hipSuccess &&
+		    hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
 	});
-	if (!ctx->stream2) { fail(RT_ERR_DEVICE, "rt_stream: could not create the second stream"); return nullptr; }
-	return (void *) ctx->stream2;
+	if (!st) { fail(RT_ERR_DEVICE, "rt_stream: could not create stream %d", which); return nullptr; }
+	return (void *) st;
 }
 
 extern "C" {
@@ -411,7 +416,7 @@ void rt_destroy(rt_context *ctx)
 	if (ctx->copy_stream) { (void) hipStreamSynchronize(ctx->copy_stream); (void) hipStreamDestroy(ctx->copy_stream); }
 	for (auto &f : ctx->fq) { if (f.copied) (void) hipEventDestroy(f.copied); if (f.rendered) (void) hipEventDestroy(f.rendered); (void) hipFree(f.d_buf); }
 	for (auto &t : ctx->tickets) if (t.copied) (void) hipEventDestroy(t.copied);
-	if (ctx->stream2) { (void) hipStreamSynchronize(ctx->stream2); (void) hipStreamDestroy(ctx->stream2); }
+	for (hipStream_t st : ctx->more_streams) if (st) { (void) hipStreamSynchronize(st); (void) hipStreamDestroy(st); }
 	if (ctx->h_words) (void) hipHostFree(ctx->h_words);
 	/* (the compiled scene's module belongs to the process-wide cache of rt_jit.cpp: never unloaded) */
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
@@ -659,7 +664,7 @@ static void give_event(rt_context *ctx, hipEvent_t e) { if (e) ctx->event_pool.p
  * fills for the trace kernel (grown on demand).  Any schedule renders the same frame. */
 static int prepare_scratch(rt_context *ctx, rt_launch &L, unsigned which)
 {
-	rt_context::launch_slot &sl = ctx->slot[which & 1u];
+	rt_context::launch_slot &sl = ctx->slot[which % RT_LAUNCH_SETS];
 	const long long pixel_blocks = (long long) ((L.width + 7) / 8) * ((L.local_rows + 7) / 8);
 	/* 64 lists (a single dequeue counter takes ~88 atomics per microsecond: 4 K waves asking for their first pixels at
 	 * once would already queue up) unless the launch is small */
@@ -716,7 +721,7 @@ int rt_reserve(rt_context *ctx, int width, int height)
 	rt_launch L;
 	memset(&L, 0, sizeof(L));
 	L.width = width; L.local_rows = rt_strip_rows(height, 8, 1);
-	for (unsigned which = 0; which < 2; which++) { const int rc = prepare_scratch(ctx, L, which); if (rc != RT_OK) return rc; }     /* (nothing is announced: nothing is launched) */
+	for (unsigned which = 0; which < RT_LAUNCH_SETS; which++) { const int rc = prepare_scratch(ctx, L, which); if (rc != RT_OK) return rc; }     /* (nothing is announced: nothing is launched) */
 	const size_t need = (size_t) L.local_rows * width * 3 * sizeof(float);
 	if (need > ctx->frame_bytes) {
 		(void) hipFree(ctx->d_frame); ctx->d_frame = nullptr; ctx->frame_bytes = 0;
@@ -811,11 +816,11 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 		e0 = take_event(ctx); em = ctx->profiling_split ? take_event(ctx) : nullptr; e1 = take_event(ctx);
 		if (!e0 || (!em && ctx->profiling_split) || !e1) { give_event(ctx, e0); give_event(ctx, em); give_event(ctx, e1); unpublish_launch(ctx); return fail(RT_ERR_DEVICE, "rt_render_device: hipEventCreate failed"); }
 	}
-	ctx->slot[ctx->launches & 1u].lists_key = 0;
+	ctx->slot[ctx->launches % RT_LAUNCH_SETS].lists_key = 0;
 	ctx->primary_passes++;
 	const bool audit = ctx->tuning.audit_known_taps != 0;
-	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, trace_kernel_for(ctx, audit), ctx->slot[ctx->launches & 1u].d_counter, e0, ctx->slot[ctx->launches & 1u].started, ctx->num_cus, workgroups_per_cu_for(ctx, stream), stream,
-	                                false, &ctx->slot[ctx->launches & 1u].expect, em, audit);
+	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, trace_kernel_for(ctx, audit), ctx->slot[ctx->launches % RT_LAUNCH_SETS].d_counter, e0, ctx->slot[ctx->launches % RT_LAUNCH_SETS].started, ctx->num_cus, workgroups_per_cu_for(ctx, stream), stream,
+	                                false, &ctx->slot[ctx->launches % RT_LAUNCH_SETS].expect, em, audit);
 	if (le == hipSuccess && ctx->profiling) le = hipEventRecord(e1, stream);
 	if (ctx->profiling) {
 		if (le == hipSuccess) ctx->events.push_back({ e0, em, e1 });
@@ -887,7 +892,7 @@ static int frame_submit(rt_context *ctx, const rt_render_params *p, int slot, Ve
 		HIP_TRY(hipMalloc((void**) &f.d_buf, need));
 		f.bytes = need;
 	}
-	hipStream_t stream = (ctx->frames_submitted & 1ull) ? (hipStream_t) rt_stream(ctx, 1) : ctx->stream;
+	hipStream_t stream = (hipStream_t) rt_stream(ctx, (int) (ctx->frames_submitted % RT_LAUNCH_SETS));
 	if (!stream) return RT_ERR_DEVICE;                                  /* rt_stream() left the text */
 	rc = rt_render_device(ctx, p, f.d_buf, stream);
 	if (rc != RT_OK) return rc;
@@ -1209,7 +1214,7 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 		for (size_t i = 0; i < sizeof(K); i++) key = (key ^ b[i]) * 0x100000001b3ull;
 		if (key == 0) key = 1;
 	}
-	rt_context::launch_slot &sl = ctx->slot[ctx->launches & 1u];
+	rt_context::launch_slot &sl = ctx->slot[ctx->launches % RT_LAUNCH_SETS];
 	const bool reuse = !ctx->tuning.poison_frame && !batch && sl.lists_key == key;      /* (a batch's sky pixels are sums: never the same twice) */
 	sl.lists_key = 0;
 	{
@@ -1222,10 +1227,8 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 	sl.lists_key = ctx->tuning.poison_frame || batch ? 0 : key;
 	/* the low-resolution frame now holds THIS launch's sky pixels: lists of the other set that belong to anything else
 	 * (a pass at another scale before the ladder came back to this one) no longer have theirs */
-	{
-		rt_context::launch_slot &other = ctx->slot[(ctx->launches & 1u) ^ 1u];
-		if (other.lists_key != key) other.lists_key = 0;
-	}
+	for (unsigned o = 0; o < RT_LAUNCH_SETS; o++)
+		if (o != ctx->launches % RT_LAUNCH_SETS && ctx->slot[o].lists_key != key) ctx->slot[o].lists_key = 0;
 	const float weight = 1.0f / (s * s);                                         /* main.c:278 */
 	/* accum += pass * weight and accum_counts += weight (main.c:394-396), both on the device and both skipped for a pass
 	 * that rt_cancel() cut short (main.c:382): the count can never include a pass the buffer does not */

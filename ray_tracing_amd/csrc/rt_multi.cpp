@@ -14,12 +14,12 @@
  * the gather, the de-interleave and the copy of frame k run beside the renders of frames k+1 and k+2;
  * rt_multi_render() is submit + wait.
  *
- * Streams per device: the context's two render streams (frame k on stream k & 1: consecutive strips overlap on the
- * GPU, rt_api.cpp) and one high-priority stream for the collective (and, on device 0, the de-interleave); device 0
- * has one more for the copy to the host.  Strips rotate through three buffers per device: the persistent trace kernel of
- * frame k+1 holds every compute unit until it drains, so the collective of frame k only gets to run then, and a render
- * stream must not wait for it -- it waits (through an event) for the gather three frames back, whose strip buffer it
- * reuses.
+ * Streams per device: the context's render streams (frame k on stream k % RT_LAUNCH_SETS: consecutive strips overlap on
+ * the GPU, three of them resident -- one draining, one running, one starting --, rt_api.cpp) and one high-priority stream for
+ * the collective (and, on device 0, the de-interleave); device 0 has one more for the copy to the host.  Strips rotate
+ * through four buffers per device: the persistent trace kernels of the following frames hold every compute unit until they
+ * drain, so the collective of frame k only gets to run then, and a render stream must not wait for it -- it waits (through
+ * an event) for the gather four frames back, whose strip buffer it reuses.
  *
  * RCCL is loaded with dlopen() on the first multi-device create (as rt_jit.cpp does for hiprtc) and the handful of
  * entry points used are declared here, so the library needs neither RCCL's headers nor its .so at build or load time,
@@ -79,7 +79,7 @@ Rccl &rccl()
 	return r;
 }
 
-constexpr int STRIP_BUFFERS = 3;
+constexpr int STRIP_BUFFERS = RT_LAUNCH_SETS + 1;     /* strips in flight: RT_LAUNCH_SETS renders and the gather of the one before them */
 
 } // namespace
 
@@ -92,16 +92,16 @@ struct rt_multi {
 	std::vector<ncclComm_t>   comms;            /* made on first use of the collective */
 
 	struct per_device {
-		float      *d_strip[STRIP_BUFFERS] = { nullptr, nullptr, nullptr };
-		hipEvent_t  gathered[STRIP_BUFFERS] = { nullptr, nullptr, nullptr };   /* behind the gather that read d_strip[j] */
-		bool        gathered_set[STRIP_BUFFERS] = { false, false, false };
+		float      *d_strip[STRIP_BUFFERS] = {};
+		hipEvent_t  gathered[STRIP_BUFFERS] = {};   /* behind the gather that read d_strip[j] */
+		bool        gathered_set[STRIP_BUFFERS] = {};
 		hipStream_t gather_stream = nullptr;    /* the collective (device 0: and the de-interleave) */
 	};
 	std::vector<per_device> dev;
 	size_t strip_floats = 0;                    /* capacity of every strip buffer */
 
 	/* device 0 */
-	float *d_strips[STRIP_BUFFERS] = { nullptr, nullptr, nullptr };   /* n strips back to back: the gather's destination */
+	float *d_strips[STRIP_BUFFERS] = {};   /* n strips back to back: the gather's destination */
 	size_t strips_floats = 0;
 	hipStream_t copy_stream = nullptr;
 	unsigned int *h_control = nullptr;          /* pinned: RT_CTL_WORDS control words of the launch of (slot, device) at (slot * 64 + device) * RT_CTL_WORDS */
@@ -114,7 +114,7 @@ struct rt_multi {
 		bool       plain = false;               /* the frame went through rt_frame_submit() of the only context */
 		std::vector<rt_launch_expect> expect;   /* per device: what its launch must leave in its control words (rt_judge_launch) */
 	} fq[RT_FRAME_SLOTS];
-	unsigned long long frames = 0;              /* frame k: render streams k & 1, strip buffers k % 3 */
+	unsigned long long frames = 0;              /* frame k: render stream k % RT_LAUNCH_SETS, strip buffers k % STRIP_BUFFERS */
 	int prog_w = 0, prog_h = 0;                 /* rt_multi_progressive_begin's frame */
 };
 
@@ -314,14 +314,17 @@ int rt_multi_compile_scene(rt_multi *m)                       { FOR_ALL(rt_compi
 
 /* the strips of frame buffer j to device 0: ONE grouped ncclGather, each rank's part on its own collective stream -- or, for a
  * group whose contexts share one device (testing aid), the copies that gather amounts to there */
-static int gather_strips(rt_multi *m, int j, size_t strip_floats)
+static int gather_strips(rt_multi *m, int j, size_t strip_floats, const std::vector<hipEvent_t> &reported)
 {
 	const int n = m->n;
 	if (m->one_device) {
 		/* on the ROOT's collective stream, where the collective's receives run too: behind the root's own earlier work on the
-		 * destination (the de-interleave that read d_strips[j] three frames back) and behind every context's render */
+		 * destination (the de-interleave that read d_strips[j] four frames back) and behind every context's render AND the copy of
+		 * its launch's control words (`reported`: on the context's own collective stream, behind the render) -- a real collective
+		 * orders the root behind those by itself: a rank's send sits behind them on its stream, and the root's receive completes
+		 * after every send */
 		for (int i = 0; i < n; i++) {
-			hipError_t e = i == 0 ? hipSuccess : hipStreamWaitEvent(m->dev[0].gather_stream, (hipEvent_t) rt_context_launch_done(m->ctx[(size_t) i]), 0);
+			hipError_t e = i == 0 ? hipSuccess : hipStreamWaitEvent(m->dev[0].gather_stream, reported[(size_t) i], 0);
 			if (e == hipSuccess)
 				e = hipMemcpyAsync(m->d_strips[j] + (size_t) i * strip_floats, m->dev[(size_t) i].d_strip[j], strip_floats * sizeof(float),
 				                   hipMemcpyDeviceToDevice, m->dev[0].gather_stream);
@@ -358,12 +361,13 @@ static int multi_frame_submit(rt_multi *m, const rt_render_params *params, int s
 	if (!m->one_device) { const int rc = init_communicators(m); if (rc != RT_OK) return rc; }
 	{ const int rc = prepare(m, W, H, rb, slot); if (rc != RT_OK) return rc; }
 	const size_t strip_floats = (size_t) rt_strip_rows(H, rb, n) * W * 3, frame_floats = (size_t) H * W * 3;
-	const int j = (int) (m->frames % STRIP_BUFFERS), which = (int) (m->frames & 1ull);
+	const int j = (int) (m->frames % STRIP_BUFFERS), which = (int) (m->frames % RT_LAUNCH_SETS);
 
 	/* every device renders its interleaved row blocks, concurrently (the calls only enqueue); its collective stream
 	 * takes over behind the render */
 	int rc = RT_OK;
 	int enqueued = 0;
+	std::vector<hipEvent_t> reported((size_t) n, nullptr);      /* per device: behind the copy of its launch's control words */
 	for (int i = 0; i < n && rc == RT_OK; i++) {
 		rt_multi::per_device &d = m->dev[(size_t) i];
 		rt_context *ctx = m->ctx[(size_t) i];
@@ -381,11 +385,11 @@ static int multi_frame_submit(rt_multi *m, const rt_render_params *params, int s
 		 * give up after rt_cancel(), did the launch account for every pixel), for rt_multi_frame_wait() -- not on the render
 		 * stream: a copy between two kernels there costs the overlap of consecutive launches */
 		e = hipStreamWaitEvent(d.gather_stream, (hipEvent_t) rt_context_launch_done(ctx), 0);
-		if (e == hipSuccess) { rc = rt_context_read_control(ctx, &m->h_control[(size_t) (slot * 64 + i) * RT_CTL_WORDS], d.gather_stream, nullptr, &f.expect[(size_t) i]); if (rc != RT_OK) break; }
+		if (e == hipSuccess) { rc = rt_context_read_control(ctx, &m->h_control[(size_t) (slot * 64 + i) * RT_CTL_WORDS], d.gather_stream, &reported[(size_t) i], &f.expect[(size_t) i]); if (rc != RT_OK) break; }
 		if (e != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: device %d: %s", m->devices[(size_t) i], hipGetErrorString(e));
 	}
 	/* ONE gather of the finished strips to device 0, each rank's part on its own collective stream */
-	if (rc == RT_OK) rc = gather_strips(m, j, strip_floats);
+	if (rc == RT_OK) rc = gather_strips(m, j, strip_floats, reported);
 	for (int i = 0; i < n && rc == RT_OK; i++) {
 		rt_multi::per_device &d = m->dev[(size_t) i];
 		hipError_t e = hipSetDevice(m->devices[(size_t) i]);

@@ -20,6 +20,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+LAUNCH_SETS = 3       # RT_LAUNCH_SETS: the scratch sets and streams a context rotates its launches through
+
 
 def strip_rows(height, row_block, world):
     """Rows in one rank's strip, padded so that all ranks match (== rt_strip_rows in the C ABI)."""
@@ -103,14 +105,14 @@ class TiledFrame:
     """The N-GPU frame loop of bench.py: render own strip -> gather -> de-interleave on rank 0 -> frame in
     pinned host memory on rank 0 (what update_frame() hands to the presenter, main.c:467-479).
 
-    step() enqueues one frame and returns at once; up to three frames are in flight.  flush() completes
+    step() enqueues one frame and returns at once; up to four frames are in flight.  flush() completes
     everything and leaves the last frame in `host_frame` (rank 0).  `seed` may be changed between steps
     (`step(seed=...)`): every frame is rendered from scratch, nothing is reused across frames.
 
-    Streams (N > 1).  Frame k is rendered on streams[k & 1] (the renderer's two streams: consecutive strips overlap on
-    the GPU) into strip buffer k % 3, and its gather is issued behind it.  What FOLLOWS the gather -- waiting for it,
+    Streams (N > 1).  Frame k is rendered on streams[k % 3] (the renderer's three streams: consecutive strips overlap on
+    the GPU, one draining, one running, one starting) into strip buffer k % 4, and its gather is issued behind it.  What FOLLOWS the gather -- waiting for it,
     the de-interleave, handing the frame to the copy stream -- is enqueued on a third stream (`post`): the render
-    streams never wait for a collective of the last two frames, only (through an event) for the one three frames back
+    streams never wait for a collective of the last three frames, only (through an event) for the one four frames back
     whose strip buffer they reuse.  The collective's kernels only get compute units when the persistent trace kernel
     of the next frame starts to drain, so a render stream that waited for the previous gather would lose the overlap
     of consecutive strips.
@@ -129,13 +131,13 @@ class TiledFrame:
         # on a one-rank process group: all of the real backend's stream semantics that a 1-GPU box can show
         self.multi = world > 1 or force_collective
         rows = strip_rows(height, row_block, world)
-        # render + collective hand-off: frame k on streams[k & 1].  The library's own two streams, wrapped: they have
+        # render + collective hand-off: frame k on streams[k % 3].  The library's own streams, wrapped: they have
         # different priorities, so they never share a hardware queue and consecutive frames overlap on the GPU
         # (two torch streams of equal priority were seen to share one: then nothing overlaps)
         if overlap_frames:
-            self.streams = [torch.cuda.ExternalStream(renderer.stream(w), device=device) for w in (0, 1)]
+            self.streams = [torch.cuda.ExternalStream(renderer.stream(w), device=device) for w in range(LAUNCH_SETS)]
         else:
-            self.streams = [torch.cuda.Stream(device)] * 2
+            self.streams = [torch.cuda.Stream(device)] * LAUNCH_SETS
         self.stream = self.streams[0]
         # frame -> pinned host memory.  High priority: its own hardware queue (streams of equal priority share a handful of
         # queues, and two streams on one queue run in enqueue order: the copy of frame k would then sit between render k and
@@ -145,7 +147,9 @@ class TiledFrame:
         self.post = torch.cuda.Stream(device, priority=-1) if self.multi else None
         assert all(s.cuda_stream != 0 for s in self.streams)
         self.primitive = collective_for() if self.multi else None
-        self.depth = 3 if self.multi else 2            # strip buffers in rotation
+        # strip buffers in rotation: LAUNCH_SETS renders in flight (one draining, one running, one starting: the library's
+        # scratch sets and streams) and, N > 1, the gather of the one before them
+        self.depth = LAUNCH_SETS + 1 if self.multi else LAUNCH_SETS
         with torch.cuda.stream(self.stream):
             self.strip = [torch.empty((rows, width, 3), dtype=torch.float32, device=device) for _ in range(self.depth)]
             self.strips = self.frame = None
@@ -158,7 +162,7 @@ class TiledFrame:
         self.host_frames = [torch.empty((height, width, 3), dtype=torch.float32, pin_memory=True) for _ in range(2)] if self.to_host else None
         self.host_frame = self.host_frames[0] if self.to_host else None     # the most recently delivered frame
         self.delivered = 0
-        self.copied = [None, None]        # event: the host copy that read frame / strip buffer k & 1 has finished
+        self.copied = [None] * max(self.depth, 2)   # event: the host copy that read strip buffer j (one rank) / frame buffer k & 1 (N > 1) has finished
         self.gathered = [None] * self.depth    # event (post): the gather that read strip[j] (and wrote strips[j]) is complete
         self.assembled = [None] * self.depth   # event (post): the de-interleave that read strips[j] is complete
         # every strip launch accounts for itself (rt_launch_check_*): ticket k % CHECK_TICKETS takes frame k's control words on the
@@ -174,15 +178,15 @@ class TiledFrame:
     def step(self, seed=None):
         k = self.k
         self.k += 1
-        s = self.streams[k & 1]
+        s = self.streams[k % LAUNCH_SETS]
         j = k % self.depth
         with torch.cuda.stream(s):
             if not self.multi:
                 if self.copied[j] is not None:
-                    s.wait_event(self.copied[j])           # the copy two frames ago still reads strip[j]
+                    s.wait_event(self.copied[j])           # the copy `depth` frames ago still reads strip[j]
             else:
                 if self.gathered[j] is not None:
-                    s.wait_event(self.gathered[j])         # the gather three frames ago still reads strip[j] ...
+                    s.wait_event(self.gathered[j])         # the gather `depth` frames ago still reads strip[j] ...
                 if self.assembled[j] is not None:
                     s.wait_event(self.assembled[j])        # ... and its de-interleave reads strips[j], which this gather overwrites
             p = self.r.params(self.W, self.H, self.spp, self.max_bounces, seed=self.seed if seed is None else seed,
