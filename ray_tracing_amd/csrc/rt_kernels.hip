@@ -934,6 +934,12 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 #define WF_QUEUE   128                 /* tap ring: at most 63 waiting + 64 pushed at a time */
 #define WF_STREAMS 8                   /* pixels a wave adds up concurrently (at most) */
 #define WF_WINDOW  384                 /* sample slots per wave, shared equally by its streams */
+#define WF_CLAIM   8                   /* pixels a wave claims from its list at a time ... */
+/* ... until the list is down to this many such claims for every wave that shares it; from then on a wave claims what its streams ask for:
+ * at the end of a launch no wave may sit on a reserve while others have run dry, and a pixel of 256 samples is 0.4 ms of a wave --
+ * measured against "always what is asked for" (profiles/r05/ab_claim_generations.txt): 3 claims: C1 -2.6 %, C2 +6 %; 6: -2.8 / +1 %;
+ * 12: -2.1 / +0.2 %, C4 strip -0.3 % -- hence more of them the more samples a pixel has */
+#define WF_CLAIM_GENERATIONS(spp) (3u + (unsigned int) (spp) / 32u)
 #define WF_EMPTY   0xffffffffu         /* window slot not written yet (a colour channel is in [0,1]: never this pattern) */
 #define WF_LAST    0x8000              /* slot word: this sample is the last one of its pixel */
 #define REC_VALID    1                /* per-bounce record handed from the front to the back (wavefront_body) */
@@ -963,7 +969,10 @@ struct WaveLDS {
 	/* ... added up per workgroup in the first wave's copy of this struct (g_left: waves of the workgroup that have left): 4 096
 	 * waves reporting to one address each would queue up for 50 us at the end of every launch (an address takes ~88 atomics per
 	 * microsecond); the last wave of a workgroup reports for all of them */
-	unsigned int g_written, g_audited, g_disagree, g_left, pad_;
+	unsigned int g_written, g_audited, g_disagree, g_left;
+	/* the wave's reserve: list entries [res_next, res_end) (absolute record numbers) it has claimed and not yet given to a stream;
+	 * res_seen: entries its list had left after that claim */
+	unsigned int res_next, res_end, res_seen, pad_[2];
 };
 
 /* The launch record as the code that takes a new pixel block reads it.  Kernel arguments are invariant, so the
@@ -1176,7 +1185,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 		W.s_nxt[lane] = spp; W.s_seq[lane] = 0u; W.s_drained[lane] = 0u;
 		W.s_sum[0][lane] = 0.0f; W.s_sum[1][lane] = 0.0f; W.s_sum[2][lane] = 0.0f;
 	}
-	if (lane == 0) { W.n_written = 0u; W.n_audited = 0u; W.n_disagree = 0u; }
+	if (lane == 0) { W.n_written = 0u; W.n_audited = 0u; W.n_disagree = 0u; W.res_next = 0u; W.res_end = 0u; W.res_seen = ~0u; }
 	wave_fence();
 
 	/* wave-uniform pixel supply: object pixels are dealt from the lists rt_primary_pass filled, each with its own
@@ -1300,9 +1309,13 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 				const rt_launch_cold C = cold_view();
 				const gcounters block_counter = counters_of(C);
 				const int asked = __popcll(nmask);
-				int got = 0;
-				size_t first = 0;
-				if (!exhausted) {
+				/* Pixels are CLAIMED from the list WF_CLAIM at a time and handed to the streams from the wave's reserve: consecutive
+				 * entries are neighbours in a row of an 8x8 block (rt_primary_pass lists a block row by row), so a wave's streams work on
+				 * a run of a frame row and their 12-byte pixel writes land in the same 32-byte sectors, from the same compute unit,
+				 * within a few rounds of each other -- L2 merges them -- instead of one pixel per wave all over the chip (six times the
+				 * frame's bytes written).  Also an eighth of the atomics. */
+				unsigned int res_next = (unsigned int) __builtin_amdgcn_readfirstlane((int) W.res_next), res_end = (unsigned int) __builtin_amdgcn_readfirstlane((int) W.res_end);
+				if (res_next == res_end && !exhausted) {
 					typedef const __attribute__((address_space(1))) unsigned int *guint;
 					typedef __attribute__((address_space(1))) unsigned int *gwuint;
 					/* rt_cancel() (main.c:316-317: the frame has been invalidated).  The host stores its request in a word of host
@@ -1312,11 +1325,14 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 					 * every other wave reads when it fetches pixels.  Told to stop, a wave hands out nothing more, lets the paths in
 					 * flight finish and leaves; the launch is marked incomplete.  (A wave that has no pixels left to fetch does not
 					 * ask any more: it is about to leave anyway.) */
+					const unsigned int seen = (unsigned int) __builtin_amdgcn_readfirstlane((int) W.res_seen);
+					const unsigned int until = (unsigned int) C->trace_workgroups * (unsigned int) (BLOCK / 64) / (unsigned int) C->num_shards * (unsigned int) WF_CLAIM * WF_CLAIM_GENERATIONS(spp);
+					const unsigned int want = (WF_CLAIM > 0 && !direct && seen > until && asked < WF_CLAIM) ? (unsigned int) WF_CLAIM : (unsigned int) asked;
 					unsigned int word = 0u, k = 0u;
 					if (lane == 0) {
 						word = (blockIdx.x < 8u && wave == 0) ? __hip_atomic_load((guint) C->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - C->launch_id
 						                                      : __hip_atomic_load((guint) C->control + RT_CTL_STOP_RELAY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
-						k = __hip_atomic_fetch_add(block_counter + shard * 32u, (unsigned int) asked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						k = __hip_atomic_fetch_add(block_counter + shard * 32u, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					}
 					k = (unsigned int) __builtin_amdgcn_readfirstlane((int) k);
 					if ((int) __builtin_amdgcn_readfirstlane((int) word) >= 0) {      /* the request covers this launch / another wave has seen it */
@@ -1327,9 +1343,11 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 					const unsigned int drop = C->test_drop_pixels;          /* (testing aid: 0 in production) */
 					unsigned int filled = (unsigned int) __builtin_amdgcn_readfirstlane((int) fill_counts[shard * 32u]);
 					filled -= filled < drop ? filled : drop;
-					got = k < filled && !cancelled ? (filled - k < (unsigned int) asked ? (int) (filled - k) : asked) : 0;
-					first = (size_t) shard * (size_t) C->pix_shard_cap + k;
-					if (got < asked) {
+					const unsigned int take = k < filled && !cancelled ? (filled - k < want ? filled - k : want) : 0u;
+					res_next = shard * (unsigned int) C->pix_shard_cap + k;
+					res_end = res_next + take;
+					if (lane == 0) W.res_seen = filled > k + want ? filled - (k + want) : 0u;
+					if (take < want) {
 						/* This list has run out: look at all of them at once (lane s reads list s's two counters; a stale
 						 * dequeue count can only show more pixels left than there are, never fewer) and move to the next
 						 * one that still has pixels.  None: the launch has no pixels left to hand out. */
@@ -1341,13 +1359,18 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 							left = have > taken ? have - taken : 0u;
 						}
 						const unsigned long long some = __ballot(left != 0u);
-						if (some == 0ull || cancelled) { exhausted = true; STAMP_DRY; }
+						/* (nothing left anywhere, and nothing in the reserve: the wave has no pixels to hand out any more) */
+						if ((some == 0ull && take == 0u) || cancelled) { exhausted = true; STAMP_DRY; }
+						else if (some == 0ull) { }
 						else {      /* the waves spread over the lists that are left (one address takes ~88 atomics per microsecond) */
 							const int pick = (int) ((blockIdx.x * (BLOCK / 64) + (unsigned int) wave) % (unsigned int) __popcll(some));
 							shard = (unsigned int) __builtin_ctzll(__ballot(left != 0u && lanes_below(some) == pick));
 						}
 					}
 				}
+				const int got = (int) (res_end - res_next) < asked ? (int) (res_end - res_next) : asked;
+				const size_t first = (size_t) res_next;
+				if (lane == 0) { W.res_next = res_next + (unsigned int) got; W.res_end = res_end; }
 				const int rr = lanes_below(nmask);
 				if (need_pixel && rr < got) {
 					const PixelRec px = load_pixel(C, first + (size_t) rr);
