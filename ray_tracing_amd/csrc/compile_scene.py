@@ -8,6 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OPTS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-DRT_SPEC_ONLY",
         "-DRT_SPEC_HEADER=\"rt_scene_spec.h\"", "-DRT_WAVES_PER_SIMD=4"]
 kind, tool, header, out = sys.argv[1:5]
+OPTS = OPTS + sys.argv[5:]          # (development: e.g. -gline-tables-only for scripts/instruction_budget.py)
 if kind == "hipcc":
     with tempfile.TemporaryDirectory() as d:
         with open(os.path.join(d, "rt_scene_spec.h"), "w") as f:

@@ -1500,7 +1500,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 
 			bool specular = __float_as_int(m1.w) != 0;
 			if (!specular)
-				specular = rng_draw(rng) <= (FAST ? third_of(fresnel.x + fresnel.y + fresnel.z) : (fresnel.x + fresnel.y + fresnel.z) / 3.0f);
+				{ STAT(31); specular = rng_draw(rng) <= (FAST ? third_of(fresnel.x + fresnel.y + fresnel.z) : (fresnel.x + fresnel.y + fresnel.z) / 3.0f); }
 			V3 out_dir;
 			if (specular) {
 				STAT(15);
@@ -1553,7 +1553,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 		};
 		auto tap_answer = [&](int meta, int obj) { W.tap[(meta >> 12) & 3][((meta >> 8) & 15) - 2][meta & 255] = (short) obj; };
 		auto trace_taps = [&](int count) {         /* the `count` <= 64 oldest taps */
-			STAT(12);
+			STAT(36);
 			if (CULL) {            /* every lane takes part in the culled trace (its work is shared out over the wave); lanes without a tap pass `on` = false */
 				const bool on = lane < count;
 				V3 o = mk3(0, 0, 0), d = mk3(1, 0, 0); int meta = 0;
@@ -1563,7 +1563,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 				if (on) tap_answer(meta, hit.obj);
 			} else
 			if (lane < count) {
-				STAT(13);
+				STAT(37);
 				V3 o, d; int meta;
 				tap_ray((q_head + (unsigned int) lane) & (WF_QUEUE - 1), o, d, meta);
 				const V3 dn = unit3_sel<FAST>(d);                                         /* scene.c:158 */
@@ -1593,7 +1593,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 				}
 			q_tail += all;
 			wave_fence();
-			while (q_tail - q_head >= 64u) trace_taps(64);
+			while (q_tail - q_head >= 64u) { STAT(40); trace_taps(64); }
 		} else
 #pragma unroll 1
 		for (int kind = 2; kind < 5; kind++) {
@@ -1602,7 +1602,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 			case 3:  push((tapmask & 2) != 0, hp, tap_j1, 3); break;
 			default: push((tapmask & 4) != 0, hp, tap_j2, 4); break;
 			}
-			while (q_tail - q_head >= 64u) trace_taps(64);
+			while (q_tail - q_head >= 64u) { STAT(41); trace_taps(64); }
 		}
 
 		/* ---- 4. the bounce rays: every lane traces its own, straight from its registers -- no queue, no LDS ---------- */
@@ -1646,7 +1646,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 		 * traced now, in a batch that need not be full */
 		const unsigned int due = phase == 2u ? 0u : phase + 1u;
 		while (q_tail != q_head && ((unsigned int) __builtin_amdgcn_readfirstlane((int) W.qmeta[q_head & (WF_QUEUE - 1)]) >> 12 & 3u) == due)
-			trace_taps(q_tail - q_head < 64u ? (int) (q_tail - q_head) : 64);
+			{ STAT(42); trace_taps(q_tail - q_head < 64u ? (int) (q_tail - q_head) : 64); }
 
 		STAMP(2);
 		/* ---- 5. back: retire the bounce shaded two rounds ago (its taps are traced by now), take this round's
@@ -1659,6 +1659,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 			rad = add3(rad, had3(mk3(m3.x, m3.y, m3.z), carry));                    /* main.c:232 */
 			if (!(rec2 & REC_SPECULAR)) carry = had3(carry, mk3(m2.x, m2.y, m2.z));  /* main.c:248 */
 			if (ptaps) {
+				STAT(38);
 				V3 lit = mk3(0, 0, 0);
 				int taps = 0;
 				if (only_light) {
@@ -1694,7 +1695,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 					carry = scale3(carry, 1.0f - w);
 				}
 			}
-			if (rec2 & REC_LAST) {              /* the path ended with that bounce: sky (main.c:171) or bounce limit (main.c:158) */
+			if (rec2 & REC_LAST) { STAT(39);    /* the path ended with that bounce: sky (main.c:171) or bounce limit (main.c:158) */
 				if (rec2 & REC_SKY) rad = add3(rad, had3(sky_colour<FAST>(sky2), carry));
 				const V3 col = mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z));     /* main.c:267-269 */
 				if (direct) {                   /* the pixel's only sample: 0 + colour (main.c:394), resolved (main.c:476) */
