@@ -151,19 +151,20 @@ RT_API int rt_render(rt_context *ctx, const rt_render_params *params, Vector3 *f
 /* Same, but the destination is DEVICE memory (rt_strip_rows()*width*12 bytes) and the call only
  * enqueues work on `hip_stream` (a hipStream_t; NULL = the context's own non-blocking stream;
  * RT_STREAM_LEGACY = the device's legacy null stream, which a literal 0 cannot name here).  No sync.
- * A context owns TWO sets of launch scratch (pixel lists, counters) and uses them alternately: a launch is
- * ordered (through an event, when the streams differ) behind the launch before the previous one, never behind the
- * previous one -- two consecutive launches enqueued on different streams may be on the GPU together, the second
- * filling the compute units as the first runs out of pixels (about 10 % more frames per second for strips of a
- * millisecond; they must of course write different destinations).  Launches on one stream run in stream order as
- * always.  rt_set_scene / rt_set_skybox wait for the context's own launches only, not for the whole device. */
+ * A context owns RT_LAUNCH_SETS (three) sets of launch scratch (pixel lists, counters) and uses them in rotation: a launch is
+ * ordered (through an event, when the streams differ) behind the launch RT_LAUNCH_SETS before it, never behind the ones in
+ * between -- consecutive launches enqueued on different streams may be on the GPU together: one draining, the next running, the
+ * one after it starting in the workgroup slots the first leaves (strips of a millisecond: a tenth more frames per second than one
+ * launch after the other, profiles/r05/strip_loop_probe.txt; they must of course write different destinations).  Launches on
+ * one stream run in stream order as always.  rt_set_scene / rt_set_skybox wait for the context's own launches only, not for
+ * the whole device. */
 #define RT_STREAM_LEGACY ((void *) (intptr_t) -1)
 #define RT_LAUNCH_SETS 3        /* scratch sets, and streams (rt_stream), a context rotates its launches through */
 RT_API int rt_render_device(rt_context *ctx, const rt_render_params *params, void *d_strip, void *hip_stream);
 
-/* The context's streams as hipStream_t: which = 0 the stream NULL stands for above; which = 1 a second one (created on
- * first request, with the device's lowest stream priority so that it gets a hardware queue of its own) for hosts that
- * alternate consecutive frames between two streams to let them overlap.  NULL on error. */
+/* The context's streams as hipStream_t: which = 0 the stream NULL stands for above; which = 1 ... RT_LAUNCH_SETS - 1 more
+ * (created on first request, with the device's lowest stream priority so that they get hardware queues of their own) for
+ * hosts that rotate consecutive frames through the streams to let them overlap.  NULL on error. */
 RT_API void *rt_stream(rt_context *ctx, int which);
 
 /* Optional: allocate the launch scratch (2 x 48 bytes per pixel of pixel records) and rt_render()'s device frame for
@@ -196,7 +197,7 @@ RT_API int rt_synchronize(rt_context *ctx);
  * (main.c:354-408 vs main.c:450-482).  rt_render() above is one blocking call per frame; here a frame is SUBMITTED --
  * the call only enqueues: render into the slot's device buffer, copy to `frame_out` on a copy stream of its own -- and
  * WAITED for later, so that the copy of frame k to the host overlaps the render of frame k+1, and consecutive renders
- * overlap each other on the context's two streams (the waves of frame k+1 fill the compute units as the waves of frame
+ * overlap each other on the context's streams (the waves of frame k+1 fill the compute units as the waves of frame
  * k run out of pixels).  A slot holds one frame at a time; RT_FRAME_SLOTS of them can be in flight:
  *
  *     rt_frame_submit(ctx, &p0, 0, frame[0]);
@@ -306,9 +307,9 @@ RT_API int  rt_multi_set_tuning(rt_multi *m, const rt_tuning *tuning);
 RT_API int  rt_multi_compile_scene(rt_multi *m);
 RT_API int  rt_multi_render(rt_multi *m, const rt_render_params *params, Vector3 *frame_out);
 /* The same with frames in flight (rt_frame_submit / rt_frame_wait above, same rules): every device renders frame k's
- * strip on its context's streams alternately, into one of three strip buffers; the grouped ncclGather of frame k, the
+ * strip on its context's streams in rotation, into one of four strip buffers; the grouped ncclGather of frame k, the
  * de-interleave on the first device and the copy to frame_out run on streams of their own behind events, beside the
- * renders of frames k+1 and k+2 -- a render stream only ever waits for the gather three frames back, whose strip buffer
+ * renders of frames k+1 ... k+3 -- a render stream only ever waits for the gather four frames back, whose strip buffer
  * it reuses.  (The persistent trace kernel of the next frame holds every compute unit until it drains, so a render
  * stream that waited for the previous frame's collective would lose the overlap of consecutive strips.)  With one
  * device and no rt_tuning.force_collective this is rt_frame_submit() on that device's context. */

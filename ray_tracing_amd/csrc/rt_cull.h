@@ -25,6 +25,11 @@
  *   (2^20: squares stay far from the top of the float range) get no clusters: every object is tested, as before.
  * A wave one of whose rays starts farther out than 2 S -- a camera far outside the scene -- tests every object as well.
  *
+ *   - inside a cluster the members are tested as their conservative boxes QUANTISED outwards on the cluster's grid (rt_device.h): the
+ *     box only grows (checked here in double: lo + q_lo * step <= member lo, lo + q_hi * step >= member hi with the float step the
+ *     kernels form), and the kernels' parameter of a grid plane, fma(q, step * r, fma(lo, r, -o * r)), has an error of at most
+ *     2^-24 (|q step r| + |o r| + |b| + |t|) <= 6.0e-7 S / |d| = 3.8e-5 / |d| at S = 64: the margin keeps a factor of 51.
+ *
  * Clusters: the leaves of a median-split tree over the objects' centres, RT_CLUSTER_SIZE objects each (members keep their object
  * indices: ties between equal distances go to the lowest INDEX whatever the order of the tests).
  */
@@ -134,6 +139,23 @@ static inline rt_cull_info rt_cull_build(std::vector<rt_geom> &geom, int n, std:
 		}
 		K.lo[0] = lo[0]; K.lo[1] = lo[1]; K.lo[2] = lo[2]; K.hi0 = hi[0]; K.hi1 = hi[1]; K.hi2 = hi[2];
 		K.count = cnt;
+		/* the members' boxes on the cluster's grid, rounded outwards */
+		for (int j = 0; j < cnt; j++) {
+			float blo[3], bhi[3];
+			rt_cull_object_box(geom[(size_t) members[j]], margin, blo, bhi);
+			for (int k = 0; k < 3; k++) {
+				const double origin = (double) lo[k], step = (double) RT_CLUSTER_STEP(lo[k], hi[k]);
+				int qa = 0, qb = 255;
+				if (step > 0.0) {
+					qa = (int) floor(((double) blo[k] - origin) / step); qb = (int) ceil(((double) bhi[k] - origin) / step);
+					qa = qa < 0 ? 0 : (qa > 255 ? 255 : qa); qb = qb < 0 ? 0 : (qb > 255 ? 255 : qb);
+					while (qa > 0 && origin + qa * step > (double) blo[k]) qa--;
+					while (qb < 255 && origin + qb * step < (double) bhi[k]) qb++;
+				}
+				K.qbox[j][k] = (unsigned char) qa;
+				K.qbox[j][3 + k] = (unsigned char) qb;
+			}
+		}
 	}
 	info.num_clusters = C;
 	info.origin_max = 2.0f * S;

@@ -46,19 +46,24 @@ typedef struct {
 
 /* Large scenes (more objects than a scene-specialised kernel takes): objects grouped into clusters of up to RT_CLUSTER_SIZE
  * spatially close ones, so that a ray first asks RT_CLUSTER_SIZE times fewer boxes "could anything in here be hit at all"
- * (rt_kernels.hip nearest_hit_culled, rt_cull.h).  32 + 2 x RT_CLUSTER_SIZE bytes: a conservative bounding box of the members' own conservative boxes,
- * and the members' object indices (0xffff: none). */
-#ifndef RT_CLUSTER_SIZE
+ * (rt_kernels.hip nearest_hit_culled, rt_cull.h).  112 bytes = seven 16-byte LDS slots (an odd number: a wave's lanes reading one
+ * field of different clusters spread over all sixteen slots of a bank row): a conservative bounding box of the members' own
+ * conservative boxes; the members' object indices (0xffff: none); and the members' conservative boxes once more, QUANTISED on the
+ * cluster's own grid -- RT_CLUSTER_GRID steps from lo to hi on every axis, a byte per plane, rounded outwards (rt_cull.h): what the
+ * lanes test a cluster's members against, 64 bytes per cluster instead of 8 x 32 of geometry records. */
 #define RT_CLUSTER_SIZE 8
-#endif
 #define RT_MAX_CLUSTERS 128
-#define RT_CLUSTER_F4 ((32 + 2 * RT_CLUSTER_SIZE) / 16)      /* a cluster as float4 words: 2 of box and count, then the members */
+#define RT_CLUSTER_F4 7              /* a cluster as float4 words: 2 of box and count, 1 of members, 4 of quantised member boxes */
+#define RT_CLUSTER_GRID 254
 typedef struct {
 	float          lo[3], hi0;
 	float          hi1, hi2;
 	int            count, pad;
 	unsigned short member[RT_CLUSTER_SIZE];
+	unsigned char  qbox[RT_CLUSTER_SIZE][8];   /* member j: lo.x lo.y lo.z hi.x | hi.y hi.z 0 0, in steps of (hi - lo) * RN(1 / RT_CLUSTER_GRID) from lo */
 } rt_cluster;
+/* the grid's step along one axis, formed the same way -- one subtraction, one product by the literal -- on the host and in the kernels */
+#define RT_CLUSTER_STEP(lo, hi) (((hi) - (lo)) * (1.0f / (float) RT_CLUSTER_GRID))
 
 /* The control words of a launch: one 128-byte line behind the pixel lists' counters (rt_launch.control), cleared when the
  * launch is enqueued, copied to the host behind it (the first RT_CTL_WORDS words) and judged there (rt_api.cpp judge_launch):

@@ -67,15 +67,13 @@ struct SceneLDS {
 	const float4 *shade;   /* 4 x float4 per object */
 };
 
-/* Large scenes (the culled kernels): only the geometry goes to LDS -- 32 B an object, read per lane by the members' tests --;
- * the shading records, 64 B an object and touched once per bounce, are read from memory (L2), so that a scene of 1024 objects
- * leaves room for two workgroups per CU instead of one (one wave per SIMD is latency-bound: 22 vs 12 ms on C1). */
-RT_DEV SceneLDS stage_geometry(const rt_launch &L, float4 *lds, int n)
+/* Large scenes (the culled kernels): neither geometry nor shading records go to LDS -- the lanes test a cluster's members against
+ * the cluster record's quantised boxes (stage_clusters), the few exact tests that follow read the 32-byte geometry records from
+ * memory (L2), as the shading records, touched once per bounce, already were: a scene of 1024 objects takes 14 KB of LDS per
+ * workgroup instead of 34 (round 4: 32 KB of geometry, read 8 x 32 bytes per ray and cluster at four lanes to a bank). */
+RT_DEV SceneLDS stage_geometry(const rt_launch &L)
 {
-	const float4 *g = reinterpret_cast<const float4*>(L.geom);
-	for (int i = threadIdx.x; i < 2 * n; i += (int) blockDim.x) lds[i] = g[i];
-	__syncthreads();
-	SceneLDS sc; sc.shade = reinterpret_cast<const float4*>(L.shade); sc.geom = lds;
+	SceneLDS sc; sc.geom = reinterpret_cast<const float4*>(L.geom); sc.shade = reinterpret_cast<const float4*>(L.shade);
 	return sc;
 }
 
@@ -339,8 +337,7 @@ RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d, bool want_nor
  * "lowest index among equal distances" (strict `<` in index order, scene.c:168) is kept explicitly, because the clusters
  * are visited out of index order. */
 typedef const __attribute__((address_space(4))) float *rt_const_f;        /* memory read with scalar loads when the address is wave-uniform */
-#define RT_CLUSTER_MEMBER_F4 (RT_CLUSTER_F4 - 2)      /* a cluster's member list as float4 words: what the culled trace keeps in LDS (the boxes are read with scalar loads) */
-struct ClusterLDS { const float4 *members; rt_const_f mem; int count; float margin, origin_max; };      /* members: RT_CLUSTER_MEMBER_F4 x float4 per cluster, in LDS; mem: the rt_cluster records in memory */
+struct ClusterLDS { const float4 *recs; rt_const_f mem; int count; float margin, origin_max; };      /* recs: the rt_cluster records (RT_CLUSTER_F4 x float4 each) in LDS; mem: the same in memory, for scalar loads */
 /* a wave's scratch for the culled trace: the rays' best hits, and the queue of (ray, object) candidates waiting for their exact test */
 #define CULL_QUEUE 128
 struct CullWave { unsigned long long best[64]; unsigned short queue[CULL_QUEUE]; };
@@ -353,6 +350,20 @@ RT_DEV bool slab_may_touch(V3 oi, V3 inv, V3 lo, V3 hi)
 	const float ax = __builtin_fmaf(lo.x, inv.x, -oi.x), bx = __builtin_fmaf(hi.x, inv.x, -oi.x);
 	const float ay = __builtin_fmaf(lo.y, inv.y, -oi.y), by = __builtin_fmaf(hi.y, inv.y, -oi.y);
 	const float az = __builtin_fmaf(lo.z, inv.z, -oi.z), bz = __builtin_fmaf(hi.z, inv.z, -oi.z);
+	const float enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+	const float leave = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+	return enter <= leave && leave >= 0.0f;
+}
+
+/* A cluster's member j against a ray, on the cluster's grid (rt_device.h rt_cluster.qbox): the parameter of grid plane q along an
+ * axis is (lo + q step - o) / d = q (step r) + (lo r - o r), one fused multiply-add with the per-(ray, cluster) constants gs = step r
+ * and gb = fma(lo, r, -o r); v_cvt_f32_ubyteN turns byte N of a word into the float q.  The boxes were rounded outwards on the host
+ * (rt_cull.h), so this never misses what the members' own conservative boxes would catch. */
+RT_DEV bool grid_box_may_touch(uint32_t w0, uint32_t w1, V3 gs, V3 gb)
+{
+	const float ax = __builtin_fmaf((float) (w0 & 255u), gs.x, gb.x), ay = __builtin_fmaf((float) ((w0 >> 8) & 255u), gs.y, gb.y);
+	const float az = __builtin_fmaf((float) ((w0 >> 16) & 255u), gs.z, gb.z), bx = __builtin_fmaf((float) (w0 >> 24), gs.x, gb.x);
+	const float by = __builtin_fmaf((float) (w1 & 255u), gs.y, gb.y), bz = __builtin_fmaf((float) ((w1 >> 8) & 255u), gs.z, gb.z);
 	const float enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
 	const float leave = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
 	return enter <= leave && leave >= 0.0f;
@@ -466,7 +477,7 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, C
 		const uint32_t m0 = from_lane(mask[0], src), m1 = from_lane(mask[1], src), m2 = from_lane(mask[2], src), m3 = from_lane(mask[3], src);
 		const V3 sinv = mk3(from_lane(rp.inv.x, src), from_lane(rp.inv.y, src), from_lane(rp.inv.z, src));
 		const V3 soi = mk3(from_lane(oi.x, src), from_lane(oi.y, src), from_lane(oi.z, src));
-		const unsigned short *member = reinterpret_cast<const unsigned short*>(cl.members);
+		const unsigned short *member = reinterpret_cast<const unsigned short*>(cl.recs + 2);
 		uint32_t cand = 0u;
 		if (mine) {
 			int word = 0;
@@ -481,20 +492,22 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, C
 			t_ = (uint32_t) __popc(mm & 0x3u);    if (r >= t_) { pos += 2;  r -= t_; mm >>= 2; }
 			t_ = mm & 1u;                         if (r >= t_) { pos += 1; }
 			const int c = 32 * word + pos;
-			member = reinterpret_cast<const unsigned short*>(cl.members + RT_CLUSTER_MEMBER_F4 * c);
+			/* the cluster's record: six reads of 16 bytes (box and count, four words of member boxes; the member indices only if a member
+			 * is touched) where the members' geometry records took sixteen -- and seven slots apart, the lanes' reads spread over the
+			 * whole bank row */
+			const float4 *rec = cl.recs + RT_CLUSTER_F4 * c;
+			member = reinterpret_cast<const unsigned short*>(rec + 2);
+			const float4 k0 = rec[0], k1 = rec[1];
+			const V3 gs = mk3(RT_CLUSTER_STEP(k0.x, k0.w) * sinv.x, RT_CLUSTER_STEP(k0.y, k1.x) * sinv.y, RT_CLUSTER_STEP(k0.z, k1.y) * sinv.z);
+			const V3 gb = mk3(__builtin_fmaf(k0.x, sinv.x, -soi.x), __builtin_fmaf(k0.y, sinv.y, -soi.y), __builtin_fmaf(k0.z, sinv.z, -soi.z));
 #pragma unroll
-			for (int j = 0; j < RT_CLUSTER_SIZE; j++) {
-				const uint32_t idx = member[j];
-				if (idx != 0xffffu) {
-					STAT(34);
-					const float4 g0 = sc.geom[2 * idx], g1 = sc.geom[2 * idx + 1];
-					const bool box = __float_as_int(g1.z) == RT_GEOM_CUBE;
-					const float e = box ? cl.margin : g1.x;                       /* a sphere's record carries its half extent (rt_cull.h) */
-					const V3 lo = mk3(g0.x - e, g0.y - e, g0.z - e);
-					const V3 hi = mk3((box ? g0.w : g0.x) + e, (box ? g1.x : g0.y) + e, (box ? g1.y : g0.z) + e);
-					if (slab_may_touch(soi, sinv, lo, hi)) cand |= 1u << j;
-				}
+			for (int jj = 0; jj < RT_CLUSTER_SIZE / 2; jj++) {
+				const float4 qq = rec[3 + jj];          /* members 2 jj and 2 jj + 1 */
+				STAT(34);
+				if (grid_box_may_touch(__float_as_uint(qq.x), __float_as_uint(qq.y), gs, gb)) cand |= 1u << (2 * jj);
+				if (grid_box_may_touch(__float_as_uint(qq.z), __float_as_uint(qq.w), gs, gb)) cand |= 2u << (2 * jj);
 			}
+			cand &= (1u << __float_as_int(k1.z)) - 1u;          /* (the last cluster may have fewer members: their slots hold zeros) */
 		}
 		/* the members that passed: into the queue, one per lane at a time (at most 63 wait there, so 64 more always fit) */
 		for (;;) {
@@ -533,14 +546,13 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, C
 	return hit;
 }
 
-/* the clusters' member lists behind the geometry in LDS (their boxes stay in memory: scalar loads) */
+/* the cluster records in LDS (for the lanes' reads; the wave-uniform pass over the cluster boxes uses scalar loads from memory) */
 RT_DEV ClusterLDS stage_clusters(const rt_launch &L, float4 *dst)
 {
 	const float4 *src = reinterpret_cast<const float4*>(L.clusters);
-	for (int i = threadIdx.x; i < RT_CLUSTER_MEMBER_F4 * L.num_clusters; i += (int) blockDim.x)
-		dst[i] = src[RT_CLUSTER_F4 * (i / RT_CLUSTER_MEMBER_F4) + 2 + i % RT_CLUSTER_MEMBER_F4];
+	for (int i = threadIdx.x; i < RT_CLUSTER_F4 * L.num_clusters; i += (int) blockDim.x) dst[i] = src[i];
 	__syncthreads();
-	ClusterLDS cl; cl.members = dst; cl.mem = (rt_const_f) (unsigned long long) L.clusters; cl.count = L.num_clusters; cl.margin = L.cull_margin; cl.origin_max = L.cull_origin_max;
+	ClusterLDS cl; cl.recs = dst; cl.mem = (rt_const_f) (unsigned long long) L.clusters; cl.count = L.num_clusters; cl.margin = L.cull_margin; cl.origin_max = L.cull_origin_max;
 	return cl;
 }
 
@@ -806,11 +818,11 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 {
 	extern __shared__ float4 lds[];
 	const int n = L.num_objects;
-	const SceneLDS sc = CULL ? stage_geometry(L, lds, n) : stage_scene(L, lds, n);
-	ClusterLDS cl; cl.members = nullptr; cl.mem = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
-	if (CULL) cl = stage_clusters(L, lds + 2 * n);
+	const SceneLDS sc = CULL ? stage_geometry(L) : stage_scene(L, lds, n);
+	ClusterLDS cl; cl.recs = nullptr; cl.mem = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
+	if (CULL) cl = stage_clusters(L, lds);
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	CullWave *cull_wave = reinterpret_cast<CullWave*>(lds + 2 * n + RT_CLUSTER_MEMBER_F4 * L.num_clusters) + wave;     /* (CULL) */
+	CullWave *cull_wave = reinterpret_cast<CullWave*>(lds + RT_CLUSTER_F4 * L.num_clusters) + wave;     /* (CULL) */
 	const int tiles_x = (L.width + 7) >> 3, tiles_y = (L.local_rows + 7) >> 3;
 	const unsigned int total = (unsigned int) (tiles_x * tiles_y);
 	/* the workgroup's share of the blocks: blocks_per_group consecutive ones.  Its object pixels go to list
@@ -1129,9 +1141,9 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 	const int n = L.num_objects;
 #endif
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (CULL ? 2 * n + RT_CLUSTER_MEMBER_F4 * L.num_clusters : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
+	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (CULL ? RT_CLUSTER_F4 * L.num_clusters : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
 	if (threadIdx.x == 0) { W.g_written = 0u; W.g_audited = 0u; W.g_disagree = 0u; W.g_left = 0u; }     /* (ordered before any wave's report at the end by the staging barrier) */
-	const SceneLDS sc = CULL ? stage_geometry(L, lds, n) : stage_scene(L, lds, n);
+	const SceneLDS sc = CULL ? stage_geometry(L) : stage_scene(L, lds, n);
 	/* the grids of the "taps certainly lit" table (rt_lit.h), when the launcher found room for them: 3 x float4 per object */
 	if (L.lit_grids_in_lds) {
 		const float4 *gsrc = reinterpret_cast<const float4*>(L.lit_grids);
@@ -1144,9 +1156,9 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 	const rt_lit_grid *lit_grids_mem = reinterpret_cast<const rt_lit_grid*>(L.lit_grids);
 	const bool grids_in_lds = L.lit_grids_in_lds != 0;
 	/* large scenes: the clusters of rt_cull.h behind the scene records (such scenes have no lit-taps table: it needs <= 64 objects) */
-	ClusterLDS cl; cl.members = nullptr; cl.mem = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
-	if (CULL) cl = stage_clusters(L, lds + 2 * n);
-	CullWave *cull_wave = reinterpret_cast<CullWave*>(reinterpret_cast<WaveLDS*>(lds + 2 * n + RT_CLUSTER_MEMBER_F4 * L.num_clusters) + BLOCK / 64) + wave;   /* (CULL) */
+	ClusterLDS cl; cl.recs = nullptr; cl.mem = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
+	if (CULL) cl = stage_clusters(L, lds);
+	CullWave *cull_wave = reinterpret_cast<CullWave*>(reinterpret_cast<WaveLDS*>(lds + RT_CLUSTER_F4 * L.num_clusters) + BLOCK / 64) + wave;   /* (CULL) */
 
 	/* rt_launch.sum_onto (several interactive passes in one launch): a pixel's samples are added to what the frame holds so far.
 	 * That value takes the window slot BEFORE the pixel's first sample, as if it were a sample: 0 + value is the value (it is
@@ -2122,7 +2134,7 @@ size_t rt_counter_bytes() { return RT_COUNTER_BYTES; }
 size_t rt_scene_lds_bytes(int num_objects) { return (size_t) num_objects * (sizeof(rt_geom) + sizeof(rt_shade)); }
 
 size_t rt_wavefront_lds_bytes(int num_objects) { return rt_scene_lds_bytes(num_objects) + (RT_BLOCK / 64) * sizeof(WaveLDS); }
-static_assert(sizeof(rt_cluster) == 16 * RT_CLUSTER_F4 && RT_CLUSTER_SIZE % 8 == 0 && RT_CLUSTER_SIZE <= 32, "the kernels read a cluster as RT_CLUSTER_F4 float4 words");
+static_assert(sizeof(rt_cluster) == 16 * RT_CLUSTER_F4 && RT_CLUSTER_SIZE == 8 && RT_CLUSTER_F4 % 2 == 1, "the kernels read a cluster as RT_CLUSTER_F4 float4 words: box, count, eight members, their boxes as eight byte pairs of words");
 
 /* rt_primary_pass: a few workgroups per CU, each with a run of consecutive 8x8 pixel blocks (at least one per wave) */
 void rt_primary_geometry(int width, int local_rows, int num_cus, unsigned int *groups_out, int *per_group_out)
@@ -2172,7 +2184,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	/* (a scene the host has had compiled keeps its compiled kernel: clusters are built from RT_CULL_MIN_OBJECTS objects, scenes
 	 * of up to 64 can be compiled) */
 	const bool cull = L.num_clusters > 0 && L.clusters != nullptr && scene_fast_ok && variant == 0 && !spec_fn;
-	size_t lds = cull ? (size_t) 2 * L.num_objects * 16 + (size_t) L.num_clusters * RT_CLUSTER_MEMBER_F4 * 16 + (RT_BLOCK / 64) * (sizeof(WaveLDS) + sizeof(CullWave))
+	size_t lds = cull ? (size_t) L.num_clusters * RT_CLUSTER_F4 * 16 + (RT_BLOCK / 64) * (sizeof(WaveLDS) + sizeof(CullWave))
 	                  : rt_wavefront_lds_bytes(L.num_objects);
 	int per_cu = (int) ((160u * 1024u) / lds);
 	if (per_cu < 1) per_cu = 1;
@@ -2190,7 +2202,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	/* a large scene whose records leave room for fewer than three workgroups of four waves: one workgroup of twelve (rt_trace_wavefront_wide) */
 	int block = RT_BLOCK;
 	if (cull && per_cu < 3 && workgroups_per_cu < 1) {
-		const size_t wide = (size_t) 2 * L.num_objects * 16 + (size_t) L.num_clusters * RT_CLUSTER_MEMBER_F4 * 16 + (RT_BLOCK_WIDE / 64) * (sizeof(WaveLDS) + sizeof(CullWave));
+		const size_t wide = (size_t) L.num_clusters * RT_CLUSTER_F4 * 16 + (RT_BLOCK_WIDE / 64) * (sizeof(WaveLDS) + sizeof(CullWave));
 		if (wide <= 160u * 1024u) { block = RT_BLOCK_WIDE; lds = wide; per_cu = 1; }
 	}
 	if (workgroups_per_cu >= 1 && workgroups_per_cu < per_cu) per_cu = workgroups_per_cu;     /* rt_tuning */
@@ -2216,7 +2228,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	} else {
 		unsigned int groups; int per_group;
 		rt_primary_geometry(L.width, L.local_rows, num_cus, &groups, &per_group);
-		const size_t plds = cull ? (size_t) 2 * L.num_objects * 16 + (size_t) L.num_clusters * RT_CLUSTER_MEMBER_F4 * 16 + (RT_BLOCK / 64) * sizeof(CullWave)
+		const size_t plds = cull ? (size_t) L.num_clusters * RT_CLUSTER_F4 * 16 + (RT_BLOCK / 64) * sizeof(CullWave)
 		                         : rt_scene_lds_bytes(L.num_objects);
 		if (variant == 2 || !scene_fast_ok)
 			hipLaunchKernelGGL(rt_primary_pass<false>, dim3(groups), dim3(RT_BLOCK), plds, stream, L, per_group);

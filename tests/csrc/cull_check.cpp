@@ -59,6 +59,23 @@ static bool may_touch(V o, V inv, const float lo[3], const float hi[3])     /* s
 	return enter <= leave && leave >= 0.0f;
 }
 
+/* grid_box_may_touch of rt_kernels.hip: member j of cluster K on the cluster's grid -- fma(q, step * inv, fma(lo, inv, -o * inv)) */
+static bool grid_may_touch(V o, V inv, const rt_cluster &K, int j)
+{
+	const float clo[3] = { K.lo[0], K.lo[1], K.lo[2] }, chi[3] = { K.hi0, K.hi1, K.hi2 };
+	const float oo[3] = { o.x, o.y, o.z }, ii[3] = { inv.x, inv.y, inv.z };
+	float a[3], b[3];
+	for (int k = 0; k < 3; k++) {
+		const float gs = RT_CLUSTER_STEP(clo[k], chi[k]) * ii[k];
+		const float gb = fmaf(clo[k], ii[k], -(oo[k] * ii[k]));
+		a[k] = fmaf((float) K.qbox[j][k], gs, gb);
+		b[k] = fmaf((float) K.qbox[j][3 + k], gs, gb);
+	}
+	const float enter = fmaxf(fmaxf(fminf(a[0], b[0]), fminf(a[1], b[1])), fminf(a[2], b[2]));
+	const float leave = fminf(fminf(fmaxf(a[0], b[0]), fmaxf(a[1], b[1])), fmaxf(a[2], b[2]));
+	return enter <= leave && leave >= 0.0f;
+}
+
 int main(int argc, char **argv)
 {
 	const int scenes = argc > 1 ? atoi(argv[1]) : 20, rays = argc > 2 ? atoi(argv[2]) : 20000;
@@ -80,16 +97,22 @@ int main(int argc, char **argv)
 		std::vector<rt_cluster> cl;
 		const rt_cull_info info = rt_cull_build(geom, n, cl);
 		if (info.num_clusters <= 0) { refused++; continue; }      /* (coordinates beyond RT_CULL_MAX_COORD: none here) */
-		std::vector<int> owner((size_t) n, -1);
+		std::vector<int> owner((size_t) n, -1), place((size_t) n, -1);
 		for (int c = 0; c < info.num_clusters; c++)
 			for (int j = 0; j < RT_CLUSTER_SIZE; j++) {
 				const int i = cl[(size_t) c].member[j];
 				if (i == 0xffff) continue;
-				if (i >= n || owner[(size_t) i] >= 0) structure_bad++; else owner[(size_t) i] = c;
+				if (i >= n || owner[(size_t) i] >= 0) structure_bad++; else { owner[(size_t) i] = c; place[(size_t) i] = j; }
+				if (j >= cl[(size_t) c].count) structure_bad++;         /* members fill the first `count` places: the kernel masks the others */
 				float lo[3], hi[3];
 				rt_cull_object_box(geom[(size_t) i], info.margin, lo, hi);
 				const float clo[3] = { cl[(size_t) c].lo[0], cl[(size_t) c].lo[1], cl[(size_t) c].lo[2] }, chi[3] = { cl[(size_t) c].hi0, cl[(size_t) c].hi1, cl[(size_t) c].hi2 };
 				for (int k = 0; k < 3; k++) if (lo[k] < clo[k] || hi[k] > chi[k]) structure_bad++;
+				/* ... and inside its own box on the cluster's grid (the kernels' float step, the comparison in double) */
+				for (int k = 0; k < 3; k++) {
+					const double step = (double) RT_CLUSTER_STEP(clo[k], chi[k]);
+					if ((double) clo[k] + cl[(size_t) c].qbox[j][k] * step > (double) lo[k] || (double) clo[k] + cl[(size_t) c].qbox[j][3 + k] * step < (double) hi[k]) structure_bad++;
+				}
 			}
 		for (int i = 0; i < n; i++) if (owner[(size_t) i] < 0) structure_bad++;
 		for (int r = 0; r < rays; r++) {
@@ -125,7 +148,9 @@ int main(int argc, char **argv)
 				rt_cull_object_box(geom[(size_t) i], info.margin, lo, hi);
 				const rt_cluster &K = cl[(size_t) owner[(size_t) i]];
 				const float clo[3] = { K.lo[0], K.lo[1], K.lo[2] }, chi[3] = { K.hi0, K.hi1, K.hi2 };
-				if (!may_touch(o, inv, lo, hi) || !may_touch(o, inv, clo, chi)) bad++;
+				/* the cluster's box, and the member's box as the kernel tests it: quantised on the cluster's grid */
+				if (!may_touch(o, inv, clo, chi) || !grid_may_touch(o, inv, K, place[(size_t) i])) bad++;
+				(void) lo; (void) hi;
 			}
 		}
 	}
