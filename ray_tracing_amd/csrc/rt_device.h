@@ -145,8 +145,8 @@ typedef struct {
 	 *   num_shards   pixel lists in use (1 or 64), each with its own fill and dequeue counter */
 	int    num_shards;
 	/* written by rt_primary_pass, read by the trace kernels: one 12-word record per object pixel (camera-ray hit
-	 * point xyz, normal xyz, object, camera ray xyz, RNG pixel index, offset in the strip), word k of record c at
-	 * pix[k * num_shards * pix_shard_cap + c]; list s holds records s * pix_shard_cap ... + pix_count[32 * s] */
+	 * point xyz, normal xyz, object, camera ray xyz, RNG pixel index, offset in the strip), record c = the 48 bytes at
+	 * pix + 12 c (three 16-byte words); list s holds records s * pix_shard_cap ... + pix_count[32 * s] */
 	float *pix;
 	unsigned int *pix_count;   /* one fill counter per list, 128 bytes apart; the word behind it: 8x8 blocks finished by the waves that append to the list */
 	int    pix_shard_cap;

@@ -829,7 +829,6 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 	 * blockIdx.x % num_shards: one atomic per block with object pixels, spread over the lists' counters (a single
 	 * address takes ~88 atomics per microsecond: one counter for all blocks would cost more than the camera rays) */
 	const unsigned int shard = blockIdx.x % (unsigned int) L.num_shards;
-	const size_t plane = (size_t) L.pix_shard_cap * (size_t) L.num_shards;
 	const V3 cam = ld3(L.pos);
 	const float inv_spp = L.sum_onto ? 1.0f : 1.0f / (float) L.spp;
 	const unsigned int first = blockIdx.x * (unsigned int) blocks_per_group;
@@ -891,13 +890,13 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 			if (lane == 0) base = atomicAdd(L.pix_count + shard * 32u, (unsigned int) __popcll(om));
 			base = (unsigned int) __builtin_amdgcn_readfirstlane((int) base);
 			if (obj >= 0) {
-				float *dst = L.pix + (size_t) shard * L.pix_shard_cap + base + (unsigned int) lanes_below(om);
-				dst[0] = a.x;  dst[plane] = a.y;  dst[2 * plane] = a.z;
-				dst[3 * plane] = nn.x; dst[4 * plane] = nn.y; dst[5 * plane] = nn.z;
-				dst[6 * plane] = __int_as_float(obj | known);
-				dst[7 * plane] = pd.x; dst[8 * plane] = pd.y; dst[9 * plane] = pd.z;
-				dst[10 * plane] = __uint_as_float((uint32_t) ((j * L.pix_scale) * L.pix_width + i * L.pix_scale));   /* main.c:286 order */
-				dst[11 * plane] = __int_as_float(lr * L.width + i);
+				/* the record as three 16-byte words, 48 bytes apart from its neighbours': a wave's stores fill whole cache lines, and
+				 * the lane that takes the pixel later reads three words of one or two lines instead of twelve words of twelve */
+				float4 *dst = reinterpret_cast<float4*>(L.pix) + 3 * ((size_t) shard * L.pix_shard_cap + base + (unsigned int) lanes_below(om));
+				dst[0] = make_float4(a.x, a.y, a.z, nn.x);
+				dst[1] = make_float4(nn.y, nn.z, __int_as_float(obj | known), pd.x);
+				dst[2] = make_float4(pd.y, pd.z, __uint_as_float((uint32_t) ((j * L.pix_scale) * L.pix_width + i * L.pix_scale)) /* main.c:286 order */,
+				                     __int_as_float(lr * L.width + i));
 			}
 		}
 	}
@@ -1020,18 +1019,19 @@ struct PixelRec { V3 a, n; int obj; V3 dir; uint32_t index; int off; };
 /* record c of the pixel lists rt_primary_pass filled */
 RT_DEV PixelRec load_pixel(rt_launch_cold C, size_t c)
 {
-	const size_t plane = (size_t) C->pix_shard_cap * (size_t) C->num_shards;
-	/* (the pointer comes out of the launch record in memory: said to be a global one, the twelve loads are global loads off
+	/* (the pointer comes out of the launch record in memory: said to be a global one, the three loads are global loads off
 	 * one base instead of flat loads with a 64-bit address each) */
-	typedef const __attribute__((address_space(1))) float *gfloat;
-	const gfloat src = (gfloat) C->pix + c;
+	typedef float word4 __attribute__((ext_vector_type(4)));
+	typedef const __attribute__((address_space(1))) word4 *gword4;
+	const gword4 src = (gword4) C->pix + 3 * c;
+	const word4 w0 = src[0], w1 = src[1], w2 = src[2];
 	PixelRec p;
-	p.a = mk3(src[0], src[plane], src[2 * plane]);
-	p.n = mk3(src[3 * plane], src[4 * plane], src[5 * plane]);
-	p.obj = __float_as_int(src[6 * plane]);
-	p.dir = mk3(src[7 * plane], src[8 * plane], src[9 * plane]);
-	p.index = __float_as_uint(src[10 * plane]);
-	p.off = __float_as_int(src[11 * plane]);
+	p.a = mk3(w0.x, w0.y, w0.z);
+	p.n = mk3(w0.w, w1.x, w1.y);
+	p.obj = __float_as_int(w1.z);
+	p.dir = mk3(w1.w, w2.x, w2.y);
+	p.index = __float_as_uint(w2.z);
+	p.off = __float_as_int(w2.w);
 	return p;
 }
 

@@ -108,7 +108,10 @@ static void append_float(std::string &s, float f)
 }
 
 /* The header the specialised translation unit includes (nearest_hit_spec in rt_kernels.hip).  Its text is also the key
- * under which compiled scenes are cached and embedded: same text, same kernel. */
+ * under which compiled scenes are cached and embedded: same text, same kernel.  (The text prints geom.b1 of a sphere as it finds
+ * it: 0 as packed -- what the build's tool embeds the shipped scenes under --, and the sphere's half extent for the cull once
+ * rt_cull_build() has run, i.e. in scenes of 32 objects and more, whose key therefore also depends on the scene's extent and
+ * margin.  Harmless: such scenes are never the embedded ones, and equal scenes still get equal keys.) */
 std::string rt_jit_scene_header(const rt_geom *geom, int n, int light_index, const float light_pos[3], int only_light_emits)
 {
 	std::string h = "/* generated by rt_compile_scene */\n#define SPEC_N " + std::to_string(n) + "\n";
