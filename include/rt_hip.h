@@ -264,8 +264,9 @@ RT_API int rt_last_launch_counts(rt_context *ctx, unsigned long long *pixels_lis
  *     &&  no audited tap (rt_tuning.audit_known_taps) contradicts csrc/rt_lit.h.
  * RT_CANCELLED (rt_cancel() cut the launch short) takes precedence: that frame is incomplete on request.  The contents of
  * frame_out are undefined after RT_ERR_DEVICE.  An interactive pass that is incomplete is not published (its weight is not
- * counted either) and the error is reported by the next call that looks at the count.  Cost: one LDS add per pixel, three
- * atomics per wave, 64 bytes instead of 4 in the copy that already fetched the cancel word. */
+ * counted either) and the error is reported by the next call that looks at the count.  Cost: nothing in the rounds (a wave's
+ * pixels are its streams' drained-slot counters at exit), one report per workgroup and per dequeue line when waves leave, 64
+ * bytes instead of 4 in the copy that already fetched the cancel word: not measurable (profiles/r05/ab_r04_vs_verified_launches.txt). */
 typedef struct {
 	int                launch_checked;      /* 0: the kernel does not account for itself (RT_KERNEL_SIMPLE, the cross-check kernel) */
 	unsigned int       launch_id, stamp;    /* the launch's number; the stamp its last wave left (0: none) */
