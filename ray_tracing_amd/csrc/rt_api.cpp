@@ -170,7 +170,13 @@ struct rt_context {
 		int      rank = 0, world = 1, rows = 0;   /* this context accumulates the frame rows of the row blocks b % world == rank: `rows` of them */
 		uint64_t seed = 0;
 		uint32_t generation = 0;
-		float   *d_accum = nullptr, *d_low = nullptr, *d_out = nullptr;
+		float   *d_accum = nullptr, *d_out = nullptr;
+		float   *d_low[RT_LAUNCH_SETS] = {};  /* a pass's low-resolution frame, one per scratch set: pass n + 1 renders while pass n is being added to the sums */
+		/* the sums and their count are read and written by the publish steps of passes that render on different streams (and by
+		 * invalidate / resolve on the context's own): whoever touches them waits for the last one that did, and says so */
+		hipEvent_t  sums_touched = nullptr;
+		hipStream_t sums_stream = nullptr;
+		bool        sums_used = false;
 		float   *d_count = nullptr;          /* RT_COUNT_WORDS words (rt_device.h): the sum of the published passes' weights (accum_counts[], main.c:396), written by
 		                                      * rt_accumulate; a word that stays zero; the launches not published because they were incomplete */
 		size_t   accum_bytes = 0, low_bytes = 0;
@@ -422,7 +428,8 @@ void rt_destroy(rt_context *ctx)
 	(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
 	(void) hipFree(ctx->d_lit_cells); (void) hipFree(ctx->d_lit_grids); (void) hipFree(ctx->d_clusters);
 	(void) hipFree(ctx->d_sky);  (void) hipFree(ctx->d_frame);
-	(void) hipFree(ctx->prog.d_accum); (void) hipFree(ctx->prog.d_low); (void) hipFree(ctx->prog.d_out); (void) hipFree(ctx->prog.d_count);
+	(void) hipFree(ctx->prog.d_accum); for (float *low : ctx->prog.d_low) (void) hipFree(low); (void) hipFree(ctx->prog.d_out); (void) hipFree(ctx->prog.d_count);
+	if (ctx->prog.sums_touched) (void) hipEventDestroy(ctx->prog.sums_touched);
 	(void) hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -1074,6 +1081,26 @@ int rt_strip_of_rank(int rank, int world)
 
 /* ---- progressive accumulation: worker() scale ladder + update_frame() (main.c:354-408, 450-482) ---- */
 
+} /* extern "C" */
+
+/* `stream` is about to read or write the ladder's sums or their count ... */
+static int sums_wait(rt_context *ctx, hipStream_t stream)
+{
+	auto &g = ctx->prog;
+	if (g.sums_used && g.sums_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, g.sums_touched, 0));
+	return RT_OK;
+}
+/* ... and has enqueued what it does with them */
+static int sums_mark(rt_context *ctx, hipStream_t stream)
+{
+	auto &g = ctx->prog;
+	HIP_TRY(hipEventRecord(g.sums_touched, stream));
+	g.sums_stream = stream; g.sums_used = true;
+	return RT_OK;
+}
+
+extern "C" {
+
 int rt_progressive_begin(rt_context *ctx, int width, int height, int init_scale, int max_bounces, uint64_t seed)
 {
 	return rt_progressive_begin_rank(ctx, width, height, init_scale, max_bounces, seed, 0, 1);
@@ -1102,10 +1129,13 @@ int rt_progressive_begin_rank(rt_context *ctx, int width, int height, int init_s
 	}
 	if (!g.d_count) HIP_TRY(hipMalloc((void**) &g.d_count, RT_COUNT_WORDS * sizeof(float)));
 	if (low_bytes != g.low_bytes) {
-		(void) hipFree(g.d_low); g.d_low = nullptr; g.low_bytes = 0;
-		HIP_TRY(hipMalloc((void**) &g.d_low, low_bytes));
+		{ const int rc = wait_for_launches(ctx); if (rc != RT_OK) return rc; }     /* (passes of the frame before may still be writing theirs) */
+		for (float *&low : g.d_low) { (void) hipFree(low); low = nullptr; }
+		g.low_bytes = 0;
+		for (float *&low : g.d_low) HIP_TRY(hipMalloc((void**) &low, low_bytes));
 		g.low_bytes = low_bytes;
 	}
+	if (!g.sums_touched) HIP_TRY(hipEventCreateWithFlags(&g.sums_touched, hipEventDisableTiming));
 	g.width = width; g.height = height; g.init_scale = init_scale; g.max_bounces = max_bounces; g.seed = seed;
 	g.rank = rank; g.world = world; g.rows = rows;
 	g.active = true;
@@ -1125,8 +1155,10 @@ int rt_progressive_invalidate(rt_context *ctx)
 	/* a pass still in flight is given up as soon as its waves notice (main.c:316-317) and is not published
 	 * (main.c:382: rt_accumulate looks at control[1]); the clear below is ordered behind it */
 	if (ctx->launches) { const int rc = rt_cancel(ctx); if (rc != RT_OK) return rc; }
+	{ const int rc = sums_wait(ctx, ctx->stream); if (rc != RT_OK) return rc; }
 	HIP_TRY(hipMemsetAsync(g.d_accum, 0, g.accum_bytes, ctx->stream));
 	HIP_TRY(hipMemsetAsync(g.d_count, 0, RT_COUNT_WORDS * sizeof(float), ctx->stream));
+	{ const int rc = sums_mark(ctx, ctx->stream); if (rc != RT_OK) return rc; }
 	g.passes = 0; g.scale = g.init_scale; g.generation++;
 	return RT_OK;
 }
@@ -1144,6 +1176,14 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 	auto &g = ctx->prog;
 	const int s = g.scale;
 	const int lw = g.width / s, lh = g.height / s, lcw = g.width / s + 1;     /* main.c:284-286 */
+	/* Passes rotate through the context's scratch sets, render streams and low-resolution frames, so that the next pass's waves
+	 * take the compute units this one's leave (a 1080p pass of one sample per pixel is ramp-up and tail from end to end: one
+	 * stream 0.254 ms per pass, docs/lab/r05.md section 3); only the publish steps -- sums += pass, in pass order -- wait for
+	 * each other. */
+	const unsigned which = ctx->launches % RT_LAUNCH_SETS;
+	hipStream_t stream = (hipStream_t) rt_stream(ctx, (int) which);
+	if (!stream) return RT_ERR_DEVICE;
+	float *const d_low = g.d_low[which];
 
 	rt_launch L;
 	memset(&L, 0, sizeof(L));
@@ -1171,7 +1211,7 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 		L.local_rows = mine * L.row_block;
 	}
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.sky_wm1 = (float) (ctx->sky_w - 1); L.sky_hm1 = (float) (ctx->sky_h - 1);
-	L.frame = g.d_low;
+	L.frame = d_low;
 	L.sum_onto = batch ? g.d_accum : nullptr;
 	/* (the flags are kept with the lists: a camera position pays once for all its passes -- reckoned as sixteen) */
 	L.skip_known_taps = classify_pixels(ctx, samples > 16 ? samples : 16);
@@ -1182,25 +1222,28 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 		L.clusters = ctx->d_clusters; L.num_clusters = ctx->cull.num_clusters; L.cull_margin = ctx->cull.margin; L.cull_origin_max = ctx->cull.origin_max;
 	}
 	{ const int rc = prepare_launch(ctx, L, ctx->launches); if (rc != RT_OK) { unpublish_launch(ctx); return rc; } }
-	{ const int rc = order_behind_previous(ctx, ctx->stream); if (rc != RT_OK) { unpublish_launch(ctx); return rc; } }
+	{ const int rc = order_behind_previous(ctx, stream); if (rc != RT_OK) { unpublish_launch(ctx); return rc; } }
+	if (batch) { const int rc = sums_wait(ctx, stream); if (rc != RT_OK) { unpublish_launch(ctx); return rc; } }     /* (its trace kernel reads the sums so far) */
 	if (ctx->tuning.poison_frame) {
-		const hipError_t pe = hipMemsetAsync(g.d_low, 0xff, g.low_bytes, ctx->stream);
+		const hipError_t pe = hipMemsetAsync(d_low, 0xff, g.low_bytes, stream);
 		if (pe != hipSuccess) { unpublish_launch(ctx); return fail(RT_ERR_DEVICE, "hipMemsetAsync(poison): %s", hipGetErrorString(pe)); }
 	}
 	if (L.local_rows <= 0) {
 		unpublish_launch(ctx);              /* nothing is launched for a rank without rows at this scale */
 		/* a rank without rows at this scale -- its few frame rows lie below the last whole low-resolution row -- renders
 		 * nothing and adds nothing, but the pass counts (main.c:396): those rows are divided by the same count as all others */
+		{ const int rc = sums_wait(ctx, stream); if (rc != RT_OK) return rc; }
 		for (int k = 0; k < samples; k++)
-			HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), nullptr, rt_launch_expect{ 0u, 0, 0u }, g.d_count,
-			                             RT_PROGRESSIVE_ROW_BLOCK, g.rank, g.world, 0, ctx->stream));
+			HIP_TRY(rt_launch_accumulate(g.d_accum, d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), nullptr, rt_launch_expect{ 0u, 0, 0u }, g.d_count,
+			                             RT_PROGRESSIVE_ROW_BLOCK, g.rank, g.world, 0, stream));
+		{ const int rc = sums_mark(ctx, stream); if (rc != RT_OK) return rc; }
 		g.passes += samples;
 		if (g.scale > 1) g.scale >>= 1;
 		if (weight_out) *weight_out = 1.0f / (s * s);
 		return RT_OK;
 	}
-	/* A pass differs from the pass before last (same scratch set) in its sample number only, once the scale ladder has
-	 * reached full resolution and until the camera moves: the camera rays, their hits and the sky pixels in the
+	/* A pass differs from the last pass of its scratch set (RT_LAUNCH_SETS passes ago) in its sample number only, once the scale
+	 * ladder has reached full resolution and until the camera moves: the camera rays, their hits and the sky pixels in the set's
 	 * low-resolution frame are the same, so rt_primary_pass's output is kept (a sixth of a 1080p pass).  The key is
 	 * everything that output depends on. */
 	uint64_t key = 0;
@@ -1208,36 +1251,40 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 		rt_launch K = L;
 		K.seed = 0; K.sample_base = 0; K.max_bounces = 0; K.lit_cells = nullptr; K.lit_grids = nullptr; K.lit_grids_in_lds = 0;
 		K.launch_id = 0;
-		K.pix = nullptr; K.pix_count = nullptr; K.control = nullptr;      /* the scratch set's own addresses: the same output in either set has the same key */
+		K.pix = nullptr; K.pix_count = nullptr; K.control = nullptr; K.frame = nullptr;     /* the scratch set's own addresses: the same output in any set has the same key */
 		key = 0xcbf29ce484222325ull ^ ctx->input_version;
 		const unsigned char *b = reinterpret_cast<const unsigned char*>(&K);
 		for (size_t i = 0; i < sizeof(K); i++) key = (key ^ b[i]) * 0x100000001b3ull;
 		if (key == 0) key = 1;
 	}
-	rt_context::launch_slot &sl = ctx->slot[ctx->launches % RT_LAUNCH_SETS];
+	rt_context::launch_slot &sl = ctx->slot[which];
 	const bool reuse = !ctx->tuning.poison_frame && !batch && sl.lists_key == key;      /* (a batch's sky pixels are sums: never the same twice) */
 	sl.lists_key = 0;
 	{
 		const bool audit = ctx->tuning.audit_known_taps != 0;
-		const hipError_t le = rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, trace_kernel_for(ctx, audit), sl.d_counter, nullptr, sl.started, ctx->num_cus, ctx->tuning.workgroups_per_cu, ctx->stream, reuse, &sl.expect,
-		                                      nullptr, audit);
+		const hipError_t le = rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, trace_kernel_for(ctx, audit), sl.d_counter, nullptr, sl.started, ctx->num_cus,
+		                                      /* (batches run one after the other: each needs the sums of the one before) */
+		                                      batch ? ctx->tuning.workgroups_per_cu : workgroups_per_cu_for(ctx, stream), stream, reuse, &sl.expect, nullptr, audit);
 		if (le != hipSuccess) { unpublish_launch(ctx); return fail(RT_ERR_DEVICE, "trace launch: %s", hipGetErrorString(le)); }
 	}
 	if (!reuse) ctx->primary_passes++;
 	sl.lists_key = ctx->tuning.poison_frame || batch ? 0 : key;
-	/* the low-resolution frame now holds THIS launch's sky pixels: lists of the other set that belong to anything else
-	 * (a pass at another scale before the ladder came back to this one) no longer have theirs */
-	for (unsigned o = 0; o < RT_LAUNCH_SETS; o++)
-		if (o != ctx->launches % RT_LAUNCH_SETS && ctx->slot[o].lists_key != key) ctx->slot[o].lists_key = 0;
 	const float weight = 1.0f / (s * s);                                         /* main.c:278 */
 	/* accum += pass * weight and accum_counts += weight (main.c:394-396), both on the device and both skipped for a pass
 	 * that rt_cancel() cut short (main.c:382): the count can never include a pass the buffer does not */
+	/* (on the pass's own stream: a stream for the publish steps alone, of the highest priority, was tried -- a hop between queues
+	 * costs 50 ... 80 us here, and priority does not make a workgroup slot where persistent kernels hold them all) */
+	hipStream_t pub = stream;
+	{ const int rc = sums_wait(ctx, pub); if (rc != RT_OK) return rc; }
 	if (batch)        /* the launch wrote sums-so-far + its samples: they become the sums, and `samples` passes count */
-		HIP_TRY(rt_launch_commit_sums(g.d_accum, g.d_low, (size_t) g.width * L.local_rows * 3, samples, L.control, sl.expect, g.d_count, ctx->stream));
+		HIP_TRY(rt_launch_commit_sums(g.d_accum, d_low, (size_t) g.width * L.local_rows * 3, samples, L.control, sl.expect, g.d_count, pub));
 	else
-	HIP_TRY(rt_launch_accumulate(g.d_accum, g.d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), L.control, sl.expect, g.d_count,
-	                             RT_PROGRESSIVE_ROW_BLOCK, g.rank, g.world, g.rows, ctx->stream));
-	{ const int rc = mark_launch(ctx, ctx->stream); if (rc != RT_OK) return rc; }
+	HIP_TRY(rt_launch_accumulate(g.d_accum, d_low, g.width, g.height, s, lcw, lh, 1.0f / (s * s), L.control, sl.expect, g.d_count,
+	                             RT_PROGRESSIVE_ROW_BLOCK, g.rank, g.world, g.rows, pub));
+	{ const int rc = sums_mark(ctx, pub); if (rc != RT_OK) return rc; }
+	/* (the launch is done when it is published: the scratch set's next launch, RT_LAUNCH_SETS passes on, clears the control words
+	 * the publish step reads and writes the low-resolution frame it adds) */
+	{ const int rc = mark_launch(ctx, pub); if (rc != RT_OK) return rc; }
 	g.passes += samples;
 	if (g.scale > 1) g.scale >>= 1;                                              /* main.c:402-403 */
 	if (weight_out) *weight_out = weight;
@@ -1279,7 +1326,9 @@ int rt_progressive_resolve(rt_context *ctx, Vector3 *frame_out)
 	if ((double) count < 0.0001)
 		return fail(RT_ERR_STATE, "rt_progressive_resolve: nothing accumulated yet (every pass so far was cancelled)");
 	/* frame = accum * (1 / count) (main.c:467-477) */
+	{ const int rc = sums_wait(ctx, ctx->stream); if (rc != RT_OK) return rc; }
 	HIP_TRY(rt_launch_resolve(g.d_accum, g.d_out, (size_t) g.width * g.rows * 3, g.d_count, ctx->stream));
+	{ const int rc = sums_mark(ctx, ctx->stream); if (rc != RT_OK) return rc; }      /* (the next publish step must not overtake the read) */
 	HIP_TRY(hipMemcpyAsync(frame_out, g.d_out, g.accum_bytes, hipMemcpyDeviceToHost, ctx->stream));     /* one rank of several: its rows */
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	return RT_OK;
@@ -1291,7 +1340,9 @@ int rt_progressive_resolve_device(rt_context *ctx, void **d_strip)
 	if (!ctx || !ctx->prog.active || !d_strip) return fail(RT_ERR_STATE, "rt_progressive_resolve: call rt_progressive_begin first");
 	auto &g = ctx->prog;
 	HIP_TRY(hipSetDevice(ctx->device));
+	{ const int rc = sums_wait(ctx, ctx->stream); if (rc != RT_OK) return rc; }
 	HIP_TRY(rt_launch_resolve(g.d_accum, g.d_out, (size_t) g.width * g.rows * 3, g.d_count, ctx->stream));
+	{ const int rc = sums_mark(ctx, ctx->stream); if (rc != RT_OK) return rc; }
 	*d_strip = g.d_out;
 	return RT_OK;
 }
@@ -1303,14 +1354,19 @@ int rt_progressive_count(rt_context *ctx, float *count)
 	if (!ctx || !ctx->prog.active || !count) return fail(RT_ERR_STATE, "rt_progressive_state: call rt_progressive_begin first");
 	HIP_TRY(hipSetDevice(ctx->device));
 	float *h_count = reinterpret_cast<float*>(&ctx->h_words[RT_COUNT_WORD]);
+	{ const int rc = sums_wait(ctx, ctx->stream); if (rc != RT_OK) return rc; }
 	HIP_TRY(hipMemcpyAsync(h_count, ctx->prog.d_count, RT_COUNT_WORDS * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	*count = *h_count;
 	/* passes whose launch was incomplete were not published (rt_accumulate / rt_commit_sums looked at the launch's control words
 	 * on the device): the sums are those of the other passes, and the caller is told */
 	const unsigned int incomplete = ctx->h_words[RT_COUNT_WORD + RT_COUNT_INCOMPLETE];
-	if (incomplete)
+	if (incomplete) {
+		/* (a launch that did not end as launches end may not have left its scratch set's counters as the next one expects them:
+		 * no set's lists are kept, so every set is cleared by its next launch) */
+		for (auto &sl : ctx->slot) sl.lists_key = 0;
 		return fail(RT_ERR_DEVICE, "rt_progressive: %u launch(es) since the last rt_progressive_invalidate() were incomplete and were not published (rt_last_launch_report() has the most recent launch's numbers)", incomplete);
+	}
 	return RT_OK;
 }
 

@@ -71,16 +71,17 @@ typedef struct {
  * of it (main.c:377-396). */
 #define RT_CTL_STAMP       0    /* the launch's number, written by the LAST wave of the trace kernel to leave, behind the sums below:
                                  * a launch whose waves did not all leave has no stamp */
-#define RT_CTL_CANCELLED   1    /* a wave gave up because of rt_cancel(): the frame is incomplete, and meant to be */
-#define RT_CTL_STOP_RELAY  2    /* the request, relayed from the waves that read the host's word to all others */
+#define RT_CTL_CANCELLED   1    /* by the last wave: a wave gave up because of rt_cancel() (the relay word below was set): the frame is incomplete, and meant to be */
+#define RT_CTL_STOP_RELAY  2    /* the request, relayed from the waves that read the host's word to all others; back to zero when the last wave leaves */
 #define RT_CTL_WAVES_LEFT  3    /* by the last wave: waves of the trace kernel that have left (the workgroups count themselves on the lists' dequeue lines) */
 #define RT_CTL_WRITTEN     4    /* by the last wave: object pixels resolved and written to the frame (the workgroups report them on the lists' dequeue lines as they leave) */
 #define RT_CTL_PRIMARY     5    /* by the last wave: 8x8 pixel blocks the camera-ray pass finished (sum over the lists' lines) */
 #define RT_CTL_LISTED      6    /* by the last wave: object pixels the camera-ray pass listed */
 #define RT_CTL_FETCHED     7    /* by the last wave: ... of which the trace kernel's waves fetched */
-#define RT_CTL_AUDITED     8    /* (64 bits) soft-shadow taps answered by rt_lit.h that were traced all the same (rt_launch.audit_taps) */
+#define RT_CTL_AUDITED     8    /* (64 bits) by the last wave (sum over the dequeue lines' words 4-5 / 6-7): soft-shadow taps answered by rt_lit.h that were traced all the same (rt_launch.audit_taps) */
 #define RT_CTL_DISAGREE    10   /* (64 bits) ... whose trace contradicts the answer */
-#define RT_CTL_LINES_DONE  12   /* dequeue lines whose workgroups have all left: the workgroup that completes the last one is the launch's last */
+#define RT_CTL_LINES_DONE  12   /* dequeue lines whose workgroups have all left: the workgroup that completes the last one is the launch's last -- and sets this, and the
+                                 * dequeue lines, back to zero: a launch that keeps its scratch set's pixel lists has nothing to clear (rt_launch_trace) */
 #define RT_CTL_WORDS       16
 /* What a launch is expected to leave in those words, kept by the host until they have been copied back and judged. */
 typedef struct {

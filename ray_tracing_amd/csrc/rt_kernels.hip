@@ -1097,14 +1097,15 @@ RT_DEV void leave_launch(WaveLDS *Wp, int wave)
 		const unsigned int nw = G.g_written, na = G.g_audited, nd = G.g_disagree;
 		const gwuint mine = (gwuint) block_counter + line * 32u;
 		if (nw) __hip_atomic_fetch_add(mine + 1, nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (na) __hip_atomic_fetch_add((gwulong) (ctl + RT_CTL_AUDITED), (unsigned long long) na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (nd) __hip_atomic_fetch_add((gwulong) (ctl + RT_CTL_DISAGREE), (unsigned long long) nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (na) __hip_atomic_fetch_add((gwulong) (mine + 4), (unsigned long long) na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* (words 4-5, 6-7: audited taps, and those that disagree) */
+		if (nd) __hip_atomic_fetch_add((gwulong) (mine + 6), (unsigned long long) nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (__hip_atomic_fetch_add(mine + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == on_line)
 			last = __hip_atomic_fetch_add(ctl + RT_CTL_LINES_DONE, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == (groups < lists ? groups : lists);
 	}
 	if (__ballot(last) == 0ull) return;
 	/* the launch's last workgroup: lane s adds up list s */
 	unsigned int listed = 0u, fetched = 0u, blocks = 0u, written = 0u, left = 0u;
+	unsigned long long audited = 0ull, disagree = 0ull;
 	if (lane < C->num_shards) {
 		const gwuint fill = (gwuint) C->pix_count + (unsigned int) lane * 32u, taken_at = (gwuint) block_counter + (unsigned int) lane * 32u;
 		listed = __hip_atomic_load(fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1115,13 +1116,32 @@ RT_DEV void leave_launch(WaveLDS *Wp, int wave)
 		fetched = taken < listed ? taken : listed;
 		written = __hip_atomic_load(taken_at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		left = __hip_atomic_load(taken_at + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		audited = __hip_atomic_load((gwulong) (taken_at + 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		disagree = __hip_atomic_load((gwulong) (taken_at + 6), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		/* ... and leaves the line as a launch must find it: the scratch set's next launch -- which starts when this one and whoever
+		 * reads its control words are done -- has nothing to clear when it keeps the lists (an interactive pass that differs from
+		 * the set's last in its sample number only, rt_api.cpp: two memsets per pass were a fifth of it) */
+		__hip_atomic_store(taken_at, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(taken_at + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(taken_at + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store((gwulong) (taken_at + 4), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store((gwulong) (taken_at + 6), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 #pragma unroll
 	for (int m = 1; m < 64; m <<= 1) {
 		listed += from_lane(listed, lane ^ m); fetched += from_lane(fetched, lane ^ m);
 		blocks += from_lane(blocks, lane ^ m); written += from_lane(written, lane ^ m); left += from_lane(left, lane ^ m);
+		audited += (unsigned long long) from_lane((uint32_t) audited, lane ^ m) | ((unsigned long long) from_lane((uint32_t) (audited >> 32), lane ^ m) << 32);
+		disagree += (unsigned long long) from_lane((uint32_t) disagree, lane ^ m) | ((unsigned long long) from_lane((uint32_t) (disagree >> 32), lane ^ m) << 32);
 	}
 	if (lane == 0) {
+		/* every word a reader looks at is WRITTEN here, none is counted up in place: the line needs no clearing either.  "Cut short by
+		 * rt_cancel()" is the relay word, which a wave sets when it gives up; it and the count of finished lines go back to zero. */
+		ctl[RT_CTL_CANCELLED] = __hip_atomic_load(ctl + RT_CTL_STOP_RELAY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+		__hip_atomic_store(ctl + RT_CTL_STOP_RELAY, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(ctl + RT_CTL_LINES_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		ctl[RT_CTL_AUDITED] = (unsigned int) audited; ctl[RT_CTL_AUDITED + 1] = (unsigned int) (audited >> 32);
+		ctl[RT_CTL_DISAGREE] = (unsigned int) disagree; ctl[RT_CTL_DISAGREE + 1] = (unsigned int) (disagree >> 32);
 		ctl[RT_CTL_LISTED] = listed; ctl[RT_CTL_FETCHED] = fetched; ctl[RT_CTL_PRIMARY] = blocks; ctl[RT_CTL_WRITTEN] = written;
 		ctl[RT_CTL_WAVES_LEFT] = left * (unsigned int) (BLOCK / 64);
 		__hip_atomic_store(ctl + RT_CTL_STAMP, C->launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1349,7 +1369,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 					k = (unsigned int) __builtin_amdgcn_readfirstlane((int) k);
 					if ((int) __builtin_amdgcn_readfirstlane((int) word) >= 0) {      /* the request covers this launch / another wave has seen it */
 						cancelled = true;
-						if (lane == 0) { C->control[RT_CTL_CANCELLED] = 1u; __hip_atomic_store((gwuint) C->control + RT_CTL_STOP_RELAY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+						if (lane == 0) __hip_atomic_store((gwuint) C->control + RT_CTL_STOP_RELAY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     /* (becomes control[RT_CTL_CANCELLED] when the launch's last workgroup leaves) */
 					}
 					const guint fill_counts = (guint) C->pix_count;
 					const unsigned int drop = C->test_drop_pixels;          /* (testing aid: 0 in production) */
@@ -2217,9 +2237,10 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	Lq.trace_workgroups = (int) grid;
 	/* counter block: WF_SHARDS dequeue counters, WF_SHARDS fill counters, one line of control words.  When the lists of the
 	 * previous launch of this scratch set are this launch's lists (an interactive pass with nothing changed but the
-	 * sample number: rt_api.cpp), the fill counters and the records stay and rt_primary_pass is not run */
-	hipError_t e = hipMemsetAsync(block_counter, 0, reuse_pixel_lists ? (size_t) WF_SHARDS * 128 : (size_t) RT_COUNTER_BYTES, stream);
-	if (e == hipSuccess && reuse_pixel_lists) e = hipMemsetAsync(block_counter + 2 * WF_SHARDS * 32, 0, 128, stream);
+	 * sample number: rt_api.cpp), the fill counters and the records stay and rt_primary_pass is not run
+	 * -- and nothing is cleared: the last workgroup of a launch leaves the dequeue lines and the control line as the next launch
+	 * must find them (leave_launch) */
+	hipError_t e = reuse_pixel_lists ? hipSuccess : hipMemsetAsync(block_counter, 0, (size_t) RT_COUNTER_BYTES, stream);
 	if (e == hipSuccess && cleared) e = hipEventRecord(cleared, stream);
 	if (e != hipSuccess) return e;
 	if (reuse_pixel_lists) {

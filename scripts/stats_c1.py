@@ -1,4 +1,5 @@
-"""Per-site lane utilisation of the wavefront kernel on C1 (needs `make -C ray_tracing_amd/csrc stats`)."""
+"""Per-site lane utilisation of the wavefront kernel on C1 (needs `make -C ray_tracing_amd/csrc stats`).
+usage: stats_c1.py [scene [jit|stamps|lib [spp [bounces]]]]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ray_tracing_amd as rt
@@ -7,6 +8,8 @@ jit = len(sys.argv) > 2 and sys.argv[2] in ("jit", "stamps")      # the scene-sp
 stamps = len(sys.argv) > 2 and sys.argv[2] == "stamps"              # section time stamps only (the per-site atomics distort them)
 if not jit: rt.LIB_PATH = os.path.join(os.path.dirname(rt.LIB_PATH), "librt_hip_stats.so")
 W, H, spp, nb = (1920, 1080, 64, 4) if scene == 0 else (1920, 1080, 256, 8)
+if len(sys.argv) > 3: spp = int(sys.argv[3])
+if len(sys.argv) > 4: nb = int(sys.argv[4])
 g = rt.Renderer(0)
 g.set_skybox(rt.load_skybox()); g.set_scene(f"{rt.DATA_DIR}/scene_{scene}.txt")
 out = (C.c_ulonglong * 64)()
