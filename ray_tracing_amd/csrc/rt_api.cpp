@@ -1262,9 +1262,15 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 	sl.lists_key = 0;
 	{
 		const bool audit = ctx->tuning.audit_known_taps != 0;
+		/* Resident workgroups per CU.  Batches run one after the other (each needs the sums of the one before): all the slots.  Single
+		 * passes enqueued ahead of the GPU: ONE of four -- three passes are resident at a time; a 1080p pass is five pixels per lane
+		 * with all the slots, and a wave then spends more rounds on the last of its paths (ten bounces, a few lanes) than on all the
+		 * others: 15.3 rounds per wave and pass, 7.6 of them nearly empty, against 44.4 / 8.8 for a quarter of the waves, i.e. 62 700
+		 * against 45 500 rounds per pass (profiles/r05/progressive_stats.txt); 0.191 -> 0.174 ms per pass. */
+		int wg = ctx->tuning.workgroups_per_cu;
+		if (!batch && wg < 1) { wg = workgroups_per_cu_for(ctx, stream); if (wg == 2) wg = 1; }
 		const hipError_t le = rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, trace_kernel_for(ctx, audit), sl.d_counter, nullptr, sl.started, ctx->num_cus,
-		                                      /* (batches run one after the other: each needs the sums of the one before) */
-		                                      batch ? ctx->tuning.workgroups_per_cu : workgroups_per_cu_for(ctx, stream), stream, reuse, &sl.expect, nullptr, audit);
+		                                      wg, stream, reuse, &sl.expect, nullptr, audit);
 		if (le != hipSuccess) { unpublish_launch(ctx); return fail(RT_ERR_DEVICE, "trace launch: %s", hipGetErrorString(le)); }
 	}
 	if (!reuse) ctx->primary_passes++;
@@ -1295,8 +1301,8 @@ int rt_progressive_pass(rt_context *ctx, float *weight_out) { return progressive
 
 /* `count` worker iterations.  While the ladder is below full resolution they are what `count` calls of rt_progressive_pass()
  * are; at full resolution the rest go into launches of up to RT_PROGRESSIVE_BATCH samples per pixel.  Same sums, same count,
- * same sample numbers: the frame is bit-identical -- a 1080p pass of one sample per pixel is a quarter of a millisecond of
- * launch, camera rays and half-empty waves, sixty of them in one launch take a third of sixty launches. */
+ * same sample numbers: the frame is bit-identical -- a 1080p pass of one sample per pixel is 0.18 ms, most of it waves running out
+ * their last few paths, sixty of them in one launch take half the time of sixty launches. */
 int rt_progressive_passes(rt_context *ctx, int count)
 {
 	if (!ctx || !ctx->prog.active) return fail(RT_ERR_STATE, "rt_progressive_passes: call rt_progressive_begin first");

@@ -5,12 +5,14 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ray_tracing_amd as rt
+if os.environ.get("RT_LIB_FILE"): rt.LIB_PATH = os.path.abspath(os.environ["RT_LIB_FILE"])
 si = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 W, H, nb = 1920, 1080, 10
 wg = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 g = rt.Renderer(0)
 g.set_skybox(rt.load_skybox()); g.set_scene(f"{rt.DATA_DIR}/scene_{si}.txt"); g.compile_scene()
-if wg: g.set_tuning(workgroups_per_cu=wg)
+flags = os.environ.get('RT_JIT_FLAGS')
+if wg or flags: g.set_tuning(workgroups_per_cu=wg, jit_flags=flags); g.compile_scene()
 def run(calls, per_call):
     g.progressive_begin(W, H, init_scale=1, max_bounces=nb, seed=1)
     (g.progressive_passes(8) if per_call > 1 else [g.progressive_pass() for _ in range(8)]); g.synchronize()
