@@ -91,7 +91,7 @@ def parse_args(argv=None):
     ap.add_argument("--leave-early", action="store_true",
                     help="testing aid (scripts/repro_verify_race.py): ranks other than 0 do not wait for rank 0's verification before they "
                          "tear their contexts down -- the bench's behaviour when its verification failed intermittently in round 3")
-    ap.add_argument("--depth", type=int, default=0, help="frames in flight in the C ABI's frame queue (default 2; 4 on the N-GPU path)")
+    ap.add_argument("--depth", type=int, default=0, help="frames in flight in the C ABI's frame queue (default 2; RT_LAUNCH_SETS + 1 = 6 on the N-GPU path)")
     return ap.parse_args(argv)
 
 
@@ -367,6 +367,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+
     # ---- the frame loop: the library's own frame queue behind the C ABI at N = 1 (rt_frame_submit / rt_frame_wait; with
     # --force-collective the N-GPU path of rt_multi_frame_* over a one-rank RCCL communicator), torch.distributed's
     # collective around rt_render_device when every GPU has its own process (N > 1) -----------------------------------
@@ -397,7 +398,7 @@ def main():
         # (one GPU: two frames in flight measure better than three -- 5.465 against 5.52 ms per C1 step, profiles/r05/bench_depth.txt: a
         # third frame enqueued ahead makes every launch take half the workgroup slots; the N-GPU path keeps a strip draining, one
         # running and one starting, plus the gather of the one before)
-        depth = args.depth or (4 if multi_path else 2)
+        depth = args.depth or (rt.LAUNCH_SETS + 1 if multi_path else 2)
         loop = FrameLoop(queue, W, H, spp, nb, depth=depth, row_block=ROW_BLOCK, kernel=args.kernel)
         primitive = ("device copies on one GPU (testing aid)" if args.one_device else "ncclGather (native, one process)") if multi_path else None
 
@@ -614,7 +615,7 @@ def main():
     interactive = None
     if native and not multi_path and not args.no_extras and world == 1:
         n_pass = 256
-        rates = {}
+        rates, enqueued = {}, {}
         for batched in (False, True):
             gpu.progressive_begin(W, H, init_scale=1, max_bounces=10, seed=seed)
             if batched: gpu.progressive_passes(8)
@@ -623,9 +624,11 @@ def main():
             t1 = time.perf_counter()
             if batched: gpu.progressive_passes(n_pass)
             else: [gpu.progressive_pass() for _ in range(n_pass)]
+            enqueued[batched] = (time.perf_counter() - t1) / n_pass
             fence()
             rates[batched] = (time.perf_counter() - t1) / n_pass
         interactive = {"ms_per_pass": round(rates[False] * 1e3, 4), "ms_per_pass_batched": round(rates[True] * 1e3, 4),
+                       "host_enqueue_ms_per_pass": round(enqueued[False] * 1e3, 4),
                        "msamples_per_s": round(W * H / rates[False] / 1e6, 1), "msamples_per_s_batched": round(W * H / rates[True] / 1e6, 1),
                        "region": f"{n_pass} passes of 1 sample per pixel at {W}x{H}, 10 bounces, after the scale ladder: one launch per pass "
                                  "(rt_progressive_pass) / all in one launch (rt_progressive_passes); host enqueue -> synchronised"}

@@ -151,15 +151,17 @@ RT_API int rt_render(rt_context *ctx, const rt_render_params *params, Vector3 *f
 /* Same, but the destination is DEVICE memory (rt_strip_rows()*width*12 bytes) and the call only
  * enqueues work on `hip_stream` (a hipStream_t; NULL = the context's own non-blocking stream;
  * RT_STREAM_LEGACY = the device's legacy null stream, which a literal 0 cannot name here).  No sync.
- * A context owns RT_LAUNCH_SETS (three) sets of launch scratch (pixel lists, counters) and uses them in rotation: a launch is
+ * A context owns RT_LAUNCH_SETS (five) sets of launch scratch (pixel lists, counters) and uses them in rotation: a launch is
  * ordered (through an event, when the streams differ) behind the launch RT_LAUNCH_SETS before it, never behind the ones in
- * between -- consecutive launches enqueued on different streams may be on the GPU together: one draining, the next running, the
- * one after it starting in the workgroup slots the first leaves (strips of a millisecond: a tenth more frames per second than one
- * launch after the other, profiles/r05/strip_loop_probe.txt; they must of course write different destinations).  Launches on
+ * between -- consecutive launches enqueued on different streams may be on the GPU together: one draining, the others running, the
+ * last starting in the workgroup slots the first leaves (strips of a millisecond: a seventh more frames per second than one
+ * launch after the other, profiles/r05/strip_loop_probe_five_sets.txt; they must of course write different destinations).  A host
+ * that keeps five small launches in flight (the strips of an N-GPU frame) is given ONE workgroup slot per CU and launch: a wave
+ * then has four times the pixels, and the rounds it spends on the last of them weigh a quarter.  Launches on
  * one stream run in stream order as always.  rt_set_scene / rt_set_skybox wait for the context's own launches only, not for
  * the whole device. */
 #define RT_STREAM_LEGACY ((void *) (intptr_t) -1)
-#define RT_LAUNCH_SETS 3        /* scratch sets, and streams (rt_stream), a context rotates its launches through */
+#define RT_LAUNCH_SETS 5        /* scratch sets, and streams (rt_stream), a context rotates its launches through */
 RT_API int rt_render_device(rt_context *ctx, const rt_render_params *params, void *d_strip, void *hip_stream);
 
 /* The context's streams as hipStream_t: which = 0 the stream NULL stands for above; which = 1 ... RT_LAUNCH_SETS - 1 more
@@ -213,7 +215,7 @@ RT_API int rt_synchronize(rt_context *ctx);
  * RT_CANCELLED when rt_cancel() cut the frame short; rt_frame_poll() never blocks: RT_PENDING while the frame is not
  * there yet.  Submitting into a slot that holds a frame nobody waited for is an error (RT_ERR_STATE); params->world
  * must be 1.  rt_set_scene / rt_set_skybox / rt_destroy wait for the frames in flight. */
-#define RT_FRAME_SLOTS 4
+#define RT_FRAME_SLOTS 8
 RT_API int rt_frame_submit(rt_context *ctx, const rt_render_params *params, int slot, Vector3 *frame_out);
 RT_API int rt_frame_wait(rt_context *ctx, int slot);
 RT_API int rt_frame_poll(rt_context *ctx, int slot);

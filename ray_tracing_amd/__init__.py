@@ -277,7 +277,8 @@ def strip_rows(height, row_block, world):
 
 # ---- the GPU path ---------------------------------------------------------------------------------
 
-FRAME_SLOTS = 4          # RT_FRAME_SLOTS
+FRAME_SLOTS = 8          # RT_FRAME_SLOTS
+LAUNCH_SETS = 5          # RT_LAUNCH_SETS
 CHECK_TICKETS = 8        # RT_CHECK_TICKETS
 PENDING, CANCELLED = 2, 1
 

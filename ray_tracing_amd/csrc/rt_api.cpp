@@ -230,14 +230,39 @@ static int order_behind_previous(rt_context *ctx, hipStream_t stream)
  * frame k has been delivered, and until then frame k+1 would have half a chip to itself (C1 whole frames +2.7 %).  That is
  * what the test tells apart: such a host finds the previous launch running.  A launch with nothing beside it (rt_render(),
  * the first frame of a run, every launch of a host that uses one stream) takes all the slots. */
-static int workgroups_per_cu_for(rt_context *ctx, hipStream_t stream)
+/* Round 5: ... and ONE slot per CU when the launch is small and the host keeps at least four more in flight (the launch four
+ * before this one has not finished: the N-GPU loops rotate five strips through the five scratch sets).  A strip of one of eight
+ * ranks is five object pixels per stream of a full grid: a wave spends a fifth of its life on the last of them, at thinning lanes,
+ * and with a quarter of the waves per launch -- five launches resident or queued for the four slots -- that weighs a quarter.  C1,
+ * strips of 8 / 4 / 2 ranks: 0.716 / 1.381 / 2.630 -> 0.682 / 1.344 / 2.620 ms per step; a whole frame loses 1.5 % that way and
+ * keeps two slots (profiles/r05/strip_loop_probe_five_sets.txt).  `pixels`: those of the launch, sky included. */
+#define RT_SMALL_LAUNCH_PIXELS_PER_STREAM 64
+static int workgroups_per_cu_for(rt_context *ctx, hipStream_t stream, long long pixels)
 {
 	if (ctx->tuning.workgroups_per_cu > 0) return ctx->tuning.workgroups_per_cu;
 	const rt_context::launch_slot &prev = ctx->slot[ctx->cur];
 	if (!ctx->launches || !prev.used || prev.stream == stream) return 0;
 	const hipError_t q = hipEventQuery(prev.started);
 	(void) hipGetLastError();           /* "not ready" is an answer, not an error the launch below should find */
-	return q == hipErrorNotReady ? 2 : 0;
+	if (q != hipErrorNotReady) return 0;
+	const long long streams_at_two = (long long) ctx->num_cus * 2 * 4 * 8;      /* two workgroups of four waves per CU, eight streams per wave (rt_kernels.hip) */
+	if (ctx->launches >= 4 && pixels < streams_at_two * RT_SMALL_LAUNCH_PIXELS_PER_STREAM) {
+		/* five launches on five streams (a host that is far ahead on fewer streams has fewer launches on the GPU: they keep two slots) */
+		hipStream_t seen[5] = { stream, nullptr, nullptr, nullptr, nullptr };
+		bool distinct = true;
+		for (unsigned back = 1; back <= 4 && distinct; back++) {
+			const rt_context::launch_slot &b = ctx->slot[(ctx->launches - back) % RT_LAUNCH_SETS];
+			distinct = b.used;
+			for (unsigned k = 0; k < back && distinct; k++) distinct = seen[k] != b.stream;
+			seen[back] = b.stream;
+		}
+		if (distinct) {
+			const hipError_t d = hipEventQuery(ctx->slot[(ctx->launches - 4) % RT_LAUNCH_SETS].done);
+			(void) hipGetLastError();
+			if (d == hipErrorNotReady) return 1;
+		}
+	}
+	return 2;
 }
 
 /* Does rt_primary_pass classify the object pixels' taps (rt_lit.h: rt_taps_class)?  It looks at every object for every object
@@ -322,7 +347,7 @@ extern "C" void *rt_stream(rt_context *ctx, int which)
 {
 	if (!ctx || which < 0 || which >= RT_LAUNCH_SETS) return nullptr;
 	if (which == 0) return (void *) ctx->stream;
-	/* Made on first request (a stream nobody uses only makes busy ones share a hardware queue), with the lowest priority
+	/* (made by rt_create(), see there) with the lowest priority
 	 * the device offers: streams of different priority never share a queue, so their launches overlap those of stream 0
 	 * (and each other's: the runtime deals the streams of one priority over several hardware queues). */
 	hipStream_t &st = ctx->more_streams[which - 1];
@@ -401,6 +426,11 @@ int rt_create(rt_context **out, int device_id)
 	}
 	rt_camera_default(&ctx->camera);
 	ctx->have_camera = true;     /* the reference starts from its default pose too (camera.c:33-35) */
+	/* The render streams are made now, in order, before any other stream of the context (the copy stream of the frame queue): made
+	 * on first request -- as they were until round 5 -- a host that ran the frame queue first got interactive passes that did not
+	 * overlap (0.230 instead of 0.178 ms per pass; scripts/probes/progressive_reps.py first-frames): which hardware queue a
+	 * stream gets depends on what exists when it is made. */
+	for (int which = 1; which < RT_LAUNCH_SETS; which++) (void) rt_stream(ctx, which);
 	*out = ctx;
 	return RT_OK;
 }
@@ -826,7 +856,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	ctx->slot[ctx->launches % RT_LAUNCH_SETS].lists_key = 0;
 	ctx->primary_passes++;
 	const bool audit = ctx->tuning.audit_known_taps != 0;
-	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, trace_kernel_for(ctx, audit), ctx->slot[ctx->launches % RT_LAUNCH_SETS].d_counter, e0, ctx->slot[ctx->launches % RT_LAUNCH_SETS].started, ctx->num_cus, workgroups_per_cu_for(ctx, stream), stream,
+	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, trace_kernel_for(ctx, audit), ctx->slot[ctx->launches % RT_LAUNCH_SETS].d_counter, e0, ctx->slot[ctx->launches % RT_LAUNCH_SETS].started, ctx->num_cus, workgroups_per_cu_for(ctx, stream, (long long) L.width * L.local_rows), stream,
 	                                false, &ctx->slot[ctx->launches % RT_LAUNCH_SETS].expect, em, audit);
 	if (le == hipSuccess && ctx->profiling) le = hipEventRecord(e1, stream);
 	if (ctx->profiling) {
@@ -1163,6 +1193,7 @@ int rt_progressive_invalidate(rt_context *ctx)
 	return RT_OK;
 }
 
+#define RT_PASSES_IN_FLIGHT 3
 /* One launch of the ladder: `samples` = 1 is one worker iteration (main.c:354-408) at the ladder's current scale; more than one
  * (full resolution only) is that many iterations in ONE launch -- the trace kernel adds the pixel's samples, in pass order, onto
  * the sums so far (rt_launch.sum_onto), which is what `samples` publish steps (main.c:394) would have done one after the other. */
@@ -1176,12 +1207,13 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 	auto &g = ctx->prog;
 	const int s = g.scale;
 	const int lw = g.width / s, lh = g.height / s, lcw = g.width / s + 1;     /* main.c:284-286 */
-	/* Passes rotate through the context's scratch sets, render streams and low-resolution frames, so that the next pass's waves
+	/* Passes rotate through the context's scratch sets and low-resolution frames, and through THREE of its render streams (three
+	 * passes in flight: more measure worse -- each gets fewer slots, none gets done; profiles/r05/interactive_passes_scratch_sets_probe.txt), so that the next pass's waves
 	 * take the compute units this one's leave (a 1080p pass of one sample per pixel is ramp-up and tail from end to end: one
 	 * stream 0.254 ms per pass, docs/lab/r05.md section 3); only the publish steps -- sums += pass, in pass order -- wait for
 	 * each other. */
 	const unsigned which = ctx->launches % RT_LAUNCH_SETS;
-	hipStream_t stream = (hipStream_t) rt_stream(ctx, (int) which);
+	hipStream_t stream = (hipStream_t) rt_stream(ctx, (int) (ctx->launches % RT_PASSES_IN_FLIGHT));
 	if (!stream) return RT_ERR_DEVICE;
 	float *const d_low = g.d_low[which];
 
@@ -1268,7 +1300,7 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 		 * others: 15.3 rounds per wave and pass, 7.6 of them nearly empty, against 44.4 / 8.8 for a quarter of the waves, i.e. 62 700
 		 * against 45 500 rounds per pass (profiles/r05/progressive_stats.txt); 0.191 -> 0.174 ms per pass. */
 		int wg = ctx->tuning.workgroups_per_cu;
-		if (!batch && wg < 1) { wg = workgroups_per_cu_for(ctx, stream); if (wg == 2) wg = 1; }
+		if (!batch && wg < 1) { wg = workgroups_per_cu_for(ctx, stream, (long long) L.width * L.local_rows); if (wg == 2) wg = 1; }
 		const hipError_t le = rt_launch_trace(L, RT_KERNEL_AUTO, ctx->scene_fast_ok, trace_kernel_for(ctx, audit), sl.d_counter, nullptr, sl.started, ctx->num_cus,
 		                                      wg, stream, reuse, &sl.expect, nullptr, audit);
 		if (le != hipSuccess) { unpublish_launch(ctx); return fail(RT_ERR_DEVICE, "trace launch: %s", hipGetErrorString(le)); }

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-LAUNCH_SETS = 3       # RT_LAUNCH_SETS: the scratch sets and streams a context rotates its launches through
+LAUNCH_SETS = 5       # RT_LAUNCH_SETS: the scratch sets and streams a context rotates its launches through
 
 
 def strip_rows(height, row_block, world):
@@ -149,7 +149,7 @@ class TiledFrame:
         self.primitive = collective_for() if self.multi else None
         # strip buffers in rotation: LAUNCH_SETS renders in flight (one draining, one running, one starting: the library's
         # scratch sets and streams) and, N > 1, the gather of the one before them
-        self.depth = LAUNCH_SETS + 1 if self.multi else LAUNCH_SETS
+        self.depth = LAUNCH_SETS + 1 if self.multi else 3
         with torch.cuda.stream(self.stream):
             self.strip = [torch.empty((rows, width, 3), dtype=torch.float32, device=device) for _ in range(self.depth)]
             self.strips = self.frame = None

@@ -1,16 +1,18 @@
 """One rank's share of a C1 frame on N GPUs, as the frame loop runs it (launches rotating through the context's streams and
 scratch sets, frames left on the device): ms per strip step for world = 1, 2, 4, 8 -- what the kernel side of the N-GPU step costs
 on ONE device, to set beside frame / N.
-usage: strip_loop_probe.py [streams]      streams = launches in flight: 2, or 3 (default: RT_LAUNCH_SETS)"""
+usage: strip_loop_probe.py [streams [workgroups per CU]]      streams = launches in flight: 2 ... RT_LAUNCH_SETS (the default);
+workgroups per CU: rt_tuning.workgroups_per_cu (0: the library decides)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ray_tracing_amd as rt
 if os.environ.get("RT_LIB_FILE"): rt.LIB_PATH = os.path.abspath(os.environ["RT_LIB_FILE"])
 W, H, spp, nb = 1920, 1080, 64, 4
-S = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+S = int(sys.argv[1]) if len(sys.argv) > 1 else rt.LAUNCH_SETS
 g = rt.Renderer(0)
 g.set_skybox(rt.load_skybox()); g.set_scene(f"{rt.DATA_DIR}/scene_0.txt"); g.compile_scene()
+if len(sys.argv) > 2 and int(sys.argv[2]): g.set_tuning(workgroups_per_cu=int(sys.argv[2]))
 base = None
 for world in (1, 2, 4, 8):
     rank = world // 2

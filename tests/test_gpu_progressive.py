@@ -166,8 +166,8 @@ def test_kept_pixel_lists_change_no_bit(oracle, scene_paths):
         assert (bits(g.progressive_resolve()) == bits(want)).all(), what
 
     before = rt.lib().rt_primary_passes_run(g._ctx)
-    check(1, 7, "seven full-resolution passes: four of them on kept lists")
-    assert rt.lib().rt_primary_passes_run(g._ctx) - before == 3          # one per scratch set (RT_LAUNCH_SETS)
+    check(1, 7, "seven full-resolution passes: two of them on kept lists")
+    assert rt.lib().rt_primary_passes_run(g._ctx) - before == rt.LAUNCH_SETS          # one per scratch set
     check(4, 8, "ladder 4, 2, 1 and five more passes")
     cam = dict(pos=(2, 3, 9), front=(0.1, -0.3, -1), up=(0, 1, 0), fov=30.0)
     g.set_camera(**cam); oracle.set_camera(**cam)
