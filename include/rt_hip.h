@@ -310,9 +310,9 @@ RT_API int  rt_multi_set_tuning(rt_multi *m, const rt_tuning *tuning);
 RT_API int  rt_multi_compile_scene(rt_multi *m);
 RT_API int  rt_multi_render(rt_multi *m, const rt_render_params *params, Vector3 *frame_out);
 /* The same with frames in flight (rt_frame_submit / rt_frame_wait above, same rules): every device renders frame k's
- * strip on its context's streams in rotation, into one of four strip buffers; the grouped ncclGather of frame k, the
+ * strip on its context's streams in rotation, into one of RT_LAUNCH_SETS + 1 strip buffers; the grouped ncclGather of frame k, the
  * de-interleave on the first device and the copy to frame_out run on streams of their own behind events, beside the
- * renders of frames k+1 ... k+3 -- a render stream only ever waits for the gather four frames back, whose strip buffer
+ * renders of the frames after it -- a render stream only ever waits for the gather RT_LAUNCH_SETS + 1 frames back, whose strip buffer
  * it reuses.  (The persistent trace kernel of the next frame holds every compute unit until it drains, so a render
  * stream that waited for the previous frame's collective would lose the overlap of consecutive strips.)  With one
  * device and no rt_tuning.force_collective this is rt_frame_submit() on that device's context. */

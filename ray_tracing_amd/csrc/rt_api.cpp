@@ -115,10 +115,11 @@ struct rt_context {
 
 	/* Scratch of a launch.  There are RT_LAUNCH_SETS sets, used in rotation, so that consecutive launches enqueued on
 	 * different streams can be on the GPU together: the waves of the next fill the compute units as the waves of the
-	 * first run out of pixels (the last wave of a launch leaves 100 us after the average one).  Three sets:
-	 * with two, launch n + 2 had to wait for the END of launch n, whose scratch it took over -- and for all of launch n's tail the
+	 * first run out of pixels (the last wave of a launch leaves 100 us after the average one).  With two
+	 * sets, launch n + 2 had to wait for the END of launch n, whose scratch it took over -- and for all of launch n's tail the
 	 * workgroup slots its waves left stayed empty beside launch n + 1 (a strip of an eighth of a frame: 0.748 ms per step against
-	 * 0.672 ideal); with three, launch n + 2 is resident while launch n drains. */
+	 * 0.672 ideal); with three, launch n + 2 is resident while launch n drains (0.720); with five, small launches take ONE workgroup
+	 * slot per CU each and five are resident or queued for the four slots (workgroups_per_cu_for(): 0.690). */
 	struct launch_slot {
 		unsigned int *d_counter = nullptr;   /* dequeue + fill counters of the pixel lists, launch control words */
 		float       *d_pix = nullptr;        /* rt_primary_pass output: pixel records (rt_device.h) */

@@ -105,14 +105,14 @@ class TiledFrame:
     """The N-GPU frame loop of bench.py: render own strip -> gather -> de-interleave on rank 0 -> frame in
     pinned host memory on rank 0 (what update_frame() hands to the presenter, main.c:467-479).
 
-    step() enqueues one frame and returns at once; up to four frames are in flight.  flush() completes
+    step() enqueues one frame and returns at once; up to six frames are in flight (N > 1; three on one rank).  flush() completes
     everything and leaves the last frame in `host_frame` (rank 0).  `seed` may be changed between steps
     (`step(seed=...)`): every frame is rendered from scratch, nothing is reused across frames.
 
-    Streams (N > 1).  Frame k is rendered on streams[k % 3] (the renderer's three streams: consecutive strips overlap on
-    the GPU, one draining, one running, one starting) into strip buffer k % 4, and its gather is issued behind it.  What FOLLOWS the gather -- waiting for it,
+    Streams (N > 1).  Frame k is rendered on streams[k % 5] (the renderer's five streams: consecutive strips overlap on
+    the GPU -- the library gives each of five small launches one workgroup slot per CU --) into strip buffer k % 6, and its gather is issued behind it.  What FOLLOWS the gather -- waiting for it,
     the de-interleave, handing the frame to the copy stream -- is enqueued on a third stream (`post`): the render
-    streams never wait for a collective of the last three frames, only (through an event) for the one four frames back
+    streams never wait for a collective of the last five frames, only (through an event) for the one six frames back
     whose strip buffer they reuse.  The collective's kernels only get compute units when the persistent trace kernel
     of the next frame starts to drain, so a render stream that waited for the previous gather would lose the overlap
     of consecutive strips.

@@ -2,7 +2,7 @@
 `strip=<s>` on the command line picks another, `strip=0` is the un-rotated hand-out of rounds 1-2), the
 root's local share of the gather (a device copy of its strip into the gather buffer), the de-interleave of all eight
 strips into the frame and the copy of the frame to pinned host memory -- pipelined as multi_gpu.TiledFrame pipelines
-them (render streams k & 1, post stream, copy stream, three strip buffers).  Only the xGMI transfer of the seven peer
+them (the context's render streams in rotation, post stream, copy stream, one strip buffer more than streams).  Only the xGMI transfer of the seven peer
 strips is missing.  Prints ms per step for: strips alone, + gather stand-in and de-interleave, + host copy.
 Also prints the time of one of the OTHER ranks' strips alone (strip 0: a longest one), which bounds the step from below.
 usage: rank0_probe.py [C1|C4] [world] [strip=<s>]"""
@@ -23,19 +23,20 @@ dev = torch.device("cuda", 0)
 g = rt.Renderer(0)
 g.set_skybox(rt.load_skybox()); g.set_scene(f"{rt.DATA_DIR}/scene_0.txt"); g.set_camera(); g.compile_scene()
 rows = rt.strip_rows(H, 8, world)
-streams = [torch.cuda.ExternalStream(g.stream(w), device=dev) for w in (0, 1)]
+S = rt.LAUNCH_SETS
+streams = [torch.cuda.ExternalStream(g.stream(w), device=dev) for w in range(S)]
 post, copy = torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev, priority=-1)
-strip = [torch.empty((rows, W, 3), dtype=torch.float32, device=dev) for _ in range(3)]
-strips = [torch.zeros((world, rows, W, 3), dtype=torch.float32, device=dev) for _ in range(3)]
+strip = [torch.empty((rows, W, 3), dtype=torch.float32, device=dev) for _ in range(S + 1)]
+strips = [torch.zeros((world, rows, W, 3), dtype=torch.float32, device=dev) for _ in range(S + 1)]
 frame = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)]
 host = [torch.empty((H, W, 3), dtype=torch.float32, pin_memory=True) for _ in range(2)]
 
 def run(level, mine=mine):
-    gathered, copied = [None] * 3, [None] * 2
+    gathered, copied = [None] * (S + 1), [None] * 2
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(N):
-        s, j, f = streams[k & 1], k % 3, k & 1
+        s, j, f = streams[k % S], k % (S + 1), k & 1
         with torch.cuda.stream(s):
             if gathered[j] is not None: s.wait_event(gathered[j])
             g.render_device(g.params(W, H, spp, nb, seed=k, row_block=8, rank=mine, world=world), strip[j].data_ptr(), s.cuda_stream)
