@@ -371,3 +371,60 @@ def test_cancelled_batch_publishes_none_of_its_passes(oracle, scene_paths):
     g.progressive_passes(9)
     assert g.progressive_state()["count"] == 19.0
     g.close()
+
+
+def test_overlapped_passes_and_what_a_host_does_between_them(oracle, scene_paths):
+    """Round 5: consecutive single passes render on three of the context's streams into the scratch sets' own low-resolution
+    frames and only their publish steps wait for each other; a pass that keeps its set's pixel lists clears nothing, because the
+    last workgroup of the set's previous launch left the counters clean.  A presenter that resolves after every pass, renders
+    something else in between, cancels passes in flight and goes on must get the oracle's ladder bit for bit."""
+    import torch
+    sky = synthetic_skybox(32, seed=7)
+    g = rt.Renderer(0)
+    g.set_skybox(sky); g.set_scene(scene_paths[0]); oracle.set_skybox(sky); oracle.load_scene(scene_paths[0])
+    oracle.set_camera()
+    W, H, nb, seed = 160, 96, 6, 9
+    g.progressive_begin(W, H, init_scale=1, max_bounces=nb, seed=seed)
+    before = rt.lib().rt_primary_passes_run(g._ctx)
+    shown = {}
+    for k in range(1, 13):
+        g.progressive_pass()
+        frame = g.progressive_resolve()                     # update_frame() after every worker iteration (main.c:450-482)
+        if k in (1, 6, 12): shown[k] = frame.copy()
+    assert rt.lib().rt_primary_passes_run(g._ctx) - before == rt.LAUNCH_SETS      # the other seven kept their sets' lists
+    other = g.render(320, 180, 8, 4, seed=3)               # takes a scratch set and a stream of its own
+    assert (bits(other) == bits(g.render(320, 180, 8, 4, seed=3, kernel=rt.KERNEL_SIMPLE))).all()
+    for _ in range(5):
+        g.progressive_pass()
+    shown[17] = g.progressive_resolve().copy()
+    for k, frame in shown.items():
+        want, _, count, _ = oracle_progressive(oracle, W, H, 1, k, nb, seed)
+        assert (bits(frame) == bits(want)).all(), k
+    # passes in flight are cancelled (some of them cut short: their last workgroups leave "cancelled" behind), the ladder starts
+    # again -- on the same lists, nothing changed but the sample numbers -- and the sets' next launches must come out whole
+    big = rt.Renderer(0)
+    big.set_skybox(rt.load_skybox()); big.set_scene(scene_paths[0]); big.compile_scene()
+    big.progressive_begin(1920, 1080, init_scale=1, max_bounces=10, seed=2)
+    for _ in range(2 * rt.LAUNCH_SETS):
+        big.progressive_pass()
+    big.synchronize()
+    for _ in range(12):
+        big.progressive_pass()
+    big.progressive_invalidate()                            # rt_cancel() + clear (main.c:115-124)
+    runs = rt.lib().rt_primary_passes_run(big._ctx)
+    for _ in range(2 * rt.LAUNCH_SETS):
+        big.progressive_pass()
+    assert rt.lib().rt_primary_passes_run(big._ctx) == runs                     # every pass on kept lists
+    st = big.progressive_state()
+    assert st["passes"] == 2 * rt.LAUNCH_SETS and st["count"] == float(2 * rt.LAUNCH_SETS)
+    got = big.progressive_resolve()
+    ref = rt.Renderer(0)
+    ref.set_skybox(rt.load_skybox()); ref.set_scene(scene_paths[0]); ref.compile_scene()
+    ref.set_tuning(poison_frame=True)                       # (never keeps lists)
+    ref.progressive_begin(1920, 1080, init_scale=1, max_bounces=10, seed=2)
+    for _ in range(2 * rt.LAUNCH_SETS):
+        ref.progressive_pass()
+    assert (bits(got) == bits(ref.progressive_resolve())).all()
+    rc, rep = big.last_launch_report()
+    assert rc == 0 and rep["stamp"] == rep["launch_id"] and not rep["cancelled"] and rep["pixels_written"] == rep["pixels_listed"] > 0
+    for r in (g, big, ref): r.close()
