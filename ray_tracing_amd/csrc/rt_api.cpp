@@ -245,7 +245,17 @@ static int workgroups_per_cu_for(rt_context *ctx, hipStream_t stream, long long 
 	if (!ctx->launches || !prev.used || prev.stream == stream) return 0;
 	const hipError_t q = hipEventQuery(prev.started);
 	(void) hipGetLastError();           /* "not ready" is an answer, not an error the launch below should find */
-	if (q != hipErrorNotReady) return 0;
+	if (q != hipErrorNotReady) {
+		/* the previous launch is running.  A host with two frames in flight stops here (all the slots: it submits the next frame
+		 * only when this one's predecessor has been delivered); one that keeps three has the launch BEFORE the previous one still
+		 * unfinished as well: two are resident side by side then, and this one joins them at half the slots */
+		if (ctx->launches < 2) return 0;
+		const rt_context::launch_slot &before = ctx->slot[(ctx->launches - 2) % RT_LAUNCH_SETS];
+		if (!before.used || before.stream == stream || before.stream == prev.stream) return 0;
+		const hipError_t d = hipEventQuery(before.done);
+		(void) hipGetLastError();
+		return d == hipErrorNotReady ? 2 : 0;
+	}
 	const long long streams_at_two = (long long) ctx->num_cus * 2 * 4 * 8;      /* two workgroups of four waves per CU, eight streams per wave (rt_kernels.hip) */
 	if (ctx->launches >= 4 && pixels < streams_at_two * RT_SMALL_LAUNCH_PIXELS_PER_STREAM) {
 		/* five launches on five streams (a host that is far ahead on fewer streams has fewer launches on the GPU: they keep two slots) */
