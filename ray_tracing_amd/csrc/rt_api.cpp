@@ -60,12 +60,12 @@ int rt_fail(int code, const char *fmt, ...)      /* for the library's other tran
 			return fail(RT_ERR_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
 	} while (0)
 
-/* the context's pinned host words (h_words), in blocks of RT_CTL_WORDS: block 0 takes the control words of rt_render()'s launch,
+/* the context's pinned host words (h_words), in blocks of RT_CTL_COPY_WORDS (rt_internal.h): block 0 takes the control words of rt_render()'s launch,
  * blocks 1 ... RT_FRAME_SLOTS those of the frames in flight, the next RT_CHECK_TICKETS the tickets of rt_launch_check_*(); behind
  * them rt_cancel()'s request (read by the trace kernels through rt_launch.stop) and the ladder's count words */
-#define RT_WORDS_FRAME(slot)   ((1 + (slot)) * RT_CTL_WORDS)
-#define RT_WORDS_TICKET(t)     ((1 + RT_FRAME_SLOTS + (t)) * RT_CTL_WORDS)
-#define RT_STOP_WORD           ((1 + RT_FRAME_SLOTS + RT_CHECK_TICKETS) * RT_CTL_WORDS)
+#define RT_WORDS_FRAME(slot)   ((1 + (slot)) * RT_CTL_COPY_WORDS)
+#define RT_WORDS_TICKET(t)     ((1 + RT_FRAME_SLOTS + (t)) * RT_CTL_COPY_WORDS)
+#define RT_STOP_WORD           ((1 + RT_FRAME_SLOTS + RT_CHECK_TICKETS) * RT_CTL_COPY_WORDS)
 #define RT_COUNT_WORD          (RT_STOP_WORD + 16)
 #define RT_HOST_WORDS          (RT_COUNT_WORD + 16)
 
@@ -203,6 +203,17 @@ static int wait_for_launches(rt_context *ctx)
 	return RT_OK;
 }
 
+/* Is the previous launch the only unfinished one ahead of the launch about to be enqueued? */
+static bool lone_launch_ahead(rt_context *ctx)
+{
+	if (ctx->launches < 2) return true;
+	const rt_context::launch_slot &before = ctx->slot[(ctx->launches - 2) % RT_LAUNCH_SETS];
+	if (!before.used) return true;
+	const hipError_t d = hipEventQuery(before.done);
+	(void) hipGetLastError();           /* "not ready" is an answer, not an error the launch below should find */
+	return d != hipErrorNotReady;
+}
+
 /* Called before launch number ctx->launches is enqueued on `stream`: launch n - RT_LAUNCH_SETS used the same scratch set,
  * so this one is ordered behind it when that ran on a different stream.  (The launches in between have the other sets:
  * they may overlap with this one.) */
@@ -215,7 +226,19 @@ static int order_behind_previous(rt_context *ctx, hipStream_t stream)
 	 * together would share the chip half and half from start to end, and finish together: nothing gained, and the late
 	 * half of either grid finds no pixels left.) */
 	rt_context::launch_slot &prev = ctx->slot[ctx->cur];
-	if (ctx->launches && prev.used && prev.stream != stream) HIP_TRY(hipStreamWaitEvent(stream, prev.started, 0));
+	if (ctx->launches && prev.used && prev.stream != stream) {
+		/* The second launch of a run -- its predecessor enqueued a moment ago into an idle GPU, nothing else ahead -- waits for the
+		 * predecessor's END: the two would become ready together after all (the predecessor's workgroups are still being dispatched
+		 * when this one's camera-ray pass and trace kernel follow), share the chip, and the first frame of a run of twenty arrived
+		 * after 10.7 ms instead of 6.0, the second after 15.9 either way.  One tail without overlap, once per run. */
+		bool after_the_end = false;
+		if (lone_launch_ahead(ctx)) {
+			const hipError_t q = hipEventQuery(prev.started);
+			(void) hipGetLastError();
+			after_the_end = q == hipErrorNotReady;
+		}
+		HIP_TRY(hipStreamWaitEvent(stream, after_the_end ? prev.done : prev.started, 0));
+	}
 	/* ... and a frame in flight must have read them (rt_frame_submit) */
 	if (sl.readback_pending) { sl.readback_pending = false; if (sl.readback_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, sl.readback, 0)); }
 	return RT_OK;
@@ -243,19 +266,12 @@ static int workgroups_per_cu_for(rt_context *ctx, hipStream_t stream, long long 
 	if (ctx->tuning.workgroups_per_cu > 0) return ctx->tuning.workgroups_per_cu;
 	const rt_context::launch_slot &prev = ctx->slot[ctx->cur];
 	if (!ctx->launches || !prev.used || prev.stream == stream) return 0;
-	const hipError_t q = hipEventQuery(prev.started);
-	(void) hipGetLastError();           /* "not ready" is an answer, not an error the launch below should find */
-	if (q != hipErrorNotReady) {
-		/* the previous launch is running.  A host with two frames in flight stops here (all the slots: it submits the next frame
-		 * only when this one's predecessor has been delivered); one that keeps three has the launch BEFORE the previous one still
-		 * unfinished as well: two are resident side by side then, and this one joins them at half the slots */
-		if (ctx->launches < 2) return 0;
-		const rt_context::launch_slot &before = ctx->slot[(ctx->launches - 2) % RT_LAUNCH_SETS];
-		if (!before.used || before.stream == stream || before.stream == prev.stream) return 0;
-		const hipError_t d = hipEventQuery(before.done);
-		(void) hipGetLastError();
-		return d == hipErrorNotReady ? 2 : 0;
-	}
+	/* Two launches unfinished ahead of this one -- the previous one and the one before it -- : the host keeps three in flight, two are
+	 * (or will be) resident side by side, and this one joins them at half the slots.  Only ONE ahead (a host with two frames in
+	 * flight; the second launch of any run): all the slots -- it gets them as its predecessor drains, and nothing else is there
+	 * to take the rest.  (Until round 5 the test was "the previous launch has not started": the second frame of every run then
+	 * ran at half the chip by itself until the third was submitted -- 9.9 ms instead of 5.3, 0.23 ms per step of a run of twenty.) */
+	if (lone_launch_ahead(ctx)) return 0;
 	const long long streams_at_two = (long long) ctx->num_cus * 2 * 4 * 8;      /* two workgroups of four waves per CU, eight streams per wave (rt_kernels.hip) */
 	if (ctx->launches >= 4 && pixels < streams_at_two * RT_SMALL_LAUNCH_PIXELS_PER_STREAM) {
 		/* five launches on five streams (a host that is far ahead on fewer streams has fewer launches on the GPU: they keep two slots) */
@@ -308,7 +324,7 @@ static hipStream_t pick_stream(rt_context *ctx, void *hip_stream)
 
 void *rt_context_stream(rt_context *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
 
-/* The control words of the context's most recent launch (rt_device.h RT_CTL_*) are copied to h_dst[0 ... RT_CTL_WORDS) (pinned)
+/* The control words of the context's most recent launch (rt_device.h RT_CTL_*) are copied to h_dst[0 ... RT_CTL_COPY_WORDS) (pinned; the first RT_CTL_WORDS matter)
  * on `stream`, which the caller has already ordered behind that launch -- NOT the launch's own stream: a copy between
  * two kernels of a render stream costs the overlap of consecutive launches (measured: +0.15 ms per C1 frame).  The
  * scratch set's next launch clears the word: it is ordered behind this copy.  *behind (optional) = an event recorded
@@ -318,7 +334,7 @@ int rt_context_read_control(rt_context *ctx, unsigned int *h_dst, hipStream_t st
 	rt_context::launch_slot &sl = ctx->slot[ctx->cur];
 	if (!sl.readback) HIP_TRY(hipEventCreateWithFlags(&sl.readback, hipEventDisableTiming));
 	if (expect) *expect = sl.expect;
-	HIP_TRY(hipMemcpyAsync(h_dst, sl.d_counter + 128 * 32, RT_CTL_WORDS * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+	HIP_TRY(hipMemcpyAsync(h_dst, sl.d_counter + 128 * 32, RT_CTL_COPY_BYTES, hipMemcpyDeviceToHost, stream));
 	HIP_TRY(hipEventRecord(sl.readback, stream));
 	sl.readback_pending = true; sl.readback_stream = stream;
 	if (behind) *behind = sl.readback;
@@ -419,8 +435,8 @@ int rt_create(rt_context **out, int device_id)
 		if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
 			ctx->num_cus = prop.multiProcessorCount;
 		for (auto &sl : ctx->slot) {
-			if (e == hipSuccess) e = hipMalloc((void**) &sl.d_counter, rt_counter_bytes());
-			if (e == hipSuccess) e = hipMemsetAsync(sl.d_counter, 0, rt_counter_bytes(), ctx->stream);
+			if (e == hipSuccess) e = hipMalloc((void**) &sl.d_counter, rt_counter_bytes() + RT_CTL_COPY_BYTES);      /* (the copy of the control words reads that far behind them) */
+			if (e == hipSuccess) e = hipMemsetAsync(sl.d_counter, 0, rt_counter_bytes() + RT_CTL_COPY_BYTES, ctx->stream);
 			if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
 			if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.started, hipEventDisableTiming);
 		}
@@ -899,7 +915,7 @@ int rt_render(rt_context *ctx, const rt_render_params *p, Vector3 *frame_out)
 	/* the launch's control words follow the frame in the same stream: one synchronisation, then the verdict (rt_judge_launch: a
 	 * launch that did not account for every pixel gives an error, not a frame with a hole in it -- round 3 saw a blocking render
 	 * lose the pixels a launch deals last, twice, cause unknown: docs/lab/r04.md) */
-	HIP_TRY(hipMemcpyAsync(&ctx->h_words[0], ctx->slot[ctx->cur].d_counter + 128 * 32, RT_CTL_WORDS * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(&ctx->h_words[0], ctx->slot[ctx->cur].d_counter + 128 * 32, RT_CTL_COPY_BYTES, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	return rt_judge_launch(&ctx->h_words[0], ctx->slot[ctx->cur].expect, "rt_render", nullptr);
 }

@@ -12,7 +12,15 @@ struct rt_context;
 /* rt_api.cpp: sets the thread's error text (rt_last_error()) and returns `code`; the context's own stream */
 int        rt_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 void      *rt_context_stream(rt_context *ctx);
-/* copies the RT_CTL_WORDS control words of the context's most recent launch to pinned h_dst[] on `stream`, which the caller has
+/* A launch's control words travel to the host in a copy of RT_CTL_COPY_BYTES, of which the first RT_CTL_WORDS words matter.  The runtime
+ * does device-to-host copies of up to 16 KB with a KERNEL, and a kernel needs a workgroup slot: behind a persistent launch that holds
+ * every slot a 64-byte copy took 7.5 ms -- until that launch drained -- and every frame of a frame loop was delivered one launch late
+ * (the copy sits between the frame and the event the host waits for).  From 64 KB on a DMA engine does the copy: 0.05 ms beside
+ * the same launch (profiles/r05/copy_beside_kernel.txt).  Destinations are pinned blocks of RT_CTL_COPY_BYTES; the scratch sets'
+ * counter blocks are allocated that much longer. */
+#define RT_CTL_COPY_BYTES 65536
+#define RT_CTL_COPY_WORDS (RT_CTL_COPY_BYTES / 4)
+/* copies the control words of the context's most recent launch to pinned h_dst[0 ... RT_CTL_COPY_WORDS) on `stream`, which the caller has
  * ordered behind that launch (not the launch's own stream); *behind (optional) = an event behind the copy; *expect = what
  * rt_judge_launch() is to hold the words against */
 int        rt_context_read_control(rt_context *ctx, unsigned int *h_dst, hipStream_t stream, hipEvent_t *behind, rt_launch_expect *expect);

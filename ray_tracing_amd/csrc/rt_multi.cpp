@@ -104,7 +104,7 @@ struct rt_multi {
 	float *d_strips[STRIP_BUFFERS] = {};   /* n strips back to back: the gather's destination */
 	size_t strips_floats = 0;
 	hipStream_t copy_stream = nullptr;
-	unsigned int *h_control = nullptr;          /* pinned: RT_CTL_WORDS control words of the launch of (slot, device) at (slot * 64 + device) * RT_CTL_WORDS */
+	unsigned int *h_control = nullptr;          /* pinned: the control words of the launch of (slot, device) at (slot * n + device) * RT_CTL_COPY_WORDS (rt_internal.h) */
 	struct frame_slot {
 		float     *d_frame = nullptr;           /* the frame in row order */
 		size_t     floats = 0;
@@ -202,8 +202,8 @@ static int prepare(rt_multi *m, int W, int H, int rb, int slot)
 			MULTI_HIP(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
 	}
 	if (!m->h_control) {
-		MULTI_HIP(hipHostMalloc((void **) &m->h_control, (size_t) RT_FRAME_SLOTS * 64 * RT_CTL_WORDS * sizeof(unsigned int), hipHostMallocPortable));   /* every device writes its words */
-		memset(m->h_control, 0, (size_t) RT_FRAME_SLOTS * 64 * RT_CTL_WORDS * sizeof(unsigned int));
+		MULTI_HIP(hipHostMalloc((void **) &m->h_control, (size_t) RT_FRAME_SLOTS * (size_t) n * RT_CTL_COPY_BYTES, hipHostMallocPortable));   /* every device writes its words */
+		memset(m->h_control, 0, (size_t) RT_FRAME_SLOTS * (size_t) n * RT_CTL_COPY_BYTES);
 	}
 	rt_multi::frame_slot &f = m->fq[slot];
 	f.expect.assign((size_t) n, rt_launch_expect{ 0u, 0, 0u });
@@ -385,7 +385,7 @@ static int multi_frame_submit(rt_multi *m, const rt_render_params *params, int s
 		 * give up after rt_cancel(), did the launch account for every pixel), for rt_multi_frame_wait() -- not on the render
 		 * stream: a copy between two kernels there costs the overlap of consecutive launches */
 		e = hipStreamWaitEvent(d.gather_stream, (hipEvent_t) rt_context_launch_done(ctx), 0);
-		if (e == hipSuccess) { rc = rt_context_read_control(ctx, &m->h_control[(size_t) (slot * 64 + i) * RT_CTL_WORDS], d.gather_stream, &reported[(size_t) i], &f.expect[(size_t) i]); if (rc != RT_OK) break; }
+		if (e == hipSuccess) { rc = rt_context_read_control(ctx, &m->h_control[((size_t) slot * (size_t) m->n + (size_t) i) * RT_CTL_COPY_WORDS], d.gather_stream, &reported[(size_t) i], &f.expect[(size_t) i]); if (rc != RT_OK) break; }
 		if (e != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: device %d: %s", m->devices[(size_t) i], hipGetErrorString(e));
 	}
 	/* ONE gather of the finished strips to device 0, each rank's part on its own collective stream */
@@ -471,7 +471,7 @@ static int finish_slot(rt_multi *m, int slot)
 	 * incomplete strip is an error (its text names the launch), one cancelled strip a cancelled frame */
 	int verdict = RT_OK;
 	for (int i = 0; i < m->n; i++) {
-		const int rc = rt_judge_launch(&m->h_control[(size_t) (slot * 64 + i) * RT_CTL_WORDS], f.expect[(size_t) i], "rt_multi_frame_wait", nullptr);
+		const int rc = rt_judge_launch(&m->h_control[((size_t) slot * (size_t) m->n + (size_t) i) * RT_CTL_COPY_WORDS], f.expect[(size_t) i], "rt_multi_frame_wait", nullptr);
 		if (rc < 0) return rc;
 		if (rc == RT_CANCELLED) verdict = RT_CANCELLED;
 	}
