@@ -91,7 +91,7 @@ def parse_args(argv=None):
     ap.add_argument("--leave-early", action="store_true",
                     help="testing aid (scripts/repro_verify_race.py): ranks other than 0 do not wait for rank 0's verification before they "
                          "tear their contexts down -- the bench's behaviour when its verification failed intermittently in round 3")
-    ap.add_argument("--depth", type=int, default=0, help="frames in flight in the C ABI's frame queue (default 2; RT_LAUNCH_SETS + 1 = 6 on the N-GPU path)")
+    ap.add_argument("--depth", type=int, default=0, help="frames in flight in the C ABI's frame queue (default 3; RT_LAUNCH_SETS + 1 = 6 on the N-GPU path)")
     return ap.parse_args(argv)
 
 
@@ -395,10 +395,11 @@ def main():
                 collective["note"] = "testing aid: all contexts on one GPU, the gather is device copies (no communicator: ranks_seen 0)"
         else:
             prof = gpu
-        # (one GPU: two frames in flight measure better than three -- 5.465 against 5.52 ms per C1 step, profiles/r05/bench_depth.txt: a
-        # third frame enqueued ahead makes every launch take half the workgroup slots; the N-GPU path keeps a strip draining, one
-        # running and one starting, plus the gather of the one before)
-        depth = args.depth or (rt.LAUNCH_SETS + 1 if multi_path else 2)
+        # (one GPU: three frames in flight -- two are resident side by side at half the workgroup slots each, the third is queued:
+        # 5.28 against 5.35 ms per C1 step over the driver's twenty steps, steady state 5.16 against 5.33; four and more only make
+        # the first deliveries of a run irregular (profiles/r05/bench_depth.txt).  The N-GPU path keeps five strips rendering and the
+        # gather of the one before)
+        depth = args.depth or (rt.LAUNCH_SETS + 1 if multi_path else 3)
         loop = FrameLoop(queue, W, H, spp, nb, depth=depth, row_block=ROW_BLOCK, kernel=args.kernel)
         primitive = ("device copies on one GPU (testing aid)" if args.one_device else "ncclGather (native, one process)") if multi_path else None
 
@@ -597,19 +598,21 @@ def main():
     if native and not multi_path and not args.no_extras:
         n_dev = max(args.steps, 10)
         p_of = lambda k: rt.Renderer.params(W, H, spp, nb, seed=seed + k, row_block=ROW_BLOCK, kernel=args.kernel)   # noqa: E731
-        for k in range(2):
+        d_dev = max(1, min(depth, rt.FRAME_SLOTS))
+        for k in range(d_dev):
             gpu.frame_submit_device(p_of(k), k); gpu.frame_wait(k)
         fence()
         t1 = time.perf_counter()
-        gpu.frame_submit_device(p_of(0), 0)
+        for k in range(min(d_dev - 1, n_dev)):
+            gpu.frame_submit_device(p_of(k), k % d_dev)
         for k in range(n_dev):
-            if k + 1 < n_dev:
-                gpu.frame_submit_device(p_of(k + 1), (k + 1) & 1)
-            gpu.frame_wait(k & 1)
+            if k + d_dev - 1 < n_dev:
+                gpu.frame_submit_device(p_of(k + d_dev - 1), (k + d_dev - 1) % d_dev)
+            gpu.frame_wait(k % d_dev)
         dt_dev = (time.perf_counter() - t1) / n_dev
         device_resident = {"ms_per_step": round(dt_dev * 1e3, 4), "value": round(samples_per_step / dt_dev / 1e6, 2), "unit": "Msamples/s", "steps": n_dev,
-                           "region": "K frames through rt_frame_submit_device / rt_frame_wait, two in flight: the frame stays in HBM, only the "
-                                     "launch's control words (64 bytes) go to the host"}
+                           "region": f"K frames through rt_frame_submit_device / rt_frame_wait, {d_dev} in flight: the frame stays in HBM, only the "
+                                     "launch's control words go to the host"}
     # ---- the interactive ladder at full resolution (main.c:354-408): passes of one sample per pixel, one launch
     # each (rt_progressive_pass) and RT_PROGRESSIVE_BATCH to a launch (rt_progressive_passes: same sums, bit for bit)
     interactive = None
