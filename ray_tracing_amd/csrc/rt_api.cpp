@@ -226,19 +226,7 @@ static int order_behind_previous(rt_context *ctx, hipStream_t stream)
 	 * together would share the chip half and half from start to end, and finish together: nothing gained, and the late
 	 * half of either grid finds no pixels left.) */
 	rt_context::launch_slot &prev = ctx->slot[ctx->cur];
-	if (ctx->launches && prev.used && prev.stream != stream) {
-		/* The second launch of a run -- its predecessor enqueued a moment ago into an idle GPU, nothing else ahead -- waits for the
-		 * predecessor's END: the two would become ready together after all (the predecessor's workgroups are still being dispatched
-		 * when this one's camera-ray pass and trace kernel follow), share the chip, and the first frame of a run of twenty arrived
-		 * after 10.7 ms instead of 6.0, the second after 15.9 either way.  One tail without overlap, once per run. */
-		bool after_the_end = false;
-		if (lone_launch_ahead(ctx)) {
-			const hipError_t q = hipEventQuery(prev.started);
-			(void) hipGetLastError();
-			after_the_end = q == hipErrorNotReady;
-		}
-		HIP_TRY(hipStreamWaitEvent(stream, after_the_end ? prev.done : prev.started, 0));
-	}
+	if (ctx->launches && prev.used && prev.stream != stream) HIP_TRY(hipStreamWaitEvent(stream, prev.started, 0));
 	/* ... and a frame in flight must have read them (rt_frame_submit) */
 	if (sl.readback_pending) { sl.readback_pending = false; if (sl.readback_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, sl.readback, 0)); }
 	return RT_OK;
@@ -270,7 +258,7 @@ static int workgroups_per_cu_for(rt_context *ctx, hipStream_t stream, long long 
 	 * (or will be) resident side by side, and this one joins them at half the slots.  Only ONE ahead (a host with two frames in
 	 * flight; the second launch of any run): all the slots -- it gets them as its predecessor drains, and nothing else is there
 	 * to take the rest.  (Until round 5 the test was "the previous launch has not started": the second frame of every run then
-	 * ran at half the chip by itself until the third was submitted -- 9.9 ms instead of 5.3, 0.23 ms per step of a run of twenty.) */
+	 * ran at half the chip by itself until the third was submitted.) */
 	if (lone_launch_ahead(ctx)) return 0;
 	const long long streams_at_two = (long long) ctx->num_cus * 2 * 4 * 8;      /* two workgroups of four waves per CU, eight streams per wave (rt_kernels.hip) */
 	if (ctx->launches >= 4 && pixels < streams_at_two * RT_SMALL_LAUNCH_PIXELS_PER_STREAM) {
