@@ -11,9 +11,9 @@ through) and logged.  One GPU is enough: ranks share it (gloo moves the strips),
                                            bench inside the suite): six processes on the GPU
   stress_frame_loop.py loop    [frames]    4 ranks sharing the GPU: multi_gpu.TiledFrame over gloo, per-frame compare on rank 0
   stress_frame_loop.py rccl1   [frames]    one rank: TiledFrame(force_collective) over a one-rank RCCL group
-  stress_frame_loop.py native  [frames]    one rank: rt_multi_frame_* over a one-rank RCCL communicator (depth 2, 3, 4)
-  stress_frame_loop.py queue   [frames]    one rank: rt_frame_* (depth 2, 3, 4)
-  stress_frame_loop.py onedev  [frames]    one process: rt_multi_frame_* over EIGHT contexts on the one GPU (depth 2, 3, 4)
+  stress_frame_loop.py native  [frames]    one rank: rt_multi_frame_* over a one-rank RCCL communicator (depth 2, 3, 6, 8)
+  stress_frame_loop.py queue   [frames]    one rank: rt_frame_* (depth 2, 3, 6, 8)
+  stress_frame_loop.py onedev  [frames]    one process: rt_multi_frame_* over EIGHT contexts on the one GPU (depth 2, 3, 6, 8)
 
 Results: one JSON line per mode on stdout and in gpurun_out/stress/<mode>.json.
 """
@@ -318,7 +318,7 @@ def _queue_mode(frames, native, contexts=0):
     ref = references(rt, np)
     out = {"mode": f"onedev (rt_multi_frame_* over {contexts} contexts on one GPU)" if contexts else
                    "native (rt_multi_frame_* over a one-rank RCCL communicator)" if native else "queue (rt_frame_*)", "depths": {}}
-    for depth in (2, 3, 4):
+    for depth in (2, 3, 6, 8):
         if contexts:
             q = rt.MultiRenderer([0], on_one_device=contexts)
             q.set_scene(os.path.join(rt.DATA_DIR, "scene_0.txt")); q.set_skybox(rt.load_skybox()); q.set_camera(); q.compile_scene()
