@@ -400,7 +400,8 @@ def main():
         # 5.28 against 5.35 ms per C1 step over the driver's twenty steps, steady state 5.16 against 5.33; four and more only make
         # the first deliveries of a run irregular (profiles/r05/bench_depth.txt).  The N-GPU path keeps five strips rendering and the
         # gather of the one before)
-        depth = args.depth or (rt.LAUNCH_SETS + 1 if multi_path else w.get("frames_in_flight", 3))
+        # (the deep queue is for strips: a one-rank group -- --force-collective, a testing aid -- renders whole frames)
+        depth = args.depth or (rt.LAUNCH_SETS + 1 if multi_path and ngpus > 1 else w.get("frames_in_flight", 3))
         loop = FrameLoop(queue, W, H, spp, nb, depth=depth, row_block=ROW_BLOCK, kernel=args.kernel)
         primitive = ("device copies on one GPU (testing aid)" if args.one_device else "ncclGather (native, one process)") if multi_path else None
 
