@@ -110,7 +110,7 @@ def test_cancel_gives_up_a_frame_in_flight(scene_paths, compiled):
 
 def test_cancel_reaches_both_launches_in_flight(scene_paths):
     """Two launches on the context's two streams are on the GPU together (rt_stream); rt_cancel() stops both, and
-    the next launches on either stream -- each reuses one of the two scratch sets -- are complete and correct."""
+    the next launches on either stream -- each takes the next of the scratch sets -- are complete and correct."""
     import threading
     import time
     import torch

@@ -102,7 +102,7 @@ def _nccl_worker(rank, world, port, q, backend="nccl", share_gpu=False, size=(32
 
 
 def test_consecutive_launches_overlap_on_the_two_streams(gpu):
-    """rt_stream(ctx, 0 / 1): launches alternate between the context's two streams and use its two scratch sets, so
+    """rt_stream(ctx, 0 / 1): launches alternate between two of the context's streams and rotate through its scratch sets, so
     consecutive ones are on the GPU together.  Every launch has its own seed and destination; each frame must equal the
     one rendered alone.  Large enough (a few hundred microseconds a launch) for the launches to really overlap."""
     W, H, spp, nb = 1920, 1080, 16, 4
