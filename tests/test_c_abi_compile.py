@@ -116,15 +116,23 @@ GLFW_SYMBOLS = ["glfwInit", "glfwTerminate", "glfwWindowHint", "glfwCreateWindow
                 "glfwWindowShouldClose", "glfwGetCursorPos", "glfwSetErrorCallback"]
 
 
+LADDER_CALLS = ("rt_progressive_begin", "rt_progressive_passes", "rt_progressive_resolve", "rt_progressive_invalidate", "rt_progressive_state")
+BLOCKING_CALLS = ("rt_render", "rt_cancel", "rt_reserve", "rt_default_params")
+
+
 @pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="the reference checkout is not on this machine")
-def test_the_integration_patch_applies_compiles_and_links(tmp_path):
+@pytest.mark.parametrize("variant", ["--ladder", "--blocking"])
+def test_the_integration_patch_applies_compiles_and_links(tmp_path, variant):
     """INTEGRATION.md section 2 as a build: scripts/patches/reference_main_rt.py turns the reference's main.c -- start_workers()
     at :516, update_frame() at :450-482, invalidate_accumulation() at :115-124, stop_workers() -- into the host that calls
-    librt_hip.so, and adds the two camera getters camera.c lacks.  The patched text is piped into the compiler (nothing of the
+    librt_hip.so, and adds the two camera getters camera.c lacks.  Both variants: --ladder (the documented one: passes accumulate
+    until the camera moves and the image refines from 1/init_scale, main.c:354-408 -- rt_progressive_begin / _passes / _resolve /
+    _invalidate, wired to the reference's own `init_scale` global of main.c:50, :585-634) and --blocking (one rt_render() per
+    shown frame).  The patched text is piped into the compiler (nothing of the
     reference is written to disk), compiled with the reference's own flags and headers, and linked with the reference's other
     translation units against the library: with --no-undefined, so every rt_* call resolves; the only symbols allowed to stay
     open are the 19 entry points of GLFW the reference's window code uses (this image has no libglfw: main() is compiled and
-    linked, never run).  Compile and link only."""
+    linked, never run).  Compile and link only; the ladder text is RUN by tests/test_gpu_ladder_binding.py."""
     ref = os.path.dirname(REF_SRC)
     patch = os.path.join(ROOT, "scripts", "patches", "reference_main_rt.py")
     flags = ["-std=c11", "-O2", "-DNDEBUG", "-fPIC", "-ffunction-sections", "-fdata-sections", "-Werror=implicit-function-declaration",
@@ -133,16 +141,38 @@ def test_the_integration_patch_applies_compiles_and_links(tmp_path):
              "-I", os.path.join(ref, "3p", "glfw-3.4.bin.WIN64", "include"), "-I", os.path.join(ROOT, "include")]
     objs = []
     for which, src in (("main", "main.c"), ("camera", "camera.c")):
-        text = subprocess.run([sys.executable, patch, which], stdin=open(os.path.join(REF_SRC, src)), check=True, capture_output=True, text=True).stdout
-        assert "rt_render(rt, &p, frame)" in text or which == "camera"
+        args = [sys.executable, patch, which] + ([variant] if which == "main" else [])
+        text = subprocess.run(args, stdin=open(os.path.join(REF_SRC, src)), check=True, capture_output=True, text=True).stdout
+        if which == "main":
+            # the text the GPU test runs is the text that went into main.c
+            binding = subprocess.run([sys.executable, patch, "binding", variant], check=True, capture_output=True, text=True).stdout
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("reference_main_rt", patch)
+            mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+            pieces = mod.VARIANTS[variant]
+            assert binding == "".join(pieces) and all(piece in text for piece in pieces)
+            assert ("rt_progressive_begin(rt, frame_w, frame_h, init_scale, 10, 0)" in text) == (variant == "--ladder")
+            assert ("rt_render(rt, &p, frame)" in text) == (variant == "--blocking")
         obj = tmp_path / (which + "_rt.o")
         subprocess.run(["gcc"] + flags + ["-x", "c", "-c", "-", "-o", str(obj)], input=text, check=True, capture_output=True, text=True)
         objs.append(str(obj))
     # the patched main() calls into the library and nothing else of the workers is left in it
     syms = subprocess.run(["nm", "--undefined-only", objs[0]], check=True, capture_output=True, text=True).stdout.split()
-    for name in ("rt_create", "rt_set_scene", "rt_set_skybox", "rt_compile_scene", "rt_set_camera", "rt_render", "rt_cancel", "rt_reserve",
-                 "rt_destroy", "rt_default_params", "rt_last_error", "get_camera_front", "get_camera_up", "move_frame_to_the_gpu"):
+    for name in ("rt_create", "rt_set_scene", "rt_set_skybox", "rt_compile_scene", "rt_set_camera",
+                 "rt_destroy", "rt_last_error", "get_camera_front", "get_camera_up", "move_frame_to_the_gpu"):
         assert name in syms, name
+    for name in LADDER_CALLS:
+        assert (name in syms) == (variant == "--ladder"), name
+    for name in BLOCKING_CALLS:
+        assert (name in syms) == (variant == "--blocking"), name
+    # the ladder reads the reference's own --init-scale global (defined in main.c itself, so it shows as a data symbol there)
+    defined = subprocess.run(["nm", "--defined-only", objs[0]], check=True, capture_output=True, text=True).stdout
+    assert " init_scale" in defined
+    if variant == "--ladder":
+        dis = subprocess.run(["objdump", "-dr", "--no-show-raw-insn", objs[0]], check=True, capture_output=True, text=True).stdout
+        body = dis[dis.index("<update_frame>:"):]
+        body = body[:body.index("\n\n")] if "\n\n" in body else body
+        assert "init_scale" in body and "rt_progressive_begin" in body       # update_frame() passes the global on
     others = [os.path.join(REF_SRC, f) for f in ("scene.c", "vector.c", "os.c", "utils.c", "gpu_and_windowing.c")] + [os.path.join(ref, "3p", "glad", "src", "glad.c")]
     out = tmp_path / "ray_trace_rt.so"
     link = (["gcc", "-shared", "-o", str(out)] + objs + [f for f in flags if not f.startswith("-Werror")] + ["-w"] + others +
@@ -153,4 +183,4 @@ def test_the_integration_patch_applies_compiles_and_links(tmp_path):
     needed = subprocess.run(["readelf", "-d", str(out)], check=True, capture_output=True, text=True).stdout
     assert "librt_hip.so" in needed
     undefined = subprocess.run(["nm", "-D", "--undefined-only", str(out)], check=True, capture_output=True, text=True).stdout
-    assert "rt_render" in undefined and "glfwInit" in undefined      # (bound to the library at load time / left to a GLFW the box lacks)
+    assert ("rt_progressive_passes" if variant == "--ladder" else "rt_render") in undefined and "glfwInit" in undefined      # (bound to the library at load time / left to a GLFW the box lacks)
