@@ -505,7 +505,7 @@ def main():
         check.set_tuning(poison_frame=True)           # a pixel the check render leaves unwritten is a NaN, not whatever the fresh buffer held
         into(check)
         want = check.render(W, H, spp, nb, seed=last_seed)          # generic kernel, one GPU, blocking
-        check_counts = check.last_launch_counts()
+        check_counts = check.last_launch_report()[1]
         check.close()
         same = bool((got.view(np.uint32) == want.view(np.uint32)).all())
         verified = {"last_frame_seed": last_seed, "equals_blocking_rt_render": same, "frame_mean": round(float(got.mean()), 6),
@@ -518,7 +518,7 @@ def main():
             # write -- and every buffer of the timed loop had been filled by earlier frames, the check render's were fresh.
             verified["mismatch_diagnosis"] = {"nan_pixels_in_timed_frame": int(np.isnan(got).any(axis=2).sum()),
                                               "nan_pixels_in_check_render": int(np.isnan(want).any(axis=2).sum()),
-                                              "check_render_launch": check_counts, "timed_loop_last_launch": gpu.last_launch_counts()}
+                                              "check_render_launch": check_counts, "timed_loop_last_launch": gpu.last_launch_report()[1]}
             verified["mismatch"] = {"pixels": int(bad.sum()), "rows": int(rows_bad.size), "first_rows": [int(r) for r in rows_bad[:12]],
                                     "last_rows": [int(r) for r in rows_bad[-4:]],
                                     "pixels_in_first_row": int(bad[rows_bad[0]].sum()) if rows_bad.size else 0,

@@ -72,33 +72,30 @@ typedef struct {
 
 RT_API void rt_default_params(rt_render_params *p, int width, int height, int spp, int max_bounces);
 
+/* Which revision of this header a library was built from: changes whenever a struct layout or a function signature here
+ * changes.  A host compares rt_abi_version() with the RT_ABI_VERSION it was compiled against before anything else. */
+#define RT_ABI_VERSION 6
+RT_API int rt_abi_version(void);
+
 /* Scheduling knobs of the trace kernels.  None of them changes a single bit of any frame (tests render with
- * several settings and compare); they exist for measurement scripts and for tests that must reach a
- * particular code path.  0 / NULL = let the library decide.  Set per context, read at every launch; the
- * library never reads environment variables. */
+ * several settings and compare); they exist for hosts with a loop of their own and for measurement scripts.  0 / NULL = let the
+ * library decide.  Set per context, read at every launch; the library never reads environment variables.
+ * `size` is sizeof(rt_tuning) as the HOST was compiled: rt_default_tuning() sets it, rt_set_tuning() returns RT_ERR_ARGUMENT when
+ * it is not the library's own -- a host built against another revision of this header is told so instead of having a struct of
+ * another layout read.  (The knobs that exist for the test suite only -- poisoned frames, injected faults -- are in
+ * rt_hip_testing.h: rt_test_knobs.) */
 typedef struct {
+	size_t size;                /* = sizeof(rt_tuning); set by rt_default_tuning() */
 	int    dequeue_shards;      /* lists the object pixels are dealt from: 1 or 64 */
 	int    workgroups_per_cu;   /* resident workgroups per CU, 1..8, capped by what fits (0: all that fit -- half of them for a launch
 	                             * enqueued before the previous one, on the context's other stream, has started: the two are resident
 	                             * side by side; any setting also keeps a large scene's culled kernel on workgroups of four waves) */
 	int    jit_waves_per_simd;  /* rt_compile_scene: register budget = 512 / this many VGPRs (default 4) */
-	const char *jit_flags;      /* rt_compile_scene: extra hiprtc options, space separated (copied) */
-	int    force_collective;    /* testing aid: rt_multi_render() runs its ncclGather + de-interleave path even for a
-	                             * single device (a one-rank communicator), so that path can be checked on a 1-GPU box */
-	int    poison_frame;        /* testing aid: fill the destination with NaNs before every launch, so that a pixel the
-	                             * launch fails to write cannot pass for correct because an earlier frame left it there */
-	int    trace_known_taps;    /* testing aid: trace every soft-shadow tap, also those of camera-ray hit points from which
-	                             * every tap provably reaches the emitter first (csrc/rt_lit.h; normally answered untraced) */
-	int    test_every_object;   /* testing / measurement aid: scenes of 32 objects and more are rendered without the cluster cull
-	                             * (csrc/rt_cull.h) -- every ray tests every object, as the reference does; same frames, slower */
-	int    audit_known_taps;    /* csrc/rt_lit.h audited in production: k >= 1 -- of the answers "these soft-shadow taps need no tracing" (per
+	int    audit_known_taps;    /* csrc/rt_lit.h audited in production: k = 1 ... 24 -- of the answers "these soft-shadow taps need no tracing" (per
 	                             * camera-ray hit point, per cell of the scene's table), one in 2^k (k = -1: every one) is marked: bounces that
 	                             * use a marked answer have their taps traced all the same and compared; the frame is unchanged, a
 	                             * disagreement fails the launch (RT_ERR_DEVICE, rt_launch_report.taps_disagreeing).  0: off */
-	int    test_drop_pixels;    /* TESTING AID: the trace kernel's waves see every pixel list this many entries shorter -- a launch that
-	                             * loses its tail, which every delivering call must then refuse (RT_ERR_DEVICE) */
-	int    test_corrupt_lit_table; /* TESTING AID, read by rt_set_scene(): every cell of the scene's lit-taps table says "certainly lit" --
-	                             * a wrong csrc/rt_lit.h, which audit_known_taps must then catch */
+	const char *jit_flags;      /* rt_compile_scene: extra hiprtc options, space separated (copied) */
 } rt_tuning;
 RT_API void rt_default_tuning(rt_tuning *t);
 
@@ -124,17 +121,8 @@ RT_API const char *rt_compiled_scene_info(rt_context *ctx);
 /* Compiled scenes are cached per process -- key: device, scene geometry and emitter, options -- and shared by the contexts
  * that compile the same scene.  The cache holds at most 32 entries, least recently used out first; an evicted entry's module
  * stays loaded (contexts that still use it are unaffected) but is never looked up again.  *cached = entries in the cache,
- * *parked = modules evicted so far.  rt_compiled_scene_cache_cap(cap >= 1) changes the cap (testing aid; returns the old one). */
+ * *parked = modules evicted so far. */
 RT_API void rt_compiled_scene_counts(int *cached, int *parked);
-RT_API int  rt_compiled_scene_cache_cap(int cap);
-/* development aid: instrumentation counters of a compiled kernel built with jit_flags "-DRT_STATS" (scripts/stats_c1.py).
- * They are variables of the compiled MODULE, i.e. per (device, scene, options), not per context: contexts that share a
- * compiled scene read and reset the same counters (the same holds for rt_spec_symbol_read). */
-RT_API int rt_spec_stats_read(rt_context *ctx, unsigned long long out[64], int reset);
-/* development aid: copy the named device variable of the compiled kernel's module (e.g. "rt_wave_log" of a build with
- * "-DRT_STATS -DRT_STATS_LIFETIMES_ONLY", scripts/probes/tail_probe.py) to dst, at most `bytes` bytes; *copied = bytes copied.  The
- * empty name "" stands for the compiled kernel's code object itself (*copied = its full size), for disassembly. */
-RT_API int rt_spec_symbol_read(rt_context *ctx, const char *name, void *dst, size_t bytes, size_t *copied);
 /* chan must be 3 or 4 (what stb_image returns for the shipped JPEGs is 3); all faces w x h */
 RT_API int rt_set_skybox(rt_context *ctx, const Cubemap *skybox);
 RT_API int rt_set_camera(rt_context *ctx, const rt_camera *camera);
@@ -165,8 +153,9 @@ RT_API int rt_render(rt_context *ctx, const rt_render_params *params, Vector3 *f
 RT_API int rt_render_device(rt_context *ctx, const rt_render_params *params, void *d_strip, void *hip_stream);
 
 /* The context's streams as hipStream_t: which = 0 the stream NULL stands for above; which = 1 ... RT_LAUNCH_SETS - 1 more
- * (created on first request, with the device's lowest stream priority so that they get hardware queues of their own) for
- * hosts that rotate consecutive frames through the streams to let them overlap.  NULL on error. */
+ * (all made by rt_create(), in this order -- the hardware queue a stream is given depends on what exists when it is made --, with
+ * the device's lowest stream priority so that they get hardware queues of their own) for hosts that rotate consecutive frames
+ * through the streams to let them overlap.  NULL on error. */
 RT_API void *rt_stream(rt_context *ctx, int which);
 
 /* Optional: allocate the launch scratch (2 x 48 bytes per pixel of pixel records) and rt_render()'s device frame for
@@ -248,10 +237,6 @@ RT_API void rt_host_free(void *p);
  * in flight, and that pass is not accumulated. */
 RT_API int rt_cancel(rt_context *ctx);
 RT_API int rt_was_cancelled(rt_context *ctx);
-/* Diagnostic aid (bench.py's verification logs it when frames differ): what the context's most recent launch left in its
- * counters -- object pixels listed by the camera-ray pass, how many of them the trace kernel's waves fetched (all of them unless
- * the launch was cut short), and the launch's four control words ([1] != 0: a wave gave up after rt_cancel).  Waits for it. */
-RT_API int rt_last_launch_counts(rt_context *ctx, unsigned long long *pixels_listed, unsigned long long *pixels_fetched, unsigned int control[4]);
 
 /* ---- every delivered frame is a complete frame ---------------------------------------------------------------------------
  * The reference publishes a column when render_column() has returned for all of it, under the mutex, or not at all
@@ -267,8 +252,11 @@ RT_API int rt_last_launch_counts(rt_context *ctx, unsigned long long *pixels_lis
  * RT_CANCELLED (rt_cancel() cut the launch short) takes precedence: that frame is incomplete on request.  The contents of
  * frame_out are undefined after RT_ERR_DEVICE.  An interactive pass that is incomplete is not published (its weight is not
  * counted either) and the error is reported by the next call that looks at the count.  Cost: nothing in the rounds (a wave's
- * pixels are its streams' drained-slot counters at exit), one report per workgroup and per dequeue line when waves leave, 64
- * bytes instead of 4 in the copy that already fetched the cancel word: not measurable (profiles/r05/ab_r04_vs_verified_launches.txt). */
+ * pixels are its streams' drained-slot counters at exit), one report per workgroup and per dequeue line when waves leave, and
+ * the copy that already fetched the cancel word: 64 KB per launch through a DMA engine (the runtime does copies of up to 16 KB with
+ * a kernel, which would wait for a workgroup slot behind the next persistent launch), into pinned blocks -- 64 KB x (1 +
+ * RT_FRAME_SLOTS + RT_CHECK_TICKETS) per context, RT_FRAME_SLOTS x n x 64 KB more per rt_multi group.  Not measurable in a
+ * frame's time (profiles/r05/ab_r04_vs_verified_launches.txt, profiles/r05/copy_beside_kernel.txt). */
 typedef struct {
 	int                launch_checked;      /* 0: the kernel does not account for itself (RT_KERNEL_SIMPLE, the cross-check kernel) */
 	unsigned int       launch_id, stamp;    /* the launch's number; the stamp its last wave left (0: none) */
@@ -315,7 +303,7 @@ RT_API int  rt_multi_render(rt_multi *m, const rt_render_params *params, Vector3
  * renders of the frames after it -- a render stream only ever waits for the gather RT_LAUNCH_SETS + 1 frames back, whose strip buffer
  * it reuses.  (The persistent trace kernel of the next frame holds every compute unit until it drains, so a render
  * stream that waited for the previous frame's collective would lose the overlap of consecutive strips.)  With one
- * device and no rt_tuning.force_collective this is rt_frame_submit() on that device's context. */
+ * device and no rt_test_knobs.force_collective (rt_hip_testing.h) this is rt_frame_submit() on that device's context. */
 RT_API int  rt_multi_frame_submit(rt_multi *m, const rt_render_params *params, int slot, Vector3 *frame_out);
 RT_API int  rt_multi_frame_wait(rt_multi *m, int slot);
 RT_API int  rt_multi_frame_poll(rt_multi *m, int slot);
@@ -325,13 +313,8 @@ RT_API int  rt_multi_frame_poll(rt_multi *m, int slot);
 RT_API int  rt_multi_frame_submit_device(rt_multi *m, const rt_render_params *params, int slot, void **d_frame, void **hip_event);
 /* What the group's RCCL communicator itself says (not what the host asked for): *ranks = ncclCommCount, devices[i] =
  * ncclCommCuDevice of rank i's communicator (room for 64), *version = ncclGetVersion (e.g. 22707).  A group that has no
- * communicator -- one device without rt_tuning.force_collective -- reports *ranks = 0. */
+ * communicator -- one device without rt_test_knobs.force_collective (rt_hip_testing.h) -- reports *ranks = 0. */
 RT_API int  rt_multi_collective_info(rt_multi *m, int *ranks, int devices[64], int *version);
-/* TESTING AID for 1-GPU boxes: a group of n contexts that all live on ONE device.  Everything the n-device path does runs --
- * n strips from n contexts on their own streams, three strip buffers each, the rotated hand-out, the de-interleave, the
- * frame queue, the ladder -- except RCCL, which refuses two ranks on one device: the gather is the n device-to-device copies
- * it amounts to there.  Frames are bit-identical to rt_render()'s.  Not a performance configuration. */
-RT_API int  rt_multi_create_on_one_device(rt_multi **out, int device_id, int n);
 
 /* ---- progressive accumulation: the reference's interactive protocol ----------------------------
  * worker() renders passes of 1 sample per (low-resolution) pixel, starting at 1/init_scale resolution
@@ -359,9 +342,6 @@ RT_API int rt_progressive_pass(rt_context *ctx, float *weight_out);
 #define RT_PROGRESSIVE_BATCH 256
 #define RT_PROGRESSIVE_BATCH_MIN 8        /* fewer passes than this are launched one by one (faster: profiles/r04/progressive_rate.txt) */
 RT_API int rt_progressive_passes(rt_context *ctx, int count);
-/* Development / test aid: how many of this context's launches ran rt_primary_pass (camera rays) -- an interactive pass that
- * differs from the pass before last in its sample number only keeps that pass's camera rays instead. */
-RT_API long long rt_primary_passes_run(rt_context *ctx);
 /* (RT_ERR_STATE when nothing has been published yet -- every pass so far was cut short --: frame_out is then untouched) */
 RT_API int rt_progressive_resolve(rt_context *ctx, Vector3 *frame_out);
 RT_API int rt_progressive_invalidate(rt_context *ctx);
@@ -410,16 +390,6 @@ RT_API int rt_profile_collect_span(rt_context *ctx, double *kernel_ms_total, int
  * predecessor waits for workgroup slots between its two kernels. */
 RT_API int rt_profile_collect_split(rt_context *ctx, double *kernel_ms_total, int *launches, double *span_ms, double *primary_ms_total);
 
-/* On-GPU self-test of the exact-arithmetic shortcuts the tuned kernel uses (shared-reciprocal
- * division, vector normalisation): compares them bit-for-bit with the plain IEEE forms on
- * blocks*256*iters random operand sets.  which = 0 (f32 divide), 1 (f64 divide), 2 (normalize), 3 (f64 sqrt of a float), 4 (|x| < 0.0001 threshold), 7 (normalize of a `draw * 2 - 1` vector).
- * Three sweeps are exhaustive instead of random: which = 3 checks the fp64 square root of every normal
- * float up to 2^120 (`iters` ignored); which = 5 checks the refined reciprocal for all 2^23
- * significands and the 3-instruction quotient for every denominator significand x `iters` numerator
- * significands (iters = 8388608 covers all 2^46 pairs, ~1 min; `seed` picks the first numerator);
- * which = 6 checks the tuned sqrtf on every float in [2^-30, 2^60] (`iters` ignored).
- * out[0] = mismatches (must be 0); out[1..7] = operands of one mismatch, for diagnosis. */
-RT_API int rt_selftest(rt_context *ctx, int which, uint64_t seed, int blocks, int iters, unsigned long long out[8]);
 
 /* ---- host-side mirror of the reference's loaders / camera (plain C, no GPU needed) ---------- */
 /* scene.c:611 parse_scene_file(): same grammar, defaults, range checks, float accumulation and

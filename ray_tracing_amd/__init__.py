@@ -48,10 +48,19 @@ class RenderParams(C.Structure):
 
 
 class Tuning(C.Structure):
-    _fields_ = [("dequeue_shards", C.c_int),
-                ("workgroups_per_cu", C.c_int), ("jit_waves_per_simd", C.c_int), ("jit_flags", C.c_char_p),
-                ("force_collective", C.c_int), ("poison_frame", C.c_int), ("trace_known_taps", C.c_int), ("test_every_object", C.c_int),
-                ("audit_known_taps", C.c_int), ("test_drop_pixels", C.c_int), ("test_corrupt_lit_table", C.c_int)]
+    """rt_tuning (include/rt_hip.h): `size` is set by rt_default_tuning() and checked by rt_set_tuning()."""
+    _fields_ = [("size", C.c_size_t), ("dequeue_shards", C.c_int), ("workgroups_per_cu", C.c_int), ("jit_waves_per_simd", C.c_int),
+                ("audit_known_taps", C.c_int), ("jit_flags", C.c_char_p)]
+
+
+class TestKnobs(C.Structure):
+    """rt_test_knobs (include/rt_hip_testing.h): the test suite's knobs and fault injections."""
+    __test__ = False
+    _fields_ = [("size", C.c_size_t), ("force_collective", C.c_int), ("poison_frame", C.c_int), ("trace_known_taps", C.c_int),
+                ("test_every_object", C.c_int), ("test_drop_pixels", C.c_int), ("test_corrupt_lit_table", C.c_int)]
+
+
+TEST_KNOB_NAMES = tuple(n for n, _ in TestKnobs._fields_ if n != "size")
 
 
 class LaunchReport(C.Structure):
@@ -73,16 +82,16 @@ class MouseState(C.Structure):
                 ("last_x", C.c_float), ("last_y", C.c_float)]
 
 
-# every symbol include/rt_hip.h declares (tests check the library exports all of them)
+# every symbol include/rt_hip.h and include/rt_hip_testing.h declare (tests check the library exports all of them)
 EXPORTS = [
-    "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
+    "rt_abi_version", "rt_default_test_knobs", "rt_set_test_knobs", "rt_multi_set_test_knobs", "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
     "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_compiled_scene_info", "rt_compiled_scene_counts", "rt_compiled_scene_cache_cap", "rt_spec_stats_read", "rt_spec_symbol_read", "rt_render", "rt_render_device", "rt_stream", "rt_reserve", "rt_strip_rows", "rt_deinterleave_device", "rt_deinterleave_rotated_device", "rt_strip_of_rank",
     "rt_frame_submit", "rt_frame_submit_device", "rt_frame_wait", "rt_frame_poll", "rt_host_alloc", "rt_host_free",
     "rt_multi_frame_submit_device", "rt_multi_collective_info", "rt_multi_create_on_one_device",
     "rt_multi_frame_submit", "rt_multi_frame_wait", "rt_multi_frame_poll", "rt_profile_collect_span", "rt_profile_collect_split",
     "rt_progressive_begin_rank", "rt_progressive_resolve_device", "rt_multi_progressive_begin", "rt_multi_progressive_pass", "rt_multi_progressive_passes", "rt_progressive_passes",
     "rt_multi_progressive_resolve", "rt_multi_progressive_invalidate", "rt_multi_progressive_state",
-    "rt_synchronize", "rt_cancel", "rt_was_cancelled", "rt_last_launch_counts", "rt_last_launch_report", "rt_launch_check_submit", "rt_launch_check_wait", "rt_primary_passes_run", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
+    "rt_synchronize", "rt_cancel", "rt_was_cancelled", "rt_last_launch_report", "rt_launch_check_submit", "rt_launch_check_wait", "rt_primary_passes_run", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_resolve",
     "rt_progressive_invalidate", "rt_progressive_state", "rt_selftest", "rt_profile_enable", "rt_profile_collect", "rt_parse_scene_file",
     "rt_parse_scene_string", "rt_load_cubemap", "rt_free_cubemap", "rt_decode_jpeg_file",
     "rt_camera_default", "rt_camera_basis_for", "rt_mouse_state_default", "rt_move_camera",
@@ -119,6 +128,9 @@ def lib():
     L.rt_set_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
     L.rt_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
     L.rt_default_tuning.argtypes = [C.POINTER(Tuning)]
+    if hasattr(L, "rt_set_test_knobs"):
+        L.rt_set_test_knobs.argtypes = [C.c_void_p, C.POINTER(TestKnobs)]
+        L.rt_default_test_knobs.argtypes = [C.POINTER(TestKnobs)]
     L.rt_compile_scene.argtypes = [C.c_void_p]
     L.rt_scene_is_compiled.argtypes = [C.c_void_p]
     if hasattr(L, "rt_compiled_scene_info"):
@@ -151,6 +163,8 @@ def lib():
         L.rt_multi_set_skybox.argtypes = [C.c_void_p, C.POINTER(Cubemap)]
         L.rt_multi_set_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
         L.rt_multi_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
+        if hasattr(L, "rt_multi_set_test_knobs"):
+            L.rt_multi_set_test_knobs.argtypes = [C.c_void_p, C.POINTER(TestKnobs)]
         L.rt_multi_compile_scene.argtypes = [C.c_void_p]
         L.rt_multi_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p]
     if hasattr(L, "rt_frame_submit"):
@@ -406,32 +420,30 @@ class Renderer(_FrameQueue):
     def set_tuning(self, dequeue_shards=0, workgroups_per_cu=0,
                    jit_waves_per_simd=0, jit_flags=None, poison_frame=None, trace_known_taps=None, test_every_object=None,
                    audit_known_taps=None, test_drop_pixels=None, test_corrupt_lit_table=None):
-        """rt_set_tuning(): scheduling knobs (0 / None = automatic).  They never change a frame.  poison_frame, trace_known_taps,
-        test_every_object, audit_known_taps and test_drop_pixels stay as last set until set again."""
+        """rt_set_tuning() (scheduling knobs, 0 / None = automatic: they never change a frame) and, for the arguments that are the test
+        suite's -- poison_frame, trace_known_taps, test_every_object, test_drop_pixels, test_corrupt_lit_table --,
+        rt_set_test_knobs() (include/rt_hip_testing.h).  Those and audit_known_taps stay as last set until set again."""
         t = Tuning()
         lib().rt_default_tuning(C.byref(t))
         t.dequeue_shards = dequeue_shards
         t.workgroups_per_cu, t.jit_waves_per_simd = workgroups_per_cu, jit_waves_per_simd
         t.jit_flags = jit_flags.encode() if jit_flags else None
-        if poison_frame is not None:
-            self._poison = bool(poison_frame)
-        t.poison_frame = 1 if getattr(self, "_poison", False) else 0
-        if trace_known_taps is not None:
-            self._trace_known = bool(trace_known_taps)
-        t.trace_known_taps = 1 if getattr(self, "_trace_known", False) else 0
-        if test_every_object is not None:
-            self._every_object = bool(test_every_object)
-        t.test_every_object = 1 if getattr(self, "_every_object", False) else 0
         if audit_known_taps is not None:
             self._audit = int(audit_known_taps)
         t.audit_known_taps = getattr(self, "_audit", 0)
-        if test_drop_pixels is not None:
-            self._drop = int(test_drop_pixels)
-        t.test_drop_pixels = getattr(self, "_drop", 0)
-        if test_corrupt_lit_table is not None:
-            self._corrupt_lit = int(test_corrupt_lit_table)
-        t.test_corrupt_lit_table = getattr(self, "_corrupt_lit", 0)
         _check(lib().rt_set_tuning(self._ctx, C.byref(t)), "rt_set_tuning")
+        kept = getattr(self, "_test_knobs", None) or {}
+        for name, value in (("poison_frame", poison_frame), ("trace_known_taps", trace_known_taps), ("test_every_object", test_every_object),
+                            ("test_drop_pixels", test_drop_pixels), ("test_corrupt_lit_table", test_corrupt_lit_table)):
+            if value is not None:
+                kept[name] = int(value)
+        self._test_knobs = kept
+        if kept:
+            k = TestKnobs()
+            lib().rt_default_test_knobs(C.byref(k))
+            for name, value in kept.items():
+                setattr(k, name, value)
+            _check(lib().rt_set_test_knobs(self._ctx, C.byref(k)), "rt_set_test_knobs")
 
     @staticmethod
     def params(width, height, spp, max_bounces, seed=0, row_block=8, rank=0, world=1, kernel=KERNEL_AUTO):
@@ -530,15 +542,6 @@ class Renderer(_FrameQueue):
         if rc < 0:
             _check(rc, "rt_was_cancelled")
         return rc == 1
-
-    def last_launch_counts(self):
-        """(object pixels listed, object pixels fetched by the trace kernel, the launch's control words) of the most recent launch."""
-        a, b = C.c_ulonglong(), C.c_ulonglong()
-        w = (C.c_uint * 4)()
-        f = lib().rt_last_launch_counts
-        f.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)]
-        _check(f(self._ctx, C.byref(a), C.byref(b), w), "rt_last_launch_counts")
-        return {"pixels_listed": a.value, "pixels_fetched": b.value, "control": list(w)}
 
     def last_launch_report(self):
         """rt_last_launch_report(): (status, dict) of the most recent launch -- status 0 complete, 1 cancelled, < 0 incomplete
@@ -655,11 +658,18 @@ class MultiRenderer(_FrameQueue):
         _check(lib().rt_multi_set_camera(self._m, C.byref(cam)), "rt_multi_set_camera")
 
     def set_tuning(self, **kw):
+        """rt_multi_set_tuning() for rt_tuning's fields, rt_multi_set_test_knobs() for rt_test_knobs' (include/rt_hip_testing.h)."""
         t = Tuning()
         lib().rt_default_tuning(C.byref(t))
-        for k, v in kw.items():
-            setattr(t, k, v)
+        k = TestKnobs()
+        lib().rt_default_test_knobs(C.byref(k))
+        for name, v in kw.items():
+            if name == "jit_flags" and isinstance(v, str):
+                v = v.encode()
+            setattr(k if name in TEST_KNOB_NAMES else t, name, v)
         _check(lib().rt_multi_set_tuning(self._m, C.byref(t)), "rt_multi_set_tuning")
+        if any(name in TEST_KNOB_NAMES for name in kw):
+            _check(lib().rt_multi_set_test_knobs(self._m, C.byref(k)), "rt_multi_set_test_knobs")
 
     def compile_scene(self):
         _check(lib().rt_multi_compile_scene(self._m), "rt_multi_compile_scene")

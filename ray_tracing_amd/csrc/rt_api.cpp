@@ -183,8 +183,8 @@ struct rt_context {
 		size_t   accum_bytes = 0, low_bytes = 0;
 	} prog;
 
-	rt_tuning    tuning = {};
-	std::string  jit_flags;              /* owns tuning.jit_flags */
+	rt_knobs     tuning;                 /* rt_set_tuning() + rt_set_test_knobs() */
+	std::string  jit_flags;              /* rt_tuning.jit_flags, copied */
 
 	bool         profiling = false;
 	bool         profiling_split = false;   /* rt_profile_enable(ctx, 2): also an event BETWEEN the camera-ray pass and the trace kernel (it costs a launch ~20 us) */
@@ -341,11 +341,13 @@ int rt_judge_launch(const unsigned int *w, const rt_launch_expect &x, const char
 	r.taps_audited = (unsigned long long) w[RT_CTL_AUDITED] | ((unsigned long long) w[RT_CTL_AUDITED + 1] << 32);
 	r.taps_disagreeing = (unsigned long long) w[RT_CTL_DISAGREE] | ((unsigned long long) w[RT_CTL_DISAGREE + 1] << 32);
 	if (report) *report = r;
-	if (r.cancelled) return RT_CANCELLED;
-	if (!x.stamped) return RT_OK;
-	if (r.stamp != x.launch_id)
+	/* the stamp first: until a launch's own last wave has written the line, `cancelled` may be what the scratch set's PREVIOUS launch
+	 * left there (launches that keep the set's pixel lists clear nothing); a launch cut short by rt_cancel() still ends with its stamp */
+	if (x.stamped && r.stamp != x.launch_id)
 		return fail(RT_ERR_DEVICE, "%s: launch %u ended without the stamp of its last wave (stamp %u, %u waves left it, %llu pixels written): the frame is incomplete",
 		            who, x.launch_id, r.stamp, r.waves_left, r.pixels_written);
+	if (r.cancelled) return RT_CANCELLED;
+	if (!x.stamped) return RT_OK;
 	if (r.pixels_fetched != r.pixels_listed || r.pixels_written != r.pixels_listed || r.primary_blocks_done != r.primary_blocks_expected)
 		return fail(RT_ERR_DEVICE, "%s: launch %u is incomplete: object pixels listed %llu, fetched %llu, written %llu; camera-ray blocks %u of %u",
 		            who, x.launch_id, r.pixels_listed, r.pixels_fetched, r.pixels_written, r.primary_blocks_done, r.primary_blocks_expected);
@@ -381,18 +383,40 @@ extern "C" {
 
 const char *rt_last_error(void) { return g_error; }
 
-void rt_default_tuning(rt_tuning *t) { if (t) memset(t, 0, sizeof(*t)); }
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+void rt_default_tuning(rt_tuning *t) { if (t) { memset(t, 0, sizeof(*t)); t->size = sizeof(*t); } }
 
 int rt_set_tuning(rt_context *ctx, const rt_tuning *t)
 {
-	if (!ctx || !t) return fail(RT_ERR_ARGUMENT, "rt_set_tuning: NULL argument");
+	if (!t) return fail(RT_ERR_ARGUMENT, "rt_set_tuning: NULL argument");
+	/* (only `size` is looked at until it has been found to be this library's: a struct of another revision of the header is not
+	 * read; checked before anything else, so that a host can find out with no context at all) */
+	if (t->size != sizeof(rt_tuning))
+		return fail(RT_ERR_ARGUMENT, "rt_set_tuning: rt_tuning.size is %zu, this library's rt_tuning has %zu bytes (ABI version %d): was the host compiled against "
+		            "another revision of rt_hip.h, or the struct not initialised with rt_default_tuning()?", t->size, sizeof(rt_tuning), RT_ABI_VERSION);
+	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_set_tuning: NULL context");
 	if ((t->dequeue_shards != 0 && t->dequeue_shards != 1 && t->dequeue_shards != 64) ||
 	    t->workgroups_per_cu < 0 || t->workgroups_per_cu > 8 || t->jit_waves_per_simd < 0 || t->jit_waves_per_simd > 8 ||
-	    t->audit_known_taps < -1 || t->audit_known_taps > 30 || t->test_drop_pixels < 0)
+	    t->audit_known_taps < -1 || t->audit_known_taps > RT_AUDIT_MAX_LOG2)
 		return fail(RT_ERR_ARGUMENT, "rt_set_tuning: value out of range");
-	ctx->tuning = *t;
+	ctx->tuning.dequeue_shards = t->dequeue_shards; ctx->tuning.workgroups_per_cu = t->workgroups_per_cu;
+	ctx->tuning.jit_waves_per_simd = t->jit_waves_per_simd; ctx->tuning.audit_known_taps = t->audit_known_taps;
 	ctx->jit_flags = t->jit_flags ? t->jit_flags : "";
-	ctx->tuning.jit_flags = ctx->jit_flags.c_str();
+	return RT_OK;
+}
+
+void rt_default_test_knobs(rt_test_knobs *k) { if (k) { memset(k, 0, sizeof(*k)); k->size = sizeof(*k); } }
+
+int rt_set_test_knobs(rt_context *ctx, const rt_test_knobs *k)
+{
+	if (!ctx || !k) return fail(RT_ERR_ARGUMENT, "rt_set_test_knobs: NULL argument");
+	if (k->size != sizeof(rt_test_knobs))
+		return fail(RT_ERR_ARGUMENT, "rt_set_test_knobs: rt_test_knobs.size is %zu, this library's has %zu bytes", k->size, sizeof(rt_test_knobs));
+	if (k->test_drop_pixels < 0) return fail(RT_ERR_ARGUMENT, "rt_set_test_knobs: value out of range");
+	ctx->tuning.force_collective = k->force_collective; ctx->tuning.poison_frame = k->poison_frame; ctx->tuning.trace_known_taps = k->trace_known_taps;
+	ctx->tuning.test_every_object = k->test_every_object; ctx->tuning.test_drop_pixels = k->test_drop_pixels;
+	ctx->tuning.test_corrupt_lit_table = k->test_corrupt_lit_table;
 	return RT_OK;
 }
 
@@ -811,7 +835,7 @@ static int mark_audited_cells(rt_context *ctx)
 	if (k != 0) {
 		const uint32_t mask = k < 0 ? 0u : (1u << k) - 1u;
 		for (size_t b = 0; b < cells.size(); b++)
-			if (cells[b] && ((uint32_t) ((b * 0x9E3779B97F4A7C15ull) >> 40) & mask) == 0u) cells[b] |= 4u;
+			if (cells[b] && ((uint32_t) ((b * 0x9E3779B97F4A7C15ull) >> (64 - RT_AUDIT_MAX_LOG2)) & mask) == 0u) cells[b] |= 4u;
 	}
 	HIP_TRY(hipMemcpy(ctx->d_lit_cells, cells.data(), cells.size(), hipMemcpyHostToDevice));
 	ctx->lit_audit_marked = k;
@@ -1077,27 +1101,6 @@ int rt_was_cancelled(rt_context *ctx)
 	unsigned int w = 0;
 	HIP_TRY(hipMemcpy(&w, ctx->slot[ctx->cur].d_counter + 128 * 32 + RT_CTL_CANCELLED, sizeof(w), hipMemcpyDeviceToHost));
 	return w ? RT_CANCELLED : RT_OK;
-}
-
-/* Diagnostic aid: what the context's most recent launch left in its counters -- how many object pixels rt_primary_pass listed,
- * how many of them the trace kernel's waves fetched (all of them, unless the launch was cut short), and its control words
- * ([1]: a wave gave up because of rt_cancel, [2]: the relayed request).  Waits for the launch. */
-int rt_last_launch_counts(rt_context *ctx, unsigned long long *pixels_listed, unsigned long long *pixels_fetched, unsigned int control[4])
-{
-	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_last_launch_counts: NULL context");
-	HIP_TRY(hipSetDevice(ctx->device));
-	{ const int rc = wait_for_launches(ctx); if (rc != RT_OK) return rc; }
-	std::vector<unsigned int> words(rt_counter_bytes() / sizeof(unsigned int));
-	HIP_TRY(hipMemcpy(words.data(), ctx->slot[ctx->cur].d_counter, rt_counter_bytes(), hipMemcpyDeviceToHost));
-	unsigned long long listed = 0, fetched = 0;
-	for (int s = 0; s < 64; s++) {
-		const unsigned int fill = words[(size_t) (64 + s) * 32], taken = words[(size_t) s * 32];
-		listed += fill; fetched += taken < fill ? taken : fill;
-	}
-	if (pixels_listed) *pixels_listed = listed;
-	if (pixels_fetched) *pixels_fetched = fetched;
-	if (control) for (int k = 0; k < 4; k++) control[k] = words[(size_t) 128 * 32 + k];
-	return RT_OK;
 }
 
 int rt_deinterleave_rotated_device(rt_context *ctx, const void *d_strips, void *d_frame,

@@ -83,6 +83,7 @@ typedef struct {
 #define RT_CTL_LINES_DONE  12   /* dequeue lines whose workgroups have all left: the workgroup that completes the last one is the launch's last -- and sets this, and the
                                  * dequeue lines, back to zero: a launch that keeps its scratch set's pixel lists has nothing to clear (rt_launch_trace) */
 #define RT_CTL_WORDS       16
+#define RT_AUDIT_MAX_LOG2  24   /* rt_tuning.audit_known_taps = k marks one answer in 2^k by a 24-bit hash of its cell / pixel: k up to this */
 /* What a launch is expected to leave in those words, kept by the host until they have been copied back and judged. */
 typedef struct {
 	unsigned int launch_id;

@@ -7,8 +7,14 @@
 #include <vector>
 #include "rt_device.h"
 #include "../../include/rt_hip.h"
+#include "../../include/rt_hip_testing.h"
 
 struct rt_context;
+/* everything a context can be told about how to run its launches: rt_tuning (rt_hip.h) and rt_test_knobs (rt_hip_testing.h) land here */
+struct rt_knobs {
+	int dequeue_shards = 0, workgroups_per_cu = 0, jit_waves_per_simd = 0, audit_known_taps = 0;
+	int force_collective = 0, poison_frame = 0, trace_known_taps = 0, test_every_object = 0, test_drop_pixels = 0, test_corrupt_lit_table = 0;
+};
 /* rt_api.cpp: sets the thread's error text (rt_last_error()) and returns `code`; the context's own stream */
 int        rt_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 void      *rt_context_stream(rt_context *ctx);

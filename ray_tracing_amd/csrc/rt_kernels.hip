@@ -1819,9 +1819,13 @@ rt_trace_spec(const rt_launch L, unsigned int *block_counter)
 RT_DEV bool launch_may_be_published(const unsigned int *control, unsigned int launch_id, int stamped, unsigned int primary_blocks, float *count)
 {
 	if (!control) return true;            /* nothing was launched (a rank without rows at this scale) */
-	if (control[RT_CTL_CANCELLED]) return false;
+	/* The stamp FIRST: a launch that keeps its scratch set's pixel lists clears nothing (rt_api.cpp), so until its own last wave has
+	 * written the line, CANCELLED is what the set's previous launch left there -- a launch that died without a last wave behind a
+	 * cancelled one must count as incomplete, not as cancelled.  (A launch cut short by rt_cancel() still ends with its stamp.) */
+	const bool stamp_ok = !stamped || control[RT_CTL_STAMP] == launch_id;
+	if (stamp_ok && control[RT_CTL_CANCELLED]) return false;
 	if (!stamped) return true;
-	const bool complete = control[RT_CTL_STAMP] == launch_id && control[RT_CTL_FETCHED] == control[RT_CTL_LISTED] &&
+	const bool complete = stamp_ok && control[RT_CTL_FETCHED] == control[RT_CTL_LISTED] &&
 	                      control[RT_CTL_WRITTEN] == control[RT_CTL_LISTED] && control[RT_CTL_PRIMARY] == primary_blocks &&
 	                      control[RT_CTL_DISAGREE] == 0u && control[RT_CTL_DISAGREE + 1] == 0u;
 	if (!complete && blockIdx.x == 0 && threadIdx.x == 0) {

@@ -37,6 +37,7 @@
 #include <time.h>
 
 #include "../../include/rt_hip.h"
+#include "../../include/rt_hip_testing.h"     /* --force-collective only */
 
 static const char *out_file = "frame.ppm";
 
@@ -120,6 +121,10 @@ int main(int argc, char **argv)
 	for (int i = 0; i < gpus; i++) ids[i] = i;
 	if (gpus < 1) { gpus = 1; ids[0] = device; }
 	rt_multi *group = NULL;
+	if (rt_abi_version() != RT_ABI_VERSION) {
+		fprintf(stderr, "Error: librt_hip.so has ABI version %d, this host was compiled against %d\n", rt_abi_version(), RT_ABI_VERSION);
+		return -1;
+	}
 	if (rt_multi_create(&group, ids, gpus) != RT_OK || rt_multi_set_scene(group, &scene) != RT_OK || rt_multi_set_skybox(group, &skybox) != RT_OK) {
 		fprintf(stderr, "Error: %s\n", rt_last_error());
 		return -1;
@@ -129,10 +134,10 @@ int main(int argc, char **argv)
 	rt_multi_set_camera(group, &cam);
 
 	if (force_collective) {
-		rt_tuning t;
-		rt_default_tuning(&t);
-		t.force_collective = 1;
-		rt_multi_set_tuning(group, &t);
+		rt_test_knobs k;
+		rt_default_test_knobs(&k);
+		k.force_collective = 1;
+		rt_multi_set_test_knobs(group, &k);
 	}
 	if (compile) {
 		const double tc = now_s();

@@ -305,10 +305,11 @@ rt_context *rt_multi_context(rt_multi *m, int i) { return m && i >= 0 && i < m->
 int rt_multi_set_scene(rt_multi *m, const Scene *scene)       { FOR_ALL(rt_set_scene(ctx, scene)); }
 int rt_multi_set_skybox(rt_multi *m, const Cubemap *skybox)   { FOR_ALL(rt_set_skybox(ctx, skybox)); }
 int rt_multi_set_camera(rt_multi *m, const rt_camera *camera) { FOR_ALL(rt_set_camera(ctx, camera)); }
-int rt_multi_set_tuning(rt_multi *m, const rt_tuning *tuning)
+int rt_multi_set_tuning(rt_multi *m, const rt_tuning *tuning) { FOR_ALL(rt_set_tuning(ctx, tuning)); }
+int rt_multi_set_test_knobs(rt_multi *m, const rt_test_knobs *knobs)
 {
-	if (m && tuning) m->force_collective = tuning->force_collective != 0;
-	FOR_ALL(rt_set_tuning(ctx, tuning));
+	if (m && knobs && knobs->size == sizeof(rt_test_knobs)) m->force_collective = knobs->force_collective != 0;
+	FOR_ALL(rt_set_test_knobs(ctx, knobs));
 }
 int rt_multi_compile_scene(rt_multi *m)                       { FOR_ALL(rt_compile_scene(ctx)); }
 
@@ -549,10 +550,30 @@ int rt_multi_progressive_invalidate(rt_multi *m)
 	return RT_OK;
 }
 
+/* The ladder's sum of published weights, as EVERY device holds it.  A pass whose launch was incomplete on one device is not
+ * published there (and that device says so: RT_ERR_DEVICE); all devices publish the same passes or the gathered frame would mix
+ * rows of different sample counts -- so every context is asked, the first error is returned, and counts that differ are an
+ * error of their own. */
+static int group_count(rt_multi *m, float *count, const char *who)
+{
+	float first = 0;
+	for (int i = 0; i < m->n; i++) {
+		float c = 0;
+		const int rc = rt_progressive_count(m->ctx[(size_t) i], &c);
+		if (rc != RT_OK) return rc;
+		if (i == 0) first = c;
+		else if (c != first)
+			return rt_fail(RT_ERR_DEVICE, "%s: device %d of the group has published a weight sum of %.9g, the first device %.9g: their rows would not be of one frame", who, i, (double) c, (double) first);
+	}
+	*count = first;
+	return RT_OK;
+}
+
 int rt_multi_progressive_state(rt_multi *m, int *next_scale, float *count, uint32_t *generation, int *passes)
 {
 	if (!m) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_progressive_state: NULL handle");
-	return rt_progressive_state(m->ctx[0], next_scale, count, generation, passes);    /* the first device always has rows */
+	if (count) { const int rc = group_count(m, count, "rt_multi_progressive_state"); if (rc != RT_OK) return rc; }
+	return rt_progressive_state(m->ctx[0], next_scale, nullptr, generation, passes);    /* (host-side state: the same on every device) */
 }
 
 int rt_multi_progressive_resolve(rt_multi *m, Vector3 *frame_out)
@@ -571,7 +592,7 @@ int rt_multi_progressive_resolve(rt_multi *m, Vector3 *frame_out)
 	{	/* the count first (update_frame() waits for it, main.c:461-464): with nothing published there is nothing to divide by,
 		 * and frame_out is left as it is */
 		float count = 0;
-		const int crc = rt_progressive_count(m->ctx[0], &count);
+		const int crc = group_count(m, &count, "rt_multi_progressive_resolve");
 		if (crc != RT_OK) return crc;
 		if ((double) count < 0.0001) return rt_fail(RT_ERR_STATE, "rt_multi_progressive_resolve: nothing accumulated yet (every pass so far was cancelled)");
 	}

@@ -71,6 +71,75 @@ def test_header_is_valid_cxx_and_links(tmp_path, scene_paths):
     _build_and_run(tmp_path, "g++", "-std=c++17", "host.cpp", scene_paths[0])
 
 
+ROUND5_HOST = textwrap.dedent(r'''
+    /* A host compiled against ROUND 5's rt_hip.h: rt_tuning had no size field and eleven members (include/rt_hip.h at b83836b).
+     * Its binary must be told so by today's library -- RT_ERR_ARGUMENT from the size check -- instead of having its struct read
+     * with today's layout.  (Only the declarations such a host would have had are repeated here.) */
+    #include <stdio.h>
+    #include <string.h>
+    typedef struct rt_context rt_context;
+    typedef struct {
+        int dequeue_shards, workgroups_per_cu, jit_waves_per_simd;
+        const char *jit_flags;
+        int force_collective, poison_frame, trace_known_taps, test_every_object, audit_known_taps, test_drop_pixels, test_corrupt_lit_table;
+    } rt_tuning_round5;
+    void rt_default_tuning(rt_tuning_round5 *t);           /* (what round 5 declared: it memset the struct to zero) */
+    int rt_set_tuning(rt_context *ctx, const rt_tuning_round5 *t);
+    const char *rt_last_error(void);
+    int rt_abi_version(void);
+
+    int main(void)
+    {
+        int worst = 0;
+        for (int shards = 0; shards <= 64; shards += 64)
+            for (int wg = 0; wg <= 8; wg++) {
+                rt_tuning_round5 t;
+                memset(&t, 0, sizeof t);                   /* round 5's rt_default_tuning() */
+                t.dequeue_shards = shards; t.workgroups_per_cu = wg; t.poison_frame = 1;
+                const int rc = rt_set_tuning((rt_context *) 0, &t);
+                if (rc != -1 || !strstr(rt_last_error(), "rt_tuning.size")) { printf("shards %d wg %d: rc %d, %s\n", shards, wg, rc, rt_last_error()); worst = 1; }
+            }
+        printf("abi %d\n", rt_abi_version());
+        return worst;
+    }
+''')
+
+
+def test_a_host_built_against_the_round5_header_is_refused(tmp_path):
+    """rt_tuning carries its own size (set by rt_default_tuning, checked by rt_set_tuning before anything else is read), and the
+    library says which revision of the header it was built from (rt_abi_version)."""
+    src = tmp_path / "round5_host.c"
+    src.write_text(ROUND5_HOST)
+    exe = tmp_path / "round5_host"
+    libdir = os.path.dirname(rt.LIB_PATH)
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", str(src), "-o", str(exe), "-L", libdir, "-lrt_hip", f"-Wl,-rpath,{libdir}"],
+                   check=True, capture_output=True, text=True)
+    p = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout
+    header = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
+    import re
+    assert p.stdout.split()[-1] == re.search(r"#define RT_ABI_VERSION (\d+)", header).group(1)
+    # today's struct, as today's rt_default_tuning() leaves it, passes the size check (and is then refused for the NULL context)
+    t = rt.Tuning()
+    rt.lib().rt_default_tuning(t)
+    assert t.size == __import__("ctypes").sizeof(rt.Tuning) == 32
+    assert rt.lib().rt_set_tuning(None, t) == -1 and b"NULL context" in rt.lib().rt_last_error()
+    k = rt.TestKnobs()
+    rt.lib().rt_default_test_knobs(k)
+    assert k.size == __import__("ctypes").sizeof(rt.TestKnobs)
+
+
+def test_the_boundary_header_carries_no_test_knobs():
+    """rt_hip.h is what a maintainer binds; fault injections, self-tests and instrumentation read-outs are declared in rt_hip_testing.h."""
+    public = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
+    for name in ("test_drop_pixels", "test_corrupt_lit_table", "test_every_object", "poison_frame", "rt_selftest", "rt_spec_stats_read",
+                 "rt_spec_symbol_read", "rt_primary_passes_run", "rt_multi_create_on_one_device", "rt_last_launch_counts"):
+        assert name not in public, name
+    testing = open(os.path.join(ROOT, "include", "rt_hip_testing.h")).read()
+    for name in ("test_drop_pixels", "rt_selftest", "rt_spec_stats_read", "rt_primary_passes_run", "rt_multi_create_on_one_device"):
+        assert name in testing, name
+
+
 REF_SRC = "/root/reference/src"
 
 REF_HOST = textwrap.dedent(r'''
