@@ -133,7 +133,7 @@ def algorithmic_work(oracle_count, W, H, max_bounces, seed):
     c = oracle_count.counters()
     n = max(c["samples"], 1)
     return {k: c[k] / n for k in ("flops", "rays", "object_tests", "rng_draws", "sky_fetches",
-                                  "box_tests", "box_flops", "sphere_tests", "sphere_flops", "sky_samples", "sky_sample_flops")}
+                                  "box_tests", "box_flops", "sphere_tests", "sphere_flops", "sky_samples", "sky_sample_flops", "first_ray_flops")}
 
 
 # measured issue cost of a wave64 VALU instruction per SIMD, four waves per SIMD (profiles/r02/valu_rates.txt, cycles)
@@ -455,6 +455,10 @@ def main():
     fence()
     prof.profile(True)
     first_timed = seed + args.warmup
+    # N > 1 (either host): every rank's phases of the timed frames (strip render / wait for the gather / de-interleave / copy / idle)
+    phases_native = native and multi_path and queue is not gpu
+    if phases_native:
+        queue.profile_phases(True)
     if not native:
         tiled.record_events = True
         start = torch.cuda.Event(enable_timing=True)
@@ -495,6 +499,24 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+
+    # ---- where each rank's step went (outside the timed region; the events were recorded inside it).  One entry per rank / device:
+    # ms per step of strip render / de-interleave / frame copy / wait for the gather / idle -- every instant of the rank's timed
+    # window given to what its device was doing, summing to its step (ray_tracing_amd.attribute_phases, rt_multi_profile_collect)
+    # -- then the rank with the least slack and what bounds the step there.  If a SCALE run lands at 5 x instead of 6.8 x, this says why.
+    per_rank = None
+    if multi_path:
+        if phases_native:
+            per_rank = queue.collect_phases()
+            queue.profile_phases(False)
+        elif not native:
+            mine = tiled.phases()
+            if world > 1:
+                gathered_phases = [None] * world
+                dist.all_gather_object(gathered_phases, mine)
+                per_rank = gathered_phases
+            else:
+                per_rank = [mine]
 
     # ---- what was timed is what was asked for: the last frame of the timed region against a blocking rt_render() of its
     # seed (whole frame, bit for bit) and against rows of the CPU oracle.  Outside the timed region. -------------------
@@ -664,12 +686,28 @@ def main():
         }
         if collective is not None:
             out["collective"] = collective
+        if per_rank:
+            out["per_rank"] = [{"rank": i, **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}} for i, r in enumerate(per_rank)]
+            out.update(rt.judge_phases(per_rank))
+            out["per_rank_note"] = ("ms per step, per rank: every instant between the rank's first and last frame end (rank 0: frame in host memory; others: their "
+                                    "gather done) belongs to what its device was doing then, for whichever frame in flight: strip render (incl. waiting for "
+                                    "workgroup slots) > de-interleave > copy to the host > a rendered strip waiting for the gather > idle (no launch there to run); "
+                                    "the five are disjoint and sum to step_ms.  critical_rank: least slack (gather wait + idle); step_bound: its largest share, "
+                                    "in {render, gather, copy, host}")
         if step_ms:
             med = step_ms[len(step_ms) // 2]
             out["ms_per_step_median"] = round(med, 4)
             out["ms_per_step_p90_max"] = [round(step_ms[(len(step_ms) * 9) // 10], 4), round(step_ms[-1], 4)]
             out["slowest_step"] = slowest
             out["value_at_median_step"] = round(samples_per_step / med / 1e3, 2)
+            # the loop once it is full: the intervals between delivered frames from the `depth`-th timed frame on (the first frames of
+            # the timed region are delivered at the pipeline's fill rate, whatever the depth), their median -- what a host that runs for
+            # seconds sees per frame; `ms_per_step` above stays the mean over ALL K steps, which is what `value` is computed from
+            steady = sorted(step_list[min(depth, max(len(step_list) - 3, 0)):])
+            if steady:
+                out["steady_state_ms_per_step"] = round(steady[len(steady) // 2], 4)
+                out["steady_state"] = {"intervals": len(steady), "skipped_after_fill": len(step_list) - len(steady), "min_ms": round(steady[0], 4), "max_ms": round(steady[-1], 4),
+                                       "value": round(samples_per_step / steady[len(steady) // 2] / 1e3, 2), "frames_in_flight": depth}
         if latency is not None:
             out["frame_latency"] = {"median_ms": round(latency, 4), "runs": 7,
                                     "msamples_per_s": round(samples_per_step / latency / 1e3, 2),
@@ -725,6 +763,7 @@ def main():
                     executed = executed_work_of_culled_scene(rt, scene_path, camera, sky, W, H, spp, nb, seed)
                 except Exception as e:
                     out["executed_work_error"] = repr(e)
+            culled_launch = bool(executed)
             if executed:
                 # A culled scene: the numerator is the work the kernel EXECUTES, priced with the reference's cost table (the
                 # oracle's per-test averages: a box test 21 flops incl. its far corner, a sphere test ~38), so that frac <= 1 by
@@ -754,37 +793,58 @@ def main():
             if iss:
                 trace["issue"] = iss
 
-            # -- the camera-ray pass against HBM: what it has to move is 4 B of texel + 12 B of frame per sky pixel, 48 B of record per
-            # object pixel; what it moved is the PMC traffic of the committed passes
+            # -- the camera-ray pass: one trace_ray per PIXEL (and, for the pixels whose camera ray leaves the scene, the rest of the
+            # sample: texel, colour -- added spp times onto the sum).  It is a VALU kernel like the trace kernel (round 5 labelled it
+            # "hbm" at 2-11 % of the HBM peak with the VALUs 70 % busy: wrong label).  Numerator: its own flops as written -- per object
+            # pixel the camera ray and the first trace_ray, per sky pixel the whole sample (oracle counters first_ray_flops,
+            # sky_sample_flops; the frame at 1 spp, so per sample = per pixel).  The bytes it moves are side keys.
             sky_px = work["sky_samples"] * pixels_per_launch
             obj_px = pixels_per_launch - sky_px
             p_bytes = sky_px * (4.0 + 12.0) + obj_px * 48.0
-            primary = {"kernel": "rt_primary_pass", "bound": "hbm", "ms": round(primary_ms, 4), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                       "algorithmic_bytes": round(p_bytes), "algorithmic_GBps": round(p_bytes / max(primary_ms, 1e-6) / 1e6, 2)}
+            p_flops = (work["first_ray_flops"] + work["sky_sample_flops"]) * pixels_per_launch
+            primary = {"kernel": "rt_primary_pass", "bound": "valu", "ms": round(primary_ms, 4), "peak": round(PEAK_VALU_NOFMA_TFLOPS, 2), "unit": "TFLOP/s",
+                       "achieved": round(p_flops / max(primary_ms, 1e-6) / 1e9, 3), "frac": round(p_flops / max(primary_ms, 1e-6) / 1e9 / PEAK_VALU_NOFMA_TFLOPS, 4),
+                       "numerator": "as written, once per PIXEL: camera ray + first trace_ray of object pixels, the whole sample of sky pixels",
+                       "flops_per_pixel": round(work["first_ray_flops"] + work["sky_sample_flops"], 1),
+                       "bytes": {"algorithmic_bytes": round(p_bytes), "algorithmic_GBps": round(p_bytes / max(primary_ms, 1e-6) / 1e6, 2), "hbm_peak_GBps": PEAK_HBM_GBPS,
+                                 "note": "4 B of texel + 12 B of frame per sky pixel, 48 B of record per object pixel"}}
             pp = pk.get("rt_primary_pass")
             if pp and "fetch_bytes" in pp and "write_bytes" in pp:
                 moved = pp["fetch_bytes"] + pp["write_bytes"]
-                primary.update({"traffic": round(moved), "achieved": round(moved / max(primary_ms, 1e-6) / 1e6, 2),
-                                "frac": round(moved / max(primary_ms, 1e-6) / 1e6 / PEAK_HBM_GBPS, 4), "achieved_from": "PMC traffic of the committed passes / this run's kernel time"})
-            else:
-                primary.update({"traffic": None, "achieved": primary["algorithmic_GBps"], "frac": round(primary["algorithmic_GBps"] / PEAK_HBM_GBPS, 4),
-                                "achieved_from": "algorithmic bytes / this run's kernel time (no PMC pass committed for this kernel)"})
+                primary["bytes"].update({"traffic": round(moved), "traffic_GBps": round(moved / max(primary_ms, 1e-6) / 1e6, 2),
+                                         "frac_of_hbm_peak": round(moved / max(primary_ms, 1e-6) / 1e6 / PEAK_HBM_GBPS, 4),
+                                         "traffic_from": "PMC traffic of the committed passes / this run's kernel time"})
+            if culled_launch:     # (a culled scene's camera rays are culled too: their executed work is in the launch-level figure below)
+                for key in ("achieved", "frac"):
+                    primary.pop(key)
+                primary["numerator"] = "executed work of both kernels is priced at launch level (roofline.frac); this entry has the time only"
+            if primary_ms <= 0:   # (--no-extras: no launch had the GPU to itself, the event between the two kernels was not recorded)
+                for key in ("achieved", "frac"):
+                    primary.pop(key, None)
+                primary["numerator"] = "not timed apart in this run (--no-extras)"
+            pi = simd_issue_estimate(pp, primary_ms) if primary_ms > 0 else None
+            if pi:
+                primary["issue"] = pi
 
-            # The line's own roofline fields.  Where most samples are traced (C1, C2, the large scenes) they price the LAUNCH -- both kernels'
-            # time against all the flops the reference would spend on the frame (or, culled scenes, the flops executed) -- as every round
-            # before did; where most samples are sky (C3: 97 %, one camera ray per PIXEL and its colour added spp times) a launch-level
-            # flop count is not what the kernels do, and the fields are those of the kernel that takes more of the launch.
-            if work["rays"] < 1.25:
-                dominant = trace if trace_ms >= primary_ms else primary
+            # The line's own roofline fields: those of the DOMINANT KERNEL -- the one that takes more of the launch -- on the work that
+            # kernel itself does, over its own time (launches that had the GPU to themselves).  Until round 5 the line priced the whole
+            # launch -- both kernels' time against all the flops the reference would spend on the frame --, which credits the samples of
+            # sky pixels (C1: 36 %, C2: 83 %) to a trace kernel that never sees them: C2 printed 0.47 for a kernel at 0.27.  That figure
+            # stays, as frac_launch_as_written.  (A culled scene's numerator is EXECUTED work, counted for both kernels together: its
+            # top-level fields are the launch's.)
+            num = (trace["executed_flops_per_sample"] if executed else work["flops"]) * samples_per_launch
+            launch_ach = num / (avg_ms * 1e-3) / 1e12
+            if executed:
+                dominant = {"bound": "valu", "achieved": round(launch_ach, 3), "peak": round(PEAK_VALU_NOFMA_TFLOPS, 2), "unit": "TFLOP/s",
+                            "frac": round(launch_ach / PEAK_VALU_NOFMA_TFLOPS, 4), "kernel": "rt_primary_pass + " + trace_name,
+                            "numerator": "executed, both kernels over the launch's time (kernels.trace has the counts and the cost table; algorithmic_as_written beside it)"}
             else:
-                num = (trace["executed_flops_per_sample"] if executed else work["flops"]) * samples_per_launch
-                ach = num / (avg_ms * 1e-3) / 1e12
-                dominant = {"bound": "valu", "achieved": round(ach, 3), "peak": round(PEAK_VALU_NOFMA_TFLOPS, 2), "unit": "TFLOP/s",
-                            "frac": round(ach / PEAK_VALU_NOFMA_TFLOPS, 4), "kernel": "rt_primary_pass + " + trace_name}
-                if executed:
-                    dominant["numerator"] = "executed (kernels.trace has the counts and the cost table; algorithmic_as_written beside it)"
+                dominant = dict(trace if trace_ms >= primary_ms else primary)
             out["roofline"] = {"bound": dominant["bound"], "achieved": dominant["achieved"], "peak": dominant["peak"], "unit": dominant["unit"], "frac": dominant["frac"],
-                               "kernel": dominant["kernel"], "traffic": None,
+                               "kernel": dominant["kernel"], "kernel_ms": dominant.get("ms", round(avg_ms, 4)), "numerator": dominant.get("numerator"), "traffic": None,
+                               "frac_launch_as_written": round(launch_ach / PEAK_VALU_NOFMA_TFLOPS, 4), "achieved_launch_as_written": round(launch_ach, 3),
+                               "launch_as_written_note": "rounds 1-5's top-level figure: " + ("executed" if executed else "all the flops the reference spends on the frame, sky samples included,")
+                                                         + " over both kernels' time in the timed region (avg_kernel_ms)",
                                "avg_kernel_ms": round(avg_ms, 4), "launches": launches,
                                "avg_kernel_ms_per_launch_events": round(per_launch_ms / launches, 4),
                                "avg_kernel_ms_span": round(span_ms / span_launches, 4) if span_launches else None,
@@ -793,8 +853,8 @@ def main():
                                "object_tests_per_sample": round(work["object_tests"], 2), "rng_draws_per_sample": round(work["rng_draws"], 2),
                                "sky_samples_share": round(work["sky_samples"], 4),
                                "note": "two kernels per launch, priced apart (`kernels`); the top-level fields are those of the one that takes more of the "
-                                       "launch.  peak (valu) = fp32 VALU issue rate without FMA (parity forbids contraction) = 157.3/2 TFLOP/s, flops counted "
-                                       "as written in the reference (SURVEY.md 8d) unless `numerator` says executed; peak (hbm) = 8 TB/s.  Kernel times: HIP "
+                                       "launch, on ITS OWN work and time.  peak (valu) = fp32 VALU issue rate without FMA (parity forbids contraction) = 157.3/2 TFLOP/s, flops counted "
+                                       "as written in the reference (SURVEY.md 8d) unless `numerator` says executed.  Kernel times: HIP "
                                        "events inside the library over the timed region -- first compute unit -> event between the kernels -> end of the "
                                        "trace kernel (which contains the in-order sample sum); avg_kernel_ms = the smaller of the per-launch sum (overlapping "
                                        "launches share time) and the span / launches"}

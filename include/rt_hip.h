@@ -391,6 +391,25 @@ RT_API int rt_profile_collect_span(rt_context *ctx, double *kernel_ms_total, int
 RT_API int rt_profile_collect_split(rt_context *ctx, double *kernel_ms_total, int *launches, double *span_ms, double *primary_ms_total);
 
 
+/* Where a step of the N-GPU frame loop goes, per device -- so that a scaling run that falls short says WHY.  After
+ * rt_multi_profile_enable(m, 1) every rt_multi_frame_submit() brackets each phase of the frame on each device with timed events;
+ * rt_multi_profile_collect() waits for the frames in flight and fills per_device[0 ... rt_multi_size(m)).  Several frames are in
+ * flight, so every instant between the device's first and last frame END (first device: frame in host memory; the others: their
+ * part of the gather done) is given to what the device was doing then, whichever frame it was for, by priority: a strip render
+ * in progress (incl. its wait for workgroup slots) > the de-interleave > the copy to the host (these two: first device only) > a
+ * rendered strip waiting for its gather > idle (no launch was there to run).  The five shares are disjoint, sum to step_ms --
+ * the mean interval between two frame ends -- and are ms per step.  Reading: a device that renders all of its step bounds the
+ * frame rate; one that mostly waits for the gather has slack; idle time is the host's.  Costs two to five event records per
+ * device and frame; collect resets the log.  (One device without the collective path records nothing: frames == 0.)
+ * main.c:695-718 is the fan-out this instruments. */
+typedef struct {
+	int    frames;                      /* intervals the means are over */
+	double step_ms;
+	double idle_ms, render_ms, gather_ms, deinterleave_ms, copy_ms;
+} rt_multi_phases;
+RT_API int rt_multi_profile_enable(rt_multi *m, int on);
+RT_API int rt_multi_profile_collect(rt_multi *m, rt_multi_phases *per_device, int capacity);
+
 /* ---- host-side mirror of the reference's loaders / camera (plain C, no GPU needed) ---------- */
 /* scene.c:611 parse_scene_file(): same grammar, defaults, range checks, float accumulation and
  * stderr diagnostics.  Returns RT_OK / RT_ERR_IO / RT_ERR_FORMAT. */

@@ -44,6 +44,7 @@ static void flush_counters(void)
 	g_cnt.box_tests += tl_cnt.box_tests;       g_cnt.box_flops += tl_cnt.box_flops;
 	g_cnt.sphere_tests += tl_cnt.sphere_tests; g_cnt.sphere_flops += tl_cnt.sphere_flops;
 	g_cnt.sky_samples += tl_cnt.sky_samples;   g_cnt.sky_sample_flops += tl_cnt.sky_sample_flops;
+	g_cnt.first_ray_flops += tl_cnt.first_ray_flops;
 	pthread_mutex_unlock(&g_cnt_lock);
 	memset(&tl_cnt, 0, sizeof(tl_cnt));
 }
@@ -388,6 +389,7 @@ static V3 shade_path(float px, float py, float aspect, int max_bounces, uint64_t
 	COUNT(samples, 1);
 	const uint64_t sample_began = FLOPS_NOW();
 	int left_at_once = 0;             /* (counters) the camera ray left the scene: a sky sample */
+	uint64_t first_ray = 0;           /* (counters) flops up to the return of the first trace_ray */
 	const Scene *sc = &G.scene;
 	Ray ray = primary_ray(px, py, aspect);                           /* main.c:135 */
 
@@ -400,6 +402,7 @@ static V3 shade_path(float px, float py, float aspect, int max_bounces, uint64_t
 
 	for (int bounce = 0; bounce < max_bounces; bounce++) {
 		Hit hit = nearest_hit(ray);                                  /* main.c:161 */
+		if (bounce == 0) first_ray = FLOPS_NOW() - sample_began;
 		if (hit.object < 0) {
 			left_at_once = bounce == 0;
 			V3 sky = sky_lookup(unit(ray.direction));                /* main.c:170 */
@@ -467,7 +470,8 @@ static V3 shade_path(float px, float py, float aspect, int max_bounces, uint64_t
 		ray = next;
 	}
 	if (left_at_once) COUNT_SPAN(sky_samples, sky_sample_flops, sample_began);
-	(void) sample_began; (void) left_at_once;
+	else COUNT(first_ray_flops, first_ray);
+	(void) sample_began; (void) left_at_once; (void) first_ray;
 	return v3(clampf(radiance.x, 0, 1), clampf(radiance.y, 0, 1), clampf(radiance.z, 0, 1));
 }
 

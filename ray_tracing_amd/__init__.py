@@ -63,6 +63,67 @@ class TestKnobs(C.Structure):
 TEST_KNOB_NAMES = tuple(n for n, _ in TestKnobs._fields_ if n != "size")
 
 
+class MultiPhases(C.Structure):
+    """rt_multi_phases: where a device's step of the N-GPU frame loop goes (include/rt_hip.h)."""
+    _fields_ = [("frames", C.c_int), ("step_ms", C.c_double), ("idle_ms", C.c_double), ("render_ms", C.c_double), ("gather_ms", C.c_double),
+                ("deinterleave_ms", C.c_double), ("copy_ms", C.c_double)]
+
+
+PHASES = ("idle_ms", "render_ms", "gather_ms", "deinterleave_ms", "copy_ms")
+
+
+def attribute_phases(frames):
+    """Where a device's time goes per step of a PIPELINED frame loop -- the Python twin of rt_multi_profile_collect() (rt_multi.cpp), for
+    hosts that record their own events (multi_gpu.TiledFrame).  frames: per frame, the times (ms, one clock) at which its render
+    stream reached the launch, its strip was rendered, its gather was done, its frame was de-interleaved, its copy to the host was
+    done (a rank that does not assemble the frame repeats the gather's time).
+
+    Several frames are in flight, so a frame's own phases say little about the step: frame f was rendered while frame f - 3 was
+    gathered.  Instead every instant between the first and the last frame END is given to what the device was doing then, whichever
+    frame it was for, by priority: a strip render in progress (from the stream reaching the launch to the end of its trace kernel)
+    > a de-interleave > a copy to the host > a rendered strip waiting for its gather > nothing (idle: no launch was there to run).
+    The five shares are disjoint and sum to the window; divided by the intervals in it they are ms per step."""
+    out = {"frames": 0, "step_ms": 0.0, **{k: 0.0 for k in PHASES}}
+    frames = [tuple(float(x) for x in f) for f in frames]
+    if len(frames) < 2:
+        return out
+    ends = [f[4] for f in frames]
+    t0, t1 = ends[0], max(ends)
+    if not t1 > t0:
+        return out
+    # (class, from, to) of every activity; classes in priority order
+    order = ("render_ms", "deinterleave_ms", "copy_ms", "gather_ms")
+    spans = []
+    for b, r, g, a, c in frames:
+        spans += [("render_ms", b, r), ("gather_ms", r, g), ("deinterleave_ms", g, a), ("copy_ms", a, c)]
+    cuts = sorted({t0, t1} | {t for _, a, b in spans for t in (a, b) if t0 < t < t1})
+    for lo, hi in zip(cuts, cuts[1:]):
+        mid = 0.5 * (lo + hi)
+        active = {k for k, a, b in spans if a <= mid < b}
+        key = next((k for k in order if k in active), "idle_ms")
+        out[key] += hi - lo
+    n = len(frames) - 1
+    out["frames"] = n
+    out["step_ms"] = (t1 - t0) / n
+    for k in PHASES:
+        out[k] /= n
+    return out
+
+
+def judge_phases(per_rank):
+    """From every rank's shares: the critical rank -- the one whose device has the least slack: the smallest share of waiting for the
+    gather or for work --, and what bounds the step there: `render` (its strips, their wait for workgroup slots included), `copy`
+    (de-interleave + the frame's way to the host: rank 0 only), `host` (idle: no launch was there to run) -- or `gather` when even
+    that rank mostly waits for the collective."""
+    ranks = [(i, r) for i, r in enumerate(per_rank or []) if r.get("frames")]
+    if not ranks:
+        return {"critical_rank": None, "step_bound": None}
+    slack = lambda r: r["gather_ms"] + r["idle_ms"]      # noqa: E731
+    critical, c = min(ranks, key=lambda ir: (slack(ir[1]), ir[0]))
+    shares = {"render": c["render_ms"], "gather": c["gather_ms"], "copy": c["deinterleave_ms"] + c["copy_ms"], "host": c["idle_ms"]}
+    return {"critical_rank": critical, "step_bound": max(shares, key=shares.get)}
+
+
 class LaunchReport(C.Structure):
     """rt_launch_report: what a launch left in its control words, and what it was expected to leave."""
     _fields_ = [("launch_checked", C.c_int), ("launch_id", C.c_uint), ("stamp", C.c_uint), ("cancelled", C.c_uint), ("waves_left", C.c_uint),
@@ -84,7 +145,7 @@ class MouseState(C.Structure):
 
 # every symbol include/rt_hip.h and include/rt_hip_testing.h declare (tests check the library exports all of them)
 EXPORTS = [
-    "rt_abi_version", "rt_default_test_knobs", "rt_set_test_knobs", "rt_multi_set_test_knobs", "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
+    "rt_abi_version", "rt_multi_profile_enable", "rt_multi_profile_collect", "rt_default_test_knobs", "rt_set_test_knobs", "rt_multi_set_test_knobs", "rt_default_params", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_set_skybox",
     "rt_set_camera", "rt_set_tuning", "rt_default_tuning", "rt_compile_scene", "rt_scene_is_compiled", "rt_compiled_scene_info", "rt_compiled_scene_counts", "rt_compiled_scene_cache_cap", "rt_spec_stats_read", "rt_spec_symbol_read", "rt_render", "rt_render_device", "rt_stream", "rt_reserve", "rt_strip_rows", "rt_deinterleave_device", "rt_deinterleave_rotated_device", "rt_strip_of_rank",
     "rt_frame_submit", "rt_frame_submit_device", "rt_frame_wait", "rt_frame_poll", "rt_host_alloc", "rt_host_free",
     "rt_multi_frame_submit_device", "rt_multi_collective_info", "rt_multi_create_on_one_device",
@@ -174,6 +235,9 @@ def lib():
             L.rt_multi_frame_submit_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
             L.rt_multi_collective_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
             L.rt_multi_create_on_one_device.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
+        if hasattr(L, "rt_multi_profile_enable"):
+            L.rt_multi_profile_enable.argtypes = [C.c_void_p, C.c_int]
+            L.rt_multi_profile_collect.argtypes = [C.c_void_p, C.POINTER(MultiPhases), C.c_int]
         L.rt_frame_wait.argtypes = [C.c_void_p, C.c_int]
         L.rt_frame_poll.argtypes = [C.c_void_p, C.c_int]
         L.rt_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
@@ -614,6 +678,17 @@ class MultiRenderer(_FrameQueue):
         devs = (C.c_int * 64)()
         _check(lib().rt_multi_collective_info(self._m, C.byref(ranks), devs, C.byref(ver)), "rt_multi_collective_info")
         return {"ranks": ranks.value, "devices": [devs[i] for i in range(ranks.value)], "version": ver.value}
+
+    def profile_phases(self, on=True):
+        """rt_multi_profile_enable(): timed events around every phase of every frame, per device."""
+        _check(lib().rt_multi_profile_enable(self._m, 1 if on else 0), "rt_multi_profile_enable")
+
+    def collect_phases(self):
+        """rt_multi_profile_collect(): per device, dict(frames, step_ms, idle_ms, render_ms, gather_ms, deinterleave_ms, copy_ms)."""
+        n = self.size()
+        a = (MultiPhases * n)()
+        _check(lib().rt_multi_profile_collect(self._m, a, n), "rt_multi_profile_collect")
+        return [{k: getattr(a[i], k) for k, _ in MultiPhases._fields_} for i in range(n)]
 
     def close(self):
         if self._m:

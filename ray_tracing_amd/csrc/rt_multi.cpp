@@ -30,7 +30,9 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
+#include <initializer_list>
 #include <new>
 #include <vector>
 
@@ -116,7 +118,21 @@ struct rt_multi {
 	} fq[RT_FRAME_SLOTS];
 	unsigned long long frames = 0;              /* frame k: render stream k % RT_LAUNCH_SETS, strip buffers k % STRIP_BUFFERS */
 	int prog_w = 0, prog_h = 0;                 /* rt_multi_progressive_begin's frame */
+
+	/* rt_multi_profile_enable(): timed events around every phase of every frame, per device (rt_multi_profile_collect) */
+	struct phase_marks { hipEvent_t render_begins = nullptr, rendered = nullptr, gathered = nullptr, assembled = nullptr, copied = nullptr; };
+	bool profiling = false;
+	std::vector<std::vector<phase_marks>> marks;    /* [device][frame since rt_multi_profile_enable] */
 };
+
+static void free_marks(rt_multi *m);
+/* a timed event recorded on `stream` now (profiling only) */
+static hipError_t mark_now(hipEvent_t *e, hipStream_t stream)
+{
+	hipError_t rc = hipEventCreate(e);
+	if (rc == hipSuccess) rc = hipEventRecord(*e, stream);
+	return rc;
+}
 
 #define MULTI_HIP(expr)                                                                      \
 	do {                                                                                    \
@@ -235,6 +251,7 @@ static int multi_create(rt_multi **out, const int *device_ids, int n, bool one_d
 	m->devices.assign(device_ids, device_ids + n);
 	m->ctx.assign((size_t) n, nullptr);
 	m->dev.resize((size_t) n);
+	m->marks.assign((size_t) n, {});
 	for (int i = 0; i < n; i++) {
 		const int rc = rt_create(&m->ctx[(size_t) i], device_ids[i]);
 		if (rc != RT_OK) { rt_multi_destroy(m); return rc; }          /* rt_last_error() holds rt_create's text */
@@ -265,6 +282,7 @@ void rt_multi_destroy(rt_multi *m)
 {
 	if (!m) return;
 	drain(m);
+	free_marks(m);
 	for (int i = 0; i < m->n; i++) {
 		if (!m->ctx[(size_t) i]) continue;
 		rt_multi::per_device &d = m->dev[(size_t) i];
@@ -379,9 +397,14 @@ static int multi_frame_submit(rt_multi *m, const rt_render_params *params, int s
 		if (e != hipSuccess) { rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: device %d: %s", m->devices[(size_t) i], hipGetErrorString(e)); break; }
 		rt_render_params p = *params;
 		p.rank = rt_strip_of_rank(i, n); p.world = n;     /* rotated by one: device 0, the root, renders the last strip -- never the longest (rt_hip.h) */
+		if (m->profiling) {
+			m->marks[(size_t) i].emplace_back();
+			if (mark_now(&m->marks[(size_t) i].back().render_begins, rs) != hipSuccess) { rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: profiling event"); break; }
+		}
 		rc = rt_render_device(ctx, &p, d.d_strip[j], rs);
 		if (rc != RT_OK) break;
 		enqueued++;
+		if (m->profiling && mark_now(&m->marks[(size_t) i].back().rendered, rs) != hipSuccess) { rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: profiling event"); break; }
 		/* the collective stream takes over behind the render; first this launch's control words (rt_device.h RT_CTL_*: did a wave
 		 * give up after rt_cancel(), did the launch account for every pixel), for rt_multi_frame_wait() -- not on the render
 		 * stream: a copy between two kernels there costs the overlap of consecutive launches */
@@ -396,6 +419,7 @@ static int multi_frame_submit(rt_multi *m, const rt_render_params *params, int s
 		hipError_t e = hipSetDevice(m->devices[(size_t) i]);
 		/* (contexts sharing one device: all the copies ran on the root's stream) */
 		if (e == hipSuccess) e = hipEventRecord(d.gathered[j], m->one_device ? m->dev[0].gather_stream : d.gather_stream);
+		if (e == hipSuccess && m->profiling) e = mark_now(&m->marks[(size_t) i].back().gathered, m->one_device ? m->dev[0].gather_stream : d.gather_stream);
 		if (e != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: device %d: %s", m->devices[(size_t) i], hipGetErrorString(e));
 		else d.gathered_set[j] = true;
 	}
@@ -406,9 +430,11 @@ static int multi_frame_submit(rt_multi *m, const rt_render_params *params, int s
 		if (e == hipSuccess)
 			rc = rt_deinterleave_rotated_device(m->ctx[0], m->d_strips[j], f.d_frame, W, H, rb, n, n > 1 ? 1 : 0, m->dev[0].gather_stream);
 		if (rc == RT_OK && e == hipSuccess) e = hipEventRecord(f.assembled, m->dev[0].gather_stream);
+		if (rc == RT_OK && e == hipSuccess && m->profiling) e = mark_now(&m->marks[0].back().assembled, m->dev[0].gather_stream);
 		if (rc == RT_OK && e == hipSuccess) e = hipStreamWaitEvent(m->copy_stream, f.assembled, 0);
 		if (rc == RT_OK && e == hipSuccess && frame_out) e = hipMemcpyAsync(frame_out, f.d_frame, frame_floats * sizeof(float), hipMemcpyDeviceToHost, m->copy_stream);
 		if (rc == RT_OK && e == hipSuccess) e = hipEventRecord(f.copied, m->copy_stream);      /* (device-resident frame: behind the de-interleave only) */
+		if (rc == RT_OK && e == hipSuccess && m->profiling) e = mark_now(&m->marks[0].back().copied, m->copy_stream);
 		if (rc == RT_OK && e != hipSuccess) rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: %s", hipGetErrorString(e));
 	}
 	if (rc != RT_OK) {
@@ -435,6 +461,85 @@ int rt_multi_frame_submit_device(rt_multi *m, const rt_render_params *params, in
 {
 	if (!d_frame) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_frame_submit_device: d_frame is NULL");
 	return multi_frame_submit(m, params, slot, nullptr, d_frame, hip_event);
+}
+
+/* ---- where a step of the N-GPU frame loop goes, per device (include/rt_hip.h: rt_multi_phases) ----
+ * Several frames are in flight, so a frame's own phases say little about the step (frame f was rendered while frame f - 3 was
+ * gathered).  Every instant between the device's first and last frame END -- the first device: frame in host memory; the others:
+ * their part of the gather done -- is given to what the device was doing then, whichever frame it was for, by priority: a strip
+ * render in progress (from the render stream reaching the launch to the end of its trace kernel: waiting for workgroup slots
+ * behind the previous launches is in it) > a de-interleave > a copy to the host > a rendered strip waiting for its gather >
+ * nothing (idle: no launch was there to run).  The shares are disjoint and sum to the window; divided by the intervals in it
+ * they are ms per step.  (ray_tracing_amd.attribute_phases is the same in Python, for hosts that record their own events.) */
+static void free_marks(rt_multi *m)
+{
+	for (auto &per_device : m->marks)
+		for (auto &k : per_device)
+			for (hipEvent_t e : { k.render_begins, k.rendered, k.gathered, k.assembled, k.copied })
+				if (e) (void) hipEventDestroy(e);
+	m->marks.assign((size_t) m->n, {});
+}
+
+int rt_multi_profile_enable(rt_multi *m, int on)
+{
+	if (!m) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_profile_enable: NULL handle");
+	drain(m);
+	free_marks(m);
+	m->profiling = on != 0;
+	return RT_OK;
+}
+
+int rt_multi_profile_collect(rt_multi *m, rt_multi_phases *per_device, int capacity)
+{
+	if (!m || !per_device || capacity < m->n) return rt_fail(RT_ERR_ARGUMENT, "rt_multi_profile_collect: need room for rt_multi_size() entries");
+	drain(m);
+	for (int i = 0; i < m->n; i++) {
+		rt_multi_phases &out = per_device[i];
+		memset(&out, 0, sizeof(out));
+		const auto &marks = m->marks[(size_t) i];
+		if (marks.size() < 2) continue;
+		MULTI_HIP(hipSetDevice(m->devices[(size_t) i]));
+		const hipEvent_t base = marks[0].render_begins;
+		auto at = [&](hipEvent_t e, double *ms) -> hipError_t { float f = 0; const hipError_t rc = hipEventElapsedTime(&f, base, e); *ms = f; return rc; };
+		struct span { int cls; double from, to; };       /* cls in priority order: 0 render, 1 de-interleave, 2 copy, 3 waiting for the gather */
+		std::vector<span> spans;
+		std::vector<double> cuts;
+		double first_end = 0, last_end = 0;
+		int frames = 0;
+		for (const rt_multi::phase_marks &f : marks) {
+			if (!f.render_begins || !f.rendered || !f.gathered) break;              /* (a submit that failed half way) */
+			double b = 0, r = 0, g = 0, a = 0, c = 0;
+			MULTI_HIP(at(f.render_begins, &b)); MULTI_HIP(at(f.rendered, &r)); MULTI_HIP(at(f.gathered, &g));
+			a = c = g;                                                               /* a device other than the first ends with its gather */
+			if (i == 0 && f.assembled && f.copied) { MULTI_HIP(at(f.assembled, &a)); MULTI_HIP(at(f.copied, &c)); }
+			spans.push_back({ 0, b, r }); spans.push_back({ 3, r, g }); spans.push_back({ 1, g, a }); spans.push_back({ 2, a, c });
+			if (frames == 0) first_end = c;
+			if (c > last_end) last_end = c;
+			frames++;
+		}
+		if (frames < 2 || !(last_end > first_end)) continue;
+		cuts.push_back(first_end); cuts.push_back(last_end);
+		for (const span &sp : spans)
+			for (double t : { sp.from, sp.to })
+				if (t > first_end && t < last_end) cuts.push_back(t);
+		std::sort(cuts.begin(), cuts.end());
+		double share[5] = { 0, 0, 0, 0, 0 };             /* render, de-interleave, copy, gather, idle */
+		for (size_t k = 0; k + 1 < cuts.size(); k++) {
+			const double lo = cuts[k], hi = cuts[k + 1];
+			if (!(hi > lo)) continue;
+			const double mid = 0.5 * (lo + hi);
+			int cls = 4;
+			for (const span &sp : spans)
+				if (sp.from <= mid && mid < sp.to && sp.cls < cls) cls = sp.cls;
+			share[cls] += hi - lo;
+		}
+		const double inv = 1.0 / (frames - 1);
+		out.frames = frames - 1;
+		out.step_ms = (last_end - first_end) * inv;
+		out.render_ms = share[0] * inv; out.deinterleave_ms = share[1] * inv; out.copy_ms = share[2] * inv; out.gather_ms = share[3] * inv; out.idle_ms = share[4] * inv;
+	}
+	free_marks(m);
+	return RT_OK;
 }
 
 /* What the group's communicator itself reports (bench.py puts it into its line): ranks = ncclCommCount of the first

@@ -172,6 +172,7 @@ class TiledFrame:
         self.k = 0
         self.done_events = []             # one per completed frame when record_events is set
         self.render_events = []           # one behind every strip render when record_events is set
+        self.marks = []                   # per frame, its phase boundaries as timed events, when record_events is set (phases())
         self.record_events = False
 
     # -- one frame ---------------------------------------------------------------------------------
@@ -191,14 +192,20 @@ class TiledFrame:
                     s.wait_event(self.assembled[j])        # ... and its de-interleave reads strips[j], which this gather overwrites
             p = self.r.params(self.W, self.H, self.spp, self.max_bounces, seed=self.seed if seed is None else seed,
                               row_block=self.row_block, rank=self.strip_index, world=self.world, kernel=self.kernel)
+            mark = None
+            if self.record_events:           # the frame's phase boundaries (phases()): the render stream reaches the launch ...
+                mark = {"begins": torch.cuda.Event(enable_timing=True)}
+                mark["begins"].record(s)
+                self.marks.append(mark)
             self.r.render_device(p, self.strip[j].data_ptr(), s.cuda_stream)
             self._check_launch(k, s)
             if self.record_events:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(s)
                 self.render_events.append(ev)
+                mark["rendered"] = ev        # ... the strip is rendered ...
             if not self.multi:
-                self._deliver(self.strip[j][:self.H], j, s)
+                self._deliver(self.strip[j][:self.H], j, s, mark)
                 return
             # the collective is ordered behind everything enqueued on s so far (torch hands its stream an event of s)
             _, work = gather_strips(self.strip[j], self.rank, self.world, dst=0,
@@ -213,19 +220,23 @@ class TiledFrame:
             # reads the old bytes every time)
             self.post.wait_event(issued)
             work.wait()
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(enable_timing=mark is not None)
             done.record(self.post)
             self.gathered[j] = done
+            if mark is not None:
+                mark["gathered"] = done      # ... its gather is done ...
             if self.rank == 0:
                 f = k & 1
                 if self.copied[f] is not None:
                     self.post.wait_event(self.copied[f])   # frame[f] is still being copied out
                 frame = assemble(self.strips[j], self.H, self.row_block, self.world, renderer=self.r,
                                  out=self.frame[f], stream=self.post, first=self.first)
-                read = torch.cuda.Event()
+                read = torch.cuda.Event(enable_timing=mark is not None)
                 read.record(self.post)
                 self.assembled[j] = read
-                self._deliver(frame, f, self.post)
+                if mark is not None:
+                    mark["assembled"] = read     # ... the frame is de-interleaved (rank 0) ...
+                self._deliver(frame, f, self.post, mark)
 
     def _check_launch(self, k, s):
         """The control words of the launch just enqueued on `s` travel to the host on the copy stream (not on the render stream:
@@ -252,7 +263,7 @@ class TiledFrame:
                     pass
             raise
 
-    def _deliver(self, frame, slot, source):
+    def _deliver(self, frame, slot, source, mark=None):
         """frame (device, complete on stream `source`) -> pinned host memory, on the copy stream."""
         if self.to_host:
             ready = torch.cuda.Event()
@@ -270,6 +281,26 @@ class TiledFrame:
             done.record(source)
         if self.record_events:
             self.done_events.append(done)
+        if mark is not None:
+            mark["copied"] = done            # ... and in host memory (rank 0)
+
+    def phases(self):
+        """Where this rank's step goes (bench.py's `per_rank`): the frames recorded while record_events was set, divided as
+        rt_multi_profile_collect() divides them (ray_tracing_amd.attribute_phases).  Call after flush(); resets the log."""
+        from . import attribute_phases
+        marks, self.marks = self.marks, []
+        marks = [m for m in marks if "rendered" in m]
+        if len(marks) < 2:
+            return attribute_phases([])
+        base = marks[0]["begins"]
+        rows = []
+        for m in marks:
+            begins, rendered = base.elapsed_time(m["begins"]), base.elapsed_time(m["rendered"])
+            gathered = base.elapsed_time(m["gathered"]) if "gathered" in m else rendered
+            assembled = base.elapsed_time(m["assembled"]) if "assembled" in m else gathered
+            copied = base.elapsed_time(m["copied"]) if ("copied" in m and self.to_host) else assembled
+            rows.append((begins, rendered, gathered, assembled, copied))
+        return attribute_phases(rows)
 
     def flush(self):
         """Complete every frame in flight; afterwards host_frame (rank 0) holds the last one."""

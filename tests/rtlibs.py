@@ -34,7 +34,7 @@ class CameraBasis(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "object_tests", "rng_draws", "sky_fetches", "flops",
-                                          "box_tests", "box_flops", "sphere_tests", "sphere_flops", "sky_samples", "sky_sample_flops")]
+                                          "box_tests", "box_flops", "sphere_tests", "sphere_flops", "sky_samples", "sky_sample_flops", "first_ray_flops")]
 
 
 # numpy view of the reference's Object (scene.h:24-31): 68 bytes

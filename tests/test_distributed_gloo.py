@@ -70,3 +70,33 @@ def test_gather_and_deinterleave_over_gloo(world, H, rb, W):
         p.join(300)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_phase_attribution_of_a_pipelined_frame_loop():
+    """ray_tracing_amd.attribute_phases / judge_phases (the Python twin of rt_multi_profile_collect): synthetic timelines, no GPU."""
+    import ray_tracing_amd as rt
+    # a serial loop: every frame starts when the previous one is in host memory -- 1 idle, 4 render, 2 gather, 1 de-interleave, 2 copy
+    serial = [(10 * k + 1, 10 * k + 5, 10 * k + 7, 10 * k + 8, 10 * k + 10) for k in range(6)]
+    a = rt.attribute_phases(serial)
+    assert a["frames"] == 5 and a["step_ms"] == 10
+    assert [a[k] for k in rt.PHASES] == [1, 4, 2, 1, 2]
+    # a pipelined loop: renders back to back (4 ms each); gather, de-interleave and copy of frame k run beside the render of frame
+    # k + 1: the device renders ALL the time, and that is what the step is made of
+    pipe = [(4 * k, 4 * k + 4, 4 * k + 5, 4 * k + 5.5, 4 * k + 6.5) for k in range(8)]
+    b = rt.attribute_phases(pipe)
+    assert b["step_ms"] == 4 and abs(sum(b[k] for k in rt.PHASES) - 4) < 1e-9
+    assert abs(b["render_ms"] - 4 * 6 / 7 - 2.5 / 7) < 0.3 and b["idle_ms"] == 0        # (the last frame's tail is not covered by a next render)
+    # a deep pipeline whose renders take 1 of 4 ms: the rest of the step the rendered strips wait for the gather
+    waiting = [(4 * k, 4 * k + 1, 4 * k + 12, 4 * k + 12, 4 * k + 12) for k in range(40)]
+    c = rt.attribute_phases(waiting)
+    assert c["step_ms"] == 4 and abs(c["render_ms"] - 1) < 0.2 and abs(c["gather_ms"] - 3) < 0.2
+    # the critical rank is the one with the least slack; the bound is its largest share
+    root = dict(a, render_ms=1, gather_ms=6, idle_ms=0, deinterleave_ms=1, copy_ms=2)
+    fast = dict(a, render_ms=2, gather_ms=8, idle_ms=0, deinterleave_ms=0, copy_ms=0)
+    slow = dict(a, render_ms=9, gather_ms=1, idle_ms=0, deinterleave_ms=0, copy_ms=0)
+    assert rt.judge_phases([root, fast, slow]) == {"critical_rank": 2, "step_bound": "render"}
+    starved = dict(slow, render_ms=2, idle_ms=8, gather_ms=0)
+    assert rt.judge_phases([root, fast, starved, slow]) == {"critical_rank": 3, "step_bound": "render"}
+    assert rt.judge_phases([dict(root, gather_ms=1, copy_ms=7), fast]) == {"critical_rank": 0, "step_bound": "copy"}
+    assert rt.judge_phases([dict(root, gather_ms=7, render_ms=1), dict(fast, gather_ms=9, render_ms=1)]) == {"critical_rank": 0, "step_bound": "gather"}
+    assert rt.judge_phases([]) == {"critical_rank": None, "step_bound": None}

@@ -251,6 +251,28 @@ def test_native_multi_gpu_entry_two_devices(gpu):
     m.close()
 
 
+def _check_per_rank(line, ranks):
+    """The N > 1 bench line says where every rank's step went (round 6): one entry per rank, five disjoint shares of the rank's timed
+    window -- strip render, de-interleave, copy, waiting for the gather, idle -- that sum to its step, the rank with the least slack,
+    and what bounds the step there."""
+    pr = line["per_rank"]
+    assert len(pr) == ranks and [r["rank"] for r in pr] == list(range(ranks))
+    for r in pr:
+        assert r["frames"] == line["steps"] - 1, r                      # one interval fewer than frames recorded in the timed region
+        phases = [r[k] for k in ("idle_ms", "render_ms", "gather_ms", "deinterleave_ms", "copy_ms")]
+        assert all(v >= 0 for v in phases) and r["step_ms"] > 0
+        assert abs(sum(phases) - r["step_ms"]) <= 0.10 * r["step_ms"], r
+        if r["rank"] > 0:                                               # only the root assembles the frame and copies it out
+            assert r["deinterleave_ms"] == 0 and r["copy_ms"] == 0
+    assert pr[0]["copy_ms"] > 0
+    # (a run of four steps with six frames in flight may have rendered all of a rank's strips before its first frame ended)
+    assert sum(r["render_ms"] for r in pr) > 0 or line["steps"] < 8
+    # every rank's step is the same frame rate, seen from its own end of the pipeline
+    steps = [r["step_ms"] for r in pr]
+    assert max(steps) <= 1.5 * min(steps) + 0.5, steps
+    assert line["critical_rank"] in range(ranks) and line["step_bound"] in ("render", "gather", "copy", "host")
+
+
 def test_bench_self_launch_four_ranks_sharing_the_gpu():
     """`python bench.py --gpus 4 --share-gpu`: the self-launched N-rank bench (a child torch.distributed.run, one process per
     rank) end to end on the one GPU of the box -- strips over gloo -- with its built-in check of the last frame."""
@@ -265,6 +287,7 @@ def test_bench_self_launch_four_ranks_sharing_the_gpu():
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 4 and line["verified"] is True and line["verification"]["equals_blocking_rt_render"] is True
     assert "SHARING ONE GPU" in line["config"]["partition"]
+    _check_per_rank(line, 4)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (ncclGather between them)")
@@ -310,6 +333,7 @@ def test_bench_native_multi_eight_contexts_on_the_one_gpu():
     assert line["n_gpus"] == 8 and line["verified"] is True
     assert line["collective"]["contexts"] == 8 and line["collective"]["ranks_seen"] == 0      # no communicator on one device
     assert "one host process" in line["config"]["frame_loop"]
+    _check_per_rank(line, 8)
 
 
 def test_bench_native_multi_one_rank_communicator():
@@ -319,6 +343,15 @@ def test_bench_native_multi_one_rank_communicator():
     assert line["verified"] is True
     c = line["collective"]
     assert c["ranks_seen"] == 1 and c["devices_seen"] == [0] and c["rccl_version"] > 20000
+    _check_per_rank(line, 1)
+
+
+def test_bench_one_rank_process_group_over_rccl():
+    """`bench.py --force-collective --torch-loop`: the one-process-per-GPU host (multi_gpu.TiledFrame over torch.distributed, backend
+    nccl = RCCL) on a one-rank process group -- gather, de-interleave, copy stream -- with the phases of its step in the line."""
+    line = _bench_line(["--gpus", "1", "--force-collective", "--torch-loop", "--steps", "4", "--warmup", "2"])
+    assert line["verified"] is True and line["collective"]["backend"] == "nccl"
+    _check_per_rank(line, 1)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (ncclGather between them)")
