@@ -187,7 +187,8 @@ def executed_work_of_culled_scene(rt, scene, camera, sky, W, H, spp, nb, seed):
     execs = lambda site: out[2 * site]          # noqa: E731
     n = float(w * h * spp)
     return {"per_sample": {"box_tests": lanes(1) / n, "sphere_tests": lanes(3) / n, "sphere_roots": lanes(4) / n,
-                           "cluster_slab_tests": lanes(32) / n, "member_slab_tests": 2.0 * lanes(34) / n,      # (site 34 stands in front of a PAIR of members' grid boxes)
+                           "cluster_slab_tests": (lanes(32) + lanes(43) + 8.0 * lanes(45)) / n,      # every cluster box (few clusters) / group boxes + the dealt pairs' cluster boxes on the groups' grids (site 45: all EIGHT of a group)
+                           "member_slab_tests": 8.0 * lanes(34) / n,      # (site 34 stands in front of the EIGHT member boxes of a cluster)
                            "rays": lanes(13) / n + lanes(9) / n, "shading_events": lanes(8) / n, "culled_traces_of_a_wave": execs(9) / n},
             "frame": f"{w}x{h}x{spp} spp, {nb} bounces (1/16 of the bench frame's pixels, same camera and samples per pixel)",
             "source": "librt_hip_stats.so (-DRT_STATS per-site lane counters, csrc/rt_stats.hip.h), this run"}

@@ -525,14 +525,17 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 	memcpy(ctx->light_pos, info.light_pos, sizeof(ctx->light_pos));
 	/* scenes of more than 64 objects: clusters for the culled trace (also sets the half extents in the spheres' records) */
 	std::vector<rt_cluster> clusters;
-	ctx->cull = fast_ok ? rt_cull_build(geom, n, clusters) : rt_cull_info{ 0, 0.0f, 0.0f };
+	std::vector<rt_group> groups;
+	ctx->cull = fast_ok ? rt_cull_build(geom, n, clusters, groups) : rt_cull_info{ 0, 0.0f, 0.0f };
 	if (ctx->cull.num_clusters > 0) {
 		if (ctx->cull.num_clusters > ctx->clusters_capacity) {
 			(void) hipFree(ctx->d_clusters); ctx->d_clusters = nullptr; ctx->clusters_capacity = 0;
-			HIP_TRY(hipMalloc((void**) &ctx->d_clusters, (size_t) RT_MAX_CLUSTERS * sizeof(rt_cluster)));
+			HIP_TRY(hipMalloc((void**) &ctx->d_clusters, (size_t) RT_CULL_F4(RT_MAX_CLUSTERS) * 16));      /* the cluster records, the group records behind them */
 			ctx->clusters_capacity = RT_MAX_CLUSTERS;
 		}
+		static_assert(sizeof(rt_cluster) == 16 * RT_CLUSTER_F4 && sizeof(rt_group) == 16 * RT_GROUP_F4, "records as float4 words");
 		HIP_TRY(hipMemcpy(ctx->d_clusters, clusters.data(), clusters.size() * sizeof(rt_cluster), hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(ctx->d_clusters + clusters.size(), groups.data(), groups.size() * sizeof(rt_group), hipMemcpyHostToDevice));
 	}
 	ctx->h_geom.assign(geom.begin(), geom.begin() + n);
 	ctx->spec_module = nullptr; ctx->spec_fn = nullptr;      /* (not unloaded: rt_jit.cpp keeps compiled scenes for the life of the process) */

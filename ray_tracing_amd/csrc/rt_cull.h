@@ -30,6 +30,12 @@
  *     kernels form), and the kernels' parameter of a grid plane, fma(q, step * r, fma(lo, r, -o * r)), has an error of at most
  *     2^-24 (|q step r| + |o r| + |b| + |t|) <= 6.0e-7 S / |d| = 3.8e-5 / |d| at S = 64: the margin keeps a factor of 51.
  *
+ *   - one level up (round 6, rt_device.h rt_group): groups of eight consecutive clusters, tested as the union of their boxes with the
+ *     cluster-box arithmetic, and a group's clusters as their boxes QUANTISED outwards on the group's grid with the member-box
+ *     arithmetic: every box of the chain member (inflated) < cluster < quantised cluster < group contains the one before, so a ray
+ *     that the reference lets hit a member passes each of them with at least the slack the margin gives the innermost, against the
+ *     same error bounds as above (tests/csrc/cull_check.cpp holds every reference hit against the whole chain).
+ *
  * Clusters: the leaves of a median-split tree over the objects' centres, RT_CLUSTER_SIZE objects each (members keep their object
  * indices: ties between equal distances go to the lowest INDEX whatever the order of the tests).
  */
@@ -63,11 +69,30 @@ static inline void rt_cull_object_box(const rt_geom &g, float m, float lo[3], fl
 }
 
 
-/* Fills `clusters` (and the spheres' geom.b1) when the scene qualifies; returns num_clusters = 0 otherwise. */
-static inline rt_cull_info rt_cull_build(std::vector<rt_geom> &geom, int n, std::vector<rt_cluster> &clusters)
+/* box j of an array of box pairs (rt_device.h RT_QPLANE): [blo, bhi] on the grid of [lo, hi] (RT_CLUSTER_GRID steps per axis, the float
+ * step the kernels form), rounded OUTWARDS.  Checked in double: lo + q_lo * step <= blo and lo + q_hi * step >= bhi. */
+static inline void rt_cull_quantise(const float lo[3], const float hi[3], const float blo[3], const float bhi[3], unsigned char (*qpair)[12], int j)
+{
+	for (int k = 0; k < 3; k++) {
+		const double origin = (double) lo[k], step = (double) RT_CLUSTER_STEP(lo[k], hi[k]);
+		int qa = 0, qb = 255;
+		if (step > 0.0) {
+			qa = (int) floor(((double) blo[k] - origin) / step); qb = (int) ceil(((double) bhi[k] - origin) / step);
+			qa = qa < 0 ? 0 : (qa > 255 ? 255 : qa); qb = qb < 0 ? 0 : (qb > 255 ? 255 : qb);
+			while (qa > 0 && origin + qa * step > (double) blo[k]) qa--;
+			while (qb < 255 && origin + qb * step < (double) bhi[k]) qb++;
+		}
+		RT_QPLANE(qpair, j, k, 0) = (unsigned char) qa;
+		RT_QPLANE(qpair, j, k, 1) = (unsigned char) qb;
+	}
+}
+
+/* Fills `clusters` and `groups` (and the spheres' geom.b1) when the scene qualifies; returns num_clusters = 0 otherwise. */
+static inline rt_cull_info rt_cull_build(std::vector<rt_geom> &geom, int n, std::vector<rt_cluster> &clusters, std::vector<rt_group> &groups)
 {
 	rt_cull_info info = { 0, RT_CULL_MARGIN, 0.0f };
 	clusters.clear();
+	groups.clear();
 	if (n < RT_CULL_MIN_OBJECTS || n > RT_CLUSTER_SIZE * RT_MAX_CLUSTERS) return info;
 	float S = 0.0f;
 	for (int i = 0; i < n; i++) {
@@ -143,18 +168,29 @@ static inline rt_cull_info rt_cull_build(std::vector<rt_geom> &geom, int n, std:
 		for (int j = 0; j < cnt; j++) {
 			float blo[3], bhi[3];
 			rt_cull_object_box(geom[(size_t) members[j]], margin, blo, bhi);
-			for (int k = 0; k < 3; k++) {
-				const double origin = (double) lo[k], step = (double) RT_CLUSTER_STEP(lo[k], hi[k]);
-				int qa = 0, qb = 255;
-				if (step > 0.0) {
-					qa = (int) floor(((double) blo[k] - origin) / step); qb = (int) ceil(((double) bhi[k] - origin) / step);
-					qa = qa < 0 ? 0 : (qa > 255 ? 255 : qa); qb = qb < 0 ? 0 : (qb > 255 ? 255 : qb);
-					while (qa > 0 && origin + qa * step > (double) blo[k]) qa--;
-					while (qb < 255 && origin + qb * step < (double) bhi[k]) qb++;
-				}
-				K.qbox[j][k] = (unsigned char) qa;
-				K.qbox[j][3 + k] = (unsigned char) qb;
-			}
+			rt_cull_quantise(lo, hi, blo, bhi, K.qpair, j);
+		}
+	}
+	/* groups of RT_GROUP_SIZE consecutive clusters (the clusters are in the order of the split tree: neighbours in it are neighbours
+	 * in space): the union of their boxes, and their boxes on the group's grid, rounded outwards */
+	const int Gn = RT_NUM_GROUPS(C);
+	groups.assign((size_t) Gn, rt_group());
+	for (int gi = 0; gi < Gn; gi++) {
+		rt_group &Gr = groups[(size_t) gi];
+		memset(&Gr, 0, sizeof(Gr));
+		const int first = gi * RT_GROUP_SIZE, cnt = std::min(RT_GROUP_SIZE, C - first);
+		float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
+		for (int j = 0; j < cnt; j++) {
+			const rt_cluster &K = clusters[(size_t) (first + j)];
+			const float klo[3] = { K.lo[0], K.lo[1], K.lo[2] }, khi[3] = { K.hi0, K.hi1, K.hi2 };
+			for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], klo[k]); hi[k] = std::max(hi[k], khi[k]); }
+		}
+		Gr.lo[0] = lo[0]; Gr.lo[1] = lo[1]; Gr.lo[2] = lo[2]; Gr.hi0 = hi[0]; Gr.hi1 = hi[1]; Gr.hi2 = hi[2];
+		Gr.count = cnt;
+		for (int j = 0; j < cnt; j++) {
+			const rt_cluster &K = clusters[(size_t) (first + j)];
+			const float klo[3] = { K.lo[0], K.lo[1], K.lo[2] }, khi[3] = { K.hi0, K.hi1, K.hi2 };
+			rt_cull_quantise(lo, hi, klo, khi, Gr.qpair, j);
 		}
 	}
 	info.num_clusters = C;

@@ -53,17 +53,45 @@ typedef struct {
  * lanes test a cluster's members against, 64 bytes per cluster instead of 8 x 32 of geometry records. */
 #define RT_CLUSTER_SIZE 8
 #define RT_MAX_CLUSTERS 128
-#define RT_CLUSTER_F4 7              /* a cluster as float4 words: 2 of box and count, 1 of members, 4 of quantised member boxes */
+#define RT_CLUSTER_F4 7              /* a cluster as float4 words: 2 of box and count, 1 of members, 3 of quantised member boxes, 1 unused */
 #define RT_CLUSTER_GRID 254
 typedef struct {
 	float          lo[3], hi0;
 	float          hi1, hi2;
 	int            count, pad;
 	unsigned short member[RT_CLUSTER_SIZE];
-	unsigned char  qbox[RT_CLUSTER_SIZE][8];   /* member j: lo.x lo.y lo.z hi.x | hi.y hi.z 0 0, in steps of (hi - lo) * RN(1 / RT_CLUSTER_GRID) from lo */
+	unsigned char  qpair[RT_CLUSTER_SIZE / 2][12];   /* the members' boxes in steps of (hi - lo) * RN(1 / RT_CLUSTER_GRID) from lo, two members to twelve bytes (RT_QPLANE below) */
+	unsigned char  pad2[16];                   /* (seven slots: an odd number, see above) */
 } rt_cluster;
+/* Plane `upper` (0 / 1) of axis k of box j in an array of box PAIRS: three words per pair -- word 0: box 2p (lo.x hi.x lo.y hi.y), word 1:
+ * box 2p + 1 likewise, word 2: lo.z hi.z of box 2p, lo.z hi.z of box 2p + 1.  The two planes of an axis are neighbours so that ONE byte
+ * permute per word (v_perm_b32 with a selector formed once per ray from the signs of its direction) puts the plane the ray meets first in
+ * front: the slab test then needs no min / max per axis (round 6: they were a third of its cycles -- v_min / v_max issue at half the rate
+ * of v_fma on gfx950, profiles/r02/valu_rates.txt). */
+#define RT_QPLANE(qpair, j, k, upper) ((qpair)[(j) >> 1][(k) < 2 ? 4 * ((j) & 1) + 2 * (k) + (upper) : 8 + 2 * ((j) & 1) + (upper)])
 /* the grid's step along one axis, formed the same way -- one subtraction, one product by the literal -- on the host and in the kernels */
 #define RT_CLUSTER_STEP(lo, hi) (((hi) - (lo)) * (1.0f / (float) RT_CLUSTER_GRID))
+
+/* One level up (round 6): GROUPS of RT_GROUP_SIZE consecutive clusters -- consecutive in the order of the median-split tree, i.e.
+ * neighbours in space.  Asking every cluster box for every ray, wave-uniformly, was half the instructions of a culled trace at 1024
+ * objects (128 steps, of which a ray passes 4 ... 7); now the wave asks the <= 16 group boxes uniformly, and the (ray, group) pairs
+ * that pass are DEALT to the lanes 64 at a time -- as the (ray, cluster) pairs always were -- each lane testing its pair's eight
+ * cluster boxes: 16 + 3 ... 6 x 8 box tests per trace instead of 128.  A per-lane walk of a tree over the clusters would cost a wave
+ * the MAXIMUM over its lanes -- 75 ... 85 node visits, each with its own LDS reads (scripts/sim/bvh_walk_sim.py) --: dealing keeps
+ * the lanes full.  A group record: its box (the union of its clusters' boxes), the count of its clusters, and its clusters' boxes
+ * quantised outwards on the group's grid exactly as a cluster's members are on the cluster's (80 bytes = five 16-byte slots).  The
+ * records follow the cluster records in the same buffer (rt_launch.clusters + num_clusters): RT_CULL_F4 float4 words in all. */
+#define RT_GROUP_SIZE 8
+#define RT_GROUP_F4 5
+#define RT_NUM_GROUPS(clusters) (((clusters) + RT_GROUP_SIZE - 1) / RT_GROUP_SIZE)
+#define RT_CULL_F4(clusters) (RT_CLUSTER_F4 * (clusters) + RT_GROUP_F4 * RT_NUM_GROUPS(clusters))
+#define RT_GROUPS_FROM_CLUSTERS 33    /* scenes of fewer clusters ask every cluster box, as before (dealing costs more than it saves there) */
+typedef struct {
+	float          lo[3], hi0;
+	float          hi1, hi2;
+	int            count, pad;                 /* clusters in the group (the last group may have fewer than RT_GROUP_SIZE) */
+	unsigned char  qpair[RT_GROUP_SIZE / 2][12];   /* the group's clusters' boxes on the group's grid (RT_CLUSTER_STEP of the group's box), in pairs (RT_QPLANE) */
+} rt_group;
 
 /* The control words of a launch: one 128-byte line behind the pixel lists' counters (rt_launch.control), cleared when the
  * launch is enqueued, copied to the host behind it (the first RT_CTL_WORDS words) and judged there (rt_api.cpp judge_launch):

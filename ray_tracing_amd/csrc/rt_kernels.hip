@@ -337,10 +337,18 @@ RT_DEV Hit nearest_hit_fast(const SceneLDS &sc, int n, V3 o, V3 d, bool want_nor
  * "lowest index among equal distances" (strict `<` in index order, scene.c:168) is kept explicitly, because the clusters
  * are visited out of index order. */
 typedef const __attribute__((address_space(4))) float *rt_const_f;        /* memory read with scalar loads when the address is wave-uniform */
-struct ClusterLDS { const float4 *recs; rt_const_f mem; int count; float margin, origin_max; };      /* recs: the rt_cluster records (RT_CLUSTER_F4 x float4 each) in LDS; mem: the same in memory, for scalar loads */
-/* a wave's scratch for the culled trace: the rays' best hits, and the queue of (ray, object) candidates waiting for their exact test */
+/* recs: the rt_cluster records (RT_CLUSTER_F4 x float4 each) in LDS; mem: the same in memory, for scalar loads; groups / gmem: the rt_group records behind them */
+struct ClusterLDS { const float4 *recs; rt_const_f mem; int count; float margin, origin_max; const float4 *groups; rt_const_f gmem; int ngroups; };
+/* a wave's scratch for the culled trace: the rays' best hits and the queue of (ray, object) candidates waiting for their exact test --
+ * and, before those are in use, the rays' cluster masks as the dealt (ray, group) pairs fill them in, a byte per group (16 bytes per ray) */
 #define CULL_QUEUE 128
-struct CullWave { unsigned long long best[64]; unsigned short queue[CULL_QUEUE]; };
+struct CullWave {
+	union {
+		struct { unsigned long long best[64]; unsigned short queue[CULL_QUEUE]; };
+		uint32_t cmask[64][RT_MAX_CLUSTERS / 32];
+	};
+};
+static_assert(RT_MAX_CLUSTERS / RT_GROUP_SIZE == 16 && RT_GROUP_SIZE == 8, "a ray's cluster mask is sixteen bytes, one per group");
 
 /* the conservative slab test: parameters plane * (1/d) - o * (1/d), one fused multiply-add each (oi = o * inv is formed once per
  * ray).  This is the cull's own arithmetic, not the reference's: its error -- 2^-23 |t| + 2^-24 |o| / |d| <= 3.1e-5 / |d| with
@@ -355,18 +363,53 @@ RT_DEV bool slab_may_touch(V3 oi, V3 inv, V3 lo, V3 hi)
 	return enter <= leave && leave >= 0.0f;
 }
 
-/* A cluster's member j against a ray, on the cluster's grid (rt_device.h rt_cluster.qbox): the parameter of grid plane q along an
- * axis is (lo + q step - o) / d = q (step r) + (lo r - o r), one fused multiply-add with the per-(ray, cluster) constants gs = step r
- * and gb = fma(lo, r, -o r); v_cvt_f32_ubyteN turns byte N of a word into the float q.  The boxes were rounded outwards on the host
- * (rt_cull.h), so this never misses what the members' own conservative boxes would catch. */
-RT_DEV bool grid_box_may_touch(uint32_t w0, uint32_t w1, V3 gs, V3 gb)
+/* Two boxes of a record's box pairs (rt_device.h RT_QPLANE: a cluster's members on the cluster's grid, a group's clusters on the group's)
+ * against a ray.  The parameter of grid plane q along an axis is (lo + q step - o) / d = q (step r) + (lo r - o r), one fused multiply-add
+ * with the per-(ray, record) constants gs = step r and gb = fma(lo, r, -o r); v_cvt_f32_ubyteN turns byte N of a word into the float q.
+ * Which of an axis's two planes the ray meets first is the sign of r: ONE byte permute per word (selectors formed once per ray,
+ * grid_selectors) puts it in front, and the slab test is max3 / min3 / one compare -- fma is monotonic in q, so the plane picked by the
+ * sign IS the min of the two parameters, bit for bit (tests/csrc/cull_check.cpp compares the two forms).  No parameter can be a NaN
+ * (gs, gb finite: the direction window of the cull), so "enter <= leave and leave >= 0" is max(enter, 0) <= leave.  The boxes were rounded
+ * outwards on the host (rt_cull.h), so this never misses what the boxes' own conservative tests would catch.  Returns bit 0 / bit 1. */
+struct GridSel { uint32_t xy, z; };
+RT_DEV GridSel grid_selectors(V3 inv)
 {
-	const float ax = __builtin_fmaf((float) (w0 & 255u), gs.x, gb.x), ay = __builtin_fmaf((float) ((w0 >> 8) & 255u), gs.y, gb.y);
-	const float az = __builtin_fmaf((float) ((w0 >> 16) & 255u), gs.z, gb.z), bx = __builtin_fmaf((float) (w0 >> 24), gs.x, gb.x);
-	const float by = __builtin_fmaf((float) (w1 & 255u), gs.y, gb.y), bz = __builtin_fmaf((float) ((w1 >> 8) & 255u), gs.z, gb.z);
-	const float enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
-	const float leave = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-	return enter <= leave && leave >= 0.0f;
+	GridSel g;      /* word (lo.x hi.x lo.y hi.y): swap the pair of an axis the ray runs down; word (lo.z hi.z | lo.z hi.z of the second box): both or neither */
+	g.xy = (inv.x < 0.0f ? 0x0001u : 0x0100u) | (inv.y < 0.0f ? 0x02030000u : 0x03020000u);
+	g.z = inv.z < 0.0f ? 0x02030001u : 0x03020100u;
+	return g;
+}
+RT_DEV uint32_t grid_pair_may_touch(uint32_t w0, uint32_t w1, uint32_t w2, GridSel sel, V3 gs, V3 gb)
+{
+	const uint32_t a = __builtin_amdgcn_perm(w0, w0, sel.xy), b = __builtin_amdgcn_perm(w1, w1, sel.xy), z = __builtin_amdgcn_perm(w2, w2, sel.z);
+	uint32_t bits = 0u;
+	{
+		const float nx = __builtin_fmaf((float) (a & 255u), gs.x, gb.x), fx = __builtin_fmaf((float) ((a >> 8) & 255u), gs.x, gb.x);
+		const float ny = __builtin_fmaf((float) ((a >> 16) & 255u), gs.y, gb.y), fy = __builtin_fmaf((float) (a >> 24), gs.y, gb.y);
+		const float nz = __builtin_fmaf((float) (z & 255u), gs.z, gb.z), fz = __builtin_fmaf((float) ((z >> 8) & 255u), gs.z, gb.z);
+		const float enter = __builtin_fmaxf(__builtin_fmaxf(nx, ny), __builtin_fmaxf(nz, 0.0f));
+		const float leave = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+		if (enter <= leave) bits |= 1u;
+	}
+	{
+		const float nx = __builtin_fmaf((float) (b & 255u), gs.x, gb.x), fx = __builtin_fmaf((float) ((b >> 8) & 255u), gs.x, gb.x);
+		const float ny = __builtin_fmaf((float) ((b >> 16) & 255u), gs.y, gb.y), fy = __builtin_fmaf((float) (b >> 24), gs.y, gb.y);
+		const float nz = __builtin_fmaf((float) ((z >> 16) & 255u), gs.z, gb.z), fz = __builtin_fmaf((float) (z >> 24), gs.z, gb.z);
+		const float enter = __builtin_fmaxf(__builtin_fmaxf(nx, ny), __builtin_fmaxf(nz, 0.0f));
+		const float leave = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+		if (enter <= leave) bits |= 2u;
+	}
+	return bits;
+}
+/* all four pairs of a record whose three words of pairs are p0, p1, p2: one bit per box */
+RT_DEV uint32_t grid_boxes_may_touch(float4 p0, float4 p1, float4 p2, GridSel sel, V3 gs, V3 gb)
+{
+	const uint32_t w[12] = { __float_as_uint(p0.x), __float_as_uint(p0.y), __float_as_uint(p0.z), __float_as_uint(p0.w), __float_as_uint(p1.x), __float_as_uint(p1.y),
+	                         __float_as_uint(p1.z), __float_as_uint(p1.w), __float_as_uint(p2.x), __float_as_uint(p2.y), __float_as_uint(p2.z), __float_as_uint(p2.w) };
+	uint32_t bits = 0u;
+#pragma unroll
+	for (int p = 0; p < 4; p++) bits |= grid_pair_may_touch(w[3 * p], w[3 * p + 1], w[3 * p + 2], sel, gs, gb) << (2 * p);
+	return bits;
 }
 
 /* the value lane `src` holds (every lane of the wave must be active: ds_bpermute reads registers of executing lanes) */
@@ -398,23 +441,91 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, C
 		return h;
 	}
 	if (on) STAT(9);
-	/* 1. which clusters may this ray touch?  (wave-uniform loop: one box per step, read once for all lanes) */
+	/* 1. which clusters may this ray touch? */
 	uint32_t mask[RT_MAX_CLUSTERS / 32];
 	const V3 oi = mk3(o.x * rp.inv.x, o.y * rp.inv.y, o.z * rp.inv.z);
+	/* the first lane whose inclusive prefix sum exceeds q: whose pair number q is (steps 1b and 2 deal pairs to the lanes) */
+	auto owner_of = [&](uint32_t sums, uint32_t q) {
+		int src = 0;
 #pragma unroll
-	for (int w = 0; w < RT_MAX_CLUSTERS / 32; w++) {
-		uint32_t bits = 0u;
-		const int first = 32 * w, last = cl.count < first + 32 ? cl.count : first + 32;
-		for (int c = first; c < last; c++) {
-			STAT(32);
-			/* the box is the same for all lanes: two scalar loads, planes as scalar operands of the FMAs -- the LDS pipe is what the
-			 * culled trace is short of (the members' boxes, the geometry, the cross-lane fetches and the minimum all go through it) */
-			const rt_const_f km = cl.mem + 4 * RT_CLUSTER_F4 * c;
+		for (int bit = 32; bit >= 1; bit >>= 1) {
+			const uint32_t v = from_lane(sums, src + bit - 1);
+			if (v <= q) src += bit;
+		}
+		return src > 63 ? 63 : src;
+	};
+	if (cl.count >= RT_GROUPS_FROM_CLUSTERS) {
+		/* 1a. the GROUPS of eight clusters, wave-uniformly: one box per step, read once for all lanes (scalar loads, planes as scalar
+		 * operands of the FMAs) -- sixteen steps for 1024 objects where asking every cluster box took 128 */
+		uint32_t gbits = 0u;
+		for (int k = 0; k < cl.ngroups; k++) {
+			STAT(43);
+			const rt_const_f km = cl.gmem + 4 * RT_GROUP_F4 * k;
 			float4 k0, k1;
 			k0.x = km[0]; k0.y = km[1]; k0.z = km[2]; k0.w = km[3]; k1.x = km[4]; k1.y = km[5];
-			if (slab_may_touch(oi, rp.inv, mk3(k0.x, k0.y, k0.z), mk3(k0.w, k1.x, k1.y))) bits |= 1u << (c - first);
+			if (slab_may_touch(oi, rp.inv, mk3(k0.x, k0.y, k0.z), mk3(k0.w, k1.x, k1.y))) gbits |= 1u << k;
 		}
-		mask[w] = on ? bits : 0u;
+		if (!on) gbits = 0u;
+		/* 1b. the wave's (ray, group) pairs, numbered by a prefix sum over the lanes' counts and dealt 64 at a time, as the (ray, cluster)
+		 * pairs of step 2 are: lane i takes pair 64 k + i, fetches the ray from its lane's registers, tests the group's eight cluster
+		 * boxes on the group's grid (the member-box test) and writes the eight answers as ONE BYTE of that ray's mask in LDS */
+		*reinterpret_cast<uint4*>(cw->cmask[lane]) = make_uint4(0u, 0u, 0u, 0u);
+		const uint32_t gcount = (uint32_t) __popc(gbits);
+		uint32_t gupto = gcount;
+#pragma unroll
+		for (int step = 1; step < 64; step <<= 1) {
+			const uint32_t below = from_lane(gupto, lane >= step ? lane - step : lane);
+			if (lane >= step) gupto += below;
+		}
+		const uint32_t gtotal = (uint32_t) __builtin_amdgcn_readlane((int) gupto, 63);
+		wave_fence();
+		for (uint32_t base = 0; base < gtotal; base += 64u) {
+			STAT(44);
+			const uint32_t q = base + (uint32_t) lane;
+			const bool mine = q < gtotal;
+			const int src = owner_of(gupto, q);
+			uint32_t r = q - (from_lane(gupto, src) - from_lane(gcount, src));        /* its r-th group */
+			uint32_t gm = from_lane(gbits, src);
+			const V3 sinv = mk3(from_lane(rp.inv.x, src), from_lane(rp.inv.y, src), from_lane(rp.inv.z, src));
+			const V3 soi = mk3(from_lane(oi.x, src), from_lane(oi.y, src), from_lane(oi.z, src));
+			if (mine) {
+				int pos = 0;
+				uint32_t t_;
+				t_ = (uint32_t) __popc(gm & 0xffu); if (r >= t_) { pos += 8; r -= t_; gm >>= 8; }
+				t_ = (uint32_t) __popc(gm & 0xfu);  if (r >= t_) { pos += 4; r -= t_; gm >>= 4; }
+				t_ = (uint32_t) __popc(gm & 0x3u);  if (r >= t_) { pos += 2; r -= t_; gm >>= 2; }
+				t_ = gm & 1u;                       if (r >= t_) { pos += 1; }
+				const float4 *rec = cl.groups + RT_GROUP_F4 * pos;
+				const float4 k0 = rec[0], k1 = rec[1];
+				const V3 gs = mk3(RT_CLUSTER_STEP(k0.x, k0.w) * sinv.x, RT_CLUSTER_STEP(k0.y, k1.x) * sinv.y, RT_CLUSTER_STEP(k0.z, k1.y) * sinv.z);
+				const V3 gb = mk3(__builtin_fmaf(k0.x, sinv.x, -soi.x), __builtin_fmaf(k0.y, sinv.y, -soi.y), __builtin_fmaf(k0.z, sinv.z, -soi.z));
+				STAT(45);
+				uint32_t touched = grid_boxes_may_touch(rec[2], rec[3], rec[4], grid_selectors(sinv), gs, gb);      /* the group's eight clusters */
+				touched &= (1u << __float_as_int(k1.z)) - 1u;      /* (the last group may have fewer clusters: their slots hold zeros) */
+				reinterpret_cast<unsigned char*>(cw->cmask[src])[pos] = (unsigned char) touched;      /* clusters 8 pos ... 8 pos + 7: byte pos of the ray's sixteen */
+			}
+		}
+		wave_fence();
+		const uint4 mine4 = *reinterpret_cast<const uint4*>(cw->cmask[lane]);
+		mask[0] = mine4.x; mask[1] = mine4.y; mask[2] = mine4.z; mask[3] = mine4.w;
+		wave_fence();                   /* (the masks share their LDS with `best` and the queue, which are written from here on) */
+	} else {
+		/* (few clusters: every cluster box for every ray, wave-uniformly -- one box per step, read once for all lanes) */
+#pragma unroll
+		for (int w = 0; w < RT_MAX_CLUSTERS / 32; w++) {
+			uint32_t bits = 0u;
+			const int first = 32 * w, last = cl.count < first + 32 ? cl.count : first + 32;
+			for (int c = first; c < last; c++) {
+				STAT(32);
+				/* the box is the same for all lanes: two scalar loads, planes as scalar operands of the FMAs -- the LDS pipe is what the
+				 * culled trace is short of (the members' boxes, the geometry, the cross-lane fetches and the minimum all go through it) */
+				const rt_const_f km = cl.mem + 4 * RT_CLUSTER_F4 * c;
+				float4 k0, k1;
+				k0.x = km[0]; k0.y = km[1]; k0.z = km[2]; k0.w = km[3]; k1.x = km[4]; k1.y = km[5];
+				if (slab_may_touch(oi, rp.inv, mk3(k0.x, k0.y, k0.z), mk3(k0.w, k1.x, k1.y))) bits |= 1u << (c - first);
+			}
+			mask[w] = on ? bits : 0u;
+		}
 	}
 	static_assert(RT_MAX_CLUSTERS == 128, "the pair numbering below reads a lane's clusters as four 32-bit words");
 	/* 2. the wave's (ray, cluster) pairs, numbered: inclusive prefix sum of the lanes' counts */
@@ -465,14 +576,7 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, C
 		STAT(33);
 		const uint32_t q = base + (uint32_t) lane;
 		const bool mine = q < total;
-		/* whose ray: the first lane whose inclusive prefix exceeds q */
-		int src = 0;
-#pragma unroll
-		for (int bit = 32; bit >= 1; bit >>= 1) {
-			const uint32_t v = from_lane(upto, src + bit - 1);
-			if (v <= q) src += bit;
-		}
-		src = src > 63 ? 63 : src;
+		const int src = owner_of(upto, q);                                       /* whose ray */
 		uint32_t r = q - (from_lane(upto, src) - from_lane(count, src));        /* its r-th cluster */
 		const uint32_t m0 = from_lane(mask[0], src), m1 = from_lane(mask[1], src), m2 = from_lane(mask[2], src), m3 = from_lane(mask[3], src);
 		const V3 sinv = mk3(from_lane(rp.inv.x, src), from_lane(rp.inv.y, src), from_lane(rp.inv.z, src));
@@ -492,7 +596,7 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, C
 			t_ = (uint32_t) __popc(mm & 0x3u);    if (r >= t_) { pos += 2;  r -= t_; mm >>= 2; }
 			t_ = mm & 1u;                         if (r >= t_) { pos += 1; }
 			const int c = 32 * word + pos;
-			/* the cluster's record: six reads of 16 bytes (box and count, four words of member boxes; the member indices only if a member
+			/* the cluster's record: five reads of 16 bytes (box and count, three words of member boxes; the member indices only if a member
 			 * is touched) where the members' geometry records took sixteen -- and seven slots apart, the lanes' reads spread over the
 			 * whole bank row */
 			const float4 *rec = cl.recs + RT_CLUSTER_F4 * c;
@@ -500,13 +604,8 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, C
 			const float4 k0 = rec[0], k1 = rec[1];
 			const V3 gs = mk3(RT_CLUSTER_STEP(k0.x, k0.w) * sinv.x, RT_CLUSTER_STEP(k0.y, k1.x) * sinv.y, RT_CLUSTER_STEP(k0.z, k1.y) * sinv.z);
 			const V3 gb = mk3(__builtin_fmaf(k0.x, sinv.x, -soi.x), __builtin_fmaf(k0.y, sinv.y, -soi.y), __builtin_fmaf(k0.z, sinv.z, -soi.z));
-#pragma unroll
-			for (int jj = 0; jj < RT_CLUSTER_SIZE / 2; jj++) {
-				const float4 qq = rec[3 + jj];          /* members 2 jj and 2 jj + 1 */
-				STAT(34);
-				if (grid_box_may_touch(__float_as_uint(qq.x), __float_as_uint(qq.y), gs, gb)) cand |= 1u << (2 * jj);
-				if (grid_box_may_touch(__float_as_uint(qq.z), __float_as_uint(qq.w), gs, gb)) cand |= 2u << (2 * jj);
-			}
+			STAT(34);
+			cand = grid_boxes_may_touch(rec[3], rec[4], rec[5], grid_selectors(sinv), gs, gb);      /* the cluster's eight members */
 			cand &= (1u << __float_as_int(k1.z)) - 1u;          /* (the last cluster may have fewer members: their slots hold zeros) */
 		}
 		/* the members that passed: into the queue, one per lane at a time (at most 63 wait there, so 64 more always fit) */
@@ -550,9 +649,10 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, C
 RT_DEV ClusterLDS stage_clusters(const rt_launch &L, float4 *dst)
 {
 	const float4 *src = reinterpret_cast<const float4*>(L.clusters);
-	for (int i = threadIdx.x; i < RT_CLUSTER_F4 * L.num_clusters; i += (int) blockDim.x) dst[i] = src[i];
+	for (int i = threadIdx.x; i < RT_CULL_F4(L.num_clusters); i += (int) blockDim.x) dst[i] = src[i];      /* the cluster records and, behind them, the group records */
 	__syncthreads();
 	ClusterLDS cl; cl.recs = dst; cl.mem = (rt_const_f) (unsigned long long) L.clusters; cl.count = L.num_clusters; cl.margin = L.cull_margin; cl.origin_max = L.cull_origin_max;
+	cl.groups = dst + RT_CLUSTER_F4 * L.num_clusters; cl.gmem = cl.mem + 4 * RT_CLUSTER_F4 * L.num_clusters; cl.ngroups = RT_NUM_GROUPS(L.num_clusters);
 	return cl;
 }
 
@@ -822,7 +922,7 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
 	ClusterLDS cl; cl.recs = nullptr; cl.mem = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
 	if (CULL) cl = stage_clusters(L, lds);
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	CullWave *cull_wave = reinterpret_cast<CullWave*>(lds + RT_CLUSTER_F4 * L.num_clusters) + wave;     /* (CULL) */
+	CullWave *cull_wave = reinterpret_cast<CullWave*>(lds + RT_CULL_F4(L.num_clusters)) + wave;     /* (CULL) */
 	const int tiles_x = (L.width + 7) >> 3, tiles_y = (L.local_rows + 7) >> 3;
 	const unsigned int total = (unsigned int) (tiles_x * tiles_y);
 	/* the workgroup's share of the blocks: blocks_per_group consecutive ones.  Its object pixels go to list
@@ -1161,7 +1261,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 	const int n = L.num_objects;
 #endif
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (CULL ? RT_CLUSTER_F4 * L.num_clusters : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
+	WaveLDS &W = reinterpret_cast<WaveLDS*>(lds + (CULL ? RT_CULL_F4(L.num_clusters) : (L.lit_grids_in_lds ? 9 : 6) * n))[wave];
 	if (threadIdx.x == 0) { W.g_written = 0u; W.g_audited = 0u; W.g_disagree = 0u; W.g_left = 0u; }     /* (ordered before any wave's report at the end by the staging barrier) */
 	const SceneLDS sc = CULL ? stage_geometry(L) : stage_scene(L, lds, n);
 	/* the grids of the "taps certainly lit" table (rt_lit.h), when the launcher found room for them: 3 x float4 per object */
@@ -1178,7 +1278,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 	/* large scenes: the clusters of rt_cull.h behind the scene records (such scenes have no lit-taps table: it needs <= 64 objects) */
 	ClusterLDS cl; cl.recs = nullptr; cl.mem = nullptr; cl.count = 0; cl.margin = 0.0f; cl.origin_max = 0.0f;
 	if (CULL) cl = stage_clusters(L, lds);
-	CullWave *cull_wave = reinterpret_cast<CullWave*>(reinterpret_cast<WaveLDS*>(lds + RT_CLUSTER_F4 * L.num_clusters) + BLOCK / 64) + wave;   /* (CULL) */
+	CullWave *cull_wave = reinterpret_cast<CullWave*>(reinterpret_cast<WaveLDS*>(lds + RT_CULL_F4(L.num_clusters)) + BLOCK / 64) + wave;   /* (CULL) */
 
 	/* rt_launch.sum_onto (several interactive passes in one launch): a pixel's samples are added to what the frame holds so far.
 	 * That value takes the window slot BEFORE the pixel's first sample, as if it were a sample: 0 + value is the value (it is
@@ -2158,7 +2258,7 @@ size_t rt_counter_bytes() { return RT_COUNTER_BYTES; }
 size_t rt_scene_lds_bytes(int num_objects) { return (size_t) num_objects * (sizeof(rt_geom) + sizeof(rt_shade)); }
 
 size_t rt_wavefront_lds_bytes(int num_objects) { return rt_scene_lds_bytes(num_objects) + (RT_BLOCK / 64) * sizeof(WaveLDS); }
-static_assert(sizeof(rt_cluster) == 16 * RT_CLUSTER_F4 && RT_CLUSTER_SIZE == 8 && RT_CLUSTER_F4 % 2 == 1, "the kernels read a cluster as RT_CLUSTER_F4 float4 words: box, count, eight members, their boxes as eight byte pairs of words");
+static_assert(sizeof(rt_cluster) == 16 * RT_CLUSTER_F4 && sizeof(rt_group) == 16 * RT_GROUP_F4 && RT_CLUSTER_SIZE == 8 && RT_GROUP_SIZE == 8 && RT_CLUSTER_F4 % 2 == 1 && RT_GROUP_F4 % 2 == 1, "the kernels read a cluster / a group as float4 words: box, count, (eight members,) eight boxes as four pairs of three words");
 
 /* rt_primary_pass: a few workgroups per CU, each with a run of consecutive 8x8 pixel blocks (at least one per wave) */
 void rt_primary_geometry(int width, int local_rows, int num_cus, unsigned int *groups_out, int *per_group_out)
@@ -2208,7 +2308,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	/* (a scene the host has had compiled keeps its compiled kernel: clusters are built from RT_CULL_MIN_OBJECTS objects, scenes
 	 * of up to 64 can be compiled) */
 	const bool cull = L.num_clusters > 0 && L.clusters != nullptr && scene_fast_ok && variant == 0 && !spec_fn;
-	size_t lds = cull ? (size_t) L.num_clusters * RT_CLUSTER_F4 * 16 + (RT_BLOCK / 64) * (sizeof(WaveLDS) + sizeof(CullWave))
+	size_t lds = cull ? (size_t) RT_CULL_F4(L.num_clusters) * 16 + (RT_BLOCK / 64) * (sizeof(WaveLDS) + sizeof(CullWave))
 	                  : rt_wavefront_lds_bytes(L.num_objects);
 	int per_cu = (int) ((160u * 1024u) / lds);
 	if (per_cu < 1) per_cu = 1;
@@ -2226,7 +2326,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	/* a large scene whose records leave room for fewer than three workgroups of four waves: one workgroup of twelve (rt_trace_wavefront_wide) */
 	int block = RT_BLOCK;
 	if (cull && per_cu < 3 && workgroups_per_cu < 1) {
-		const size_t wide = (size_t) L.num_clusters * RT_CLUSTER_F4 * 16 + (RT_BLOCK_WIDE / 64) * (sizeof(WaveLDS) + sizeof(CullWave));
+		const size_t wide = (size_t) RT_CULL_F4(L.num_clusters) * 16 + (RT_BLOCK_WIDE / 64) * (sizeof(WaveLDS) + sizeof(CullWave));
 		if (wide <= 160u * 1024u) { block = RT_BLOCK_WIDE; lds = wide; per_cu = 1; }
 	}
 	if (workgroups_per_cu >= 1 && workgroups_per_cu < per_cu) per_cu = workgroups_per_cu;     /* rt_tuning */
@@ -2253,7 +2353,7 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
 	} else {
 		unsigned int groups; int per_group;
 		rt_primary_geometry(L.width, L.local_rows, num_cus, &groups, &per_group);
-		const size_t plds = cull ? (size_t) L.num_clusters * RT_CLUSTER_F4 * 16 + (RT_BLOCK / 64) * sizeof(CullWave)
+		const size_t plds = cull ? (size_t) RT_CULL_F4(L.num_clusters) * 16 + (RT_BLOCK / 64) * sizeof(CullWave)
 		                         : rt_scene_lds_bytes(L.num_objects);
 		if (variant == 2 || !scene_fast_ok)
 			hipLaunchKernelGGL(rt_primary_pass<false>, dim3(groups), dim3(RT_BLOCK), plds, stream, L, per_group);

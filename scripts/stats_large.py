@@ -17,7 +17,9 @@ rt.lib().rt_stats_read(out, 1)
 site = lambda k: (out[2 * k], out[2 * k + 1])
 traces, tl = site(9)
 print(f"{n} objects: {traces} culled traces of a wave, {tl / max(traces, 1):.1f} lanes active on average")
-for k, name in ((32, "cluster boxes tested (wave-uniform steps)"), (33, "cluster walk steps (a step = every lane that still has a cluster takes its next one)"),
-                (34, "member boxes tested (steps; 8 per walk step at most)"), (35, "exact tests (batches of up to 64 queued (ray, object) candidates)")):
+for k, name in ((32, "cluster boxes tested, every one for every ray (wave-uniform steps; scenes of few clusters)"),
+                (43, "group boxes tested (wave-uniform steps)"), (44, "dealt steps of (ray, group) pairs (64 pairs a step)"),
+                (45, "cluster boxes on the groups' grids (steps of EIGHT boxes; one per dealt step)"), (33, "cluster walk steps (a step = every lane that still has a cluster takes its next one)"),
+                (34, "member boxes tested (steps of EIGHT boxes; one per walk step)"), (35, "exact tests (batches of up to 64 queued (ray, object) candidates)")):
     e, l = site(k)
     print(f"  {name:90s} {e / max(traces, 1):8.1f} per trace, {l / max(e, 1):5.1f} lanes active")

@@ -26,6 +26,7 @@ __global__ void __launch_bounds__(256) k(float *out, Stamp *stamps, int iters, f
 	float b = seed * 0.999f, c = seed * 0.001f;
 	double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7, db = b, dc = c;
 	unsigned u0 = threadIdx.x * 2654435761u, u1 = u0 ^ 0x1234567, u2 = u0 + 77, u3 = u1 + 99, u4 = u0 * 3, u5 = u1 * 5, u6 = u2 * 7, u7 = u3 * 9;
+	unsigned ub = u0 ^ 0x04050607u, uc = 16u & u1;
 	unsigned long long l0 = u0, l1 = u1, l2 = u2, l3 = u3, l4 = u4, l5 = u5, l6 = u6, l7 = u7;
 	typedef float float2v __attribute__((ext_vector_type(2)));
 	float2v p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a0}, p5 = {a3, a2}, p6 = {a5, a4}, p7 = {a7, a6}, pb = {b, b}, pc = {c, c};
@@ -77,6 +78,14 @@ __global__ void __launch_bounds__(256) k(float *out, Stamp *stamps, int iters, f
 		if (WHICH == 26) { G8("v_mul_hi_u32", u, u1) }
 		if (WHICH == 27) { REP8(asm volatile("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8"
 		                                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));) }
+		if (WHICH == 32) { REP8(asm volatile("v_fma_mix_f32 %0, %8, %9, %0 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %8, %9, %1 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %8, %9, %2 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %8, %9, %3 op_sel_hi:[1,0,0]\n"
+		                                     "v_fma_mix_f32 %4, %8, %9, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %8, %9, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %6, %8, %9, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %7, %8, %9, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+		                                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(u0), "v"(c));) }
+		if (WHICH == 33) { REP8(asm volatile("v_cvt_f32_ubyte0 %0, %8\n v_cvt_f32_ubyte1 %1, %9\n v_cvt_f32_ubyte2 %2, %8\n v_cvt_f32_ubyte3 %3, %9\n v_cvt_f32_ubyte0 %4, %8\n v_cvt_f32_ubyte1 %5, %9\n v_cvt_f32_ubyte2 %6, %8\n v_cvt_f32_ubyte3 %7, %9"
+		                                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(u0), "v"(u1));) }
+		if (WHICH == 34) { F8("v_perm_b32", u, u) }
+		if (WHICH == 35) { F8("v_alignbit_b32", u, u) }
+		if (WHICH == 36) { F8("v_min3_f32", a, ) }
 		if (WHICH == 28) { REP8(asm volatile("v_cvt_f32_u32 %0, %8\n v_cvt_f32_u32 %1, %9\n v_cvt_f32_u32 %2, %8\n v_cvt_f32_u32 %3, %9\n v_cvt_f32_u32 %4, %8\n v_cvt_f32_u32 %5, %9\n v_cvt_f32_u32 %6, %8\n v_cvt_f32_u32 %7, %9"
 		                                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(u0), "v"(u1));) }
 		if (WHICH == 29) { REP8(asm volatile("v_add_co_u32 %0, vcc, %0, %8\n v_addc_co_u32 %1, vcc, %1, %9, vcc\n v_add_co_u32 %2, vcc, %2, %8\n v_addc_co_u32 %3, vcc, %3, %9, vcc\n"
@@ -129,14 +138,21 @@ template <int W> void run(const char *name, float *d_out, Stamp *d_stamps, int c
 	printf("\n");
 }
 
-int main()
+int main(int argc, char **argv)
 {
+	const bool only_new = argc > 1;      /* any argument: only the kinds added in round 6 */
 	hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
 	const int cus = p.multiProcessorCount;
 	float *d; hipMalloc(&d, sizeof(float) * cus * 8 * 256);
 	Stamp *s; hipMalloc(&s, sizeof(Stamp) * cus * 8 * 4);
 	printf("%s, %d CUs; cycles per wave64 instruction per SIMD (s_memtime), clock = d(s_memtime)/d(s_memrealtime) x 100 MHz\n", p.name, cus);
 	run<0>("v_fma_f32", d, s, cus);
+	run<32>("v_fma_mix_f32 (f16 x f32 + f32)", d, s, cus);
+	run<33>("v_cvt_f32_ubyteN", d, s, cus);
+	run<34>("v_perm_b32", d, s, cus);
+	run<35>("v_alignbit_b32", d, s, cus);
+	run<36>("v_min3_f32", d, s, cus);
+	if (only_new) return 0;
 	run<1>("v_mul_f32", d, s, cus);
 	run<2>("v_add_f32", d, s, cus);
 	run<13>("v_max_f32", d, s, cus);

@@ -59,7 +59,9 @@ static bool may_touch(V o, V inv, const float lo[3], const float hi[3])     /* s
 	return enter <= leave && leave >= 0.0f;
 }
 
-/* grid_box_may_touch of rt_kernels.hip: member j of cluster K on the cluster's grid -- fma(q, step * inv, fma(lo, inv, -o * inv)) */
+static unsigned long long form_mismatches = 0;       /* the sign form of the grid test against its min / max form (must stay 0) */
+
+/* grid_pair_may_touch of rt_kernels.hip: member j of cluster K on the cluster's grid -- fma(q, step * inv, fma(lo, inv, -o * inv)) */
 static bool grid_may_touch(V o, V inv, const rt_cluster &K, int j)
 {
 	const float clo[3] = { K.lo[0], K.lo[1], K.lo[2] }, chi[3] = { K.hi0, K.hi1, K.hi2 };
@@ -68,12 +70,41 @@ static bool grid_may_touch(V o, V inv, const rt_cluster &K, int j)
 	for (int k = 0; k < 3; k++) {
 		const float gs = RT_CLUSTER_STEP(clo[k], chi[k]) * ii[k];
 		const float gb = fmaf(clo[k], ii[k], -(oo[k] * ii[k]));
-		a[k] = fmaf((float) K.qbox[j][k], gs, gb);
-		b[k] = fmaf((float) K.qbox[j][3 + k], gs, gb);
+		a[k] = fmaf((float) RT_QPLANE(K.qpair, j, k, 0), gs, gb);
+		b[k] = fmaf((float) RT_QPLANE(K.qpair, j, k, 1), gs, gb);
 	}
-	const float enter = fmaxf(fmaxf(fminf(a[0], b[0]), fminf(a[1], b[1])), fminf(a[2], b[2]));
-	const float leave = fminf(fminf(fmaxf(a[0], b[0]), fmaxf(a[1], b[1])), fmaxf(a[2], b[2]));
-	return enter <= leave && leave >= 0.0f;
+	/* as the kernels decide it (grid_pair_may_touch): the plane the ray meets first by the SIGN of the reciprocal -- not by a min / max --
+	 * and max(enter, 0) <= leave; it must be the same answer as the min / max form, for every ray */
+	float nr[3], fr[3];
+	for (int k = 0; k < 3; k++) { const bool neg = std::signbit(ii[k]); nr[k] = neg ? b[k] : a[k]; fr[k] = neg ? a[k] : b[k]; }
+	const float enter = fmaxf(fmaxf(nr[0], nr[1]), nr[2]), leave = fminf(fminf(fr[0], fr[1]), fr[2]);
+	const bool by_sign = fmaxf(enter, 0.0f) <= leave;
+	const float enter2 = fmaxf(fmaxf(fminf(a[0], b[0]), fminf(a[1], b[1])), fminf(a[2], b[2]));
+	const float leave2 = fminf(fminf(fmaxf(a[0], b[0]), fmaxf(a[1], b[1])), fmaxf(a[2], b[2]));
+	if (by_sign != (enter2 <= leave2 && leave2 >= 0.0f)) form_mismatches++;
+	return by_sign;
+}
+
+/* the same for cluster j of group G on the group's grid (round 6: the dealt (ray, group) pairs of nearest_hit_culled, step 1b) */
+static bool group_grid_may_touch(V o, V inv, const rt_group &G, int j)
+{
+	const float clo[3] = { G.lo[0], G.lo[1], G.lo[2] }, chi[3] = { G.hi0, G.hi1, G.hi2 };
+	const float oo[3] = { o.x, o.y, o.z }, ii[3] = { inv.x, inv.y, inv.z };
+	float a[3], b[3];
+	for (int k = 0; k < 3; k++) {
+		const float gs = RT_CLUSTER_STEP(clo[k], chi[k]) * ii[k];
+		const float gb = fmaf(clo[k], ii[k], -(oo[k] * ii[k]));
+		a[k] = fmaf((float) RT_QPLANE(G.qpair, j, k, 0), gs, gb);
+		b[k] = fmaf((float) RT_QPLANE(G.qpair, j, k, 1), gs, gb);
+	}
+	float nr[3], fr[3];
+	for (int k = 0; k < 3; k++) { const bool neg = std::signbit(ii[k]); nr[k] = neg ? b[k] : a[k]; fr[k] = neg ? a[k] : b[k]; }
+	const float enter = fmaxf(fmaxf(nr[0], nr[1]), nr[2]), leave = fminf(fminf(fr[0], fr[1]), fr[2]);
+	const bool by_sign = fmaxf(enter, 0.0f) <= leave;
+	const float enter2 = fmaxf(fmaxf(fminf(a[0], b[0]), fminf(a[1], b[1])), fminf(a[2], b[2]));
+	const float leave2 = fminf(fminf(fmaxf(a[0], b[0]), fmaxf(a[1], b[1])), fmaxf(a[2], b[2]));
+	if (by_sign != (enter2 <= leave2 && leave2 >= 0.0f)) form_mismatches++;
+	return by_sign;
 }
 
 int main(int argc, char **argv)
@@ -95,8 +126,24 @@ int main(int argc, char **argv)
 			       g.b0 = g.a[0] * 1.0f + uni(0.01f, 1.0f) * s * 1.0f; g.b1 = g.a[1] * 1.0f + uni(0.01f, 1.0f) * s * 1.0f; g.b2 = g.a[2] * 1.0f + uni(0.01f, 1.0f) * s * 1.0f; }
 		}
 		std::vector<rt_cluster> cl;
-		const rt_cull_info info = rt_cull_build(geom, n, cl);
+		std::vector<rt_group> gr;
+		const rt_cull_info info = rt_cull_build(geom, n, cl, gr);
 		if (info.num_clusters <= 0) { refused++; continue; }      /* (coordinates beyond RT_CULL_MAX_COORD: none here) */
+		/* the groups: every cluster in exactly one, its box inside the group's box and inside its own box on the group's grid */
+		if ((int) gr.size() != RT_NUM_GROUPS(info.num_clusters)) structure_bad++;
+		for (int c = 0; c < info.num_clusters; c++) {
+			const rt_group &G = gr[(size_t) (c / RT_GROUP_SIZE)];
+			const int j = c % RT_GROUP_SIZE;
+			if (j >= G.count) structure_bad++;
+			const float klo[3] = { cl[(size_t) c].lo[0], cl[(size_t) c].lo[1], cl[(size_t) c].lo[2] }, khi[3] = { cl[(size_t) c].hi0, cl[(size_t) c].hi1, cl[(size_t) c].hi2 };
+			const float glo[3] = { G.lo[0], G.lo[1], G.lo[2] }, ghi[3] = { G.hi0, G.hi1, G.hi2 };
+			for (int k = 0; k < 3; k++) {
+				if (klo[k] < glo[k] || khi[k] > ghi[k]) structure_bad++;
+				const double step = (double) RT_CLUSTER_STEP(glo[k], ghi[k]);
+				if ((double) glo[k] + RT_QPLANE(G.qpair, j, k, 0) * step > (double) klo[k] || (double) glo[k] + RT_QPLANE(G.qpair, j, k, 1) * step < (double) khi[k]) structure_bad++;
+			}
+		}
+		{ int total = 0; for (const rt_group &G : gr) total += G.count; if (total != info.num_clusters) structure_bad++; }
 		std::vector<int> owner((size_t) n, -1), place((size_t) n, -1);
 		for (int c = 0; c < info.num_clusters; c++)
 			for (int j = 0; j < RT_CLUSTER_SIZE; j++) {
@@ -111,7 +158,7 @@ int main(int argc, char **argv)
 				/* ... and inside its own box on the cluster's grid (the kernels' float step, the comparison in double) */
 				for (int k = 0; k < 3; k++) {
 					const double step = (double) RT_CLUSTER_STEP(clo[k], chi[k]);
-					if ((double) clo[k] + cl[(size_t) c].qbox[j][k] * step > (double) lo[k] || (double) clo[k] + cl[(size_t) c].qbox[j][3 + k] * step < (double) hi[k]) structure_bad++;
+					if ((double) clo[k] + RT_QPLANE(cl[(size_t) c].qpair, j, k, 0) * step > (double) lo[k] || (double) clo[k] + RT_QPLANE(cl[(size_t) c].qpair, j, k, 1) * step < (double) hi[k]) structure_bad++;
 				}
 			}
 		for (int i = 0; i < n; i++) if (owner[(size_t) i] < 0) structure_bad++;
@@ -138,6 +185,12 @@ int main(int argc, char **argv)
 			const float w[3] = { fabsf(d.x), fabsf(d.y), fabsf(d.z) };
 			if (!(w[0] >= 0x1p-30f && w[1] >= 0x1p-30f && w[2] >= 0x1p-30f)) continue;       /* (outside the window the kernel tests every object) */
 			const V inv = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };                               /* rcp_refined == RN(1/d) inside the window */
+			{	/* the two forms of the grid test on boxes the ray mostly MISSES as well (form_mismatches): one cluster's members, one group's clusters */
+				const int c = (int) ((unsigned) r % (unsigned) info.num_clusters);
+				for (int j = 0; j < cl[(size_t) c].count; j++) (void) grid_may_touch(o, inv, cl[(size_t) c], j);
+				const rt_group &G = gr[(size_t) (c / RT_GROUP_SIZE)];
+				for (int j = 0; j < G.count; j++) (void) group_grid_may_touch(o, inv, G, j);
+			}
 			for (int i = 0; i < n; i++) {
 				float t = 0;
 				const bool hit = geom[(size_t) i].type == RT_GEOM_CUBE ? ref_box(o, d, geom[(size_t) i], t) : ref_sphere(o, d, geom[(size_t) i], t);
@@ -150,10 +203,16 @@ int main(int argc, char **argv)
 				const float clo[3] = { K.lo[0], K.lo[1], K.lo[2] }, chi[3] = { K.hi0, K.hi1, K.hi2 };
 				/* the cluster's box, and the member's box as the kernel tests it: quantised on the cluster's grid */
 				if (!may_touch(o, inv, clo, chi) || !grid_may_touch(o, inv, K, place[(size_t) i])) bad++;
+				/* ... and one level up, as scenes of RT_GROUPS_FROM_CLUSTERS clusters and more are tested: the group's box, then the
+				 * cluster's box on the group's grid (which replaces the float test of the cluster's own box there) */
+				const int c = owner[(size_t) i];
+				const rt_group &G = gr[(size_t) (c / RT_GROUP_SIZE)];
+				const float glo[3] = { G.lo[0], G.lo[1], G.lo[2] }, ghi[3] = { G.hi0, G.hi1, G.hi2 };
+				if (!may_touch(o, inv, glo, ghi) || !group_grid_may_touch(o, inv, G, c % RT_GROUP_SIZE)) bad++;
 				(void) lo; (void) hi;
 			}
 		}
 	}
-	printf("%llu %llu %llu %llu %llu\n", pairs, hits, bad, structure_bad, refused);
-	return bad || structure_bad ? 1 : 0;
+	printf("%llu %llu %llu %llu %llu\n", pairs, hits, bad, structure_bad + form_mismatches, refused);
+	return bad || structure_bad || form_mismatches ? 1 : 0;
 }
