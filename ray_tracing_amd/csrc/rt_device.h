@@ -85,7 +85,9 @@ typedef struct {
 #define RT_GROUP_F4 5
 #define RT_NUM_GROUPS(clusters) (((clusters) + RT_GROUP_SIZE - 1) / RT_GROUP_SIZE)
 #define RT_CULL_F4(clusters) (RT_CLUSTER_F4 * (clusters) + RT_GROUP_F4 * RT_NUM_GROUPS(clusters))
-#define RT_GROUPS_FROM_CLUSTERS 33    /* scenes of fewer clusters ask every cluster box, as before (dealing costs more than it saves there) */
+/* scenes of fewer clusters ask every cluster box, as before: dealing costs more than it saves there -- groups from 17 clusters: +5 ... 8 % at
+ * 136 ... 224 objects; from 33: +2 ... 4 % at 272 ... 448; at 512 objects (64 clusters) -6 %, 768 -11 %, 1024 -22 % (profiles/r06/ab_groups_threshold.txt) */
+#define RT_GROUPS_FROM_CLUSTERS 60
 typedef struct {
 	float          lo[3], hi0;
 	float          hi1, hi2;

@@ -1,5 +1,5 @@
 """Interleaved A/B timing of two builds of librt_hip.so on synthetic large scenes (tests/rtlibs.py large_scene), one process, one
-device; frames must be identical.  usage: ab_large.py libA.so libB.so [rounds]"""
+device; frames must be identical.  usage: ab_large.py libA.so libB.so [rounds [objects,objects,...]]"""
 import os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,7 +15,7 @@ for p in libs:
     if sky is None: sky = rt.load_skybox()
     r.set_skybox(sky); r.profile(True); rs.append(r)
 W, H, spp, nb = 1920, 1080, 8, 5
-for n in (40, 64, 128, 256, 512, 1024):
+for n in ([int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else (40, 64, 128, 256, 512, 1024)):
     scene = large_scene(n, seed=17)
     for r in rs:
         rt._lib = r._L; r.set_scene(scene); r.set_camera(**LARGE_SCENE_CAMERA)
