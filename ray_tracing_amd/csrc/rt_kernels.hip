@@ -1051,6 +1051,11 @@ rt_primary_pass(const rt_launch L, int blocks_per_group)
  * measured against "always what is asked for" (profiles/r05/ab_claim_generations.txt): 3 claims: C1 -2.6 %, C2 +6 %; 6: -2.8 / +1 %;
  * 12: -2.1 / +0.2 %, C4 strip -0.3 % -- hence more of them the more samples a pixel has */
 #define WF_CLAIM_GENERATIONS(spp) (3u + (unsigned int) (spp) / 32u)
+/* ... and only for pixels of fewer samples than this: a wave looks for rt_cancel() when it CLAIMS (the hand-outs from its reserve read
+ * nothing), so a reserve of eight pixels of 256 ... 1024 samples is 0.4 ... 1.6 ms more before a cancelled launch lets go -- and buys
+ * nothing there: claims of eight were worth -2 ... 3 % at 64 samples per pixel (neighbouring pixel writes, an eighth of the atomics) and
+ * +0.4 ... 0.6 % at 256 and 1024, where a pixel is written once per hundreds of rounds (profiles/r05/ab_claim_generations.txt) */
+#define WF_CLAIM_BELOW_SPP 128u
 #define WF_EMPTY   0xffffffffu         /* window slot not written yet (a colour channel is in [0,1]: never this pattern) */
 #define WF_LAST    0x8000              /* slot word: this sample is the last one of its pixel */
 #define REC_VALID    1                /* per-bounce record handed from the front to the back (wavefront_body) */
@@ -1459,7 +1464,7 @@ RT_DEV void wavefront_body(const rt_launch &L, unsigned int *)
 					 * ask any more: it is about to leave anyway.) */
 					const unsigned int seen = (unsigned int) __builtin_amdgcn_readfirstlane((int) W.res_seen);
 					const unsigned int until = (unsigned int) C->trace_workgroups * (unsigned int) (BLOCK / 64) / (unsigned int) C->num_shards * (unsigned int) WF_CLAIM * WF_CLAIM_GENERATIONS(spp);
-					const unsigned int want = (WF_CLAIM > 0 && !direct && seen > until && asked < WF_CLAIM) ? (unsigned int) WF_CLAIM : (unsigned int) asked;
+					const unsigned int want = (WF_CLAIM > 0 && !direct && spp < WF_CLAIM_BELOW_SPP && seen > until && asked < WF_CLAIM) ? (unsigned int) WF_CLAIM : (unsigned int) asked;
 					unsigned int word = 0u, k = 0u;
 					if (lane == 0) {
 						word = (blockIdx.x < 8u && wave == 0) ? __hip_atomic_load((guint) C->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - C->launch_id
