@@ -129,6 +129,19 @@ def test_a_host_built_against_the_round5_header_is_refused(tmp_path):
     assert k.size == __import__("ctypes").sizeof(rt.TestKnobs)
 
 
+def test_integration_md_shows_the_patch_that_is_compiled():
+    """INTEGRATION.md section 2 leads with the ladder binding, and the code it shows IS the text reference_main_rt.py inserts (both variants)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("reference_main_rt", os.path.join(ROOT, "scripts", "patches", "reference_main_rt.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for variant in ("--ladder", "--blocking"):
+        for piece in mod.VARIANTS[variant]:
+            assert piece in doc, (variant, piece[:60])
+    assert mod.START in doc
+    assert doc.index("rt_progressive_begin(rt, frame_w, frame_h, init_scale, 10, 0)") < doc.index("rt_render(rt, &p, frame)")      # the ladder first
+
+
 def test_the_boundary_header_carries_no_test_knobs():
     """rt_hip.h is what a maintainer binds; fault injections, self-tests and instrumentation read-outs are declared in rt_hip_testing.h."""
     public = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
