@@ -601,7 +601,6 @@ def main():
     split = None        # (camera-ray pass ms, trace kernel ms) per launch with nothing else on the GPU: the two kernels priced apart (roofline.kernels)
     if not args.no_extras:
         runs = []
-        prof.profile(2)
         for _ in range(7):
             fence()
             t1 = time.perf_counter()
@@ -611,6 +610,13 @@ def main():
             runs.append((time.perf_counter() - t1) * 1e3)
         runs.sort()
         latency = runs[len(runs) // 2]
+        # the two kernels apart: twelve frames ONE AT A TIME, back to back (submit, wait, submit ...: nothing overlaps, and the GPU
+        # is not left idle in between -- a launch that follows a fence and a host-side pause runs its first part at the clocks of an
+        # idle chip: 5.47 against 5.33 ms for C1's trace kernel).  This is the mode rocprofv3's serial block under profiles/ times
+        # (bench.py --depth 1), so a reader can recompute roofline.frac from that block.
+        prof.profile(2)
+        for k in range(12):
+            one_frame(seed + k)
         s_ms, s_n, _, s_primary = prof.profile_collect_split()
         prof.profile(False)
         if s_n:
@@ -745,7 +751,7 @@ def main():
             # launch's camera-ray pass waits for workgroup slots of the previous launch's trace kernel, and the event between the two
             # kernels would book that wait to the pass
             primary_ms, trace_ms = split if split else (primary_ms_total / launches, max(avg_ms - primary_ms_total / launches, 1e-6))
-            split_from = "launches with the GPU to themselves (frame_latency leg)" if split else "the timed region (launches overlap: the split is approximate)"
+            split_from = "twelve launches one at a time, back to back (the mode of rocprofv3's serial block under profiles/)" if split else "the timed region (launches overlap: the split is approximate)"
             samples_per_launch = samples_per_step / ngpus
             pixels_per_launch = samples_per_launch / spp
             trace_name = "rt_trace_spec" if compiled else ("rt_trace_wavefront (culled)" if synthetic and not args.every_object else "rt_trace_wavefront")

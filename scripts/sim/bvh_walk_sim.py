@@ -115,6 +115,19 @@ def walk_costs(o, d, label, coherent_order):
     for i in range(1, NN):
         visited[:, i] = visited[:, parent[i]] & hit_box[:, parent[i]]
     touched = (visited & hit_box & leaf[None]).sum(1)
+    # what front-to-back order with early termination could save: the clusters a ray enters before (or at) its nearest hit, and the
+    # same if only the NEAREST touched cluster were looked at first and the others then filtered by the hit found there
+    leaves_ = np.flatnonzero(leaf)
+    t_hit = nearest(o, d)[0]
+    inv = 1.0 / d
+    ent = np.full((len(o), len(leaves_)), np.inf)
+    for i0 in range(0, len(o), 4096):
+        sl = slice(i0, i0 + 4096)
+        a = (node_lo[leaves_][None] - o[sl, None]) * inv[sl, None]; b = (node_hi[leaves_][None] - o[sl, None]) * inv[sl, None]
+        en = np.minimum(a, b).max(2); lv = np.maximum(a, b).min(2)
+        ent[sl] = np.where((en <= lv) & (lv >= 0), np.maximum(en, 0), np.inf)
+    before_hit = ((ent <= t_hit[:, None]) & np.isfinite(ent)).sum(1)
+    print(f"    front to back: clusters touched {touched.mean():.2f} per ray, of which entered no later than the nearest hit {before_hit.mean():.2f} (rays that hit nothing: {np.mean(~np.isfinite(t_hit)):.2f} of all)")
     vis2 = visited.sum(1)
     # 4-wide: nodes at even depth are the 4-wide nodes; visiting one tests its (up to) four grandchildren's boxes -- or its children's where those are leaves
     wide = (depth % 2 == 0)
