@@ -252,6 +252,11 @@ static int order_behind_previous(rt_context *ctx, hipStream_t stream)
 static int workgroups_per_cu_for(rt_context *ctx, hipStream_t stream, long long pixels)
 {
 	if (ctx->tuning.workgroups_per_cu > 0) return ctx->tuning.workgroups_per_cu;
+	/* A culled scene's launches never share the chip: a large one runs as ONE workgroup of twelve waves per CU (one copy of the cluster
+	 * records, three waves per SIMD), and any other number of slots puts it back on workgroups of four -- a third of the waves.  With
+	 * three L1024 frames in flight the launches given half the slots took 24 ms each once nothing came behind them, where a frame takes
+	 * 6.4 (profiles/r06/L1024_depth.txt). */
+	if (ctx->cull.num_clusters > 0 && !ctx->tuning.test_every_object && !ctx->spec_fn && ctx->scene_fast_ok) return 0;
 	const rt_context::launch_slot &prev = ctx->slot[ctx->cur];
 	if (!ctx->launches || !prev.used || prev.stream == stream) return 0;
 	/* Two launches unfinished ahead of this one -- the previous one and the one before it -- : the host keeps three in flight, two are
