@@ -68,6 +68,47 @@ def test_cull_fuzz_against_every_object(gpu):
     gpu.set_camera()
 
 
+def test_groups_of_clusters_fuzz_against_every_object(gpu):
+    """Round 6: from 60 clusters on (473 objects) the cluster boxes are reached through GROUPS of eight clusters whose (ray, group) pairs are
+    dealt to the lanes (csrc/rt_device.h rt_group).  The boundary (59 / 60 clusters), cluster counts that leave the last group short (500
+    objects: 63 clusters, the last group has 7; 1001: 126 clusters, 6), every scale of the margin, cameras inside and outside, sky-only
+    and floorless scenes: the culled frame is the every-object frame."""
+    rng = np.random.default_rng(6)
+    sky = synthetic_skybox(16, seed=6)
+    gpu.set_skybox(sky)
+    sizes = [472, 473, 480, 481, 500, 633, 777, 1001, 1017, 1024]
+    for case, n in enumerate(sizes + [int(x) for x in rng.integers(473, 1025, 8)]):
+        extent = float([10.0, 0.5, 3.0, 30.0, 300.0, 5000.0][case % 6])
+        gpu.set_scene(large_scene(n, seed=2000 + case, extent=extent, floor=bool(case & 1), light=bool(case & 2)))
+        pos = rng.uniform(-1.5 * extent, 1.5 * extent, 3)
+        front = -pos + rng.uniform(-0.3 * extent, 0.3 * extent, 3)
+        gpu.set_camera(pos=tuple(pos), front=tuple(front), up=(0, 1, 0), fov=float(rng.uniform(0.5, 1.4)))
+        W, H, spp, nb = 128, 72, 2, 6
+        gpu.set_tuning(test_every_object=False)
+        culled = gpu.render(W, H, spp, nb, seed=case)
+        gpu.set_tuning(test_every_object=True)
+        plain = gpu.render(W, H, spp, nb, seed=case)
+        gpu.set_tuning(test_every_object=False)
+        assert (bits(culled) == bits(plain)).all(), (case, n, extent)
+    gpu.set_camera()
+
+
+@pytest.mark.parametrize("n", [473, 500])
+def test_groups_boundary_against_the_oracle(gpu, oracle, n):
+    """... and the oracle itself at the first cluster counts that use the groups (60 clusters; 63 with a short last group)."""
+    sky = synthetic_skybox(32, seed=n)
+    scene = large_scene(n, seed=n)
+    gpu.set_skybox(sky); gpu.set_scene(scene)
+    oracle.set_skybox(sky); oracle.set_scene(scene)
+    W, H, spp, nb = 96, 54, 2, 5
+    for cam in CAMERAS[:2]:
+        gpu.set_camera(**cam); oracle.set_camera(**cam)
+        got = gpu.render(W, H, spp, nb, seed=n)
+        want = oracle.render_counter(W, H, spp, nb, seed=n, threads=min(os.cpu_count() or 1, 32))
+        assert (bits(got) == bits(want)).all(), (n, cam)
+    gpu.set_camera(); oracle.set_camera()
+
+
 def test_camera_far_outside_tests_every_object(gpu, oracle):
     """A camera farther out than twice the scene's extent: its waves take the plain loop (the margins are proved for origins
     within that); the frame is the oracle's either way."""
