@@ -227,8 +227,9 @@ RT_API void rt_host_free(void *p);
  * context so far -- the one that is running and those still queued behind it (the second of two frames in flight) -- to
  * stop: its waves hand out no more samples, finish the paths in flight and leave.  A wave looks for the request when it
  * FETCHES PIXELS (eight waves of a launch read the host word and relay it through a word in device memory that every other
- * wave reads at its fetches), so the latency grows with the samples per pixel: about 1 ms at 256 spp, 2.4-3.4 ms at 1024
- * (profiles/r03/cancel_probe.txt); a queued launch stops at its first fetch.  The request is one atomic max on a word of
+ * wave reads at its fetches), so the latency grows with the samples per pixel: 0.4 ms at 64 spp, 0.76 ms at 256, 3.4 ms at 1024
+ * (profiles/r06/cancel_latency_claim_rule.txt; a wave claims several pixels at a time only below 128 samples per pixel); a queued
+ * launch stops at its first fetch.  The request is one atomic max on a word of
  * host memory that the kernels read: the call returns at once, enqueues nothing, and may come from ANY host thread while
  * another one is inside rt_render*() for the same context -- a launch is covered from the moment the render call has
  * announced it, which is before its first kernel is enqueued.  rt_render() then returns RT_CANCELLED and its frame is incomplete; after
