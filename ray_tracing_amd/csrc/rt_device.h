@@ -88,6 +88,7 @@ typedef struct {
 /* scenes of fewer clusters ask every cluster box, as before: dealing costs more than it saves there -- groups from 17 clusters: +5 ... 8 % at
  * 136 ... 224 objects; from 33: +2 ... 4 % at 272 ... 448; at 512 objects (64 clusters) -6 %, 768 -11 %, 1024 -22 % (profiles/r06/ab_groups_threshold.txt) */
 #define RT_GROUPS_FROM_CLUSTERS 60
+#define RT_GROUP_PAIRS_MAX 448u       /* (ray, group) pairs of a wave beyond which it asks every cluster box instead: seven dealt steps (rt_kernels.hip) */
 typedef struct {
 	float          lo[3], hi0;
 	float          hi1, hi2;

@@ -454,7 +454,26 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, C
 		}
 		return src > 63 ? 63 : src;
 	};
-	if (cl.count >= RT_GROUPS_FROM_CLUSTERS) {
+	/* every cluster box for every ray, wave-uniformly -- one box per step, read once for all lanes: two scalar loads, planes as scalar
+	 * operands of the FMAs (the LDS pipe is what the culled trace is short of).  Scenes of few clusters; and a wave whose rays pass
+	 * most of the groups (below) */
+	auto ask_every_cluster = [&]() {
+#pragma unroll
+		for (int w = 0; w < RT_MAX_CLUSTERS / 32; w++) {
+			uint32_t bits = 0u;
+			const int first = 32 * w, last = cl.count < first + 32 ? cl.count : first + 32;
+			for (int c = first; c < last; c++) {
+				STAT(32);
+				const rt_const_f km = cl.mem + 4 * RT_CLUSTER_F4 * c;
+				float4 k0, k1;
+				k0.x = km[0]; k0.y = km[1]; k0.z = km[2]; k0.w = km[3]; k1.x = km[4]; k1.y = km[5];
+				if (slab_may_touch(oi, rp.inv, mk3(k0.x, k0.y, k0.z), mk3(k0.w, k1.x, k1.y))) bits |= 1u << (c - first);
+			}
+			mask[w] = on ? bits : 0u;
+		}
+	};
+	bool every_cluster = cl.count < RT_GROUPS_FROM_CLUSTERS;       /* (wave-uniform) */
+	if (!every_cluster) {
 		/* 1a. the GROUPS of eight clusters, wave-uniformly: one box per step, read once for all lanes (scalar loads, planes as scalar
 		 * operands of the FMAs) -- sixteen steps for 1024 objects where asking every cluster box took 128 */
 		uint32_t gbits = 0u;
@@ -479,6 +498,12 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, C
 		}
 		const uint32_t gtotal = (uint32_t) __builtin_amdgcn_readlane((int) gupto, 63);
 		wave_fence();
+		/* A dealt step costs about as much as eighteen uniform box tests: a wave whose rays pass MOST groups -- objects that span the
+		 * scene, groups that overlap -- would pay more for its pairs than for asking every cluster box, which costs the same whatever the
+		 * rays do: such a wave does that.  (Either way the mask holds every cluster a ray may touch: the two differ in which boxes that
+		 * the ray misses they let through.) */
+		if (gtotal > RT_GROUP_PAIRS_MAX) every_cluster = true;
+		else {
 		for (uint32_t base = 0; base < gtotal; base += 64u) {
 			STAT(44);
 			const uint32_t q = base + (uint32_t) lane;
@@ -508,25 +533,10 @@ RT_DEV Hit nearest_hit_culled(const SceneLDS &sc, int n, const ClusterLDS &cl, C
 		wave_fence();
 		const uint4 mine4 = *reinterpret_cast<const uint4*>(cw->cmask[lane]);
 		mask[0] = mine4.x; mask[1] = mine4.y; mask[2] = mine4.z; mask[3] = mine4.w;
-		wave_fence();                   /* (the masks share their LDS with `best` and the queue, which are written from here on) */
-	} else {
-		/* (few clusters: every cluster box for every ray, wave-uniformly -- one box per step, read once for all lanes) */
-#pragma unroll
-		for (int w = 0; w < RT_MAX_CLUSTERS / 32; w++) {
-			uint32_t bits = 0u;
-			const int first = 32 * w, last = cl.count < first + 32 ? cl.count : first + 32;
-			for (int c = first; c < last; c++) {
-				STAT(32);
-				/* the box is the same for all lanes: two scalar loads, planes as scalar operands of the FMAs -- the LDS pipe is what the
-				 * culled trace is short of (the members' boxes, the geometry, the cross-lane fetches and the minimum all go through it) */
-				const rt_const_f km = cl.mem + 4 * RT_CLUSTER_F4 * c;
-				float4 k0, k1;
-				k0.x = km[0]; k0.y = km[1]; k0.z = km[2]; k0.w = km[3]; k1.x = km[4]; k1.y = km[5];
-				if (slab_may_touch(oi, rp.inv, mk3(k0.x, k0.y, k0.z), mk3(k0.w, k1.x, k1.y))) bits |= 1u << (c - first);
-			}
-			mask[w] = on ? bits : 0u;
 		}
+		wave_fence();                   /* (the masks share their LDS with `best` and the queue, which are written from here on) */
 	}
+	if (every_cluster) ask_every_cluster();
 	static_assert(RT_MAX_CLUSTERS == 128, "the pair numbering below reads a lane's clusters as four 32-bit words");
 	/* 2. the wave's (ray, cluster) pairs, numbered: inclusive prefix sum of the lanes' counts */
 	const uint32_t count = (uint32_t) (__popc(mask[0]) + __popc(mask[1]) + __popc(mask[2]) + __popc(mask[3]));

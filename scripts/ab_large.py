@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
 import ray_tracing_amd as rt
-from rtlibs import LARGE_SCENE_CAMERA, large_scene
+from rtlibs import LARGE_SCENE_CAMERA, large_scene, stick_scene
 libs, rounds = sys.argv[1:3], int(sys.argv[3]) if len(sys.argv) > 3 else 7
 sky, rs = None, []
 for p in libs:
@@ -16,7 +16,7 @@ for p in libs:
     r.set_skybox(sky); r.profile(True); rs.append(r)
 W, H, spp, nb = 1920, 1080, 8, 5
 for n in ([int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else (40, 64, 128, 256, 512, 1024)):
-    scene = large_scene(n, seed=17)
+    scene = stick_scene(n, seed=17) if os.environ.get("AB_SCENE") == "sticks" else large_scene(n, seed=17)      # AB_SCENE=sticks: objects that span the scene
     for r in rs:
         rt._lib = r._L; r.set_scene(scene); r.set_camera(**LARGE_SCENE_CAMERA)
     t = [[], []]; frames = [None, None]

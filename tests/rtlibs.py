@@ -114,6 +114,24 @@ def large_scene(n, seed, extent=10.0, floor=True, light=True):
     return make_scene(objs)
 
 
+def stick_scene(n, seed, extent=10.0):
+    """n objects that SPAN the scene: thin boxes running the whole length of one axis, at random places, and a few large spheres -- the
+    adversary of a spatial hierarchy (every cluster's and every group's box covers most of the scene, a ray passes most of them)."""
+    rng = np.random.default_rng(seed)
+    objs = []
+    for k in range(n):
+        if k == n // 2:
+            objs.append(dict(type="sphere", center=(0.0, extent * 0.8, 0.0), radius=1.0, albedo=(1, 1, 1), emission_power=4.0))
+        elif k % 9 == 0:
+            objs.append(dict(type="sphere", center=rng.uniform(-extent, extent, 3), radius=rng.uniform(0.5, 2.0), albedo=rng.uniform(0, 1, 3), roughness=rng.uniform(0, 1)))
+        else:
+            axis = int(rng.integers(0, 3))
+            origin = rng.uniform(-extent, extent, 3); size = rng.uniform(0.03, 0.12, 3)
+            origin[axis] = -extent; size[axis] = 2 * extent
+            objs.append(dict(type="cube", origin=origin, size=size, albedo=rng.uniform(0, 1, 3), roughness=rng.uniform(0, 1), metallic=float(k % 8 == 0)))
+    return make_scene(objs)
+
+
 LARGE_SCENE_CAMERA = dict(pos=(14, 9, 14), front=(-1, -0.5, -1), up=(0, 1, 0), fov=1.0)      # outside large_scene(), looking in
 
 

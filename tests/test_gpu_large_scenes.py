@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import ray_tracing_amd as rt
-from rtlibs import LARGE_SCENE_CAMERA, bits, large_scene, synthetic_skybox
+from rtlibs import LARGE_SCENE_CAMERA, bits, large_scene, stick_scene, synthetic_skybox
 
 pytestmark = pytest.mark.gpu
 
@@ -91,6 +91,28 @@ def test_groups_of_clusters_fuzz_against_every_object(gpu):
         gpu.set_tuning(test_every_object=False)
         assert (bits(culled) == bits(plain)).all(), (case, n, extent)
     gpu.set_camera()
+
+
+@pytest.mark.parametrize("n", [200, 600, 1024])
+def test_objects_that_span_the_scene(gpu, oracle, n):
+    """Thin boxes that run the whole length of the scene: every cluster's and group's box covers most of it, a ray passes most groups, and
+    a wave with more than RT_GROUP_PAIRS_MAX (ray, group) pairs asks every cluster box instead of dealing them (rt_kernels.hip step 1)."""
+    sky = synthetic_skybox(32, seed=n)
+    scene = stick_scene(n, seed=n)
+    gpu.set_skybox(sky); gpu.set_scene(scene)
+    oracle.set_skybox(sky); oracle.set_scene(scene)
+    W, H, spp, nb = 96, 54, 2, 5
+    for cam in CAMERAS[:2]:
+        gpu.set_camera(**cam); oracle.set_camera(**cam)
+        gpu.set_tuning(test_every_object=False)
+        culled = gpu.render(W, H, spp, nb, seed=n)
+        gpu.set_tuning(test_every_object=True)
+        plain = gpu.render(W, H, spp, nb, seed=n)
+        gpu.set_tuning(test_every_object=False)
+        assert (bits(culled) == bits(plain)).all(), (n, cam)
+        want = oracle.render_counter(W, H, spp, nb, seed=n, threads=min(os.cpu_count() or 1, 32))
+        assert (bits(culled) == bits(want)).all(), (n, cam)
+    gpu.set_camera(); oracle.set_camera()
 
 
 @pytest.mark.parametrize("n", [473, 500])
