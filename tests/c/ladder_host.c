@@ -6,7 +6,8 @@
  * stand-ins for the handful of reference globals and functions that text touches -- `frame`, `frame_w`, `frame_h`, `init_scale`,
  * the window size, realloc_frame_buffer(), the camera getters, move_frame_to_the_gpu() -- with the meaning they have in
  * main.c (:50, :71-75, :416-448) / camera.c (:33-37) / gpu_and_windowing.c (:361-376), and #includes the patch's text
- * unchanged (BINDING_TEXT: a file written by `reference_main_rt.py binding --ladder`).  main() then plays the part of the
+ * unchanged (BINDING_TEXT: a file written by `reference_main_rt.py binding --ladder`; or `binding --blocking` with
+ * -DBINDING_IS_BLOCKING, the variant that renders one independent frame per update_frame()).  main() then plays the part of the
  * reference's event loop (main.c:520-574):
  *
  *     ladder_host <scene> <skybox dir> <w> <h> <init_scale> <frames before> <frames after> <out.raw>
@@ -78,9 +79,13 @@ int main(int argc, char **argv)
 	invalidate_accumulation();
 	for (int k = 0; k < after; k++) update_frame();
 
+#ifdef BINDING_IS_BLOCKING          /* the --blocking variant keeps no ladder: frames shown since the last invalidation = the seed of the next one */
+	printf("{\"frames_since_invalidation\": %d, \"frames_shown\": %d}\n", rt_passes, shown_count);
+#else
 	int next_scale = 0, passes = 0; float count = 0; uint32_t generation = 0;
 	rt_progressive_state(rt, &next_scale, &count, &generation, &passes);
 	printf("{\"passes\": %d, \"next_scale\": %d, \"weight_sum\": %.9g, \"generation\": %u, \"frames_shown\": %d}\n", passes, next_scale, (double) count, generation, shown_count);
+#endif
 	FILE *f = fopen(argv[8], "wb");
 	if (!f || fwrite(shown, sizeof(Vector3), (size_t) screen_w * screen_h, f) != (size_t) screen_w * screen_h) return 1;
 	fclose(f);

@@ -21,17 +21,19 @@ HOST = os.path.join(ROOT, "tests", "c", "ladder_host.c")
 PASSES_PER_FRAME = 16
 
 
-def build_ladder_host(tmp_path, passes_per_frame=PASSES_PER_FRAME):
-    text = subprocess.run([sys.executable, PATCH, "binding", "--ladder"], check=True, capture_output=True, text=True).stdout
-    for call in ("rt_progressive_begin(rt, frame_w, frame_h, init_scale, 10, 0)", "rt_progressive_passes(rt, n)", "rt_progressive_resolve(rt, frame)",
-                 "rt_progressive_invalidate(rt)", "move_frame_to_the_gpu(frame_w, frame_h, frame)"):
+def build_ladder_host(tmp_path, passes_per_frame=PASSES_PER_FRAME, variant="--ladder"):
+    text = subprocess.run([sys.executable, PATCH, "binding", variant], check=True, capture_output=True, text=True).stdout
+    calls = ("rt_progressive_begin(rt, frame_w, frame_h, init_scale, 10, 0)", "rt_progressive_passes(rt, n)", "rt_progressive_resolve(rt, frame)",
+             "rt_progressive_invalidate(rt)") if variant == "--ladder" else ("rt_render(rt, &p, frame)", "rt_cancel(rt)", "rt_reserve(rt, frame_w, frame_h)")
+    for call in calls + ("move_frame_to_the_gpu(frame_w, frame_h, frame)",):
         assert call in text, call
-    inc = tmp_path / "binding_ladder.inc"
+    inc = tmp_path / f"binding{variant}.inc"
     inc.write_text(text)
-    exe = tmp_path / "ladder_host"
+    exe = tmp_path / f"host{variant}"
     libdir = os.path.dirname(rt.LIB_PATH)
     subprocess.run(["gcc", "-std=c11", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), f'-DBINDING_TEXT="{inc}"',
-                    f"-DRT_PASSES_PER_FRAME={passes_per_frame}", HOST, "-o", str(exe), "-L", libdir, "-lrt_hip", f"-Wl,-rpath,{libdir}", "-lm"],
+                    f"-DRT_PASSES_PER_FRAME={passes_per_frame}"] + (["-DBINDING_IS_BLOCKING"] if variant == "--blocking" else []) +
+                   [HOST, "-o", str(exe), "-L", libdir, "-lrt_hip", f"-Wl,-rpath,{libdir}", "-lm"],
                    check=True, capture_output=True, text=True)
     return str(exe)
 
@@ -49,10 +51,14 @@ def passes_after(frames, init_scale, per_frame):
 
 
 def test_binding_text_compiles_and_links(tmp_path):
-    """no GPU: the patch's text + the stand-ins build against the library (every rt_* call resolves)"""
+    """no GPU: the patch's text + the stand-ins build against the library (every rt_* call resolves), both variants"""
     exe = build_ladder_host(tmp_path)
     syms = subprocess.run(["nm", "-D", "--undefined-only", exe], check=True, capture_output=True, text=True).stdout
     for name in ("rt_progressive_begin", "rt_progressive_passes", "rt_progressive_resolve", "rt_progressive_invalidate", "rt_progressive_state", "rt_set_camera"):
+        assert name in syms, name
+    exe = build_ladder_host(tmp_path, variant="--blocking")
+    syms = subprocess.run(["nm", "-D", "--undefined-only", exe], check=True, capture_output=True, text=True).stdout
+    for name in ("rt_render", "rt_cancel", "rt_reserve", "rt_default_params", "rt_set_camera"):
         assert name in syms, name
 
 
@@ -77,3 +83,24 @@ def test_the_ladder_binding_shows_the_oracles_ladder_after_an_invalidation(tmp_p
     assert np.float32(line["weight_sum"]) == np.float32(count)
     shown = np.fromfile(out, np.float32).reshape(H, W, 3)
     assert (bits(shown) == bits(want)).all(), (init_scale, before, after)
+
+
+@pytest.mark.gpu
+def test_the_blocking_binding_shows_an_independent_frame_per_call(tmp_path, oracle, scene_paths):
+    """The --blocking variant of the patch, run the same way: every update_frame() is one rt_render() of sixteen samples per pixel whose seed
+    is the number of frames shown since the last invalidation; after a camera move the count starts again.  The last frame shown is the
+    oracle's frame of that seed at the new pose."""
+    exe = build_ladder_host(tmp_path, variant="--blocking")
+    W, H, before, after = 96, 64, 3, 4
+    out = tmp_path / "shown.raw"
+    p = subprocess.run([exe, scene_paths[0], os.path.join(rt.DATA_DIR, "skybox"), str(W), str(H), "8", str(before), str(after), str(out)],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["frames_since_invalidation"] == after and line["frames_shown"] == before + after
+    cam = dict(pos=(2, 3, 9), front=(0.1, -0.3, -1), up=(0, 1, 0), fov=30.0)
+    oracle.set_skybox(rt.load_skybox()); oracle.load_scene(scene_paths[0]); oracle.set_camera(**cam)
+    want = oracle.render_counter(W, H, 16, 10, seed=after - 1)
+    oracle.set_camera()
+    shown = np.fromfile(out, np.float32).reshape(H, W, 3)
+    assert (bits(shown) == bits(want)).all()
