@@ -317,3 +317,40 @@ def test_group_on_one_device_at_the_benchmark_size(sky, scene_paths):
     for k, s in enumerate(seeds):
         assert (bits(got[k]) == bits(want[s])).all(), k
     loop.close(); m.close()
+
+
+def test_group_profile_says_where_every_devices_step_went(sky, scene_paths):
+    """rt_multi_profile_enable / _collect (include/rt_hip.h rt_multi_phases): per device, five disjoint shares of the time between its
+    first and last frame end -- strip render, de-interleave, copy, waiting for the gather, idle -- that sum to its step; frames stay
+    bit-identical with the events in the streams; collect resets the log; too small an array is refused."""
+    import ctypes as C
+    from ray_tracing_amd.frames import FrameLoop
+    W, H, spp, nb, n = 640, 360, 16, 4, 4
+    seeds = list(range(50, 62))
+    want = _reference_frames(scene_paths[0], sky, W, H, spp, nb, seeds)
+    m = rt.MultiRenderer([0], on_one_device=n)
+    m.set_scene(scene_paths[0]); m.set_skybox(sky); m.set_camera()
+    m.profile_phases(True)
+    assert all(p["frames"] == 0 and p["step_ms"] == 0 for p in m.collect_phases())        # nothing submitted yet
+    loop = FrameLoop(m, W, H, spp, nb, depth=3)
+    got = []
+    loop.run(seeds, on_frame=lambda k, a: got.append(a.copy()))
+    for k, s in enumerate(seeds):
+        assert (bits(got[k]) == bits(want[s])).all(), k
+    phases = m.collect_phases()
+    assert len(phases) == n
+    for i, p in enumerate(phases):
+        assert p["frames"] == len(seeds) - 1 and p["step_ms"] > 0, p
+        shares = [p[k] for k in rt.PHASES]
+        assert all(v >= 0 for v in shares) and abs(sum(shares) - p["step_ms"]) <= 1e-6 * max(p["step_ms"], 1.0), p
+        assert (p["copy_ms"] > 0 and p["deinterleave_ms"] > 0) if i == 0 else (p["copy_ms"] == 0 and p["deinterleave_ms"] == 0), p
+    assert sum(p["render_ms"] for p in phases) > 0
+    verdict = rt.judge_phases(phases)
+    assert verdict["critical_rank"] in range(n) and verdict["step_bound"] in ("render", "gather", "copy", "host")
+    assert all(p["frames"] == 0 for p in m.collect_phases())                               # the log was reset
+    small = (rt.MultiPhases * (n - 1))()
+    assert rt.lib().rt_multi_profile_collect(m._m, small, n - 1) == -1                     # RT_ERR_ARGUMENT: room for every device is needed
+    m.profile_phases(False)
+    loop.run(seeds[:4])
+    assert all(p["frames"] == 0 for p in m.collect_phases())                               # off: nothing is recorded
+    loop.close(); m.close()
