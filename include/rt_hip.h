@@ -76,6 +76,7 @@ RT_API void rt_default_params(rt_render_params *p, int width, int height, int sp
  * changes.  A host compares rt_abi_version() with the RT_ABI_VERSION it was compiled against before anything else. */
 #define RT_ABI_VERSION 6
 RT_API int rt_abi_version(void);
+#define RT_AUDIT_OFF (-2)           /* rt_tuning.audit_known_taps */
 
 /* Scheduling knobs of the trace kernels.  None of them changes a single bit of any frame (tests render with
  * several settings and compare); they exist for hosts with a loop of their own and for measurement scripts.  0 / NULL = let the
@@ -91,10 +92,13 @@ typedef struct {
 	                             * enqueued before the previous one, on the context's other stream, has started: the two are resident
 	                             * side by side; any setting also keeps a large scene's culled kernel on workgroups of four waves) */
 	int    jit_waves_per_simd;  /* rt_compile_scene: register budget = 512 / this many VGPRs (default 4) */
-	int    audit_known_taps;    /* csrc/rt_lit.h audited in production: k = 1 ... 24 -- of the answers "these soft-shadow taps need no tracing" (per
-	                             * camera-ray hit point, per cell of the scene's table), one in 2^k (k = -1: every one) is marked: bounces that
-	                             * use a marked answer have their taps traced all the same and compared; the frame is unchanged, a
-	                             * disagreement fails the launch (RT_ERR_DEVICE, rt_launch_report.taps_disagreeing).  0: off */
+	int    audit_known_taps;    /* csrc/rt_lit.h audited in production.  Of the answers "these soft-shadow taps need no tracing" (per camera-ray
+	                             * hit point, per cell of the scene's table) some are marked: bounces that use a marked answer have their taps
+	                             * traced all the same and compared; the frame is unchanged, a disagreement fails the launch (RT_ERR_DEVICE,
+	                             * rt_launch_report.taps_disagreeing).  0, the default: the BACKGROUND audit -- one launch in 61 of a context
+	                             * is rendered that way with one answer in 8 marked (that launch costs 2 % more: 0.03 % of a frame loop;
+	                             * nothing is ever compiled for it); k = 1 ... 24: every launch, one answer in 2^k; -1: every launch, every
+	                             * answer; RT_AUDIT_OFF: never (measurement scripts that compare kernels) */
 	const char *jit_flags;      /* rt_compile_scene: extra hiprtc options, space separated (copied) */
 } rt_tuning;
 RT_API void rt_default_tuning(rt_tuning *t);

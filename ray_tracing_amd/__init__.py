@@ -359,6 +359,7 @@ FRAME_SLOTS = 8          # RT_FRAME_SLOTS
 LAUNCH_SETS = 5          # RT_LAUNCH_SETS
 CHECK_TICKETS = 8        # RT_CHECK_TICKETS
 PENDING, CANCELLED = 2, 1
+AUDIT_OFF = -2           # RT_AUDIT_OFF: rt_tuning.audit_known_taps, "never" (0 is the background audit: one launch in 61)
 
 
 class HostFrame:

@@ -85,13 +85,14 @@ struct rt_context {
 	hipFunction_t spec_fn = nullptr;
 	hipFunction_t spec_fn_audit = nullptr;  /* the same scene's kernel in its audit variant (rt_tuning.audit_known_taps), built when first asked for; valid like spec_fn */
 	bool         spec_audit_failed = false; /* ... could not be built (no hiprtc): audited launches use the generic kernel's audit variant */
+	bool         spec_audit_not_embedded = false;   /* ... does not come with the library: the background audit, which compiles nothing, uses the generic kernel's */
 	bool         scene_fast_ok = false;  /* every cube has 0 <= size, plane coordinates +0 or 2^-76 <= |x| <= 2^29, sphere data |x| <= 2^29 */
 	int          light_index = -1;
 	float        light_pos[3] = {0, 0, 0};
 	bool         only_light_emits = false;   /* no other object has a non-zero emission component (rt_device.h) */
 	/* rt_lit.h: which hit points need no soft-shadow tap traced -- one bit per cell of a grid over every object, built
 	 * by rt_set_scene on the host (a few milliseconds) */
-	unsigned char *d_lit_cells = nullptr;
+	unsigned char *d_lit_cells = nullptr;     /* the lit-taps table as built, and behind it (at + lit_cells_capacity) the copy that carries the audit's marks */
 	std::vector<unsigned char> h_lit_cells;   /* the table as built (values 1 / 2 / 0), for re-marking when the audit setting changes */
 	int          lit_audit_marked = 0;        /* the rt_tuning.audit_known_taps the device's copy is marked for (bit 2 of one cell in 2^k) */
 	void        *d_lit_grids = nullptr;
@@ -403,7 +404,7 @@ int rt_set_tuning(rt_context *ctx, const rt_tuning *t)
 	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_set_tuning: NULL context");
 	if ((t->dequeue_shards != 0 && t->dequeue_shards != 1 && t->dequeue_shards != 64) ||
 	    t->workgroups_per_cu < 0 || t->workgroups_per_cu > 8 || t->jit_waves_per_simd < 0 || t->jit_waves_per_simd > 8 ||
-	    t->audit_known_taps < -1 || t->audit_known_taps > RT_AUDIT_MAX_LOG2)
+	    t->audit_known_taps < RT_AUDIT_OFF || t->audit_known_taps > RT_AUDIT_MAX_LOG2)
 		return fail(RT_ERR_ARGUMENT, "rt_set_tuning: value out of range");
 	ctx->tuning.dequeue_shards = t->dequeue_shards; ctx->tuning.workgroups_per_cu = t->workgroups_per_cu;
 	ctx->tuning.jit_waves_per_simd = t->jit_waves_per_simd; ctx->tuning.audit_known_taps = t->audit_known_taps;
@@ -508,6 +509,8 @@ void rt_destroy(rt_context *ctx)
 	delete ctx;
 }
 
+static int mark_audited_cells(rt_context *ctx);
+
 int rt_set_scene(rt_context *ctx, const Scene *scene)
 {
 	if (!ctx || !scene) return fail(RT_ERR_ARGUMENT, "rt_set_scene: NULL argument");
@@ -544,7 +547,7 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 	}
 	ctx->h_geom.assign(geom.begin(), geom.begin() + n);
 	ctx->spec_module = nullptr; ctx->spec_fn = nullptr;      /* (not unloaded: rt_jit.cpp keeps compiled scenes for the life of the process) */
-	ctx->spec_fn_audit = nullptr; ctx->spec_audit_failed = false;
+	ctx->spec_fn_audit = nullptr; ctx->spec_audit_failed = false; ctx->spec_audit_not_embedded = false;
 	if (n > ctx->capacity || !ctx->d_geom) {
 		(void) hipFree(ctx->d_geom); (void) hipFree(ctx->d_shade);
 		ctx->d_geom = nullptr; ctx->d_shade = nullptr; ctx->capacity = 0;
@@ -581,7 +584,7 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 				                                     (!dark.empty() && ((dark[(size_t) (b >> 5)] >> (b & 31)) & 1u)) ? 2u : 0u);
 			if (cells.size() > ctx->lit_cells_capacity) {
 				(void) hipFree(ctx->d_lit_cells); ctx->d_lit_cells = nullptr; ctx->lit_cells_capacity = 0;
-				HIP_TRY(hipMalloc((void**) &ctx->d_lit_cells, cells.size()));
+				HIP_TRY(hipMalloc((void**) &ctx->d_lit_cells, 2 * cells.size()));      /* (+ the marked copy of audited launches: mark_audited_cells) */
 				ctx->lit_cells_capacity = cells.size();
 			}
 			if (n > ctx->lit_grids_capacity) {
@@ -594,6 +597,7 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 			HIP_TRY(hipMemcpy(ctx->d_lit_cells, cells.data(), cells.size(), hipMemcpyHostToDevice));
 			HIP_TRY(hipMemcpy(ctx->d_lit_grids, grids.data(), (size_t) n * sizeof(rt_lit_grid), hipMemcpyHostToDevice));
 			ctx->have_lit = true;
+			{ const int mrc = mark_audited_cells(ctx); if (mrc != RT_OK) return mrc; }      /* (now, not in front of the first launch that is audited) */
 		}
 	}
 	ctx->num_objects = n;
@@ -603,6 +607,8 @@ int rt_set_scene(rt_context *ctx, const Scene *scene)
 }
 
 /* Scene "compilation": see rt_jit.cpp.  Optional; everything works without it. */
+static hipFunction_t trace_kernel_for(rt_context *ctx, bool audit);
+
 int rt_compile_scene(rt_context *ctx)
 {
 	if (!ctx) return fail(RT_ERR_ARGUMENT, "rt_compile_scene: NULL context");
@@ -616,6 +622,9 @@ int rt_compile_scene(rt_context *ctx)
 	const int rc = rt_jit_build(ctx->h_geom.data(), n, ctx->light_index, ctx->light_pos, ctx->only_light_emits ? 1 : 0, ctx->tuning.jit_waves_per_simd, ctx->jit_flags.c_str(),
 	                            &ctx->spec_module, &ctx->spec_fn, message, &ctx->spec_code, &ctx->spec_compiler);
 	if (rc != RT_OK) { ctx->spec_module = nullptr; ctx->spec_fn = nullptr; return fail(rc, "rt_compile_scene: %s", message.c_str()); }
+	/* the audit variant, if it comes with the library (the shipped scenes' do): a module load now instead of in front of the first
+	 * launch the background audit picks */
+	if (ctx->tuning.audit_known_taps == 0) (void) trace_kernel_for(ctx, true);
 	return RT_OK;
 }
 
@@ -772,6 +781,29 @@ static int prepare_scratch(rt_context *ctx, rt_launch &L, unsigned which)
 	return RT_OK;
 }
 
+/* rt_lit.h audited in production (include/rt_hip.h rt_tuning.audit_known_taps).  k != 0: what the host asked for -- every launch,
+ * one answer in 2^k (-1: every one) -- or RT_AUDIT_OFF.  k == 0, the default, is the BACKGROUND audit (round 6; until then the
+ * default was "never", and a production host ran the taps of 80 % of C1's bounces on a table nobody looked at): every
+ * RT_AUDIT_PERIOD-th launch of a context is rendered by the audit variant with one answer in 2^RT_AUDIT_BACKGROUND_LOG2 re-traced
+ * and compared.  An audited launch costs 2 % more, i.e. 0.03 % of a frame loop; a wrong table is caught within a second of
+ * frames (RT_ERR_DEVICE, taps_disagreeing).  The background audit never compiles anything: a compiled scene's audit variant is
+ * used when it comes embedded with the library (loaded by rt_compile_scene), otherwise the generic kernel's. */
+#define RT_AUDIT_PERIOD 61u
+#define RT_AUDIT_BACKGROUND_LOG2 3
+static int audit_log2_of_launch(const rt_context *ctx, unsigned int launch)
+{
+	const int k = ctx->tuning.audit_known_taps;
+	if (k == RT_AUDIT_OFF) return 0;
+	if (k != 0) return k;
+	return launch % RT_AUDIT_PERIOD == RT_AUDIT_PERIOD - 1u ? RT_AUDIT_BACKGROUND_LOG2 : 0;
+}
+/* ... and the marks the scene's table carries for it (they mean nothing to a launch that is not audited) */
+static int audit_log2_of_table(const rt_context *ctx)
+{
+	const int k = ctx->tuning.audit_known_taps;
+	return k == RT_AUDIT_OFF ? 0 : (k != 0 ? k : RT_AUDIT_BACKGROUND_LOG2);
+}
+
 /* ... and the launch gets its number.  rt_cancel() on another thread must cover this launch from the moment its first kernel
  * can be on the GPU: the number is published BEFORE anything of the launch is enqueued (a request that arrives in between
  * stops a launch that has not started yet, at its first pixel fetch).  A launch that then fails to enqueue keeps its number:
@@ -784,7 +816,7 @@ static int prepare_launch(rt_context *ctx, rt_launch &L, unsigned which)
 	if (rc != RT_OK) return rc;
 	L.launch_id = ++ctx->last_id;
 	if (L.launch_id == 0u) L.launch_id = ++ctx->last_id;      /* (0 is "no stamp") */
-	const int k = ctx->tuning.audit_known_taps;
+	const int k = audit_log2_of_launch(ctx, which);
 	L.audit_taps = k == 0 ? 0u : (k < 0 ? 1u : 1u << k);
 	L.test_drop_pixels = (unsigned int) ctx->tuning.test_drop_pixels;
 	ctx->enqueued.store(L.launch_id, std::memory_order_release);
@@ -821,12 +853,14 @@ int rt_reserve(rt_context *ctx, int width, int height)
 static hipFunction_t trace_kernel_for(rt_context *ctx, bool audit)
 {
 	if (!audit || !ctx->spec_fn) return ctx->spec_fn;
-	if (!ctx->spec_fn_audit && !ctx->spec_audit_failed) {
+	/* (the background audit compiles nothing: what rt_compile_scene found embedded, or the generic kernel) */
+	const bool may_compile = ctx->tuning.audit_known_taps != 0;
+	if (!ctx->spec_fn_audit && !ctx->spec_audit_failed && (may_compile || !ctx->spec_audit_not_embedded)) {
 		hipModule_t module = nullptr;
 		std::string message, flags = ctx->jit_flags + (ctx->jit_flags.empty() ? "" : " ") + "-DRT_SPEC_AUDIT";
 		const int rc = rt_jit_build(ctx->h_geom.data(), ctx->num_objects, ctx->light_index, ctx->light_pos, ctx->only_light_emits ? 1 : 0, ctx->tuning.jit_waves_per_simd,
-		                            flags.c_str(), &module, &ctx->spec_fn_audit, message);
-		if (rc != RT_OK) { ctx->spec_fn_audit = nullptr; ctx->spec_audit_failed = true; }
+		                            flags.c_str(), &module, &ctx->spec_fn_audit, message, nullptr, nullptr, /* embedded_only = */ !may_compile);
+		if (rc != RT_OK) { ctx->spec_fn_audit = nullptr; if (may_compile) ctx->spec_audit_failed = true; else ctx->spec_audit_not_embedded = true; }
 	}
 	return ctx->spec_fn_audit;        /* (nullptr: the generic kernel) */
 }
@@ -836,8 +870,8 @@ static hipFunction_t trace_kernel_for(rt_context *ctx, bool audit)
  * every round of a kernel at its register limit).  The device's copy is re-marked, between launches, when the setting changed. */
 static int mark_audited_cells(rt_context *ctx)
 {
-	const int k = ctx->tuning.audit_known_taps;
-	if (!ctx->have_lit || ctx->lit_audit_marked == k) return RT_OK;
+	const int k = audit_log2_of_table(ctx);
+	if (!ctx->have_lit || ctx->lit_audit_marked == k || k == 0) return RT_OK;
 	{ const int rc = wait_for_launches(ctx); if (rc != RT_OK) return rc; }       /* launches in flight read the table */
 	std::vector<unsigned char> cells = ctx->h_lit_cells;
 	if (k != 0) {
@@ -845,7 +879,9 @@ static int mark_audited_cells(rt_context *ctx)
 		for (size_t b = 0; b < cells.size(); b++)
 			if (cells[b] && ((uint32_t) ((b * 0x9E3779B97F4A7C15ull) >> (64 - RT_AUDIT_MAX_LOG2)) & mask) == 0u) cells[b] |= 4u;
 	}
-	HIP_TRY(hipMemcpy(ctx->d_lit_cells, cells.data(), cells.size(), hipMemcpyHostToDevice));
+	/* (a copy of its own: launches that are not audited -- every one but the background audit's -- read the table without marks,
+	 * and their kernels need not mask them out) */
+	HIP_TRY(hipMemcpy(ctx->d_lit_cells + ctx->lit_cells_capacity, cells.data(), cells.size(), hipMemcpyHostToDevice));
 	ctx->lit_audit_marked = k;
 	return RT_OK;
 }
@@ -883,7 +919,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	L.sky = ctx->d_sky; L.sky_w = ctx->sky_w; L.sky_h = ctx->sky_h; L.sky_wm1 = (float) (ctx->sky_w - 1); L.sky_hm1 = (float) (ctx->sky_h - 1);
 	L.frame = (float*) d_strip;
 	L.skip_known_taps = classify_pixels(ctx, p->spp);
-	L.lit_cells = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_cells : nullptr;
+	L.lit_cells = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_cells + (audit_log2_of_launch(ctx, ctx->launches) != 0 ? ctx->lit_cells_capacity : 0) : nullptr;
 	L.lit_grids = ctx->d_lit_grids;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
 	if (ctx->cull.num_clusters > 0 && !ctx->tuning.test_every_object) {
@@ -902,7 +938,7 @@ int rt_render_device(rt_context *ctx, const rt_render_params *p, void *d_strip, 
 	}
 	ctx->slot[ctx->launches % RT_LAUNCH_SETS].lists_key = 0;
 	ctx->primary_passes++;
-	const bool audit = ctx->tuning.audit_known_taps != 0;
+	const bool audit = L.audit_taps != 0u;           /* (prepare_launch: asked for, or this launch's turn of the background audit) */
 	hipError_t le = rt_launch_trace(L, p->kernel, ctx->scene_fast_ok, trace_kernel_for(ctx, audit), ctx->slot[ctx->launches % RT_LAUNCH_SETS].d_counter, e0, ctx->slot[ctx->launches % RT_LAUNCH_SETS].started, ctx->num_cus, workgroups_per_cu_for(ctx, stream, (long long) L.width * L.local_rows), stream,
 	                                false, &ctx->slot[ctx->launches % RT_LAUNCH_SETS].expect, em, audit);
 	if (le == hipSuccess && ctx->profiling) le = hipEventRecord(e1, stream);
@@ -1273,7 +1309,7 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 	L.sum_onto = batch ? g.d_accum : nullptr;
 	/* (the flags are kept with the lists: a camera position pays once for all its passes -- reckoned as sixteen) */
 	L.skip_known_taps = classify_pixels(ctx, samples > 16 ? samples : 16);
-	L.lit_cells = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_cells : nullptr;
+	L.lit_cells = (ctx->have_lit && !ctx->tuning.trace_known_taps) ? ctx->d_lit_cells + (audit_log2_of_launch(ctx, ctx->launches) != 0 ? ctx->lit_cells_capacity : 0) : nullptr;
 	L.lit_grids = ctx->d_lit_grids;
 	L.geom = ctx->d_geom; L.shade = ctx->d_shade;
 	if (ctx->cull.num_clusters > 0 && !ctx->tuning.test_every_object) {
@@ -1309,6 +1345,9 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 		rt_launch K = L;
 		K.seed = 0; K.sample_base = 0; K.max_bounces = 0; K.lit_cells = nullptr; K.lit_grids = nullptr; K.lit_grids_in_lds = 0;
 		K.launch_id = 0;
+		/* (K.audit_taps stays in the key: the records of an audited launch carry the camera-ray hit points' audit marks, which a kernel
+		 * that is not the audit variant does not mask out -- the pass the background audit picks, one in 61, traces its camera rays
+		 * again, and so does the next pass of its scratch set) */
 		K.pix = nullptr; K.pix_count = nullptr; K.control = nullptr; K.frame = nullptr;     /* the scratch set's own addresses: the same output in any set has the same key */
 		key = 0xcbf29ce484222325ull ^ ctx->input_version;
 		const unsigned char *b = reinterpret_cast<const unsigned char*>(&K);
@@ -1319,7 +1358,7 @@ static int progressive_launch(rt_context *ctx, int samples, float *weight_out)
 	const bool reuse = !ctx->tuning.poison_frame && !batch && sl.lists_key == key;      /* (a batch's sky pixels are sums: never the same twice) */
 	sl.lists_key = 0;
 	{
-		const bool audit = ctx->tuning.audit_known_taps != 0;
+		const bool audit = L.audit_taps != 0u;
 		/* Resident workgroups per CU.  Batches run one after the other (each needs the sums of the one before): all the slots.  Single
 		 * passes enqueued ahead of the GPU: ONE of four -- three passes are resident at a time; a 1080p pass is five pixels per lane
 		 * with all the slots, and a wave then spends more rounds on the last of its paths (ten bounces, a few lanes) than on all the

@@ -54,7 +54,8 @@ hipError_t rt_launch_trace(const rt_launch &L, int variant, bool scene_fast_ok, 
                            bool audit = false);                   /* the kernel variant that compares audited answers of rt_lit.h with a trace (spec_fn, if given, must be that variant) */
 int        rt_jit_build(const rt_geom *geom, int n, int light_index, const float light_pos[3], int only_light_emits, int waves_per_simd, const char *extra_flags, hipModule_t *module, hipFunction_t *function, std::string &message,
                         std::vector<char> *code_out = nullptr,    /* the code object (development aid) */
-                        std::string *compiler = nullptr);         /* where it came from: "embedded, compiled with the library by ..." / "hiprtc x.y at run time" */
+                        std::string *compiler = nullptr,          /* where it came from: "embedded, compiled with the library by ..." / "hiprtc x.y at run time" */
+                        bool embedded_only = false);              /* only what was compiled with the library: RT_ERR_STATE, and nothing compiled, if the scene (with these flags) is not among it */
 hipError_t rt_launch_deinterleave(const float *strips, float *frame, int width, int height,
                                   int row_block, int world, int rows_per_rank, int first, hipStream_t stream);
 

@@ -249,3 +249,50 @@ def test_a_wrong_table_is_caught_by_the_audit(sky, scene_paths):
     g.render(W, H, spp, nb)
     assert g.last_launch_report()[1]["taps_disagreeing"] == 0
     g.close()
+
+
+@pytest.mark.parametrize("compiled", [False, True])
+def test_the_background_audit_looks_at_one_launch_in_61(sky, scene_paths, compiled):
+    """rt_tuning.audit_known_taps = 0, the default (round 6; until then the default was "never"): every 61st launch of a context is rendered
+    by the audit variant -- the embedded one of a shipped scene that is compiled, the generic kernel's otherwise; nothing is ever built
+    for it -- with one answer of csrc/rt_lit.h in 8 re-traced and compared.  Frames are unchanged, the other launches audit nothing,
+    RT_AUDIT_OFF audits none at all."""
+    W, H, spp, nb = 160, 90, 4, 4
+    g = rt.Renderer(0)
+    g.set_tuning(poison_frame=True)
+    g.set_scene(scene_paths[0]); g.set_skybox(sky); g.set_camera()
+    if compiled:
+        g.compile_scene()
+    want = {s: g.render(W, H, spp, nb, seed=s, kernel=rt.KERNEL_SIMPLE) for s in (3, 4)}      # (the cross-check kernel does not account for itself: these launches count all the same)
+    audited = []
+    for k in range(2, 130):                                 # launches 2 ... 129 of the context: numbers 60 and 121 are the audit's
+        got = g.render(W, H, spp, nb, seed=3 + (k & 1))
+        assert (bits(got) == bits(want[3 + (k & 1)])).all(), k
+        rc, r = g.last_launch_report()
+        assert rc == 0 and r["taps_disagreeing"] == 0
+        if r["taps_audited"]:
+            audited.append(k)
+    assert audited == [60, 121], audited
+    g.set_tuning(audit_known_taps=rt.AUDIT_OFF)
+    for k in range(130, 200):
+        g.render(W, H, spp, nb, seed=3)
+        assert g.last_launch_report()[1]["taps_audited"] == 0
+    g.close()
+
+
+def test_the_background_audit_catches_a_wrong_table(sky, scene_paths):
+    """... and a table that is wrong (the fault injection of rt_hip_testing.h) does not survive a context's first 61 launches with the
+    DEFAULT tuning: the launch the background audit picks is refused, RT_ERR_DEVICE, with the disagreeing taps counted."""
+    g = rt.Renderer(0)
+    g.set_tuning(poison_frame=True, test_corrupt_lit_table=1)
+    g.set_scene(scene_paths[0]); g.set_skybox(sky); g.set_camera(); g.compile_scene()
+    refused = []
+    for k in range(61):
+        try:
+            g.render(160, 90, 4, 4, seed=k)
+        except rt.RtError as e:
+            refused.append((k, str(e)))
+    assert len(refused) == 1 and refused[0][0] == 60 and "contradict the answer rt_lit.h gave" in refused[0][1], refused
+    rc, r = g.last_launch_report()
+    assert rc == ERR_DEVICE and 0 < r["taps_disagreeing"] <= r["taps_audited"]
+    g.close()
