@@ -405,7 +405,7 @@ RT_API int rt_profile_collect_split(rt_context *ctx, double *kernel_ms_total, in
  * rendered strip waiting for its gather > idle (no launch was there to run).  The five shares are disjoint, sum to step_ms --
  * the mean interval between two frame ends -- and are ms per step.  Reading: a device that renders all of its step bounds the
  * frame rate; one that mostly waits for the gather has slack; idle time is the host's.  Costs two to five event records per
- * device and frame; collect resets the log.  (One device without the collective path records nothing: frames == 0.)
+ * device and frame; collect resets the log (which stops growing by itself after 4 096 frames).  (One device without the collective path records nothing: frames == 0.)
  * main.c:695-718 is the fan-out this instruments. */
 typedef struct {
 	int    frames;                      /* intervals the means are over */

@@ -126,6 +126,7 @@ struct rt_multi {
 };
 
 static void free_marks(rt_multi *m);
+#define RT_PROFILE_FRAMES_MAX 4096u      /* frames rt_multi_profile_enable() records before it turns itself off (five events per device and frame) */
 /* a timed event recorded on `stream` now (profiling only) */
 static hipError_t mark_now(hipEvent_t *e, hipStream_t stream)
 {
@@ -397,6 +398,7 @@ static int multi_frame_submit(rt_multi *m, const rt_render_params *params, int s
 		if (e != hipSuccess) { rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: device %d: %s", m->devices[(size_t) i], hipGetErrorString(e)); break; }
 		rt_render_params p = *params;
 		p.rank = rt_strip_of_rank(i, n); p.world = n;     /* rotated by one: device 0, the root, renders the last strip -- never the longest (rt_hip.h) */
+		if (m->profiling && m->marks[(size_t) i].size() >= RT_PROFILE_FRAMES_MAX) m->profiling = false;      /* (a host that never collects: the log stops growing) */
 		if (m->profiling) {
 			m->marks[(size_t) i].emplace_back();
 			if (mark_now(&m->marks[(size_t) i].back().render_begins, rs) != hipSuccess) { rc = rt_fail(RT_ERR_DEVICE, "rt_multi_frame_submit: profiling event"); break; }
