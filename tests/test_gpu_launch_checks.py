@@ -296,3 +296,40 @@ def test_the_background_audit_catches_a_wrong_table(sky, scene_paths):
     rc, r = g.last_launch_report()
     assert rc == ERR_DEVICE and 0 < r["taps_disagreeing"] <= r["taps_audited"]
     g.close()
+
+
+def test_the_background_audit_compiles_nothing(sky, scene_paths, oracle):
+    """A compiled scene that is NOT among the kernels embedded in the library (one coordinate of scene_0 changed: hiprtc compiled it): the
+    launch the background audit picks is rendered by the GENERIC kernel's audit variant -- no second hiprtc build in front of a frame --,
+    audits its taps, and the frame is the compiled kernel's, bit for bit."""
+    import ctypes as C
+    from rtlibs import scene_objects
+    rc, buf = rt.parse_scene_file(scene_paths[0])
+    assert rc == 0
+    objs, n = scene_objects(buf)
+    objs[6]["geom"][1] = np.float32(1.25)                  # the first sphere, lifted a little
+    g = rt.Renderer(0)
+    g.set_tuning(poison_frame=True)
+    g.set_skybox(sky); g.set_scene(buf); g.set_camera()
+    g.compile_scene()
+    assert g.compiled_scene_info().startswith("hiprtc")
+
+    def cached():
+        a, b = C.c_int(), C.c_int()
+        rt.lib().rt_compiled_scene_counts(C.byref(a), C.byref(b))
+        return a.value + b.value
+    before = cached()
+    W, H, spp, nb = 160, 90, 4, 4
+    want = g.render(W, H, spp, nb, seed=5)
+    audited = []
+    for k in range(1, 62):
+        got = g.render(W, H, spp, nb, seed=5)
+        assert (bits(got) == bits(want)).all(), k
+        rc, r = g.last_launch_report()
+        assert rc == 0 and r["taps_disagreeing"] == 0
+        if r["taps_audited"]:
+            audited.append(k)
+    assert audited == [60] and cached() == before          # launch 60 audited, and nothing was compiled for it
+    g.close()
+    oracle.set_skybox(sky); oracle.set_scene(buf); oracle.set_camera()
+    assert (bits(want) == bits(oracle.render_counter(W, H, spp, nb, seed=5))).all()
