@@ -1118,6 +1118,7 @@ RT_DEV rt_launch_cold cold_view()
  * objects -- one workgroup less per CU costs 15 %.  (The sample window is what a wave's LDS is spent on: half the
  * slots cost 58 % on C1, 48 instead of 32 per stream buy 2 % there and 9 % at 1024 samples per pixel.) */
 static_assert(4 * sizeof(WaveLDS) + 96 * 17 <= 160 * 1024 / 4, "WaveLDS grew: scenes of up to 17 objects no longer fit four workgroups per CU");
+static_assert(sizeof(WaveLDS) % 16 == 0 && sizeof(CullWave) % 16 == 0 && sizeof(CullWave) == 1024, "the waves' LDS records follow each other: the culled trace reads and writes a ray's cluster mask as one 16-byte word");
 
 
 template <bool FAST> RT_DEV V3 unit3_sel(V3 v) { return FAST ? unit3_fast(v) : unit3(v); }
